@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- forward+backward views/sec of the GeoSplatting render path on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+prints ONE JSON line on rank 0.
+
+Workload (BASELINE.json `metric`: "fwd+bwd views/sec at 2M Gaussians, 800x800"):
+  synthetic surface splats = MGAdapter restatement on a bumpy icosphere level 7 -> 1 966 080 Gaussians, 800x800,
+  Blender-style cameras, seeded 6x512^2 HDR cubemap.  One STEP = what one training step of the
+  reference renders and back-propagates on one device (rfstudio/model/geosplat.py:856-879, batch_size 8,
+  tests/model/test_geosplat.py:28):
+      split-sum prefilter forward (S5) -> 8 x [shade -> project/bin/sort/composite -> tone-map, then the backward of
+      all of it] -> prefilter backward -> (N>1) one flat RCCL all-reduce of all parameter gradients.
+  value = views/sec = 8 * N / (max-over-ranks step time).  Weak scaling: every GPU renders its own 8 views.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured copy peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--level", type=int, default=7, help="icosphere level: 7 -> 1 966 080 Gaussians, 6 -> 491 520")
+    ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--views", type=int, default=8, help="views per step per GPU (reference batch_size = 8)")
+    ap.add_argument("--cubemap-res", type=int, default=512)
+    ap.add_argument("--no-prefilter", action="store_true", help="diagnostic only: keep the pyramid fixed")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-iters", type=int, default=20)
+    return ap.parse_args()
+
+
+def algorithmic_bytes_per_view(N, V, I, P, E):
+    """228 N + 184 V + 120 I + 44 P + 2 E (fp32, D=3, ideal single-pass sort)."""
+    return 228 * N + 184 * V + 120 * I + 44 * P + 2 * E
+
+
+def time_dominant_kernels(scene_state, iters):
+    """Per-kernel durations with HIP events on the stream the kernels are launched on (torch's current stream):
+    raster forward and raster backward (the two VALU-bound kernels) and the projection kernel (HBM-bound)."""
+    import geosplatting_amd._lib as L
+    lib = L.lib()
+    st = scene_state
+    dev = st["means2d"].device
+    W = H = st["res"]
+    V, I, D = st["V"], st["I"], 3
+    f32 = torch.float32
+    render = torch.empty(H, W, D, dtype=f32, device=dev); alphas = torch.empty(H, W, dtype=f32, device=dev)
+    last = torch.empty(H, W, dtype=torch.int32, device=dev)
+    v_render = torch.rand(H, W, D, device=dev) * 2 - 1; v_alpha = torch.rand(H, W, device=dev) * 2 - 1
+    v_m2d = torch.empty(V, 2, dtype=f32, device=dev); v_con = torch.empty(V, 3, dtype=f32, device=dev)
+    v_col = torch.empty(V, D, dtype=f32, device=dev); v_op = torch.empty(V, dtype=f32, device=dev)
+    s = L.stream()
+
+    def fwd():
+        L.check(lib.gs_raster_fwd(W, H, 16, D, L.ptr(st["means2d"]), L.ptr(st["conics"]), L.ptr(st["opacities"]),
+                                  L.ptr(st["colors"]), None, L.i64(I), L.ptr(st["offsets"]), L.ptr(st["flatten_ids"]),
+                                  L.ptr(render), L.ptr(alphas), L.ptr(last), s), "raster_fwd")
+
+    def bwd():
+        L.check(lib.gs_raster_bwd(W, H, 16, D, V, L.ptr(st["means2d"]), L.ptr(st["conics"]), L.ptr(st["opacities"]),
+                                  L.ptr(st["colors"]), None, L.i64(I), L.ptr(st["offsets"]), L.ptr(st["flatten_ids"]),
+                                  L.ptr(alphas), L.ptr(last), L.ptr(v_render), L.ptr(v_alpha), L.ptr(v_m2d), L.ptr(v_con),
+                                  L.ptr(v_col), L.ptr(v_op), s), "raster_bwd")
+    out = {}
+    for name, fn in (("raster_fwd_kernel", fwd), ("raster_bwd_kernel", bwd)):
+        fn(); torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        out[name] = e0.elapsed_time(e1) / iters       # ms per launch
+    return out
+
+
+def cpu_baseline(scene, cam, res, budget_note):
+    """The CPU oracle (plain-C restatement, OpenMP over host cores) timed on ONE view fwd+bwd of the same workload."""
+    import numpy as np
+    import geosplatting_amd as gs
+    import oracle
+    cores = os.cpu_count() or 1
+    sp = scene.splats
+    means, quats = sp.means.numpy(), sp.quats.numpy()
+    scales, opac = sp.scales.exp().numpy(), torch.sigmoid(sp.opacities).squeeze(-1).numpy()
+    lut = gs.get_fg_lut(torch.device("cpu"))[0].numpy()
+    # pyramid: the prefilter is excluded from the CPU sample (it is once per 8 views and its oracle is O(minutes) at 512^2);
+    # a seeded random pyramid of the right shape stands in -- texture values do not change the work done.
+    g = torch.Generator().manual_seed(0)
+    levels = [torch.rand(6, r, r, 3, generator=g).numpy() for r in (512, 256, 128, 64, 32, 16)]
+    base = torch.rand(6, 16, 16, 3, generator=g).numpy()
+    vm, K = cam.view_matrix.numpy(), cam.intrinsic_matrix.numpy()
+    v = (torch.rand(res, res, 4, generator=g) * 2 - 1).numpy()
+    t0 = time.time()
+    col = oracle.shade_fwd(means, scene.normals.numpy(), scene.kd.numpy(), scene.ks.numpy(), cam.c2w[:, 3].numpy(), lut,
+                           base, levels)
+    m = oracle.rasterization(means, quats, scales, opac, col, vm, K, res, res)
+    rgba = np.concatenate([m["render"], m["alphas"][..., None]], -1)
+    oracle.tonemap_fwd(rgba, 1.0, "naive")
+    v_rgba, _ = oracle.tonemap_bwd(rgba, 1.0, v, "naive")
+    gr = oracle.rasterization_bwd(means, quats, scales, opac, col, vm, K, res, res, m, v_rgba[..., :3], v_rgba[..., 3])
+    oracle.shade_bwd(means, scene.normals.numpy(), scene.kd.numpy(), scene.ks.numpy(), cam.c2w[:, 3].numpy(), lut, base,
+                     levels, gr["v_colors"])
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "views/s", "cores": cores, "kind": "port",
+            "sample": f"1 view fwd+bwd (shade+project+bin+sort+composite+tonemap and backward; prefilter excluded), "
+                      f"N={means.shape[0]}, {res}x{res}, oracle/libgs_oracle.so with OpenMP on {cores} host threads; {budget_note}",
+            "pairs_fwd": m["pairs"], "V": int(len(m["gaussian_ids"])), "I": int(len(m["flatten_ids"]))}
+
+
+def main():
+    args = parse()
+    import geosplatting_amd as gs
+    import geosplatting_amd.synthetic as syn
+    from geosplatting_amd.engine import RenderStep, params_from_scene
+    from geosplatting_amd.parallel import init_distributed_from_env
+    import torch.distributed as dist
+
+    rank, world, dev = init_distributed_from_env("cuda")
+    if world != args.gpus and rank == 0:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    torch.manual_seed(1)
+    scene = syn.sphere_scene(args.level, seed=1, cubemap_res=args.cubemap_res)
+    N = scene.splats.num
+    all_cams = syn.blender_cameras(num=args.views * world, width=args.res, height=args.res)
+    cams = [all_cams[i] for i in range(rank, args.views * world, world)]      # view i -> rank i mod world
+    params = params_from_scene(scene, dev)
+    step = RenderStep(params, prefilter=not args.no_prefilter)
+    g = torch.Generator().manual_seed(100 + rank)
+    ups = [(torch.rand(args.res, args.res, 4, generator=g) * 2 - 1).to(dev) for _ in range(len(cams))]
+
+    def one_step():
+        step(cams, lambda i, img: ups[i], all_reduce=(world > 1))
+
+    for _ in range(args.warmup):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    views_per_s = args.views * world * args.steps / dt
+
+    # ---------------- measurements for the roofline objects (rank 0, one representative view)
+    result = None
+    if rank == 0:
+        cam = cams[0]
+        with torch.no_grad():
+            env = step._static_env if args.no_prefilter else gs.as_splitsum(params.cubemap)
+            colors = gs.shade(params.means, params.normals, params.kd, params.ks, cam.c2w[:, 3].to(dev).contiguous(), env,
+                              min_roughness=0.1, max_metallic=1.0)
+            _, _, meta = gs.rasterization(params.means, params.quats, params.scales.exp(),
+                                          torch.sigmoid(params.opacities).squeeze(-1), colors,
+                                          cam.view_matrix.to(dev)[None], cam.intrinsic_matrix.to(dev)[None], args.res, args.res)
+        V, I = int(meta["radii"].shape[0]), int(meta["flatten_ids"].shape[0])
+        P = args.res * args.res
+        E = sum(6 * r * r * 3 * 4 for r in [l.shape[1] for l in env.levels]) + 6 * 16 * 16 * 3 * 4
+        st = dict(means2d=meta["means2d"], conics=meta["conics"], opacities=meta["opacities"],
+                  colors=colors[meta["gaussian_ids"]].contiguous(), offsets=meta["isect_offsets"].reshape(-1).contiguous(),
+                  flatten_ids=meta["flatten_ids"], V=V, I=I, res=args.res)
+        kt = time_dominant_kernels(st, args.kernel_iters)
+        dom = max(kt, key=kt.get)
+        # algorithmic bytes of the compositor launches:
+        #   fwd: ids 4 I + gathered geometry+colour 36 I + image write 20 P
+        #   bwd: ids 4 I + gathered geometry+colour 36 I + image read 24 P + per-visible grad write 36 V
+        kbytes = {"raster_fwd_kernel": 40 * I + 20 * P, "raster_bwd_kernel": 40 * I + 24 * P + 36 * V}
+        achieved = kbytes[dom] / (kt[dom] * 1e-3) / 1e9
+        view_bytes = algorithmic_bytes_per_view(N, V, I, P, E)
+        result = {
+            "metric": "fwd+bwd views/sec at 2M Gaussians, 800x800",
+            "value": views_per_s, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"surface splats (MGAdapter on icosphere level {args.level}) N={N}, {args.res}x{args.res}, "
+                                   f"split-sum GGX envmap {args.cubemap_res}^2, {args.views} views/step/GPU, "
+                                   f"prefilter fwd+bwd {'in' if not args.no_prefilter else 'EXCLUDED from'} every step",
+                       "N": N, "V": V, "I": I, "P": P, "views_per_step_per_gpu": args.views,
+                       "parallelism": f"dp{world} (views sharded, flat RCCL all-reduce of grads)"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": kt, "algorithmic_bytes": kbytes[dom],
+                         "note": "compositor kernels are FP32-VALU/exp bound (SURVEY 8d); HBM fraction reported as the contract asks"},
+            "view_roofline": {"algorithmic_bytes_per_view": view_bytes,
+                              "achieved_GBs": view_bytes * views_per_s / world / 1e9,
+                              "frac_of_8TBs": view_bytes * views_per_s / world / 1e9 / HBM_PEAK_GBS},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(scene, cam, args.res, "bounded to one view")
+            except Exception as e:       # the baseline must never take the bench line down
+                result["cpu_baseline"] = {"value": None, "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
+                                          "sample": f"failed: {e}"}
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

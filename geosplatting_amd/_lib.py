@@ -1,0 +1,91 @@
+"""ctypes binding of libgeosplat_hip.so (the C-ABI declared in include/geosplat_hip.h).
+
+There is NO fallback: if the HIP library is missing the import of any op raises.  PyTorch is only used for
+device memory (``tensor.data_ptr()``) and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgeosplat_hip.so")
+
+GS_MAX_LEVELS = 16
+
+
+class GsEnv(C.Structure):
+    _fields_ = [("lut", C.c_void_p), ("lut_res", C.c_int), ("base", C.c_void_p), ("base_res", C.c_int),
+                ("num_levels", C.c_int), ("levels", C.c_void_p * GS_MAX_LEVELS), ("res", C.c_int * GS_MAX_LEVELS),
+                ("min_roughness", C.c_float), ("max_roughness", C.c_float)]
+
+
+class GsEnvGrad(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("levels", C.c_void_p * GS_MAX_LEVELS)]
+
+
+# every symbol include/geosplat_hip.h declares (tests/test_abi.py checks the list against the header)
+SYMBOLS = [
+    "gs_last_error", "gs_version", "gs_project_ws_bytes", "gs_project_fwd", "gs_isect_emit", "gs_sort_ws_bytes",
+    "gs_isect_sort", "gs_isect_offsets", "gs_raster_fwd", "gs_raster_bwd", "gs_project_bwd", "gs_shade_fwd",
+    "gs_shade_bwd", "gs_tonemap_fwd", "gs_tonemap_bwd", "gs_cubemap_mip_fwd", "gs_cube_sample_linear",
+    "gs_cubemap_mip_bwd", "gs_diffuse_cubemap_fwd", "gs_diffuse_cubemap_bwd", "gs_specular_bounds",
+    "gs_specular_cubemap_fwd", "gs_specular_cubemap_bwd",
+]
+
+_lib: Optional[C.CDLL] = None
+
+
+class GeoSplatHipError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library; raises (never falls back) if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GeoSplatHipError(
+                f"{LIB_PATH} not found: build it with `python -m geosplatting_amd.build` "
+                "(hipcc --offload-arch=gfx950).  geosplatting_amd has no CPU / PyTorch fallback.")
+        l = C.CDLL(LIB_PATH)
+        l.gs_last_error.restype = C.c_char_p
+        l.gs_project_ws_bytes.restype = C.c_size_t
+        l.gs_project_ws_bytes.argtypes = [C.c_int]
+        l.gs_sort_ws_bytes.restype = C.c_size_t
+        l.gs_sort_ws_bytes.argtypes = [C.c_int64, C.c_int, C.c_int]
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise GeoSplatHipError(f"{what} failed ({rc}): {lib().gs_last_error().decode()}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[C.c_void_p]:
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensors only"
+    return C.c_void_p(t.data_ptr())
+
+
+def stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def f32(x: float) -> C.c_float:
+    return C.c_float(float(x))
+
+
+def i64(x: int) -> C.c_int64:
+    return C.c_int64(int(x))
+
+
+def require_cuda(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise GeoSplatHipError("geosplatting_amd ops run on the GPU only (tensor on %s); there is no CPU path" % t.device)

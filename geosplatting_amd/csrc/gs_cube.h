@@ -1,0 +1,164 @@
+// gs_cube.h -- seam-aware bilinear cube-map addressing shared by the shading (S3) and prefilter (S5) kernels.
+// Face order +x,-x,+y,-y,+z,-z with the (x,y) parameterisation of _cube_to_dir
+// (rfstudio/graphics/_mesh/_texture.py:178-197) == cube_to_dir (rfstudio/graphics/_mesh/_splitsum/c_src/cubemap.cu:32-46).
+// Texel semantics (edge wrap by re-projection, corner = mean of the other three) are documented in
+// oracle/gs_oracle_shade.c.
+#pragma once
+#include "gs_common.h"
+
+struct FaceMap { int a, b, c; float sx, sy; };
+static __device__ __constant__ FaceMap c_faces[6] = {
+    { 2, 1, 0, -1.0f, -1.0f }, { 2, 1, 0, 1.0f, -1.0f }, { 0, 2, 1, 1.0f, 1.0f },
+    { 0, 2, 1, 1.0f, -1.0f },  { 0, 1, 2, 1.0f, -1.0f }, { 0, 1, 2, -1.0f, -1.0f },
+};
+
+__device__ __forceinline__ int select_face(const float* d)
+{
+    const float ax = fabsf(d[0]), ay = fabsf(d[1]), az = fabsf(d[2]);
+    int f; float c;
+    if (az > fmaxf(ax, ay)) { f = 4; c = d[2]; }
+    else if (ay > ax)       { f = 2; c = d[1]; }
+    else                    { f = 0; c = d[0]; }
+    return f + (c < 0.0f ? 1 : 0);
+}
+
+__device__ __forceinline__ void face_point(int s, float x, float y, float* p)
+{
+    switch (s) {
+    case 0: p[0] = 1.0f;  p[1] = -y;    p[2] = -x;    break;
+    case 1: p[0] = -1.0f; p[1] = -y;    p[2] = x;     break;
+    case 2: p[0] = x;     p[1] = 1.0f;  p[2] = y;     break;
+    case 3: p[0] = x;     p[1] = -1.0f; p[2] = -y;    break;
+    case 4: p[0] = x;     p[1] = -y;    p[2] = 1.0f;  break;
+    default: p[0] = -x;   p[1] = -y;    p[2] = -1.0f; break;
+    }
+}
+
+__device__ __forceinline__ float comp3(const float* d, int i) { return i == 0 ? d[0] : (i == 1 ? d[1] : d[2]); }
+
+__device__ int resolve_texel(int s, int ix, int iy, int R)
+{
+    const bool ox = (ix < 0 || ix >= R), oy = (iy < 0 || iy >= R);
+    if (!ox && !oy) return (s * R + iy) * R + ix;
+    if (ox && oy) return -1;
+    const float xn = 2.0f * (((float)ix + 0.5f) / (float)R) - 1.0f;
+    const float yn = 2.0f * (((float)iy + 0.5f) / (float)R) - 1.0f;
+    float p[3];
+    face_point(s, xn, yn, p);
+    const int s2 = select_face(p);
+    const FaceMap m = c_faces[s2];
+    const float inv = 1.0f / fabsf(comp3(p, m.c));
+    const float x2 = m.sx * comp3(p, m.a) * inv, y2 = m.sy * comp3(p, m.b) * inv;
+    const float tx = (x2 + 1.0f) * 0.5f * (float)R - 0.5f, ty = (y2 + 1.0f) * 0.5f * (float)R - 0.5f;
+    int jx = (int)floorf(tx + 0.5f), jy = (int)floorf(ty + 0.5f);
+    jx = min(max(jx, 0), R - 1); jy = min(max(jy, 0), R - 1);
+    return (s2 * R + jy) * R + jx;
+}
+
+struct CubeFp {
+    bool valid;
+    int idx[4];
+    float w[4];
+    float fx, fy;
+    int face;
+    float inv_c, xn, yn;
+};
+
+__device__ void cube_footprint(const float* d, int R, CubeFp& fp)
+{
+    const int s = select_face(d);
+    const FaceMap m = c_faces[s];
+    const float ac = fabsf(comp3(d, m.c));
+    fp.valid = (ac > 0.0f) && isfinite(ac);
+    fp.face = s;
+    if (!fp.valid) return;
+    const float inv = 1.0f / ac;
+    const float xn = m.sx * comp3(d, m.a) * inv, yn = m.sy * comp3(d, m.b) * inv;
+    fp.inv_c = inv; fp.xn = xn; fp.yn = yn;
+    const float tx = (xn + 1.0f) * 0.5f * (float)R - 0.5f, ty = (yn + 1.0f) * 0.5f * (float)R - 0.5f;
+    const int ix0 = (int)floorf(tx), iy0 = (int)floorf(ty);
+    const float fx = tx - (float)ix0, fy = ty - (float)iy0;
+    fp.fx = fx; fp.fy = fy;
+    if (ix0 >= 0 && iy0 >= 0 && ix0 + 1 < R && iy0 + 1 < R) {       // interior fast path
+        const int b = (s * R + iy0) * R + ix0;
+        fp.idx[0] = b; fp.idx[1] = b + 1; fp.idx[2] = b + R; fp.idx[3] = b + R + 1;
+    } else {
+        fp.idx[0] = resolve_texel(s, ix0, iy0, R);
+        fp.idx[1] = resolve_texel(s, ix0 + 1, iy0, R);
+        fp.idx[2] = resolve_texel(s, ix0, iy0 + 1, R);
+        fp.idx[3] = resolve_texel(s, ix0 + 1, iy0 + 1, R);
+    }
+    float w[4] = { (1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy };
+    int miss = -1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (fp.idx[i] < 0) miss = i;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fp.w[i] = w[i];
+    if (miss >= 0) {
+        float wm = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (i == miss) wm = w[i] / 3.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fp.w[i] = (i == miss) ? 0.0f : w[i] + wm;
+    }
+}
+
+// bilinear cube fetch (3 channels); WITH_GRAD also returns d out / d dir (dd[c*3+k])
+template <bool WITH_GRAD>
+__device__ void cube_fetch(const float* __restrict__ tex, int R, const float* d, float* out, float* dd, CubeFp& fp)
+{
+    cube_footprint(d, R, fp);
+    if (!fp.valid) {
+        out[0] = out[1] = out[2] = 0.0f;
+        if (WITH_GRAD) { for (int i = 0; i < 9; ++i) dd[i] = 0.0f; }
+        return;
+    }
+    float t[4][3];
+    bool has_miss = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (fp.idx[i] < 0) { has_miss = true; t[i][0] = t[i][1] = t[i][2] = 0.0f; continue; }
+        const float* p = tex + (size_t)fp.idx[i] * 3;
+        t[i][0] = p[0]; t[i][1] = p[1]; t[i][2] = p[2];
+    }
+    if (has_miss) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float s = (t[0][c] + t[1][c] + t[2][c] + t[3][c]) / 3.0f;   // the missing one holds 0
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (fp.idx[i] < 0) t[i][c] = s;
+        }
+    }
+    const FaceMap m = c_faces[fp.face];
+    const float sgn_c = comp3(d, m.c) < 0.0f ? -1.0f : 1.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float top = t[0][c] + fp.fx * (t[1][c] - t[0][c]);
+        const float bot = t[2][c] + fp.fx * (t[3][c] - t[2][c]);
+        out[c] = top + fp.fy * (bot - top);
+        if (WITH_GRAD) {
+            const float dtx = (t[1][c] - t[0][c]) + fp.fy * ((t[3][c] - t[2][c]) - (t[1][c] - t[0][c]));
+            const float dty = bot - top;
+            const float gx = dtx * 0.5f * (float)R, gy = dty * 0.5f * (float)R;
+            float g[3] = { 0.0f, 0.0f, 0.0f };
+            const float va = gx * m.sx * fp.inv_c, vb = gy * m.sy * fp.inv_c;
+            const float vc = -(gx * fp.xn + gy * fp.yn) * fp.inv_c * sgn_c;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) g[k] = (k == m.a ? va : 0.0f) + (k == m.b ? vb : 0.0f) + (k == m.c ? vc : 0.0f);
+            dd[c * 3 + 0] = g[0]; dd[c * 3 + 1] = g[1]; dd[c * 3 + 2] = g[2];
+        }
+    }
+}
+
+__device__ __forceinline__ void cube_scatter(float* __restrict__ grad_tex, const CubeFp& fp, const float* g, float scale)
+{
+    if (!fp.valid) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (fp.idx[i] < 0) continue;
+        const float w = scale * fp.w[i];
+        float* p = grad_tex + (size_t)fp.idx[i] * 3;
+        gs_atomic_add(p, g[0] * w); gs_atomic_add(p + 1, g[1] * w); gs_atomic_add(p + 2, g[2] * w);
+    }
+}
+

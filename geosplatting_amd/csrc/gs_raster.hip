@@ -1,0 +1,340 @@
+// gs_raster.hip -- A5 / A6: front-to-back alpha compositing of per-tile depth-sorted Gaussian lists and
+// its stored-state backward (gsplat 1.4 `rasterize_to_pixels` fwd/bwd as reached from
+// rfstudio/model/gsplat.py:334-355; constants and loop semantics in SURVEY.md section 8a rows A5/A6).
+//
+// CDNA4 mapping (not the upstream 256-thread-block / shared-memory-batch design):
+//   * a 16x16 tile is split into four 8x8 QUADRANTS, one wave64 each; a wave never synchronises with the
+//     other three -- no LDS staging, no __syncthreads, each wave stops as soon as ITS 64 pixels are opaque;
+//   * the tile's sorted list is walked 64 entries at a time: lane l fetches entry l (coalesced index read,
+//     gathered 24-byte geometry), tests the Gaussian's alpha>=1/255 extent against the quadrant rectangle,
+//     and a 64-bit ballot compacts the survivors;
+//   * survivors are broadcast lane->SGPR with v_readlane (no LDS round trip) and evaluated by all 64
+//     pixel lanes.  Surface-aligned splats are ~2-6 px wide, so the ballot removes most of the
+//     (pixel, Gaussian) pairs a 256-pixel block would evaluate; it is exact because a culled Gaussian
+//     has alpha < 1/255 at every pixel centre of the quadrant and would have been skipped anyway.
+//   * backward: same walk back-to-front from the wave's max(last_ids); per-Gaussian partials are summed
+//     across the wave with DPP row operations and ONE lane issues the fp32 atomics.
+// Both kernels are FP32-VALU / transcendental bound (one v_exp_f32 per evaluated pair), not HBM bound.
+#include "gs_common.h"
+
+#pragma clang fp contract(off)   // sigma / compositing are spelled with explicit fmaf (bit-exact vs oracle)
+
+#define GS_TILE 16
+#define GS_ALPHA_MIN (1.0f / 255.0f)
+
+// extent of {alpha >= 1/255} for a Gaussian, conservatively inflated; returns false if it can never reach
+__device__ __forceinline__ bool alpha_extent(float ca, float cb, float cc, float o, float& hx, float& hy)
+{
+    const float tau = __logf(255.0f * o);
+    const float det = ca * cc - cb * cb;
+    if (!(tau > -0.002f)) return false;              // o*255 < ~1: never visible (also rejects NaN)
+    if (!(det > 0.0f)) { hx = hy = 1e30f; return true; }
+    const float k = 2.0f * (tau + 0.002f) / det;
+    hx = sqrtf(k * cc) * 1.0005f + 0.02f;
+    hy = sqrtf(k * ca) * 1.0005f + 0.02f;
+    return true;
+}
+
+template <int CD>
+__global__ void __launch_bounds__(256)
+raster_fwd_kernel(int W, int H, int tile_w, int n_tiles, int D,
+                  const float* __restrict__ means2d, const float* __restrict__ conics,
+                  const float* __restrict__ opacities, const float* __restrict__ colors,
+                  const float* __restrict__ background, int n_isects,
+                  const int32_t* __restrict__ offsets, const int32_t* __restrict__ flatten_ids,
+                  float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids)
+{
+    const int tile = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tx = tile % tile_w, ty = tile / tile_w;
+    const int qx0 = tx * GS_TILE + (wave & 1) * 8, qy0 = ty * GS_TILE + (wave >> 1) * 8;
+    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
+    const bool inside = pxi < W && pyi < H;
+    const float px = (float)pxi + 0.5f, py = (float)pyi + 0.5f;
+    const float rx0 = (float)qx0 + 0.5f, rx1 = (float)qx0 + 7.5f;
+    const float ry0 = (float)qy0 + 0.5f, ry1 = (float)qy0 + 7.5f;
+
+    const int start = offsets[tile];
+    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+
+    float T = 1.0f;
+    int cur_idx = 0;
+    bool done = !inside;
+    float pix[CD];
+#pragma unroll
+    for (int k = 0; k < CD; ++k) pix[k] = 0.0f;
+
+    for (int base = start; base < end; base += 64) {
+        if (__ballot(!done) == 0ull) break;
+        const int idx = base + lane;
+        bool hit = false;
+        int g = 0;
+        float mx = 0.f, my = 0.f, ha = 0.f, cb = 0.f, hc = 0.f, op = 0.f;
+        if (idx < end) {
+            g = flatten_ids[idx];
+            const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)g);
+            const float ca = conics[3 * (size_t)g], cc = conics[3 * (size_t)g + 2];
+            cb = conics[3 * (size_t)g + 1];
+            op = opacities[g];
+            mx = m.x; my = m.y;
+            float hx, hy;
+            if (alpha_extent(ca, cb, cc, op, hx, hy))
+                hit = (mx + hx >= rx0) && (mx - hx <= rx1) && (my + hy >= ry0) && (my - hy <= ry1);
+            ha = 0.5f * ca; hc = 0.5f * cc;
+        }
+        unsigned long long mask = __ballot(hit);
+        if (mask == 0ull) continue;
+        float col[CD];
+#pragma unroll
+        for (int k = 0; k < CD; ++k) col[k] = (hit && k < D) ? colors[(size_t)g * D + k] : 0.0f;
+
+        while (mask) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            const float gx = gs_readlane(mx, j), gy = gs_readlane(my, j);
+            const float ga = gs_readlane(ha, j), gb = gs_readlane(cb, j), gc = gs_readlane(hc, j);
+            const float go = gs_readlane(op, j);
+            const float dx = gx - px, dy = gy - py;
+            const float t0 = ga * dx, t1 = gc * dy, t2 = gb * dx;
+            const float sigma = fmaf(t0, dx, fmaf(t1, dy, t2 * dy));
+            const float alpha = fminf(0.999f, go * __expf(-sigma));
+            const bool ok = !done && sigma >= 0.0f && alpha >= GS_ALPHA_MIN;
+            const float next_T = T * (1.0f - alpha);
+            const bool stop = ok && next_T <= 1e-4f;
+            const bool acc = ok && !stop;
+            done = done || stop;
+            if (__ballot(acc) != 0ull) {
+                const float vis = acc ? alpha * T : 0.0f;
+#pragma unroll
+                for (int k = 0; k < CD; ++k) pix[k] = fmaf(gs_readlane(col[k], j), vis, pix[k]);
+                if (acc) { T = next_T; cur_idx = base + j; }
+            }
+        }
+    }
+
+    if (inside) {
+        const size_t pid = (size_t)pyi * W + pxi;
+        alphas[pid] = 1.0f - T;
+        last_ids[pid] = cur_idx;
+#pragma unroll
+        for (int k = 0; k < CD; ++k)
+            if (k < D) render[pid * D + k] = background ? fmaf(T, background[k], pix[k]) : pix[k];
+    }
+}
+
+template <int CD>
+__global__ void __launch_bounds__(256)
+raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D,
+                  const float* __restrict__ means2d, const float* __restrict__ conics,
+                  const float* __restrict__ opacities, const float* __restrict__ colors,
+                  const float* __restrict__ background, int n_isects,
+                  const int32_t* __restrict__ offsets, const int32_t* __restrict__ flatten_ids,
+                  const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
+                  const float* __restrict__ v_render, const float* __restrict__ v_alphas,
+                  float* __restrict__ v_means2d, float* __restrict__ v_conics, float* __restrict__ v_colors,
+                  float* __restrict__ v_opacities)
+{
+    const int tile = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tx = tile % tile_w, ty = tile / tile_w;
+    const int qx0 = tx * GS_TILE + (wave & 1) * 8, qy0 = ty * GS_TILE + (wave >> 1) * 8;
+    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
+    const bool inside = pxi < W && pyi < H;
+    const float px = (float)pxi + 0.5f, py = (float)pyi + 0.5f;
+    const float rx0 = (float)qx0 + 0.5f, rx1 = (float)qx0 + 7.5f;
+    const float ry0 = (float)qy0 + 0.5f, ry1 = (float)qy0 + 7.5f;
+
+    const int start = offsets[tile];
+    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    if (end <= start) return;
+
+    float T_final = 1.0f, v_a = 0.0f;
+    int bin_final = -1;
+    float v_rc[CD], buffer[CD];
+#pragma unroll
+    for (int k = 0; k < CD; ++k) { v_rc[k] = 0.0f; buffer[k] = 0.0f; }
+    if (inside) {
+        const size_t pid = (size_t)pyi * W + pxi;
+        T_final = 1.0f - alphas[pid];
+        bin_final = last_ids[pid];
+        v_a = v_alphas[pid];
+#pragma unroll
+        for (int k = 0; k < CD; ++k) if (k < D) v_rc[k] = v_render[pid * D + k];
+    }
+    float bg_dot = 0.0f;
+    if (background) {
+#pragma unroll
+        for (int k = 0; k < CD; ++k) if (k < D) bg_dot += background[k] * v_rc[k];
+    }
+    float T = T_final;
+
+    int top = bin_final;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) top = max(top, __shfl_xor(top, off, 64));
+    if (top >= end) top = end - 1;
+
+    for (; top >= start; top -= 64) {
+        const int idx = top - lane;
+        bool hit = false;
+        int g = 0;
+        float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, op = 0.f;
+        if (idx >= start) {
+            g = flatten_ids[idx];
+            const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)g);
+            ca = conics[3 * (size_t)g]; cb = conics[3 * (size_t)g + 1]; cc = conics[3 * (size_t)g + 2];
+            op = opacities[g];
+            mx = m.x; my = m.y;
+            float hx, hy;
+            if (alpha_extent(ca, cb, cc, op, hx, hy))
+                hit = (mx + hx >= rx0) && (mx - hx <= rx1) && (my + hy >= ry0) && (my - hy <= ry1);
+        }
+        unsigned long long mask = __ballot(hit);
+        if (mask == 0ull) continue;
+        float col[CD];
+#pragma unroll
+        for (int k = 0; k < CD; ++k) col[k] = (hit && k < D) ? colors[(size_t)g * D + k] : 0.0f;
+
+        while (mask) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            const int idxj = top - j;
+            const float gx = gs_readlane(mx, j), gy = gs_readlane(my, j);
+            const float ga = gs_readlane(ca, j), gb = gs_readlane(cb, j), gc = gs_readlane(cc, j);
+            const float go = gs_readlane(op, j);
+            const float dx = gx - px, dy = gy - py;
+            const float t0 = (0.5f * ga) * dx, t1 = (0.5f * gc) * dy, t2 = gb * dx;
+            const float sigma = fmaf(t0, dx, fmaf(t1, dy, t2 * dy));
+            const float vis = __expf(-sigma);
+            const float alpha = fminf(0.999f, go * vis);
+            const bool valid = (idxj <= bin_final) && sigma >= 0.0f && alpha >= GS_ALPHA_MIN;
+            if (__ballot(valid) == 0ull) continue;
+
+            float gcol[CD];
+#pragma unroll
+            for (int k = 0; k < CD; ++k) gcol[k] = gs_readlane(col[k], j);
+
+            float p_xy0 = 0.f, p_xy1 = 0.f, p_c0 = 0.f, p_c1 = 0.f, p_c2 = 0.f, p_o = 0.f;
+            float p_col[CD];
+#pragma unroll
+            for (int k = 0; k < CD; ++k) p_col[k] = 0.0f;
+            if (valid) {
+                const float ra = 1.0f / (1.0f - alpha);
+                T *= ra;
+                const float fac = alpha * T;
+                float v_alpha = 0.0f;
+#pragma unroll
+                for (int k = 0; k < CD; ++k) {
+                    p_col[k] = fac * v_rc[k];
+                    v_alpha += (gcol[k] * T - buffer[k] * ra) * v_rc[k];
+                }
+                v_alpha += T_final * ra * v_a;
+                if (background) v_alpha += -T_final * ra * bg_dot;
+                if (go * vis <= 0.999f) {
+                    const float v_sigma = -go * vis * v_alpha;
+                    p_c0 = 0.5f * v_sigma * dx * dx;
+                    p_c1 = v_sigma * dx * dy;
+                    p_c2 = 0.5f * v_sigma * dy * dy;
+                    p_xy0 = v_sigma * (ga * dx + gb * dy);
+                    p_xy1 = v_sigma * (gb * dx + gc * dy);
+                    p_o = vis * v_alpha;
+                }
+#pragma unroll
+                for (int k = 0; k < CD; ++k) buffer[k] += gcol[k] * fac;
+            }
+            // wave reduction, one lane commits
+            p_xy0 = gs_wave_sum(p_xy0); p_xy1 = gs_wave_sum(p_xy1);
+            p_c0 = gs_wave_sum(p_c0); p_c1 = gs_wave_sum(p_c1); p_c2 = gs_wave_sum(p_c2);
+            p_o = gs_wave_sum(p_o);
+#pragma unroll
+            for (int k = 0; k < CD; ++k) p_col[k] = gs_wave_sum(p_col[k]);
+            const int gj = gs_readlane(g, j);
+            if (lane == 0) {
+                gs_atomic_add(v_means2d + 2 * (size_t)gj, p_xy0);
+                gs_atomic_add(v_means2d + 2 * (size_t)gj + 1, p_xy1);
+                gs_atomic_add(v_conics + 3 * (size_t)gj, p_c0);
+                gs_atomic_add(v_conics + 3 * (size_t)gj + 1, p_c1);
+                gs_atomic_add(v_conics + 3 * (size_t)gj + 2, p_c2);
+                gs_atomic_add(v_opacities + gj, p_o);
+#pragma unroll
+                for (int k = 0; k < CD; ++k)
+                    if (k < D) gs_atomic_add(v_colors + (size_t)gj * D + k, p_col[k]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <int CD>
+static int launch_fwd(int W, int H, int D, const float* means2d, const float* conics, const float* opacities,
+                      const float* colors, const float* background, int64_t n_isects, const int32_t* offsets,
+                      const int32_t* flatten_ids, float* render, float* alphas, int32_t* last_ids, hipStream_t s)
+{
+    const int tile_w = (W + GS_TILE - 1) / GS_TILE, tile_h = (H + GS_TILE - 1) / GS_TILE;
+    hipLaunchKernelGGL(raster_fwd_kernel<CD>, dim3(tile_w * tile_h), dim3(256), 0, s, W, H, tile_w, tile_w * tile_h, D,
+                       means2d, conics, opacities, colors, background, (int)n_isects, offsets, flatten_ids, render,
+                       alphas, last_ids);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
+extern "C" int gs_raster_fwd(int W, int H, int tile_size, int D, const float* means2d, const float* conics,
+                             const float* opacities, const float* colors, const float* background,
+                             int64_t n_isects, const int32_t* offsets, const int32_t* flatten_ids,
+                             float* render, float* alphas, int32_t* last_ids, void* stream)
+{
+    GS_CHECK_ARG(W > 0 && H > 0, "bad image size");
+    GS_CHECK_ARG(tile_size == GS_TILE, "only tile_size=16 is built (rfstudio/model/gsplat.py:30)");
+    GS_CHECK_ARG(D >= 1 && D <= GS_MAX_CHANNELS, "1 <= D <= 32");
+    GS_CHECK_ARG(n_isects >= 0 && n_isects < (1ll << 31), "n_isects must fit int32");
+    hipStream_t s = (hipStream_t)stream;
+#define GS_FWD(CD) return launch_fwd<CD>(W, H, D, means2d, conics, opacities, colors, background, n_isects, offsets, flatten_ids, render, alphas, last_ids, s)
+    if (D <= 3) GS_FWD(3);
+    if (D <= 4) GS_FWD(4);
+    if (D <= 8) GS_FWD(8);
+    if (D <= 16) GS_FWD(16);
+    GS_FWD(32);
+#undef GS_FWD
+}
+
+template <int CD>
+static int launch_bwd(int W, int H, int D, const float* means2d, const float* conics, const float* opacities,
+                      const float* colors, const float* background, int64_t n_isects, const int32_t* offsets,
+                      const int32_t* flatten_ids, const float* alphas, const int32_t* last_ids, const float* v_render,
+                      const float* v_alphas, float* v_means2d, float* v_conics, float* v_colors, float* v_opacities,
+                      hipStream_t s)
+{
+    const int tile_w = (W + GS_TILE - 1) / GS_TILE, tile_h = (H + GS_TILE - 1) / GS_TILE;
+    hipLaunchKernelGGL(raster_bwd_kernel<CD>, dim3(tile_w * tile_h), dim3(256), 0, s, W, H, tile_w, tile_w * tile_h, D,
+                       means2d, conics, opacities, colors, background, (int)n_isects, offsets, flatten_ids, alphas,
+                       last_ids, v_render, v_alphas, v_means2d, v_conics, v_colors, v_opacities);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
+extern "C" int gs_raster_bwd(int W, int H, int tile_size, int D, int V, const float* means2d, const float* conics,
+                             const float* opacities, const float* colors, const float* background,
+                             int64_t n_isects, const int32_t* offsets, const int32_t* flatten_ids,
+                             const float* alphas, const int32_t* last_ids, const float* v_render,
+                             const float* v_alphas, float* v_means2d, float* v_conics, float* v_colors,
+                             float* v_opacities, void* stream)
+{
+    GS_CHECK_ARG(W > 0 && H > 0 && V >= 0, "bad sizes");
+    GS_CHECK_ARG(tile_size == GS_TILE, "only tile_size=16 is built (rfstudio/model/gsplat.py:30)");
+    GS_CHECK_ARG(D >= 1 && D <= GS_MAX_CHANNELS, "1 <= D <= 32");
+    GS_CHECK_ARG(n_isects >= 0 && n_isects < (1ll << 31), "n_isects must fit int32");
+    hipStream_t s = (hipStream_t)stream;
+    if (V > 0) {
+        GS_CHECK_HIP(hipMemsetAsync(v_means2d, 0, sizeof(float) * 2 * (size_t)V, s));
+        GS_CHECK_HIP(hipMemsetAsync(v_conics, 0, sizeof(float) * 3 * (size_t)V, s));
+        GS_CHECK_HIP(hipMemsetAsync(v_colors, 0, sizeof(float) * (size_t)D * (size_t)V, s));
+        GS_CHECK_HIP(hipMemsetAsync(v_opacities, 0, sizeof(float) * (size_t)V, s));
+    }
+    if (n_isects == 0 || V == 0) return GS_OK;
+#define GS_BWD(CD) return launch_bwd<CD>(W, H, D, means2d, conics, opacities, colors, background, n_isects, offsets, flatten_ids, alphas, last_ids, v_render, v_alphas, v_means2d, v_conics, v_colors, v_opacities, s)
+    if (D <= 3) GS_BWD(3);
+    if (D <= 4) GS_BWD(4);
+    if (D <= 8) GS_BWD(8);
+    if (D <= 16) GS_BWD(16);
+    GS_BWD(32);
+#undef GS_BWD
+}

@@ -1,0 +1,386 @@
+// gs_shade.hip -- S1..S4: per-Gaussian split-sum PBR shading (forward + recompute-backward) and tone mapping.
+//   S1 RenderableAttrs.splat arithmetic         rfstudio/model/geosplat.py:80-122
+//   S2 FG-LUT bilinear/clamp lookup             rfstudio/model/geosplat.py:93-98 (nvdiffrast dr.texture 2-D)
+//   S3 TextureSplitSum.sample                   rfstudio/graphics/_mesh/_texture.py:571-613
+//      (cube 'linear' on base; cube 'linear-mipmap-linear' on the specular pyramid, level = f(roughness))
+//   S4 _tone_mapping_naive/_aces                rfstudio/model/geosplat.py:474-480
+//
+// The reference runs ~25 elementwise launches plus three texture launches per view and lets autograd
+// keep ~20 N-sized temporaries; here it is ONE streaming kernel per direction: 44 B/Gaussian in
+// (means, normals, kd, ks), 12 B out, texture taps served by L2 / Infinity Cache (the whole pyramid is
+// ~25 MB).  The backward recomputes the forward (no saved state) and scatters texel gradients with fp32
+// atomics.  HBM-bound by design; cube-map texel semantics are documented in oracle/gs_oracle_shade.c.
+#include "gs_common.h"
+#include "gs_cube.h"
+
+struct EnvDev {
+    const float* lut; int lut_res;
+    const float* base; int base_res;
+    int L;
+    const float* levels[GS_MAX_LEVELS];
+    int res[GS_MAX_LEVELS];
+    float min_r, max_r;
+};
+struct EnvGradDev {
+    float* base;
+    float* levels[GS_MAX_LEVELS];
+};
+
+__device__ __forceinline__ void tex2d_linear_clamp2(const float* __restrict__ lut, int W, int H, float u, float v,
+                                                    float* out, float* d_du, float* d_dv)
+{
+    float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    bool cx = false, cy = false;
+    if (x < 0.0f) { x = 0.0f; cx = true; } else if (x > (float)(W - 1)) { x = (float)(W - 1); cx = true; }
+    if (y < 0.0f) { y = 0.0f; cy = true; } else if (y > (float)(H - 1)) { y = (float)(H - 1); cy = true; }
+    const int ix0 = (int)floorf(x), iy0 = (int)floorf(y);
+    const float fx = x - (float)ix0, fy = y - (float)iy0;
+    const int ix1 = min(ix0 + 1, W - 1), iy1 = min(iy0 + 1, H - 1);
+    const float2 t00 = *reinterpret_cast<const float2*>(lut + ((size_t)iy0 * W + ix0) * 2);
+    const float2 t10 = *reinterpret_cast<const float2*>(lut + ((size_t)iy0 * W + ix1) * 2);
+    const float2 t01 = *reinterpret_cast<const float2*>(lut + ((size_t)iy1 * W + ix0) * 2);
+    const float2 t11 = *reinterpret_cast<const float2*>(lut + ((size_t)iy1 * W + ix1) * 2);
+    const float a00[2] = { t00.x, t00.y }, a10[2] = { t10.x, t10.y }, a01[2] = { t01.x, t01.y }, a11[2] = { t11.x, t11.y };
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float top = a00[c] + fx * (a10[c] - a00[c]);
+        const float bot = a01[c] + fx * (a11[c] - a01[c]);
+        out[c] = top + fy * (bot - top);
+        d_du[c] = cx ? 0.0f : (float)W * ((a10[c] - a00[c]) + fy * ((a11[c] - a01[c]) - (a10[c] - a00[c])));
+        d_dv[c] = cy ? 0.0f : (float)H * (bot - top);
+    }
+}
+
+__device__ __forceinline__ float mip_from_roughness(float r, float min_r, float max_r, int L, float& dm)
+{
+    float m;
+    if (r < max_r) {
+        float t = (r - min_r) / (max_r - min_r);
+        const bool in = (t >= 0.0f && t <= 1.0f);
+        t = fminf(fmaxf(t, 0.0f), 1.0f);
+        m = t * (float)(L - 2);
+        dm = in ? (float)(L - 2) / (max_r - min_r) : 0.0f;
+    } else {
+        float t = (r - max_r) / (1.0f - max_r);
+        const bool in = (t >= 0.0f && t <= 1.0f);
+        t = fminf(fmaxf(t, 0.0f), 1.0f);
+        m = t + (float)(L - 2);
+        dm = in ? 1.0f / (1.0f - max_r) : 0.0f;
+    }
+    return m;
+}
+
+struct MipSample {
+    float out[3], dd[9], dmip[3];
+    CubeFp fp0, fp1;
+    float f;
+    int l0, l1;
+};
+
+template <bool WITH_GRAD>
+__device__ void cube_mip_fetch(const EnvDev& env, const float* d, float bias, MipSample& s)
+{
+    const int L = env.L;
+    const float lam = fminf(fmaxf(bias, 0.0f), (float)(L - 1));
+    const int l0 = (int)floorf(lam);
+    if (l0 >= L - 1) {
+        s.l0 = L - 1; s.l1 = -1; s.f = 0.0f;
+        cube_fetch<WITH_GRAD>(env.levels[L - 1], env.res[L - 1], d, s.out, s.dd, s.fp0);
+        s.dmip[0] = s.dmip[1] = s.dmip[2] = 0.0f;
+        return;
+    }
+    const float f = lam - (float)l0;
+    float c0[3], c1[3], dd0[9], dd1[9];
+    cube_fetch<WITH_GRAD>(env.levels[l0], env.res[l0], d, c0, dd0, s.fp0);
+    cube_fetch<WITH_GRAD>(env.levels[l0 + 1], env.res[l0 + 1], d, c1, dd1, s.fp1);
+    s.l0 = l0; s.l1 = l0 + 1; s.f = f;
+    const bool clamped = (bias < 0.0f || bias > (float)(L - 1));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        s.out[c] = c0[c] + f * (c1[c] - c0[c]);
+        s.dmip[c] = clamped ? 0.0f : (c1[c] - c0[c]);
+        if (WITH_GRAD) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s.dd[c * 3 + k] = dd0[c * 3 + k] + f * (dd1[c * 3 + k] - dd0[c * 3 + k]);
+        }
+    }
+}
+
+struct ShadeTmp {
+    float rough, metal, spec[3], diff[3];
+    float wo[3], len; bool wo_const;
+    float d, ndv, fg[2], dfg_du[2], dfg_dv[2];
+    float refl[3], mip, dmip_dr;
+    MipSample ls;
+    float ld[3], ld_dd[9]; CubeFp ld_fp;
+    float refl_c[3];
+};
+
+template <bool WITH_GRAD>
+__device__ void shade_one(const float* mean, const float* normal, const float* kd, const float* ks, const float* cam_pos,
+                          float min_roughness, float max_metallic, int mode, const EnvDev& env, float* color, ShadeTmp& t)
+{
+    t.rough = ks[0] * (1.0f - min_roughness) + min_roughness;
+    t.metal = ks[1] * max_metallic;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        t.spec[c] = (1.0f - t.metal) * 0.04f + kd[c] * t.metal;
+        t.diff[c] = kd[c] * (1.0f - t.metal);
+    }
+    const float v[3] = { cam_pos[0] - mean[0], cam_pos[1] - mean[1], cam_pos[2] - mean[2] };
+    const float len = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    t.len = len;
+    if (len < 1e-6f) { t.wo[0] = 0.0f; t.wo[1] = 0.0f; t.wo[2] = 1.0f; t.wo_const = true; }
+    else { const float l = fmaxf(len, 1e-6f); t.wo[0] = v[0] / l; t.wo[1] = v[1] / l; t.wo[2] = v[2] / l; t.wo_const = false; }
+    t.d = normal[0] * t.wo[0] + normal[1] * t.wo[1] + normal[2] * t.wo[2];
+    t.ndv = fmaxf(t.d, 1e-6f);
+    tex2d_linear_clamp2(env.lut, env.lut_res, env.lut_res, t.ndv, t.rough, t.fg, t.dfg_du, t.dfg_dv);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t.refl[k] = 2.0f * t.d * normal[k] - t.wo[k];
+    t.mip = mip_from_roughness(t.rough, env.min_r, env.max_r, env.L, t.dmip_dr);
+    if (mode != GS_MODE_DIFFUSE) cube_mip_fetch<WITH_GRAD>(env, t.refl, t.mip, t.ls);
+    else { t.ls.out[0] = t.ls.out[1] = t.ls.out[2] = 0.0f; }
+    if (mode == GS_MODE_DIFFUSE) cube_fetch<WITH_GRAD>(env.base, env.base_res, normal, t.ld, t.ld_dd, t.ld_fp);
+    else { t.ld[0] = t.ld[1] = t.ld[2] = 0.0f; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        t.refl_c[c] = t.spec[c] * t.fg[0] + t.fg[1];
+        if (mode == GS_MODE_PBR)          color[c] = t.diff[c] + t.ls.out[c] * t.refl_c[c];
+        else if (mode == GS_MODE_DIFFUSE) color[c] = t.ld[c] * t.diff[c];
+        else                              color[c] = t.ls.out[c] * t.refl_c[c];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+shade_fwd_kernel(int N, const float* __restrict__ means, const float* __restrict__ normals,
+                 const float* __restrict__ kd, const float* __restrict__ ks, const float* __restrict__ cam_pos,
+                 float min_roughness, float max_metallic, int mode, EnvDev env, float* __restrict__ colors)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float mean[3] = { means[3 * (size_t)n], means[3 * (size_t)n + 1], means[3 * (size_t)n + 2] };
+    const float nrm[3] = { normals[3 * (size_t)n], normals[3 * (size_t)n + 1], normals[3 * (size_t)n + 2] };
+    const float kdn[3] = { kd[3 * (size_t)n], kd[3 * (size_t)n + 1], kd[3 * (size_t)n + 2] };
+    const float2 ks2 = *reinterpret_cast<const float2*>(ks + 2 * (size_t)n);
+    const float ksn[2] = { ks2.x, ks2.y };
+    const float cp[3] = { cam_pos[0], cam_pos[1], cam_pos[2] };
+    ShadeTmp t;
+    float color[3];
+    shade_one<false>(mean, nrm, kdn, ksn, cp, min_roughness, max_metallic, mode, env, color, t);
+    colors[3 * (size_t)n] = color[0]; colors[3 * (size_t)n + 1] = color[1]; colors[3 * (size_t)n + 2] = color[2];
+}
+
+__global__ void __launch_bounds__(256)
+shade_bwd_kernel(int N, const float* __restrict__ means, const float* __restrict__ normals,
+                 const float* __restrict__ kd, const float* __restrict__ ks, const float* __restrict__ cam_pos,
+                 float min_roughness, float max_metallic, int mode, EnvDev env, const float* __restrict__ v_colors,
+                 float* __restrict__ v_means, float* __restrict__ v_normals, float* __restrict__ v_kd,
+                 float* __restrict__ v_ks, EnvGradDev eg)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float mean[3] = { means[3 * (size_t)n], means[3 * (size_t)n + 1], means[3 * (size_t)n + 2] };
+    const float normal[3] = { normals[3 * (size_t)n], normals[3 * (size_t)n + 1], normals[3 * (size_t)n + 2] };
+    const float kdn[3] = { kd[3 * (size_t)n], kd[3 * (size_t)n + 1], kd[3 * (size_t)n + 2] };
+    const float2 ks2 = *reinterpret_cast<const float2*>(ks + 2 * (size_t)n);
+    const float ksn[2] = { ks2.x, ks2.y };
+    const float cp[3] = { cam_pos[0], cam_pos[1], cam_pos[2] };
+    const float g[3] = { v_colors[3 * (size_t)n], v_colors[3 * (size_t)n + 1], v_colors[3 * (size_t)n + 2] };
+    ShadeTmp t;
+    float color[3];
+    shade_one<true>(mean, normal, kdn, ksn, cp, min_roughness, max_metallic, mode, env, color, t);
+
+    float v_diff[3] = { 0, 0, 0 }, v_ls[3] = { 0, 0, 0 }, v_rf[3] = { 0, 0, 0 }, v_ld[3] = { 0, 0, 0 };
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (mode == GS_MODE_PBR)          { v_diff[c] = g[c]; v_ls[c] = g[c] * t.refl_c[c]; v_rf[c] = g[c] * t.ls.out[c]; }
+        else if (mode == GS_MODE_DIFFUSE) { v_ld[c] = g[c] * t.diff[c]; v_diff[c] = g[c] * t.ld[c]; }
+        else                              { v_ls[c] = g[c] * t.refl_c[c]; v_rf[c] = g[c] * t.ls.out[c]; }
+    }
+    float v_A = 0.0f, v_B = 0.0f, v_metal = 0.0f, o_kd[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v_spec = v_rf[c] * t.fg[0];
+        v_A += v_rf[c] * t.spec[c];
+        v_B += v_rf[c];
+        o_kd[c] = v_spec * t.metal + v_diff[c] * (1.0f - t.metal);
+        v_metal += v_spec * (kdn[c] - 0.04f) - v_diff[c] * kdn[c];
+    }
+    const float v_ndv = v_A * t.dfg_du[0] + v_B * t.dfg_du[1];
+    float v_rough = v_A * t.dfg_dv[0] + v_B * t.dfg_dv[1];
+    float v_mip = 0.0f, v_refl[3] = { 0, 0, 0 }, v_n[3] = { 0, 0, 0 };
+    if (mode != GS_MODE_DIFFUSE) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            v_mip += v_ls[c] * t.ls.dmip[c];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v_refl[k] += v_ls[c] * t.ls.dd[c * 3 + k];
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v_n[k] += v_ld[c] * t.ld_dd[c * 3 + k];
+    }
+    v_rough += v_mip * t.dmip_dr;
+    float v_d = 2.0f * (v_refl[0] * normal[0] + v_refl[1] * normal[1] + v_refl[2] * normal[2]);
+    float v_wo[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { v_n[k] += 2.0f * t.d * v_refl[k]; v_wo[k] = -v_refl[k]; }
+    if (t.d >= 1e-6f) v_d += v_ndv;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { v_n[k] += v_d * t.wo[k]; v_wo[k] += v_d * normal[k]; }
+    float o_mean[3] = { 0, 0, 0 };
+    if (!t.wo_const) {
+        const float dot = t.wo[0] * v_wo[0] + t.wo[1] * v_wo[1] + t.wo[2] * v_wo[2];
+        const float l = fmaxf(t.len, 1e-6f);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o_mean[k] = -((v_wo[k] - t.wo[k] * dot) / l);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        v_means[3 * (size_t)n + k] = o_mean[k];
+        v_normals[3 * (size_t)n + k] = v_n[k];
+        v_kd[3 * (size_t)n + k] = o_kd[k];
+    }
+    *reinterpret_cast<float2*>(v_ks + 2 * (size_t)n) = make_float2(v_rough * (1.0f - min_roughness), v_metal * max_metallic);
+
+    if (mode != GS_MODE_DIFFUSE) {
+        if (t.ls.l1 < 0) cube_scatter(eg.levels[t.ls.l0], t.ls.fp0, v_ls, 1.0f);
+        else {
+            cube_scatter(eg.levels[t.ls.l0], t.ls.fp0, v_ls, 1.0f - t.ls.f);
+            cube_scatter(eg.levels[t.ls.l1], t.ls.fp1, v_ls, t.ls.f);
+        }
+    } else {
+        cube_scatter(eg.base, t.ld_fp, v_ld, 1.0f);
+    }
+}
+
+static int env_to_dev(const GsEnv* env, EnvDev& e)
+{
+    if (!env || !env->lut || !env->base || env->num_levels < 1 || env->num_levels > GS_MAX_LEVELS) return -1;
+    e.lut = env->lut; e.lut_res = env->lut_res; e.base = env->base; e.base_res = env->base_res;
+    e.L = env->num_levels; e.min_r = env->min_roughness; e.max_r = env->max_roughness;
+    for (int l = 0; l < GS_MAX_LEVELS; ++l) {
+        e.levels[l] = l < e.L ? env->levels[l] : nullptr;
+        e.res[l] = l < e.L ? env->res[l] : 0;
+        if (l < e.L && (!e.levels[l] || e.res[l] < 1)) return -1;
+    }
+    return 0;
+}
+
+extern "C" int gs_shade_fwd(int N, const float* means, const float* normals, const float* kd, const float* ks,
+                            const float* cam_pos, float min_roughness, float max_metallic, int mode,
+                            const GsEnv* env, float* colors, void* stream)
+{
+    GS_CHECK_ARG(N >= 0 && mode >= 0 && mode <= 2, "bad N or mode");
+    EnvDev e;
+    GS_CHECK_ARG(env_to_dev(env, e) == 0, "bad GsEnv");
+    if (N == 0) return GS_OK;
+    hipLaunchKernelGGL(shade_fwd_kernel, dim3(gs_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, N, means, normals,
+                       kd, ks, cam_pos, min_roughness, max_metallic, mode, e, colors);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
+extern "C" int gs_shade_bwd(int N, const float* means, const float* normals, const float* kd, const float* ks,
+                            const float* cam_pos, float min_roughness, float max_metallic, int mode,
+                            const GsEnv* env, const float* v_colors, float* v_means, float* v_normals,
+                            float* v_kd, float* v_ks, const GsEnvGrad* env_grad, void* stream)
+{
+    GS_CHECK_ARG(N >= 0 && mode >= 0 && mode <= 2, "bad N or mode");
+    EnvDev e;
+    GS_CHECK_ARG(env_to_dev(env, e) == 0, "bad GsEnv");
+    GS_CHECK_ARG(env_grad != nullptr, "env_grad must not be NULL");
+    EnvGradDev eg;
+    eg.base = env_grad->base;
+    for (int l = 0; l < GS_MAX_LEVELS; ++l) eg.levels[l] = l < e.L ? env_grad->levels[l] : nullptr;
+    if (mode == GS_MODE_DIFFUSE) GS_CHECK_ARG(eg.base != nullptr, "env_grad->base required in diffuse mode");
+    else for (int l = 0; l < e.L; ++l) GS_CHECK_ARG(eg.levels[l] != nullptr, "env_grad->levels[l] required");
+    if (N == 0) return GS_OK;
+    hipLaunchKernelGGL(shade_bwd_kernel, dim3(gs_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, N, means, normals,
+                       kd, ks, cam_pos, min_roughness, max_metallic, mode, e, v_colors, v_means, v_normals, v_kd,
+                       v_ks, eg);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// S4 tone mapping
+__device__ __forceinline__ float tone_fwd(int mode, float rgb)
+{
+    if (mode == GS_TONE_NAIVE) {
+        const float x = 1.0f - rgb, bx = 100.0f * x;
+        const float sp = bx > 20.0f ? x : log1pf(expf(bx)) / 100.0f;
+        return 1.0f - sp;
+    }
+    if (mode == GS_TONE_ACES) return (rgb * (2.51f * rgb + 0.03f)) / (rgb * (2.43f * rgb + 0.59f) + 0.14f);
+    return rgb;
+}
+__device__ __forceinline__ float tone_grad(int mode, float rgb)
+{
+    if (mode == GS_TONE_NAIVE) {
+        const float bx = 100.0f * (1.0f - rgb);
+        return bx > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-bx));
+    }
+    if (mode == GS_TONE_ACES) {
+        const float num = rgb * (2.51f * rgb + 0.03f), den = rgb * (2.43f * rgb + 0.59f) + 0.14f;
+        return ((5.02f * rgb + 0.03f) * den - num * (4.86f * rgb + 0.59f)) / (den * den);
+    }
+    return 1.0f;
+}
+
+__global__ void __launch_bounds__(256)
+tonemap_fwd_kernel(int64_t P, int mode, const float4* __restrict__ rgba, const float* __restrict__ exposure,
+                   float4* __restrict__ out)
+{
+    const float e = exposure[0];
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = rgba[p];
+        out[p] = make_float4(tone_fwd(mode, v.x * e), tone_fwd(mode, v.y * e), tone_fwd(mode, v.z * e), v.w);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+tonemap_bwd_kernel(int64_t P, int mode, const float4* __restrict__ rgba, const float* __restrict__ exposure,
+                   const float4* __restrict__ v_out, float4* __restrict__ v_rgba, float* __restrict__ v_exposure)
+{
+    const float e = exposure[0];
+    float ve = 0.0f;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = rgba[p], g = v_out[p];
+        const float gx = g.x * tone_grad(mode, v.x * e), gy = g.y * tone_grad(mode, v.y * e), gz = g.z * tone_grad(mode, v.z * e);
+        v_rgba[p] = make_float4(gx * e, gy * e, gz * e, g.w);
+        ve += gx * v.x + gy * v.y + gz * v.z;
+    }
+    ve = gs_wave_sum(ve);
+    __shared__ float s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = ve;
+    __syncthreads();
+    if (threadIdx.x == 0) gs_atomic_add(v_exposure, s[0] + s[1] + s[2] + s[3]);
+}
+
+extern "C" int gs_tonemap_fwd(int64_t P, int mode, const float* rgba, const float* exposure, float* out, void* stream)
+{
+    GS_CHECK_ARG(P >= 0 && mode >= 0 && mode <= 2, "bad P or mode");
+    if (P == 0) return GS_OK;
+    const int blocks = (int)((P + 255) / 256 < 2048 ? (P + 255) / 256 : 2048);
+    hipLaunchKernelGGL(tonemap_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, mode,
+                       (const float4*)rgba, exposure, (float4*)out);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
+extern "C" int gs_tonemap_bwd(int64_t P, int mode, const float* rgba, const float* exposure, const float* v_out,
+                              float* v_rgba, float* v_exposure, void* stream)
+{
+    GS_CHECK_ARG(P >= 0 && mode >= 0 && mode <= 2, "bad P or mode");
+    hipStream_t s = (hipStream_t)stream;
+    GS_CHECK_HIP(hipMemsetAsync(v_exposure, 0, sizeof(float), s));
+    if (P == 0) return GS_OK;
+    const int blocks = (int)((P + 255) / 256 < 1024 ? (P + 255) / 256 : 1024);
+    hipLaunchKernelGGL(tonemap_bwd_kernel, dim3(blocks), dim3(256), 0, s, P, mode, (const float4*)rgba, exposure,
+                       (const float4*)v_out, (float4*)v_rgba, v_exposure);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}

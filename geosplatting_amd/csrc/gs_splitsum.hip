@@ -1,0 +1,286 @@
+// gs_splitsum.hip -- S5: split-sum environment-map prefilter (once per training step, feeds S3).
+// HIP equivalents of the reference's in-repo CUDA plugin `rfstudio_render_utils`:
+//   DiffuseCubemapFwd/BwdKernel   rfstudio/graphics/_mesh/_splitsum/c_src/cubemap.cu:110-168
+//   SpecularBoundsKernel          .../cubemap.cu:181-244
+//   SpecularCubemapFwd/BwdKernel  .../cubemap.cu:246-350
+//   _CubeMapMip fwd / bwd         rfstudio/graphics/_mesh/_texture.py:199-226
+// Launch shapes are re-derived for wave64: one thread per output texel in 64x4 blocks over a flat texel
+// index (the reference uses 8x8 blocks over (x,y,face)); the diffuse backward is formulated as a gather
+// over input texels (no atomics, deterministic); the specular backward scatters with hardware fp32
+// atomics like the reference.
+#include "gs_common.h"
+#include "gs_cube.h"
+
+__device__ __forceinline__ float pixel_area(int x, int y, int N)
+{
+    if (N > 1) {
+        const int H = N / 2;
+        x = abs(x - H);
+        y = abs(y - H);
+        const float dx = atanf((float)(x + 1) / (float)H) - atanf((float)x / (float)H);
+        const float dy = atanf((float)(y + 1) / (float)H) - atanf((float)y / (float)H);
+        return dx * dy;
+    }
+    return 1.0f;
+}
+
+__device__ __forceinline__ void cube_to_dir(int x, int y, int side, int N, float* d)
+{
+    const float fx = 2.0f * (((float)x + 0.5f) / (float)N) - 1.0f;
+    const float fy = 2.0f * (((float)y + 0.5f) / (float)N) - 1.0f;
+    face_point(side, fx, fy, d);
+    const float l = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (l > 0.0f) { d[0] /= l; d[1] /= l; d[2] /= l; } else { d[0] = d[1] = d[2] = 0.0f; }
+}
+
+__device__ __forceinline__ float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+__device__ __forceinline__ float ndfGGX(float alphaSqr, float cosTheta)
+{
+    const float c = fminf(fmaxf(cosTheta, 0.0f), 1.0f);
+    const float d = (c * alphaSqr - c) * c + 1.0f;
+    return alphaSqr / (d * d * 3.14159265358979323846f);
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+mip_fwd_kernel(int R, int C, const float* __restrict__ in, float* __restrict__ out)
+{
+    const int H = R / 2;
+    const int64_t total = (int64_t)6 * H * H * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t t = i / C;
+        const int x = (int)(t % H), y = (int)((t / H) % H), s = (int)(t / ((int64_t)H * H));
+        const float* p = in + (((size_t)s * R + 2 * y) * R + 2 * x) * C + c;
+        out[i] = (((p[0] + p[C]) + p[(size_t)R * C]) + p[(size_t)R * C + C]) * 0.25f;
+    }
+}
+
+extern "C" int gs_cubemap_mip_fwd(int R, int C, const float* in, float* out, void* stream)
+{
+    GS_CHECK_ARG(R >= 2 && (R % 2) == 0 && C >= 1, "bad R/C");
+    const int64_t total = (int64_t)6 * (R / 2) * (R / 2) * C;
+    hipLaunchKernelGGL(mip_fwd_kernel, dim3((int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0,
+                       (hipStream_t)stream, R, C, in, out);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
+__global__ void __launch_bounds__(256)
+cube_sample_kernel(int64_t n, const float* __restrict__ tex, int R, const float* __restrict__ dirs, float scale,
+                   float* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float d[3] = { dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2] };
+    float o[3]; CubeFp fp;
+    cube_fetch<false>(tex, R, d, o, nullptr, fp);
+    out[3 * i] = o[0] * scale; out[3 * i + 1] = o[1] * scale; out[3 * i + 2] = o[2] * scale;
+}
+
+extern "C" int gs_cube_sample_linear(int64_t n, const float* tex, int R, const float* dirs, float scale, float* out,
+                                     void* stream)
+{
+    GS_CHECK_ARG(n >= 0 && R >= 1, "bad sizes");
+    if (n == 0) return GS_OK;
+    hipLaunchKernelGGL(cube_sample_kernel, dim3(gs_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n, tex, R, dirs,
+                       scale, out);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
+// _CubeMapMip.backward: v_in[s,y,x] (+)= bilinear-cube(0.25 * v_out) at the direction of fine texel (x,y,s)
+__global__ void __launch_bounds__(256)
+mip_bwd_kernel(int R /*coarse*/, const float* __restrict__ v_out, float* __restrict__ v_in, int accumulate)
+{
+    const int F = 2 * R;
+    const int64_t total = (int64_t)6 * F * F;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % F), y = (int)((i / F) % F), s = (int)(i / ((int64_t)F * F));
+    // torch.linspace(-1 + 1/res, 1 - 1/res, res)[k]
+    const float step = (2.0f - 2.0f / (float)F) / (float)(F - 1);
+    const float gx = (-1.0f + 1.0f / (float)F) + step * (float)x;
+    const float gy = (-1.0f + 1.0f / (float)F) + step * (float)y;
+    float d[3];
+    face_point(s, gx, gy, d);
+    const float l = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    d[0] /= l; d[1] /= l; d[2] /= l;
+    float o[3]; CubeFp fp;
+    cube_fetch<false>(v_out, R, d, o, nullptr, fp);
+    float* p = v_in + 3 * i;
+    if (accumulate) { p[0] += 0.25f * o[0]; p[1] += 0.25f * o[1]; p[2] += 0.25f * o[2]; }
+    else { p[0] = 0.25f * o[0]; p[1] = 0.25f * o[1]; p[2] = 0.25f * o[2]; }
+}
+
+extern "C" int gs_cubemap_mip_bwd(int R, const float* v_out, float* v_in, int accumulate, void* stream)
+{
+    GS_CHECK_ARG(R >= 1, "bad R");
+    const int64_t total = (int64_t)6 * 4 * R * R;
+    hipLaunchKernelGGL(mip_bwd_kernel, dim3(gs_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, R, v_out, v_in,
+                       accumulate);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// diffuse: out[o] = sum_i cubemap[i] * clamp(N_o . L_i, 0, 0.999) * area_i / 3.141592
+template <bool BWD>
+__global__ void __launch_bounds__(256)
+diffuse_kernel(int R, const float* __restrict__ src, float* __restrict__ dst, int accumulate)
+{
+    const int n = 6 * R * R;
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n) return;
+    const int ox = o % R, oy = (o / R) % R, os = o / (R * R);
+    float A[3]; cube_to_dir(ox, oy, os, R, A);
+    const float pa_o = pixel_area(ox, oy, R);
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    for (int i = 0; i < n; ++i) {
+        const int x = i % R, y = (i / R) % R, s = i / (R * R);
+        float B[3]; cube_to_dir(x, y, s, R, B);
+        const float costheta = fminf(fmaxf(dot3(A, B), 0.0f), 0.999f);
+        // fwd: weight uses the INPUT texel's area (i); bwd (gather over outputs i for input o): area of o
+        const float w = costheta * (BWD ? pa_o : pixel_area(x, y, R)) / 3.141592f;
+        const float* t = src + (size_t)i * 3;
+        c0 += t[0] * w; c1 += t[1] * w; c2 += t[2] * w;
+    }
+    float* p = dst + (size_t)o * 3;
+    if (accumulate) { p[0] += c0; p[1] += c1; p[2] += c2; } else { p[0] = c0; p[1] = c1; p[2] = c2; }
+}
+
+extern "C" int gs_diffuse_cubemap_fwd(int R, const float* cubemap, float* out, void* stream)
+{
+    GS_CHECK_ARG(R >= 1 && R <= 64, "diffuse prefilter expects the 16^2 level (R <= 64)");
+    hipLaunchKernelGGL(diffuse_kernel<false>, dim3(gs_cdiv(6 * R * R, 256)), dim3(256), 0, (hipStream_t)stream, R,
+                       cubemap, out, 0);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+extern "C" int gs_diffuse_cubemap_bwd(int R, const float* v_out, float* v_cubemap, int accumulate, void* stream)
+{
+    GS_CHECK_ARG(R >= 1 && R <= 64, "diffuse prefilter expects the 16^2 level (R <= 64)");
+    hipLaunchKernelGGL(diffuse_kernel<true>, dim3(gs_cdiv(6 * R * R, 256)), dim3(256), 0, (hipStream_t)stream, R,
+                       v_out, v_cubemap, accumulate);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+specular_bounds_kernel(int R, float cutoff, float* __restrict__ bounds)
+{
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= 6 * R * R) return;
+    const int px = o % R, py = (o / R) % R, pz = o / (R * R);
+    float VNR[3]; cube_to_dir(px, py, pz, R, VNR);
+    const int TILE = 16;
+    const int nt = (R + TILE - 1) / TILE;
+    for (int s = 0; s < 6; ++s) {
+        int min_x = R - 1, max_x = 0, min_y = R - 1, max_y = 0;
+        for (int tx = 0; tx < nt; ++tx)
+            for (int ty = 0; ty < nt; ++ty) {
+                const int tsx = tx * TILE, tsy = ty * TILE;
+                const int tex = min((tx + 1) * TILE, R), tey = min((ty + 1) * TILE, R);
+                float L0[3], L1[3], L2[3], L3[3];
+                cube_to_dir(tsx, tsy, s, R, L0); cube_to_dir(tex, tsy, s, R, L1);
+                cube_to_dir(tsx, tey, s, R, L2); cube_to_dir(tex, tey, s, R, L3);
+                float maxdp = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float mn = fminf(fminf(L0[k], L1[k]), fminf(L2[k], L3[k]));
+                    const float mx = fmaxf(fmaxf(L0[k], L1[k]), fmaxf(L2[k], L3[k]));
+                    maxdp += fmaxf(mn * VNR[k], mx * VNR[k]);
+                }
+                if (maxdp >= cutoff) {
+                    for (int y = tsy; y < tey; ++y)
+                        for (int x = tsx; x < tex; ++x) {
+                            float L[3]; cube_to_dir(x, y, s, R, L);
+                            if (dot3(L, VNR) >= cutoff) {
+                                min_x = min(min_x, x); max_x = max(max_x, x);
+                                min_y = min(min_y, y); max_y = max(max_y, y);
+                            }
+                        }
+                }
+            }
+        float* b = bounds + (size_t)o * 24 + s * 4;
+        b[0] = (float)min_x; b[1] = (float)max_x; b[2] = (float)min_y; b[3] = (float)max_y;
+    }
+}
+
+extern "C" int gs_specular_bounds(int R, float costheta_cutoff, float* bounds, void* stream)
+{
+    GS_CHECK_ARG(R >= 1, "bad R");
+    hipLaunchKernelGGL(specular_bounds_kernel, dim3(gs_cdiv(6 * R * R, 256)), dim3(256), 0, (hipStream_t)stream, R,
+                       costheta_cutoff, bounds);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(256)
+specular_kernel(int R, const float* __restrict__ cubemap, const float* __restrict__ bounds,
+                const float* __restrict__ v_out, float roughness, float cutoff, float* __restrict__ out,
+                float* __restrict__ v_cubemap)
+{
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= 6 * R * R) return;
+    const int px = o % R, py = (o / R) % R, pz = o / (R * R);
+    float VNR[3]; cube_to_dir(px, py, pz, R, VNR);
+    const float alpha = roughness * roughness;
+    const float alphaSqr = alpha * alpha;
+    float wsum = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (BWD) { g0 = v_out[(size_t)o * 3]; g1 = v_out[(size_t)o * 3 + 1]; g2 = v_out[(size_t)o * 3 + 2]; }
+    for (int s = 0; s < 6; ++s) {
+        const float4 b = *reinterpret_cast<const float4*>(bounds + (size_t)o * 24 + s * 4);
+        const int xmin = (int)b.x, xmax = (int)b.y, ymin = (int)b.z, ymax = (int)b.w;
+        if (xmin > xmax) continue;
+        for (int y = ymin; y <= ymax; ++y)
+            for (int x = xmin; x <= xmax; ++x) {
+                float L[3]; cube_to_dir(x, y, s, R, L);
+                const float ldv = dot3(L, VNR);
+                if (ldv >= cutoff) {
+                    float Hv[3] = { L[0] + VNR[0], L[1] + VNR[1], L[2] + VNR[2] };
+                    const float hl = sqrtf(dot3(Hv, Hv));
+                    if (hl > 0.0f) { Hv[0] /= hl; Hv[1] /= hl; Hv[2] /= hl; } else { Hv[0] = Hv[1] = Hv[2] = 0.0f; }
+                    const float wiDotN = fmaxf(ldv, 0.0f);
+                    const float VNRDotH = fmaxf(dot3(VNR, Hv), 0.0f);
+                    const float w = wiDotN * ndfGGX(alphaSqr, VNRDotH) * pixel_area(x, y, R) / 4.0f;
+                    const size_t ti = (((size_t)s * R + y) * R + x) * 3;
+                    if (BWD) {
+                        gs_atomic_add(v_cubemap + ti, g0 * w);
+                        gs_atomic_add(v_cubemap + ti + 1, g1 * w);
+                        gs_atomic_add(v_cubemap + ti + 2, g2 * w);
+                    } else {
+                        c0 += cubemap[ti] * w; c1 += cubemap[ti + 1] * w; c2 += cubemap[ti + 2] * w;
+                        wsum += w;
+                    }
+                }
+            }
+    }
+    if (!BWD) *reinterpret_cast<float4*>(out + (size_t)o * 4) = make_float4(c0, c1, c2, wsum);
+}
+
+extern "C" int gs_specular_cubemap_fwd(int R, const float* cubemap, const float* bounds, float roughness,
+                                       float costheta_cutoff, float* out, void* stream)
+{
+    GS_CHECK_ARG(R >= 1, "bad R");
+    hipLaunchKernelGGL(specular_kernel<false>, dim3(gs_cdiv(6 * R * R, 256)), dim3(256), 0, (hipStream_t)stream, R,
+                       cubemap, bounds, nullptr, roughness, costheta_cutoff, out, nullptr);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
+extern "C" int gs_specular_cubemap_bwd(int R, const float* bounds, const float* v_out_rgb, float roughness,
+                                       float costheta_cutoff, float* v_cubemap, int accumulate, void* stream)
+{
+    GS_CHECK_ARG(R >= 1, "bad R");
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) GS_CHECK_HIP(hipMemsetAsync(v_cubemap, 0, sizeof(float) * 18 * (size_t)R * R, s));
+    hipLaunchKernelGGL(specular_kernel<true>, dim3(gs_cdiv(6 * R * R, 256)), dim3(256), 0, s, R, nullptr, bounds,
+                       v_out_rgb, roughness, costheta_cutoff, nullptr, v_cubemap);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}

@@ -1,0 +1,103 @@
+"""Data-parallel layer for the path: one process per GPU, views sharded across ranks, ONE flat fp32 gradient
+bucket summed with RCCL (``torch.distributed`` backend "nccl" on ROCm) over xGMI.
+
+The reference has no distributed code at all: its 8 views per step are a Python loop on
+one device (rfstudio/model/geosplat.py:869-879) and the loss is the mean over views
+(rfstudio/trainer/geosplat_trainer.py:180).  Here every rank holds a replica of the Gaussians / PBR attributes /
+cubemap, renders its own views, and the only exchange is the gradient sum:
+   message = 76 B x N (means 12, scales 12, quats 16, opacity 4, normals 12, kd 12, ks 8) + cubemap + exposure
+   (149 MB + 18.9 MB at N = 1.97 M) in ONE all-reduce -- xGMI is point-to-point, so a single large collective
+   that RCCL can spread over all 7 links beats many small ones.
+The bucket is laid out once; gradients are copied in with a single fused foreach copy, reduced on a side
+stream, and handed back as views (no per-parameter collectives).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+
+def shard_views(num_views: int, rank: int, world_size: int) -> List[int]:
+    """View i -> rank i mod world_size; returns this rank's view indices in order."""
+    return list(range(rank, num_views, world_size))
+
+
+class GradBucket:
+    """One flat fp32 buffer holding every parameter gradient of the path."""
+
+    def __init__(self, shapes: Dict[str, Sequence[int]], device: torch.device):
+        self.names = list(shapes.keys())
+        self.shapes = {k: tuple(v) for k, v in shapes.items()}
+        self.offsets: Dict[str, int] = {}
+        off = 0
+        for k in self.names:
+            self.offsets[k] = off
+            n = 1
+            for s in self.shapes[k]:
+                n *= int(s)
+            off += (n + 63) // 64 * 64              # 256-byte aligned segments
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        self.comm_stream = torch.cuda.Stream(device=device) if device.type == "cuda" else None
+
+    def view(self, name: str) -> Tensor:
+        o = self.offsets[name]
+        n = 1
+        for s in self.shapes[name]:
+            n *= int(s)
+        return self.flat[o:o + n].view(self.shapes[name])
+
+    def pack(self, grads: Dict[str, Optional[Tensor]]) -> None:
+        """Copy (not accumulate) per-parameter gradients into the bucket; missing grads become zeros."""
+        dst, src = [], []
+        for k in self.names:
+            g = grads.get(k)
+            if g is None:
+                self.view(k).zero_()
+            else:
+                dst.append(self.view(k)); src.append(g.reshape(self.shapes[k]).to(torch.float32))
+        if dst:
+            torch._foreach_copy_(dst, src)
+
+    def all_reduce(self, average: bool = False, async_op: bool = False):
+        """Sum over ranks (RCCL on GPUs, gloo on CPU).  With async_op the collective runs on a side stream and
+        the returned callable must be invoked before the gradients are read."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return (lambda: None) if async_op else None
+        if self.comm_stream is not None and async_op:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+                if average:
+                    self.flat.div_(dist.get_world_size())
+
+            def wait():
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
+            return wait
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        if average:
+            self.flat.div_(dist.get_world_size())
+        return (lambda: None) if async_op else None
+
+    def unpack(self) -> Dict[str, Tensor]:
+        return {k: self.view(k) for k in self.names}
+
+
+def init_distributed_from_env(device_type: str = "cuda"):
+    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from torch.distributed.run.  Returns (rank, world, device)."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if device_type == "cuda":
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+    else:
+        device = torch.device("cpu")
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if device_type == "cuda" else "gloo", rank=rank, world_size=world)
+    return rank, world, device

@@ -1,0 +1,162 @@
+"""Drop-in for the rasterizer boundary of the reference: ``gsplat.rasterization`` exactly as it is called at
+rfstudio/model/gsplat.py:334-355 (and :240-261; rfstudio/model/geosplat.py:276-295 with D=14).
+
+Same argument names / meaning / return triple ``(render[1,H,W,D], alpha[1,H,W,1], meta)``; differentiable
+w.r.t. means / quats / scales / opacities / colors.  Every stage runs in libgeosplat_hip.so (hand-written HIP
+for gfx950) through the C-ABI in include/geosplat_hip.h -- there is no PyTorch or CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+
+_META_KEYS = ("gaussian_ids_i32", "radii", "means2d", "depths", "conics", "compensations", "opacities", "colors",
+              "tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets", "last_ids")
+
+
+def _forward_stages(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Tensor,
+                    viewmat: Tensor, K: Tensor, W: int, H: int, tile_size: int, eps2d: float, near: float,
+                    far: float, radius_clip: float, background: Optional[Tensor]):
+    lib = L.lib()
+    dev = means.device
+    N, D = means.shape[0], colors.shape[1]
+    tw, th = (W + tile_size - 1) // tile_size, (H + tile_size - 1) // tile_size
+    i32, f32 = torch.int32, torch.float32
+    gids = torch.empty(N, dtype=i32, device=dev); radii = torch.empty(N, dtype=i32, device=dev)
+    means2d = torch.empty(N, 2, dtype=f32, device=dev); depths = torch.empty(N, dtype=f32, device=dev)
+    conics = torch.empty(N, 3, dtype=f32, device=dev); comps = torch.empty(N, dtype=f32, device=dev)
+    opac_p = torch.empty(N, dtype=f32, device=dev); colors_p = torch.empty(N, D, dtype=f32, device=dev)
+    tpg = torch.empty(N, dtype=i32, device=dev); cum = torch.empty(N, dtype=torch.int64, device=dev)
+    ws_bytes = lib.gs_project_ws_bytes(N)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    counts = torch.empty(2, dtype=torch.int64, device=dev)
+    st = L.stream()
+    L.check(lib.gs_project_fwd(N, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opacities), L.ptr(colors), D,
+                               L.ptr(viewmat), L.ptr(K), W, H, tile_size, L.f32(eps2d), L.f32(near), L.f32(far),
+                               L.f32(radius_clip), L.ptr(gids), L.ptr(radii), L.ptr(means2d), L.ptr(depths),
+                               L.ptr(conics), L.ptr(comps), L.ptr(opac_p), L.ptr(colors_p), L.ptr(tpg), L.ptr(cum),
+                               None, L.ptr(ws), C.c_size_t(ws_bytes), L.ptr(counts), st), "gs_project_fwd")
+    V, I = (int(x) for x in counts.cpu().tolist())          # the one host sync of the forward (as upstream)
+    if V < 0 or I < 0 or I >= 2 ** 31:
+        raise L.GeoSplatHipError(f"bad intersection count V={V} I={I}")
+    gids, radii, means2d, depths = gids[:V], radii[:V], means2d[:V], depths[:V]
+    conics, comps, opac_p, colors_p, tpg, cum = conics[:V], comps[:V], opac_p[:V], colors_p[:V], tpg[:V], cum[:V]
+
+    ids = torch.empty(I, dtype=torch.int64, device=dev); flat = torch.empty(I, dtype=i32, device=dev)
+    ids_s = torch.empty(I, dtype=torch.int64, device=dev); flat_s = torch.empty(I, dtype=i32, device=dev)
+    L.check(lib.gs_isect_emit(V, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(cum), tile_size, tw, th,
+                              L.ptr(ids), L.ptr(flat), st), "gs_isect_emit")
+    sort_bytes = lib.gs_sort_ws_bytes(L.i64(I), tw, th)
+    sort_ws = torch.empty(max(sort_bytes, 1), dtype=torch.uint8, device=dev)
+    L.check(lib.gs_isect_sort(L.i64(I), L.ptr(ids), L.ptr(flat), L.ptr(ids_s), L.ptr(flat_s), tw, th, L.ptr(sort_ws),
+                              C.c_size_t(sort_bytes), st), "gs_isect_sort")
+    offsets = torch.empty(th * tw, dtype=i32, device=dev)
+    L.check(lib.gs_isect_offsets(L.i64(I), L.ptr(ids_s), tw * th, L.ptr(offsets), st), "gs_isect_offsets")
+
+    render = torch.empty(H, W, D, dtype=f32, device=dev); alphas = torch.empty(H, W, dtype=f32, device=dev)
+    last_ids = torch.empty(H, W, dtype=i32, device=dev)
+    L.check(lib.gs_raster_fwd(W, H, tile_size, D, L.ptr(means2d), L.ptr(conics), L.ptr(opac_p), L.ptr(colors_p),
+                              L.ptr(background), L.i64(I), L.ptr(offsets), L.ptr(flat_s), L.ptr(render), L.ptr(alphas),
+                              L.ptr(last_ids), st), "gs_raster_fwd")
+    state = dict(gaussian_ids_i32=gids, radii=radii, means2d=means2d, depths=depths, conics=conics,
+                 compensations=comps, opacities=opac_p, colors=colors_p, tiles_per_gauss=tpg, isect_ids=ids_s,
+                 flatten_ids=flat_s, isect_offsets=offsets, last_ids=last_ids)
+    return render, alphas, state, V, I
+
+
+class _Rasterize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, quats, scales, opacities, colors, viewmat, K, background, W, H, tile_size, eps2d, near, far,
+                radius_clip):
+        means, quats, scales = means.contiguous(), quats.contiguous(), scales.contiguous()
+        opacities, colors = opacities.contiguous(), colors.contiguous()
+        viewmat, K = viewmat.contiguous(), K.contiguous()
+        render, alphas, st, V, I = _forward_stages(means, quats, scales, opacities, colors, viewmat, K, W, H, tile_size,
+                                                   eps2d, near, far, radius_clip, background)
+        ctx.cfg = (W, H, tile_size, eps2d, V, I)
+        ctx.save_for_backward(means, quats, scales, opacities, colors, viewmat, K, background, alphas,
+                              *[st[k] for k in _META_KEYS])
+        outs = (render, alphas) + tuple(st[k] for k in _META_KEYS)
+        ctx.mark_non_differentiable(*outs[2:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, v_render, v_alphas, *_unused):
+        lib = L.lib()
+        W, H, tile_size, eps2d, V, I = ctx.cfg
+        (means, quats, scales, opacities, colors, viewmat, K, background, alphas, *meta) = ctx.saved_tensors
+        st = dict(zip(_META_KEYS, meta))
+        dev = means.device
+        N, D = means.shape[0], colors.shape[1]
+        f32 = torch.float32
+        v_render = torch.zeros(H, W, D, dtype=f32, device=dev) if v_render is None else v_render.contiguous()
+        v_alphas = torch.zeros(H, W, dtype=f32, device=dev) if v_alphas is None else v_alphas.contiguous()
+        v_m2d = torch.empty(V, 2, dtype=f32, device=dev); v_con = torch.empty(V, 3, dtype=f32, device=dev)
+        v_col = torch.empty(V, D, dtype=f32, device=dev); v_op = torch.empty(V, dtype=f32, device=dev)
+        s = L.stream()
+        L.check(lib.gs_raster_bwd(W, H, tile_size, D, V, L.ptr(st["means2d"]), L.ptr(st["conics"]),
+                                  L.ptr(st["opacities"]), L.ptr(st["colors"]), L.ptr(background), L.i64(I),
+                                  L.ptr(st["isect_offsets"]), L.ptr(st["flatten_ids"]), L.ptr(alphas),
+                                  L.ptr(st["last_ids"]), L.ptr(v_render), L.ptr(v_alphas), L.ptr(v_m2d), L.ptr(v_con),
+                                  L.ptr(v_col), L.ptr(v_op), s), "gs_raster_bwd")
+        g_means = torch.empty(N, 3, dtype=f32, device=dev); g_quats = torch.empty(N, 4, dtype=f32, device=dev)
+        g_scales = torch.empty(N, 3, dtype=f32, device=dev); g_opac = torch.empty(N, dtype=f32, device=dev)
+        g_colors = torch.empty(N, D, dtype=f32, device=dev)
+        L.check(lib.gs_project_bwd(N, V, D, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opacities), L.ptr(viewmat),
+                                   L.ptr(K), W, H, L.f32(eps2d), L.ptr(st["gaussian_ids_i32"]), L.ptr(st["conics"]),
+                                   L.ptr(st["compensations"]), L.ptr(v_m2d), None, L.ptr(v_con), L.ptr(v_op),
+                                   L.ptr(v_col), L.ptr(g_means), L.ptr(g_quats), L.ptr(g_scales), L.ptr(g_opac),
+                                   L.ptr(g_colors), s), "gs_project_bwd")
+        return (g_means, g_quats, g_scales, g_opac, g_colors) + (None,) * 10
+
+
+def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Tensor, viewmats: Tensor,
+                  Ks: Tensor, width: int, height: int, near_plane: float = 0.01, far_plane: float = 1e10,
+                  radius_clip: float = 0.0, eps2d: float = 0.3, sh_degree: Optional[int] = None, packed: bool = True,
+                  tile_size: int = 16, backgrounds: Optional[Tensor] = None, render_mode: str = "RGB",
+                  sparse_grad: bool = False, absgrad: bool = False, rasterize_mode: str = "antialiased",
+                  ) -> Tuple[Tensor, Tensor, Dict]:
+    """``gsplat.rasterization`` for the configuration the reference uses (one camera, packed, 'antialiased',
+    'RGB', no SH).  Unsupported options raise (same error behaviour as upstream: Python exceptions)."""
+    L.require_cuda(means, quats, scales, opacities, colors, viewmats, Ks)
+    if viewmats.shape[:-2] != (1,) or Ks.shape[:-2] != (1,):
+        raise ValueError("exactly one camera per call (rfstudio/model/gsplat.py:293 asserts cameras.shape == (1,))")
+    if sh_degree is not None:
+        raise NotImplementedError("sh_degree must be None (the reference passes sh_degree=None, geosplat uses sh_degree=0)")
+    if render_mode != "RGB":
+        raise NotImplementedError("render_mode 'RGB' only (depth modes are a SURVEY section 8f 'next' row)")
+    if rasterize_mode != "antialiased":
+        raise NotImplementedError("rasterize_mode 'antialiased' only (rfstudio/model/geosplat.py:796)")
+    if sparse_grad or absgrad:
+        raise NotImplementedError("sparse_grad / absgrad are False on the reference path")
+    N = means.shape[0]
+    assert means.shape == (N, 3) and quats.shape == (N, 4) and scales.shape == (N, 3) and opacities.shape == (N,)
+    assert colors.dim() == 2 and colors.shape[0] == N
+    bg = None
+    if backgrounds is not None:
+        bg = backgrounds.reshape(-1).contiguous().float()
+        assert bg.shape[0] == colors.shape[1]
+    outs = _Rasterize.apply(means.float(), quats.float(), scales.float(), opacities.float(), colors.float(),
+                            viewmats.reshape(4, 4).float(), Ks.reshape(3, 3).float(), bg, int(width), int(height),
+                            int(tile_size), float(eps2d), float(near_plane), float(far_plane), float(radius_clip))
+    render, alphas = outs[0], outs[1]
+    st = dict(zip(_META_KEYS, outs[2:]))
+    tw, th = (width + tile_size - 1) // tile_size, (height + tile_size - 1) // tile_size
+    V = st["radii"].shape[0]
+    meta = {
+        "camera_ids": torch.zeros(V, dtype=torch.int64, device=means.device),
+        "gaussian_ids": st["gaussian_ids_i32"].long(),
+        "radii": st["radii"], "means2d": st["means2d"], "depths": st["depths"], "conics": st["conics"],
+        "opacities": st["opacities"], "tile_width": tw, "tile_height": th, "tiles_per_gauss": st["tiles_per_gauss"],
+        "isect_ids": st["isect_ids"], "flatten_ids": st["flatten_ids"],
+        "isect_offsets": st["isect_offsets"].view(1, th, tw), "width": width, "height": height,
+        "tile_size": tile_size, "n_cameras": 1,
+        # extras (not in upstream's dict)
+        "compensations": st["compensations"], "last_ids": st["last_ids"].view(1, height, width),
+    }
+    return render.unsqueeze(0), alphas.view(1, height, width, 1), meta

@@ -1,0 +1,196 @@
+"""Split-sum environment pyramid (stage S5) -- host-side mirror of
+``TextureCubeMap.as_splitsum`` / ``TextureSplitSum`` (rfstudio/graphics/_mesh/_texture.py:530-613) and of the
+plugin wrappers in rfstudio/graphics/_mesh/_splitsum/_wrap.py:82-157.  All arithmetic runs in
+libgeosplat_hip.so; this file only owns tensors, the bounds cache and the autograd glue.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import _lib as L
+
+
+# ----------------------------------------------------------------------------- cutoff + bounds cache
+_cutoff_cache: Dict[Tuple[float, float], float] = {}
+_bounds_cache: Dict[Tuple[int, float, float, int], Tuple[float, Tensor]] = {}
+
+
+def ndf_cutoff(roughness: float, cutoff: float = 0.99, n_samples: int = 1000000) -> float:
+    """cos(theta) retaining `cutoff` of the GGX NDF energy -- float64 numpy CDF exactly like the reference
+    (rfstudio/graphics/_mesh/_splitsum/_wrap.py:120-135)."""
+    key = (float(roughness), float(cutoff))
+    if key not in _cutoff_cache:
+        costheta = np.cos(np.linspace(0, np.pi / 2.0, n_samples))
+        c = np.clip(costheta, 0.0, 1.0)
+        a2 = roughness ** 4
+        d = (c * a2 - c) * c + 1.0
+        D = np.cumsum(a2 / (d * d * np.pi))
+        _cutoff_cache[key] = float(costheta[np.argmax(D >= D[-1] * cutoff)])
+    return _cutoff_cache[key]
+
+
+def specular_bounds(res: int, roughness: float, cutoff: float, device: torch.device) -> Tuple[float, Tensor]:
+    """Per-texel AABBs of the lobe footprint, cached per (res, roughness, cutoff, device) like
+    _wrap.py:136,151-154."""
+    key = (res, float(roughness), float(cutoff), device.index or 0)
+    if key not in _bounds_cache:
+        ct = ndf_cutoff(roughness, cutoff)
+        b = torch.empty(6, res, res, 24, dtype=torch.float32, device=device)
+        L.check(L.lib().gs_specular_bounds(res, L.f32(ct), L.ptr(b), L.stream()), "gs_specular_bounds")
+        _bounds_cache[key] = (ct, b)
+    return _bounds_cache[key]
+
+
+# ----------------------------------------------------------------------------- autograd pieces
+class _CubeMapMip(torch.autograd.Function):
+    """rfstudio/graphics/_mesh/_texture.py:199-226"""
+
+    @staticmethod
+    def forward(ctx, cubemap: Tensor) -> Tensor:
+        cubemap = cubemap.contiguous()
+        R, Cn = cubemap.shape[1], cubemap.shape[3]
+        out = torch.empty(6, R // 2, R // 2, Cn, dtype=torch.float32, device=cubemap.device)
+        L.check(L.lib().gs_cubemap_mip_fwd(R, Cn, L.ptr(cubemap), L.ptr(out), L.stream()), "gs_cubemap_mip_fwd")
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Tensor) -> Tensor:
+        dout = dout.contiguous()
+        R = dout.shape[1]
+        assert dout.shape[3] == 3
+        g = torch.empty(6, 2 * R, 2 * R, 3, dtype=torch.float32, device=dout.device)
+        L.check(L.lib().gs_cubemap_mip_bwd(R, L.ptr(dout), L.ptr(g), 0, L.stream()), "gs_cubemap_mip_bwd")
+        return g
+
+
+class _DiffuseCubemap(torch.autograd.Function):
+    """_diffuse_cubemap_func (rfstudio/graphics/_mesh/_splitsum/_wrap.py:82-93)"""
+
+    @staticmethod
+    def forward(ctx, cubemap: Tensor) -> Tensor:
+        cubemap = cubemap.contiguous()
+        out = torch.empty_like(cubemap)
+        L.check(L.lib().gs_diffuse_cubemap_fwd(cubemap.shape[1], L.ptr(cubemap), L.ptr(out), L.stream()),
+                "gs_diffuse_cubemap_fwd")
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Tensor) -> Tensor:
+        dout = dout.contiguous()
+        g = torch.empty_like(dout)
+        L.check(L.lib().gs_diffuse_cubemap_bwd(dout.shape[1], L.ptr(dout), L.ptr(g), 0, L.stream()),
+                "gs_diffuse_cubemap_bwd")
+        return g
+
+
+class _SpecularCubemap(torch.autograd.Function):
+    """_specular_cubemap + the rgb/wsum normalisation (rfstudio/graphics/_mesh/_splitsum/_wrap.py:104-118,157)"""
+
+    @staticmethod
+    def forward(ctx, cubemap: Tensor, roughness: float, costheta_cutoff: float, bounds: Tensor) -> Tensor:
+        cubemap = cubemap.contiguous()
+        R = cubemap.shape[1]
+        raw = torch.empty(6, R, R, 4, dtype=torch.float32, device=cubemap.device)
+        L.check(L.lib().gs_specular_cubemap_fwd(R, L.ptr(cubemap), L.ptr(bounds), L.f32(roughness),
+                                                L.f32(costheta_cutoff), L.ptr(raw), L.stream()),
+                "gs_specular_cubemap_fwd")
+        wsum = raw[..., 3:]
+        ctx.save_for_backward(bounds, wsum)
+        ctx.cfg = (roughness, costheta_cutoff)
+        return raw[..., :3] / wsum
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        bounds, wsum = ctx.saved_tensors
+        roughness, ct = ctx.cfg
+        v = (dout / wsum).contiguous()             # wsum does not depend on the cubemap
+        g = torch.empty_like(v)
+        L.check(L.lib().gs_specular_cubemap_bwd(v.shape[1], L.ptr(bounds), L.ptr(v), L.f32(roughness), L.f32(ct),
+                                                L.ptr(g), 0, L.stream()), "gs_specular_cubemap_bwd")
+        return g, None, None, None
+
+
+def diffuse_cubemap(cubemap: Tensor) -> Tensor:
+    return _DiffuseCubemap.apply(cubemap)
+
+
+def specular_cubemap(cubemap: Tensor, roughness: float, cutoff: float = 0.99) -> Tensor:
+    ct, bounds = specular_bounds(cubemap.shape[1], roughness, cutoff, cubemap.device)
+    return _SpecularCubemap.apply(cubemap, float(roughness), ct, bounds)
+
+
+# ----------------------------------------------------------------------------- atlas packing (reference layout)
+def merge_mipmaps(mipmaps: List[Tensor]) -> Tensor:
+    """[6,R,R,3], [6,R/2,R/2,3], ... -> atlas [6,4,R,R] (rfstudio/graphics/_mesh/_texture.py:228-244)"""
+    R = mipmaps[0].shape[-2]
+    out = torch.stack((mipmaps[0][..., 0], mipmaps[0][..., 1], mipmaps[0][..., 2],
+                       torch.zeros_like(mipmaps[0][..., 0])), dim=-3)
+    origin = 0
+    for i in range(1, len(mipmaps)):
+        h = R // 2
+        out[..., 3, origin:origin + h, origin:origin + h] = mipmaps[i][..., 0]
+        out[..., 3, origin:origin + h, origin + h:origin + R] = mipmaps[i][..., 1]
+        out[..., 3, origin + h:origin + R, origin:origin + h] = mipmaps[i][..., 2]
+        origin += h
+        R = h
+    return out
+
+
+def split_mipmaps(atlas: Tensor, num_mipmaps: int) -> List[Tensor]:
+    """atlas [6,4,R,R] -> list of [6,R_l,R_l,3] (rfstudio/graphics/_mesh/_texture.py:247-261)"""
+    res = []
+    bs = atlas.shape[:-3]
+    for _ in range(num_mipmaps):
+        R = atlas.shape[-1]
+        res.append(atlas[..., :3, :, :].flatten(-2, -1).transpose(-2, -1).reshape(*bs, R, R, 3).contiguous())
+        h = R // 2
+        atlas = atlas[..., 3, :, :].reshape(*bs, 2, h, 2, h).transpose(-3, -2).reshape(*bs, 4, h, h)
+    return res
+
+
+# ----------------------------------------------------------------------------- the pyramid object
+@dataclass
+class TextureSplitSum:
+    """Field-compatible with rfstudio's TextureSplitSum (base, mipmaps atlas, num_mipmaps, min/max roughness);
+    additionally keeps the per-level tensors so that the fused shading kernel reads them without an
+    atlas round trip (the atlas is materialised lazily by ``.mipmaps``)."""
+    base: Tensor                       # [6,16,16,3]
+    levels: List[Tensor]               # L x [6,R_l,R_l,3]
+    min_roughness: float = 0.08
+    max_roughness: float = 0.5
+
+    @property
+    def num_mipmaps(self) -> int:
+        return len(self.levels)
+
+    @property
+    def mipmaps(self) -> Tensor:
+        return merge_mipmaps(self.levels)
+
+    @classmethod
+    def from_atlas(cls, base: Tensor, mipmaps: Tensor, num_mipmaps: int, min_roughness=0.08, max_roughness=0.5):
+        return cls(base, split_mipmaps(mipmaps, num_mipmaps), float(min_roughness), float(max_roughness))
+
+
+def as_splitsum(cubemap: Tensor, *, cutoff: float = 0.99, min_resolution: int = 16, min_roughness: float = 0.08,
+                max_roughness: float = 0.5) -> TextureSplitSum:
+    """TextureCubeMap.as_splitsum (rfstudio/graphics/_mesh/_texture.py:530-557); differentiable w.r.t. cubemap."""
+    L.require_cuda(cubemap)
+    mips = [cubemap.float()]
+    while mips[-1].shape[1] > min_resolution:
+        mips.append(_CubeMapMip.apply(mips[-1]))
+    assert len(mips) > 2, "Min resolution is too large."
+    base = diffuse_cubemap(mips[-1])
+    n = len(mips)
+    levels = []
+    for idx in range(n - 1):
+        roughness = (idx / (n - 2)) * (max_roughness - min_roughness) + min_roughness
+        levels.append(specular_cubemap(mips[idx], roughness, cutoff))
+    levels.append(specular_cubemap(mips[-1], 1.0, cutoff))
+    return TextureSplitSum(base, levels, min_roughness, max_roughness)

@@ -1,0 +1,176 @@
+"""GPU parity: fused split-sum shading (S1..S3), tone mapping (S4), prefilter (S5) and the end-to-end
+``RenderableAttrs.splat`` call vs the CPU oracle.  Tolerance 1e-4 relative (max-norm) fp32."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from tests.util import activated, rel_err, sphere_case
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _random_env(seed=3, res=(64, 32, 16)):
+    g = torch.Generator().manual_seed(seed)
+    levels = [torch.rand(6, r, r, 3, generator=g) + 0.05 for r in res]
+    base = torch.rand(6, 16, 16, 3, generator=g) + 0.05
+    return base, levels
+
+
+@pytest.mark.parametrize("mode", ["pbr", "diffuse", "specular"])
+def test_shade_fwd_bwd(cuda, mode):
+    import geosplatting_amd as gs
+    sc, cam = sphere_case(3, 64)
+    N = sc.splats.num
+    base, levels = _random_env()
+    g = torch.Generator().manual_seed(11)
+    # stress directions: perturb normals so that footprints hit cube edges and corners too
+    normals = torch.nn.functional.normalize(sc.normals + 0.3 * torch.randn(N, 3, generator=g), dim=-1)
+    normals[:64] = torch.nn.functional.normalize(torch.sign(torch.randn(64, 3, generator=g)) +
+                                                 0.01 * torch.randn(64, 3, generator=g), dim=-1)
+    ks = sc.ks.clone(); ks[:32, 0] = 1.0; ks[32:64, 0] = 0.0           # roughness extremes (mip clamp ends)
+    cam_pos = cam.c2w[:, 3].contiguous()
+    lut = gs.get_fg_lut(torch.device("cpu"))[0].numpy()
+    ref = oracle.shade_fwd(sc.splats.means.numpy(), normals.numpy(), sc.kd.numpy(), ks.numpy(), cam_pos.numpy(), lut,
+                           base.numpy(), [l.numpy() for l in levels], mode=mode)
+    d = lambda x: x.clone().to(cuda).requires_grad_(True)
+    tm, tn, tkd, tks = d(sc.splats.means), d(normals), d(sc.kd), d(ks)
+    tb = d(base); tl = [d(l) for l in levels]
+    env = gs.TextureSplitSum(tb, tl)
+    col = gs.shade(tm, tn, tkd, tks, cam_pos.to(cuda), env, min_roughness=0.1, max_metallic=1.0, mode=mode)
+    assert rel_err(col.detach().cpu().numpy(), ref) < TOL
+    vc = torch.rand(N, 3, generator=g) * 2 - 1
+    (col * vc.to(cuda)).sum().backward()
+    gref = oracle.shade_bwd(sc.splats.means.numpy(), normals.numpy(), sc.kd.numpy(), ks.numpy(), cam_pos.numpy(), lut,
+                            base.numpy(), [l.numpy() for l in levels], vc.numpy(), mode=mode)
+    z = lambda t: np.zeros(t.shape, np.float32) if t.grad is None else t.grad.cpu().numpy()
+    for name, tens in (("v_means", tm), ("v_normals", tn), ("v_kd", tkd), ("v_ks", tks), ("v_base", tb)):
+        if np.abs(gref[name]).max() == 0:
+            assert np.abs(z(tens)).max() == 0, name
+        else:
+            assert rel_err(z(tens), gref[name]) < TOL, name
+    for i, (a, b) in enumerate(zip(tl, gref["v_levels"])):
+        if np.abs(b).max() == 0:
+            assert np.abs(z(a)).max() == 0
+        else:
+            assert rel_err(z(a), b) < TOL, f"v_levels[{i}]"
+
+
+@pytest.mark.parametrize("tone", ["naive", "aces", "none"])
+def test_tonemap(cuda, tone):
+    import geosplatting_amd as gs
+    g = torch.Generator().manual_seed(1)
+    rgba = torch.rand(37, 41, 4, generator=g) * 1.6            # crosses the soft clamp at 1
+    e = 1.3
+    ref = oracle.tonemap_fwd(rgba.numpy(), e, tone)
+    x = rgba.clone().to(cuda).requires_grad_(True); et = torch.tensor(e, device=cuda, requires_grad=True)
+    out = gs.tone_map(x, et, tone)
+    assert rel_err(out.detach().cpu().numpy(), ref) < 1e-5
+    v = torch.rand(37, 41, 4, generator=g) * 2 - 1
+    (out * v.to(cuda)).sum().backward()
+    v_rgba, v_e = oracle.tonemap_bwd(rgba.numpy(), e, v.numpy(), tone)
+    assert rel_err(x.grad.cpu().numpy(), v_rgba) < 1e-5
+    assert abs(et.grad.item() - v_e) < 1e-4 * max(1.0, abs(v_e))
+
+
+def test_as_splitsum_fwd_bwd(cuda):
+    """S5 on a 64^2 cubemap (levels 64/32/16 + diffuse base): forward and cubemap gradient vs oracle."""
+    import geosplatting_amd as gs
+    import geosplatting_amd.synthetic as syn
+    cube = syn.make_cubemap(64, seed=2)
+    base_r, levels_r, saved = oracle.as_splitsum(cube.numpy())
+    x = cube.clone().to(cuda).requires_grad_(True)
+    env = gs.as_splitsum(x)
+    assert len(env.levels) == 3 and env.base.shape == (6, 16, 16, 3)
+    assert rel_err(env.base.detach().cpu().numpy(), base_r) < TOL
+    for a, b in zip(env.levels, levels_r):
+        assert rel_err(a.detach().cpu().numpy(), b) < TOL
+    g = torch.Generator().manual_seed(9)
+    vb = torch.rand(6, 16, 16, 3, generator=g) - 0.5
+    vl = [torch.rand(*l.shape, generator=g) - 0.5 for l in env.levels]
+    loss = (env.base * vb.to(cuda)).sum()
+    for l, v in zip(env.levels, vl):
+        loss = loss + (l * v.to(cuda)).sum()
+    loss.backward()
+    gref = oracle.as_splitsum_bwd(saved, vb.numpy(), [v.numpy() for v in vl])
+    assert rel_err(x.grad.cpu().numpy(), gref) < TOL
+    # atlas packing round trip (reference layout [6,4,R,R])
+    atlas = env.mipmaps
+    assert atlas.shape == (6, 4, 64, 64)
+    back = gs.TextureSplitSum.from_atlas(env.base, atlas, 3)
+    for a, b in zip(back.levels, env.levels):
+        assert torch.equal(a, b)
+
+
+def test_splat_end_to_end(cuda):
+    """RenderableAttrs.splat: shade -> rasterize -> tone-map, forward image and all parameter gradients."""
+    import geosplatting_amd as gs
+    sc, cam = sphere_case(3, 96)
+    N = sc.splats.num
+    base, levels = _random_env()
+    W = H = 96
+    exposure = 1.2
+    lut = gs.get_fg_lut(torch.device("cpu"))[0].numpy()
+    means, quats, scales, opac = activated(sc.splats)
+    cam_pos = cam.c2w[:, 3].numpy()
+    lv = [l.numpy() for l in levels]
+    # oracle chain
+    col = oracle.shade_fwd(means, sc.normals.numpy(), sc.kd.numpy(), sc.ks.numpy(), cam_pos, lut, base.numpy(), lv)
+    vm, K = cam.view_matrix.numpy(), cam.intrinsic_matrix.numpy()
+    m = oracle.rasterization(means, quats, scales, opac, col, vm, K, W, H)
+    rgba = np.concatenate([m["render"], m["alphas"][..., None]], -1)
+    img_ref = oracle.tonemap_fwd(rgba, exposure, "naive")
+    # HIP chain
+    d = lambda x: x.clone().to(cuda).requires_grad_(True)
+    sp = sc.splats
+    class G: pass
+    gsn = G(); gsn.means = d(sp.means); gsn.scales = d(sp.scales); gsn.quats = d(sp.quats); gsn.opacities = d(sp.opacities)
+    attrs = gs.RenderableAttrs(kd=d(sc.kd), ks=d(sc.ks), normals=d(sc.normals))
+    tb = d(base); tl = [d(l) for l in levels]
+    et = torch.tensor(exposure, device=cuda, requires_grad=True)
+    img = attrs.splat(gsn, [cam], exposure=et, envmap=gs.TextureSplitSum(tb, tl), min_roughness=0.1, max_metallic=1.0)
+    assert img.shape == (H, W, 4)
+    amb = m["ambiguous"]
+    assert rel_err(img.detach().cpu().numpy()[~amb], img_ref[~amb]) < TOL
+    # backward
+    g = torch.Generator().manual_seed(3)
+    v = torch.rand(H, W, 4, generator=g) * 2 - 1
+    v[torch.tensor(amb)] = 0
+    (img * v.to(cuda)).sum().backward()
+    v_rgba, v_e = oracle.tonemap_bwd(rgba, exposure, v.numpy(), "naive")
+    gr = oracle.rasterization_bwd(means, quats, scales, opac, col, vm, K, W, H, m, v_rgba[..., :3], v_rgba[..., 3])
+    gs_ = oracle.shade_bwd(means, sc.normals.numpy(), sc.kd.numpy(), sc.ks.numpy(), cam_pos, lut, base.numpy(), lv,
+                           gr["v_colors"])
+    # chain through the activations (exp / sigmoid) done by render_rgba
+    v_means = gr["v_means"] + gs_["v_means"]
+    v_logscale = gr["v_scales"] * scales
+    v_logit = (gr["v_opacities"] * opac * (1 - opac))[:, None]
+    assert abs(et.grad.item() - v_e) < 2e-4 * max(1.0, abs(v_e))
+    for name, got, want in (("means", gsn.means.grad, v_means), ("scales", gsn.scales.grad, v_logscale),
+                            ("quats", gsn.quats.grad, gr["v_quats"]), ("opacities", gsn.opacities.grad, v_logit),
+                            ("kd", attrs.kd.grad, gs_["v_kd"]), ("ks", attrs.ks.grad, gs_["v_ks"]),
+                            ("normals", attrs.normals.grad, gs_["v_normals"])):
+        assert rel_err(got.cpu().numpy(), want) < 2e-4, name
+    for i, (a, b) in enumerate(zip(tl, gs_["v_levels"])):
+        assert rel_err(a.grad.cpu().numpy(), b) < 2e-4, f"level {i}"
+    assert tb.grad is None or float(tb.grad.abs().max()) == 0.0     # 'pbr' never uses the diffuse lookup
+
+
+def test_splat_errors(cuda):
+    import geosplatting_amd as gs
+    sc, cam = sphere_case(1, 32)
+    base, levels = _random_env()
+    env = gs.TextureSplitSum(base.to(cuda), [l.to(cuda) for l in levels])
+    sp = sc.splats.to(cuda)
+    attrs = gs.RenderableAttrs(kd=sc.kd.to(cuda), ks=sc.ks.to(cuda), normals=sc.normals.to(cuda))
+    e = torch.tensor(1.0, device=cuda)
+    with pytest.raises(ValueError):
+        attrs.splat(sp, [cam], exposure=e, envmap=env, min_roughness=0.1, max_metallic=1.0, mode="bogus")
+    with pytest.raises(ValueError):
+        attrs.splat(sp, [cam], exposure=e, envmap=env, min_roughness=0.1, max_metallic=1.0, tone_type="bogus")
+    attrs_back = gs.RenderableAttrs(kd=attrs.kd, ks=attrs.ks, normals=-sp.means / sp.means.norm(dim=-1, keepdim=True) * 0 - cam.c2w[:, 3].to(cuda))
+    with pytest.raises(ValueError, match="No valid splat"):
+        attrs_back.splat(sp, [cam], exposure=e, envmap=env, min_roughness=0.1, max_metallic=1.0, culling=True)
+    img = attrs.splat(sp, [cam], exposure=e, envmap=env, min_roughness=0.1, max_metallic=1.0, culling=True)
+    assert img.shape == (32, 32, 4)

@@ -163,7 +163,8 @@ __device__ __forceinline__ void tile_range_exact(float mx, float my, int radius,
     x1 = fx1 < 0.0f ? 0 : (fx1 > (float)tw ? tw : (int)fx1);
     y1 = fy1 < 0.0f ? 0 : (fy1 > (float)th ? th : (int)fy1);
 }
-#pragma clang fp contract(fast)
+// (contraction stays off for the rest of the file: the backward mirrors the oracle's rounding as well;
+//  every kernel here is HBM-bound, the lost FMAs are free)
 
 // ---------------------------------------------------------------------------------------------------
 // Chained-scan state (one per launch, zeroed by hipMemsetAsync before the launch):

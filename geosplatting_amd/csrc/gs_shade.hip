@@ -11,6 +11,11 @@
 // ~25 MB).  The backward recomputes the forward (no saved state) and scatters texel gradients with fp32
 // atomics.  HBM-bound by design; cube-map texel semantics are documented in oracle/gs_oracle_shade.c.
 #include "gs_common.h"
+
+// Contraction OFF for the whole file: texel / LUT-cell / lobe-membership selection are discontinuous in the
+// coordinates, so the coordinates are computed in the same one-rounding-per-operation order as the CPU oracle
+// (these kernels are memory-bound; the lost FMAs cost nothing measurable).
+#pragma clang fp contract(off)
 #include "gs_cube.h"
 
 struct EnvDev {

@@ -9,6 +9,11 @@
 // over input texels (no atomics, deterministic); the specular backward scatters with hardware fp32
 // atomics like the reference.
 #include "gs_common.h"
+
+// Contraction OFF for the whole file: texel / LUT-cell / lobe-membership selection are discontinuous in the
+// coordinates, so the coordinates are computed in the same one-rounding-per-operation order as the CPU oracle
+// (these kernels are memory-bound; the lost FMAs cost nothing measurable).
+#pragma clang fp contract(off)
 #include "gs_cube.h"
 
 __device__ __forceinline__ float pixel_area(int x, int y, int N)

@@ -3,15 +3,18 @@
 // rfstudio/model/gsplat.py:334-355; constants and loop semantics in SURVEY.md section 8a rows A5/A6).
 //
 // CDNA4 mapping (not the upstream 256-thread-block / shared-memory-batch design):
+//   * STREAM: after the sort, one pass gathers every intersection's geometry (+ colour for D<=3) into a
+//     record stream laid out in SORTED order (3 x float4 per intersection, SoA).  The compositor then never
+//     chases an index: a wave reads 64 consecutive records with three 1-KiB coalesced loads, and the next
+//     batch is prefetched into registers while the current one is composited.
 //   * a 16x16 tile is split into four 8x8 QUADRANTS, one wave64 each; a wave never synchronises with the
 //     other three -- no LDS staging, no __syncthreads, each wave stops as soon as ITS 64 pixels are opaque;
-//   * the tile's sorted list is walked 64 entries at a time: lane l fetches entry l (coalesced index read,
-//     gathered 24-byte geometry), tests the Gaussian's alpha>=1/255 extent against the quadrant rectangle,
-//     and a 64-bit ballot compacts the survivors;
-//   * survivors are broadcast lane->SGPR with v_readlane (no LDS round trip) and evaluated by all 64
-//     pixel lanes.  Surface-aligned splats are ~2-6 px wide, so the ballot removes most of the
-//     (pixel, Gaussian) pairs a 256-pixel block would evaluate; it is exact because a culled Gaussian
-//     has alpha < 1/255 at every pixel centre of the quadrant and would have been skipped anyway.
+//   * lane l of a batch tests record l's {alpha >= 1/255} extent (precomputed in the stream) against the
+//     quadrant rectangle; a 64-bit ballot compacts the survivors, which are broadcast lane->SGPR with
+//     v_readlane and evaluated by all 64 pixel lanes.  Exact: a culled Gaussian has alpha < 1/255 at every
+//     pixel centre of the quadrant and the reference semantics would skip it anyway.
+//   * tiles are launched longest-list-first (LPT order from a single-block bucketing kernel) so that the
+//     silhouette tiles, whose lists are 4x the mean, do not form the tail of the launch;
 //   * backward: same walk back-to-front from the wave's max(last_ids); per-Gaussian partials are summed
 //     across the wave with DPP row operations and ONE lane issues the fp32 atomics.
 // Both kernels are FP32-VALU / transcendental bound (one v_exp_f32 per evaluated pair), not HBM bound.
@@ -35,16 +38,85 @@ __device__ __forceinline__ bool alpha_extent(float ca, float cb, float cc, float
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// stream build: rec0 = {mx, my, 0.5a, b}, rec1 = {0.5c, opacity, hx, hy}, rec2 = {c0, c1, c2, bits(g)}
+// (hx < 0 marks "can never reach alpha_min").  One thread per sorted intersection.
+__global__ void __launch_bounds__(256)
+build_stream_kernel(int n_isects, int D, const int32_t* __restrict__ flatten_ids, const float* __restrict__ means2d,
+                    const float* __restrict__ conics, const float* __restrict__ opacities,
+                    const float* __restrict__ colors, float4* __restrict__ rec0, float4* __restrict__ rec1,
+                    float4* __restrict__ rec2)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_isects) return;
+    const int g = flatten_ids[i];
+    const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)g);
+    const float ca = conics[3 * (size_t)g], cb = conics[3 * (size_t)g + 1], cc = conics[3 * (size_t)g + 2];
+    const float op = opacities[g];
+    float hx = -1.0f, hy = -1.0f;
+    if (!alpha_extent(ca, cb, cc, op, hx, hy)) { hx = -1.0f; hy = -1.0f; }
+    rec0[i] = make_float4(m.x, m.y, 0.5f * ca, cb);
+    rec1[i] = make_float4(0.5f * cc, op, hx, hy);
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    if (D <= 3) {
+        c0 = colors[(size_t)g * D];
+        if (D > 1) c1 = colors[(size_t)g * D + 1];
+        if (D > 2) c2 = colors[(size_t)g * D + 2];
+    }
+    rec2[i] = make_float4(c0, c1, c2, __int_as_float(g));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LPT tile order: bucket tiles by floor(log2(count)) descending (single block).
+__global__ void __launch_bounds__(1024)
+tile_order_kernel(int n_tiles, int n_isects, const int32_t* __restrict__ offsets, int32_t* __restrict__ order)
+{
+    __shared__ int hist[32];
+    __shared__ int base[32];
+    if (threadIdx.x < 32) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+        const int cnt = ((t == n_tiles - 1) ? n_isects : offsets[t + 1]) - offsets[t];
+        const int b = cnt > 0 ? 31 - __clz(cnt) + 1 : 0;           // 0 = empty
+        atomicAdd(&hist[31 - b], 1);                                 // reversed: big buckets first
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int b = 0; b < 32; ++b) { base[b] = acc; acc += hist[b]; }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+        const int cnt = ((t == n_tiles - 1) ? n_isects : offsets[t + 1]) - offsets[t];
+        const int b = cnt > 0 ? 31 - __clz(cnt) + 1 : 0;
+        order[atomicAdd(&base[31 - b], 1)] = t;
+    }
+}
+
+struct Batch {
+    float4 r0, r1, r2;
+};
+
+__device__ __forceinline__ Batch load_batch(const float4* __restrict__ rec0, const float4* __restrict__ rec1,
+                                            const float4* __restrict__ rec2, int idx, bool in_range)
+{
+    Batch b;
+    b.r0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    b.r1 = make_float4(0.f, 0.f, -1.0f, -1.0f);
+    b.r2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in_range) { b.r0 = rec0[idx]; b.r1 = rec1[idx]; b.r2 = rec2[idx]; }
+    return b;
+}
+
 template <int CD>
 __global__ void __launch_bounds__(256)
-raster_fwd_kernel(int W, int H, int tile_w, int n_tiles, int D,
-                  const float* __restrict__ means2d, const float* __restrict__ conics,
-                  const float* __restrict__ opacities, const float* __restrict__ colors,
-                  const float* __restrict__ background, int n_isects,
-                  const int32_t* __restrict__ offsets, const int32_t* __restrict__ flatten_ids,
+raster_fwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* __restrict__ tile_order,
+                  const float4* __restrict__ rec0, const float4* __restrict__ rec1, const float4* __restrict__ rec2,
+                  const float* __restrict__ colors, const float* __restrict__ background, int n_isects,
+                  const int32_t* __restrict__ offsets,
                   float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids)
 {
-    const int tile = blockIdx.x;
+    const int tile = tile_order[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tx = tile % tile_w, ty = tile / tile_w;
     const int qx0 = tx * GS_TILE + (wave & 1) * 8, qy0 = ty * GS_TILE + (wave >> 1) * 8;
@@ -64,29 +136,29 @@ raster_fwd_kernel(int W, int H, int tile_w, int n_tiles, int D,
 #pragma unroll
     for (int k = 0; k < CD; ++k) pix[k] = 0.0f;
 
+    Batch nxt = load_batch(rec0, rec1, rec2, start + lane, start + lane < end);
     for (int base = start; base < end; base += 64) {
         if (__ballot(!done) == 0ull) break;
-        const int idx = base + lane;
-        bool hit = false;
-        int g = 0;
-        float mx = 0.f, my = 0.f, ha = 0.f, cb = 0.f, hc = 0.f, op = 0.f;
-        if (idx < end) {
-            g = flatten_ids[idx];
-            const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)g);
-            const float ca = conics[3 * (size_t)g], cc = conics[3 * (size_t)g + 2];
-            cb = conics[3 * (size_t)g + 1];
-            op = opacities[g];
-            mx = m.x; my = m.y;
-            float hx, hy;
-            if (alpha_extent(ca, cb, cc, op, hx, hy))
-                hit = (mx + hx >= rx0) && (mx - hx <= rx1) && (my + hy >= ry0) && (my - hy <= ry1);
-            ha = 0.5f * ca; hc = 0.5f * cc;
+        const Batch cur = nxt;
+        {   // prefetch the next 64 records while this batch is composited
+            const int nidx = base + 64 + lane;
+            nxt = load_batch(rec0, rec1, rec2, nidx, nidx < end);
         }
+        const float mx = cur.r0.x, my = cur.r0.y, ha = cur.r0.z, cb = cur.r0.w;
+        const float hc = cur.r1.x, op = cur.r1.y, hx = cur.r1.z, hy = cur.r1.w;
+        const bool hit = (hx >= 0.0f) && (mx + hx >= rx0) && (mx - hx <= rx1) && (my + hy >= ry0) && (my - hy <= ry1);
         unsigned long long mask = __ballot(hit);
         if (mask == 0ull) continue;
         float col[CD];
+        if (CD <= 3) {
+            col[0] = cur.r2.x;
+            if (CD > 1) col[1] = cur.r2.y;
+            if (CD > 2) col[2] = cur.r2.z;
+        } else {
+            const int g = __float_as_int(cur.r2.w);
 #pragma unroll
-        for (int k = 0; k < CD; ++k) col[k] = (hit && k < D) ? colors[(size_t)g * D + k] : 0.0f;
+            for (int k = 0; k < CD; ++k) col[k] = (hit && k < D) ? colors[(size_t)g * D + k] : 0.0f;
+        }
 
         while (mask) {
             const int j = __builtin_ctzll(mask);
@@ -124,17 +196,16 @@ raster_fwd_kernel(int W, int H, int tile_w, int n_tiles, int D,
 
 template <int CD>
 __global__ void __launch_bounds__(256)
-raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D,
-                  const float* __restrict__ means2d, const float* __restrict__ conics,
-                  const float* __restrict__ opacities, const float* __restrict__ colors,
-                  const float* __restrict__ background, int n_isects,
-                  const int32_t* __restrict__ offsets, const int32_t* __restrict__ flatten_ids,
+raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* __restrict__ tile_order,
+                  const float4* __restrict__ rec0, const float4* __restrict__ rec1, const float4* __restrict__ rec2,
+                  const float* __restrict__ colors, const float* __restrict__ background, int n_isects,
+                  const int32_t* __restrict__ offsets,
                   const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
                   const float* __restrict__ v_render, const float* __restrict__ v_alphas,
                   float* __restrict__ v_means2d, float* __restrict__ v_conics, float* __restrict__ v_colors,
                   float* __restrict__ v_opacities)
 {
-    const int tile = blockIdx.x;
+    const int tile = tile_order[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tx = tile % tile_w, ty = tile / tile_w;
     const int qx0 = tx * GS_TILE + (wave & 1) * 8, qy0 = ty * GS_TILE + (wave >> 1) * 8;
@@ -173,36 +244,38 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D,
     for (int off = 32; off >= 1; off >>= 1) top = max(top, __shfl_xor(top, off, 64));
     if (top >= end) top = end - 1;
 
+    Batch nxt = load_batch(rec0, rec1, rec2, top - lane, top - lane >= start);
     for (; top >= start; top -= 64) {
-        const int idx = top - lane;
-        bool hit = false;
-        int g = 0;
-        float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, op = 0.f;
-        if (idx >= start) {
-            g = flatten_ids[idx];
-            const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)g);
-            ca = conics[3 * (size_t)g]; cb = conics[3 * (size_t)g + 1]; cc = conics[3 * (size_t)g + 2];
-            op = opacities[g];
-            mx = m.x; my = m.y;
-            float hx, hy;
-            if (alpha_extent(ca, cb, cc, op, hx, hy))
-                hit = (mx + hx >= rx0) && (mx - hx <= rx1) && (my + hy >= ry0) && (my - hy <= ry1);
+        const Batch cur = nxt;
+        {
+            const int nidx = top - 64 - lane;
+            nxt = load_batch(rec0, rec1, rec2, nidx, nidx >= start);
         }
+        const float mx = cur.r0.x, my = cur.r0.y, ha = cur.r0.z, cb = cur.r0.w;
+        const float hc = cur.r1.x, op = cur.r1.y, hx = cur.r1.z, hy = cur.r1.w;
+        const int g = __float_as_int(cur.r2.w);
+        const bool hit = (hx >= 0.0f) && (mx + hx >= rx0) && (mx - hx <= rx1) && (my + hy >= ry0) && (my - hy <= ry1);
         unsigned long long mask = __ballot(hit);
         if (mask == 0ull) continue;
         float col[CD];
+        if (CD <= 3) {
+            col[0] = cur.r2.x;
+            if (CD > 1) col[1] = cur.r2.y;
+            if (CD > 2) col[2] = cur.r2.z;
+        } else {
 #pragma unroll
-        for (int k = 0; k < CD; ++k) col[k] = (hit && k < D) ? colors[(size_t)g * D + k] : 0.0f;
+            for (int k = 0; k < CD; ++k) col[k] = (hit && k < D) ? colors[(size_t)g * D + k] : 0.0f;
+        }
 
         while (mask) {
             const int j = __builtin_ctzll(mask);
             mask &= mask - 1ull;
             const int idxj = top - j;
             const float gx = gs_readlane(mx, j), gy = gs_readlane(my, j);
-            const float ga = gs_readlane(ca, j), gb = gs_readlane(cb, j), gc = gs_readlane(cc, j);
+            const float ga = gs_readlane(ha, j), gb = gs_readlane(cb, j), gc = gs_readlane(hc, j);
             const float go = gs_readlane(op, j);
             const float dx = gx - px, dy = gy - py;
-            const float t0 = (0.5f * ga) * dx, t1 = (0.5f * gc) * dy, t2 = gb * dx;
+            const float t0 = ga * dx, t1 = gc * dy, t2 = gb * dx;
             const float sigma = fmaf(t0, dx, fmaf(t1, dy, t2 * dy));
             const float vis = __expf(-sigma);
             const float alpha = fminf(0.999f, go * vis);
@@ -234,8 +307,8 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D,
                     p_c0 = 0.5f * v_sigma * dx * dx;
                     p_c1 = v_sigma * dx * dy;
                     p_c2 = 0.5f * v_sigma * dy * dy;
-                    p_xy0 = v_sigma * (ga * dx + gb * dy);
-                    p_xy1 = v_sigma * (gb * dx + gc * dy);
+                    p_xy0 = v_sigma * ((2.0f * ga) * dx + gb * dy);
+                    p_xy1 = v_sigma * (gb * dx + (2.0f * gc) * dy);
                     p_o = vis * v_alpha;
                 }
 #pragma unroll
@@ -264,15 +337,42 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D,
 }
 
 // ---------------------------------------------------------------------------------------------------
+// workspace layout: [rec0 | rec1 | rec2 | tile_order], every segment 256-byte aligned
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t gs_raster_ws_bytes(int64_t n_isects, int W, int H, int tile_size)
+{
+    if (tile_size <= 0) return 0;
+    const size_t tiles = (size_t)((W + tile_size - 1) / tile_size) * (size_t)((H + tile_size - 1) / tile_size);
+    const size_t n = n_isects > 0 ? (size_t)n_isects : 1;
+    return 3 * align256(n * sizeof(float4)) + align256(tiles * sizeof(int32_t));
+}
+
+struct RasterWs {
+    float4 *rec0, *rec1, *rec2;
+    int32_t* order;
+};
+static RasterWs carve(void* ws, int64_t n_isects, int tiles)
+{
+    const size_t n = n_isects > 0 ? (size_t)n_isects : 1;
+    char* p = (char*)ws;
+    RasterWs r;
+    r.rec0 = (float4*)p; p += align256(n * sizeof(float4));
+    r.rec1 = (float4*)p; p += align256(n * sizeof(float4));
+    r.rec2 = (float4*)p; p += align256(n * sizeof(float4));
+    r.order = (int32_t*)p;
+    return r;
+}
+
 template <int CD>
-static int launch_fwd(int W, int H, int D, const float* means2d, const float* conics, const float* opacities,
-                      const float* colors, const float* background, int64_t n_isects, const int32_t* offsets,
-                      const int32_t* flatten_ids, float* render, float* alphas, int32_t* last_ids, hipStream_t s)
+static int launch_fwd(int W, int H, int D, const RasterWs& ws, const float* colors, const float* background,
+                      int64_t n_isects, const int32_t* offsets, float* render, float* alphas, int32_t* last_ids,
+                      hipStream_t s)
 {
     const int tile_w = (W + GS_TILE - 1) / GS_TILE, tile_h = (H + GS_TILE - 1) / GS_TILE;
     hipLaunchKernelGGL(raster_fwd_kernel<CD>, dim3(tile_w * tile_h), dim3(256), 0, s, W, H, tile_w, tile_w * tile_h, D,
-                       means2d, conics, opacities, colors, background, (int)n_isects, offsets, flatten_ids, render,
-                       alphas, last_ids);
+                       ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, (int)n_isects, offsets, render, alphas,
+                       last_ids);
     GS_CHECK_LAUNCH();
     return GS_OK;
 }
@@ -280,14 +380,25 @@ static int launch_fwd(int W, int H, int D, const float* means2d, const float* co
 extern "C" int gs_raster_fwd(int W, int H, int tile_size, int D, const float* means2d, const float* conics,
                              const float* opacities, const float* colors, const float* background,
                              int64_t n_isects, const int32_t* offsets, const int32_t* flatten_ids,
-                             float* render, float* alphas, int32_t* last_ids, void* stream)
+                             float* render, float* alphas, int32_t* last_ids, void* ws, size_t ws_bytes, void* stream)
 {
     GS_CHECK_ARG(W > 0 && H > 0, "bad image size");
     GS_CHECK_ARG(tile_size == GS_TILE, "only tile_size=16 is built (rfstudio/model/gsplat.py:30)");
     GS_CHECK_ARG(D >= 1 && D <= GS_MAX_CHANNELS, "1 <= D <= 32");
     GS_CHECK_ARG(n_isects >= 0 && n_isects < (1ll << 31), "n_isects must fit int32");
+    GS_CHECK_ARG(ws != nullptr, "workspace must not be NULL");
+    if (ws_bytes < gs_raster_ws_bytes(n_isects, W, H, tile_size)) { gs_set_error("gs_raster_fwd: workspace too small"); return GS_ENOSPC; }
     hipStream_t s = (hipStream_t)stream;
-#define GS_FWD(CD) return launch_fwd<CD>(W, H, D, means2d, conics, opacities, colors, background, n_isects, offsets, flatten_ids, render, alphas, last_ids, s)
+    const int tiles = ((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
+    const RasterWs r = carve(ws, n_isects, tiles);
+    if (n_isects > 0) {
+        hipLaunchKernelGGL(build_stream_kernel, dim3(gs_cdiv(n_isects, 256)), dim3(256), 0, s, (int)n_isects, D, flatten_ids,
+                           means2d, conics, opacities, colors, r.rec0, r.rec1, r.rec2);
+        GS_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, tiles, (int)n_isects, offsets, r.order);
+    GS_CHECK_LAUNCH();
+#define GS_FWD(CD) return launch_fwd<CD>(W, H, D, r, colors, background, n_isects, offsets, render, alphas, last_ids, s)
     if (D <= 3) GS_FWD(3);
     if (D <= 4) GS_FWD(4);
     if (D <= 8) GS_FWD(8);
@@ -297,31 +408,30 @@ extern "C" int gs_raster_fwd(int W, int H, int tile_size, int D, const float* me
 }
 
 template <int CD>
-static int launch_bwd(int W, int H, int D, const float* means2d, const float* conics, const float* opacities,
-                      const float* colors, const float* background, int64_t n_isects, const int32_t* offsets,
-                      const int32_t* flatten_ids, const float* alphas, const int32_t* last_ids, const float* v_render,
-                      const float* v_alphas, float* v_means2d, float* v_conics, float* v_colors, float* v_opacities,
-                      hipStream_t s)
+static int launch_bwd(int W, int H, int D, const RasterWs& ws, const float* colors, const float* background,
+                      int64_t n_isects, const int32_t* offsets, const float* alphas, const int32_t* last_ids,
+                      const float* v_render, const float* v_alphas, float* v_means2d, float* v_conics, float* v_colors,
+                      float* v_opacities, hipStream_t s)
 {
     const int tile_w = (W + GS_TILE - 1) / GS_TILE, tile_h = (H + GS_TILE - 1) / GS_TILE;
     hipLaunchKernelGGL(raster_bwd_kernel<CD>, dim3(tile_w * tile_h), dim3(256), 0, s, W, H, tile_w, tile_w * tile_h, D,
-                       means2d, conics, opacities, colors, background, (int)n_isects, offsets, flatten_ids, alphas,
-                       last_ids, v_render, v_alphas, v_means2d, v_conics, v_colors, v_opacities);
+                       ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, (int)n_isects, offsets, alphas, last_ids,
+                       v_render, v_alphas, v_means2d, v_conics, v_colors, v_opacities);
     GS_CHECK_LAUNCH();
     return GS_OK;
 }
 
-extern "C" int gs_raster_bwd(int W, int H, int tile_size, int D, int V, const float* means2d, const float* conics,
-                             const float* opacities, const float* colors, const float* background,
-                             int64_t n_isects, const int32_t* offsets, const int32_t* flatten_ids,
-                             const float* alphas, const int32_t* last_ids, const float* v_render,
-                             const float* v_alphas, float* v_means2d, float* v_conics, float* v_colors,
-                             float* v_opacities, void* stream)
+extern "C" int gs_raster_bwd(int W, int H, int tile_size, int D, int V, const float* colors, const float* background,
+                             int64_t n_isects, const int32_t* offsets, const float* alphas, const int32_t* last_ids,
+                             const float* v_render, const float* v_alphas, float* v_means2d, float* v_conics,
+                             float* v_colors, float* v_opacities, const void* ws, size_t ws_bytes, void* stream)
 {
     GS_CHECK_ARG(W > 0 && H > 0 && V >= 0, "bad sizes");
     GS_CHECK_ARG(tile_size == GS_TILE, "only tile_size=16 is built (rfstudio/model/gsplat.py:30)");
     GS_CHECK_ARG(D >= 1 && D <= GS_MAX_CHANNELS, "1 <= D <= 32");
     GS_CHECK_ARG(n_isects >= 0 && n_isects < (1ll << 31), "n_isects must fit int32");
+    GS_CHECK_ARG(ws != nullptr, "workspace (the stream written by gs_raster_fwd) must not be NULL");
+    if (ws_bytes < gs_raster_ws_bytes(n_isects, W, H, tile_size)) { gs_set_error("gs_raster_bwd: workspace too small"); return GS_ENOSPC; }
     hipStream_t s = (hipStream_t)stream;
     if (V > 0) {
         GS_CHECK_HIP(hipMemsetAsync(v_means2d, 0, sizeof(float) * 2 * (size_t)V, s));
@@ -330,7 +440,9 @@ extern "C" int gs_raster_bwd(int W, int H, int tile_size, int D, int V, const fl
         GS_CHECK_HIP(hipMemsetAsync(v_opacities, 0, sizeof(float) * (size_t)V, s));
     }
     if (n_isects == 0 || V == 0) return GS_OK;
-#define GS_BWD(CD) return launch_bwd<CD>(W, H, D, means2d, conics, opacities, colors, background, n_isects, offsets, flatten_ids, alphas, last_ids, v_render, v_alphas, v_means2d, v_conics, v_colors, v_opacities, s)
+    const int tiles = ((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
+    const RasterWs r = carve((void*)ws, n_isects, tiles);
+#define GS_BWD(CD) return launch_bwd<CD>(W, H, D, r, colors, background, n_isects, offsets, alphas, last_ids, v_render, v_alphas, v_means2d, v_conics, v_colors, v_opacities, s)
     if (D <= 3) GS_BWD(3);
     if (D <= 4) GS_BWD(4);
     if (D <= 8) GS_BWD(8);

@@ -29,6 +29,11 @@ struct EnvDev {
 struct EnvGradDev {
     float* base;
     float* levels[GS_MAX_LEVELS];
+    // LDS privatisation of the small, heavily contended levels: float offset into the block's LDS
+    // accumulator or -1 (accumulate straight into HBM with atomics)
+    int lds_base;
+    int lds_level[GS_MAX_LEVELS];
+    int lds_floats;
 };
 
 __device__ __forceinline__ void tex2d_linear_clamp2(const float* __restrict__ lut, int W, int H, float u, float v,
@@ -175,89 +180,130 @@ shade_fwd_kernel(int N, const float* __restrict__ means, const float* __restrict
     colors[3 * (size_t)n] = color[0]; colors[3 * (size_t)n + 1] = color[1]; colors[3 * (size_t)n + 2] = color[2];
 }
 
-__global__ void __launch_bounds__(256)
+// scatter into an LDS-resident private copy (ds_add_f32) -- flushed once per block
+__device__ __forceinline__ void cube_scatter_lds(float* lds, const CubeFp& fp, const float* g, float scale)
+{
+    if (!fp.valid) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (fp.idx[i] < 0) continue;
+        const float w = scale * fp.w[i];
+        float* p = lds + (size_t)fp.idx[i] * 3;
+        atomicAdd(p, g[0] * w); atomicAdd(p + 1, g[1] * w); atomicAdd(p + 2, g[2] * w);
+    }
+}
+
+// Persistent blocks (one per CU: the private texel-gradient copies of the <=32^2 levels take ~90 KB of the
+// 160 KB LDS).  2 M Gaussians send ~13 M atomics at the 4 608 floats of the 16^2 level alone: in HBM/L2 that
+// serialises per address (5.5 ms per view measured); in LDS it is a ds_add_f32 and the block flushes its
+// copy once at the end.
+#define GS_SHADE_BWD_BLOCK 512
+__global__ void __launch_bounds__(GS_SHADE_BWD_BLOCK)
 shade_bwd_kernel(int N, const float* __restrict__ means, const float* __restrict__ normals,
                  const float* __restrict__ kd, const float* __restrict__ ks, const float* __restrict__ cam_pos,
                  float min_roughness, float max_metallic, int mode, EnvDev env, const float* __restrict__ v_colors,
                  float* __restrict__ v_means, float* __restrict__ v_normals, float* __restrict__ v_kd,
                  float* __restrict__ v_ks, EnvGradDev eg)
 {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const float mean[3] = { means[3 * (size_t)n], means[3 * (size_t)n + 1], means[3 * (size_t)n + 2] };
-    const float normal[3] = { normals[3 * (size_t)n], normals[3 * (size_t)n + 1], normals[3 * (size_t)n + 2] };
-    const float kdn[3] = { kd[3 * (size_t)n], kd[3 * (size_t)n + 1], kd[3 * (size_t)n + 2] };
-    const float2 ks2 = *reinterpret_cast<const float2*>(ks + 2 * (size_t)n);
-    const float ksn[2] = { ks2.x, ks2.y };
+    extern __shared__ __attribute__((aligned(16))) float s_grad[];
+    for (int i = threadIdx.x; i < eg.lds_floats; i += blockDim.x) s_grad[i] = 0.0f;
+    __syncthreads();
     const float cp[3] = { cam_pos[0], cam_pos[1], cam_pos[2] };
-    const float g[3] = { v_colors[3 * (size_t)n], v_colors[3 * (size_t)n + 1], v_colors[3 * (size_t)n + 2] };
-    ShadeTmp t;
-    float color[3];
-    shade_one<true>(mean, normal, kdn, ksn, cp, min_roughness, max_metallic, mode, env, color, t);
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        const float mean[3] = { means[3 * (size_t)n], means[3 * (size_t)n + 1], means[3 * (size_t)n + 2] };
+        const float normal[3] = { normals[3 * (size_t)n], normals[3 * (size_t)n + 1], normals[3 * (size_t)n + 2] };
+        const float kdn[3] = { kd[3 * (size_t)n], kd[3 * (size_t)n + 1], kd[3 * (size_t)n + 2] };
+        const float2 ks2 = *reinterpret_cast<const float2*>(ks + 2 * (size_t)n);
+        const float ksn[2] = { ks2.x, ks2.y };
+        const float g[3] = { v_colors[3 * (size_t)n], v_colors[3 * (size_t)n + 1], v_colors[3 * (size_t)n + 2] };
+        ShadeTmp t;
+        float color[3];
+        shade_one<true>(mean, normal, kdn, ksn, cp, min_roughness, max_metallic, mode, env, color, t);
 
-    float v_diff[3] = { 0, 0, 0 }, v_ls[3] = { 0, 0, 0 }, v_rf[3] = { 0, 0, 0 }, v_ld[3] = { 0, 0, 0 };
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        if (mode == GS_MODE_PBR)          { v_diff[c] = g[c]; v_ls[c] = g[c] * t.refl_c[c]; v_rf[c] = g[c] * t.ls.out[c]; }
-        else if (mode == GS_MODE_DIFFUSE) { v_ld[c] = g[c] * t.diff[c]; v_diff[c] = g[c] * t.ld[c]; }
-        else                              { v_ls[c] = g[c] * t.refl_c[c]; v_rf[c] = g[c] * t.ls.out[c]; }
-    }
-    float v_A = 0.0f, v_B = 0.0f, v_metal = 0.0f, o_kd[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float v_spec = v_rf[c] * t.fg[0];
-        v_A += v_rf[c] * t.spec[c];
-        v_B += v_rf[c];
-        o_kd[c] = v_spec * t.metal + v_diff[c] * (1.0f - t.metal);
-        v_metal += v_spec * (kdn[c] - 0.04f) - v_diff[c] * kdn[c];
-    }
-    const float v_ndv = v_A * t.dfg_du[0] + v_B * t.dfg_du[1];
-    float v_rough = v_A * t.dfg_dv[0] + v_B * t.dfg_dv[1];
-    float v_mip = 0.0f, v_refl[3] = { 0, 0, 0 }, v_n[3] = { 0, 0, 0 };
-    if (mode != GS_MODE_DIFFUSE) {
+        float v_diff[3] = { 0, 0, 0 }, v_ls[3] = { 0, 0, 0 }, v_rf[3] = { 0, 0, 0 }, v_ld[3] = { 0, 0, 0 };
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            v_mip += v_ls[c] * t.ls.dmip[c];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) v_refl[k] += v_ls[c] * t.ls.dd[c * 3 + k];
+            if (mode == GS_MODE_PBR)          { v_diff[c] = g[c]; v_ls[c] = g[c] * t.refl_c[c]; v_rf[c] = g[c] * t.ls.out[c]; }
+            else if (mode == GS_MODE_DIFFUSE) { v_ld[c] = g[c] * t.diff[c]; v_diff[c] = g[c] * t.ld[c]; }
+            else                              { v_ls[c] = g[c] * t.refl_c[c]; v_rf[c] = g[c] * t.ls.out[c]; }
         }
-    } else {
+        float v_A = 0.0f, v_B = 0.0f, v_metal = 0.0f, o_kd[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < 3; ++c) {
+            const float v_spec = v_rf[c] * t.fg[0];
+            v_A += v_rf[c] * t.spec[c];
+            v_B += v_rf[c];
+            o_kd[c] = v_spec * t.metal + v_diff[c] * (1.0f - t.metal);
+            v_metal += v_spec * (kdn[c] - 0.04f) - v_diff[c] * kdn[c];
+        }
+        const float v_ndv = v_A * t.dfg_du[0] + v_B * t.dfg_du[1];
+        float v_rough = v_A * t.dfg_dv[0] + v_B * t.dfg_dv[1];
+        float v_mip = 0.0f, v_refl[3] = { 0, 0, 0 }, v_n[3] = { 0, 0, 0 };
+        if (mode != GS_MODE_DIFFUSE) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) v_n[k] += v_ld[c] * t.ld_dd[c * 3 + k];
-    }
-    v_rough += v_mip * t.dmip_dr;
-    float v_d = 2.0f * (v_refl[0] * normal[0] + v_refl[1] * normal[1] + v_refl[2] * normal[2]);
-    float v_wo[3];
+            for (int c = 0; c < 3; ++c) {
+                v_mip += v_ls[c] * t.ls.dmip[c];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { v_n[k] += 2.0f * t.d * v_refl[k]; v_wo[k] = -v_refl[k]; }
-    if (t.d >= 1e-6f) v_d += v_ndv;
+                for (int k = 0; k < 3; ++k) v_refl[k] += v_ls[c] * t.ls.dd[c * 3 + k];
+            }
+        } else {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { v_n[k] += v_d * t.wo[k]; v_wo[k] += v_d * normal[k]; }
-    float o_mean[3] = { 0, 0, 0 };
-    if (!t.wo_const) {
-        const float dot = t.wo[0] * v_wo[0] + t.wo[1] * v_wo[1] + t.wo[2] * v_wo[2];
-        const float l = fmaxf(t.len, 1e-6f);
+            for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) o_mean[k] = -((v_wo[k] - t.wo[k] * dot) / l);
-    }
+                for (int k = 0; k < 3; ++k) v_n[k] += v_ld[c] * t.ld_dd[c * 3 + k];
+        }
+        v_rough += v_mip * t.dmip_dr;
+        float v_d = 2.0f * (v_refl[0] * normal[0] + v_refl[1] * normal[1] + v_refl[2] * normal[2]);
+        float v_wo[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        v_means[3 * (size_t)n + k] = o_mean[k];
-        v_normals[3 * (size_t)n + k] = v_n[k];
-        v_kd[3 * (size_t)n + k] = o_kd[k];
-    }
-    *reinterpret_cast<float2*>(v_ks + 2 * (size_t)n) = make_float2(v_rough * (1.0f - min_roughness), v_metal * max_metallic);
+        for (int k = 0; k < 3; ++k) { v_n[k] += 2.0f * t.d * v_refl[k]; v_wo[k] = -v_refl[k]; }
+        if (t.d >= 1e-6f) v_d += v_ndv;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { v_n[k] += v_d * t.wo[k]; v_wo[k] += v_d * normal[k]; }
+        float o_mean[3] = { 0, 0, 0 };
+        if (!t.wo_const) {
+            const float dot = t.wo[0] * v_wo[0] + t.wo[1] * v_wo[1] + t.wo[2] * v_wo[2];
+            const float l = fmaxf(t.len, 1e-6f);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) o_mean[k] = -((v_wo[k] - t.wo[k] * dot) / l);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            v_means[3 * (size_t)n + k] = o_mean[k];
+            v_normals[3 * (size_t)n + k] = v_n[k];
+            v_kd[3 * (size_t)n + k] = o_kd[k];
+        }
+        *reinterpret_cast<float2*>(v_ks + 2 * (size_t)n) = make_float2(v_rough * (1.0f - min_roughness), v_metal * max_metallic);
 
-    if (mode != GS_MODE_DIFFUSE) {
-        if (t.ls.l1 < 0) cube_scatter(eg.levels[t.ls.l0], t.ls.fp0, v_ls, 1.0f);
-        else {
-            cube_scatter(eg.levels[t.ls.l0], t.ls.fp0, v_ls, 1.0f - t.ls.f);
-            cube_scatter(eg.levels[t.ls.l1], t.ls.fp1, v_ls, t.ls.f);
+        if (mode != GS_MODE_DIFFUSE) {
+            const float w0 = (t.ls.l1 < 0) ? 1.0f : 1.0f - t.ls.f;
+            if (eg.lds_level[t.ls.l0] >= 0) cube_scatter_lds(s_grad + eg.lds_level[t.ls.l0], t.ls.fp0, v_ls, w0);
+            else                            cube_scatter(eg.levels[t.ls.l0], t.ls.fp0, v_ls, w0);
+            if (t.ls.l1 >= 0) {
+                if (eg.lds_level[t.ls.l1] >= 0) cube_scatter_lds(s_grad + eg.lds_level[t.ls.l1], t.ls.fp1, v_ls, t.ls.f);
+                else                            cube_scatter(eg.levels[t.ls.l1], t.ls.fp1, v_ls, t.ls.f);
+            }
+        } else {
+            if (eg.lds_base >= 0) cube_scatter_lds(s_grad + eg.lds_base, t.ld_fp, v_ld, 1.0f);
+            else                  cube_scatter(eg.base, t.ld_fp, v_ld, 1.0f);
         }
-    } else {
-        cube_scatter(eg.base, t.ld_fp, v_ld, 1.0f);
+    }
+    // ---- flush the private copies
+    __syncthreads();
+    if (eg.lds_base >= 0) {
+        const int cnt = 18 * env.base_res * env.base_res;
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const float v = s_grad[eg.lds_base + i];
+            if (v != 0.0f) gs_atomic_add(eg.base + i, v);
+        }
+    }
+    for (int l = 0; l < env.L; ++l) {
+        if (eg.lds_level[l] < 0) continue;
+        const int cnt = 18 * env.res[l] * env.res[l];
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const float v = s_grad[eg.lds_level[l] + i];
+            if (v != 0.0f) gs_atomic_add(eg.levels[l] + i, v);
+        }
     }
 }
 
@@ -302,9 +348,29 @@ extern "C" int gs_shade_bwd(int N, const float* means, const float* normals, con
     for (int l = 0; l < GS_MAX_LEVELS; ++l) eg.levels[l] = l < e.L ? env_grad->levels[l] : nullptr;
     if (mode == GS_MODE_DIFFUSE) GS_CHECK_ARG(eg.base != nullptr, "env_grad->base required in diffuse mode");
     else for (int l = 0; l < e.L; ++l) GS_CHECK_ARG(eg.levels[l] != nullptr, "env_grad->levels[l] required");
+    // LDS layout: privatise every level of at most 32^2 texels per face (and the diffuse base) within 128 KB
+    const int lds_budget_floats = 128 * 1024 / 4;
+    int used = 0;
+    eg.lds_base = -1;
+    for (int l = 0; l < GS_MAX_LEVELS; ++l) eg.lds_level[l] = -1;
+    if (mode == GS_MODE_DIFFUSE) {
+        const int cnt = 18 * e.base_res * e.base_res;
+        if (e.base_res <= 32 && used + cnt <= lds_budget_floats) { eg.lds_base = used; used += cnt; }
+    } else {
+        for (int l = e.L - 1; l >= 0; --l) {
+            const int cnt = 18 * e.res[l] * e.res[l];
+            if (e.res[l] <= 32 && used + cnt <= lds_budget_floats) { eg.lds_level[l] = used; used += cnt; }
+        }
+    }
+    eg.lds_floats = used;
     if (N == 0) return GS_OK;
-    hipLaunchKernelGGL(shade_bwd_kernel, dim3(gs_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, N, means, normals,
-                       kd, ks, cam_pos, min_roughness, max_metallic, mode, e, v_colors, v_means, v_normals, v_kd,
+    const size_t lds_bytes = (size_t)used * sizeof(float);
+    GS_CHECK_HIP(hipFuncSetAttribute((const void*)shade_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    int blocks = gs_cdiv(N, GS_SHADE_BWD_BLOCK);
+    const int max_blocks = used > 0 ? 256 : 2048;
+    if (blocks > max_blocks) blocks = max_blocks;
+    hipLaunchKernelGGL(shade_bwd_kernel, dim3(blocks), dim3(GS_SHADE_BWD_BLOCK), lds_bytes, (hipStream_t)stream, N, means,
+                       normals, kd, ks, cam_pos, min_roughness, max_metallic, mode, e, v_colors, v_means, v_normals, v_kd,
                        v_ks, eg);
     GS_CHECK_LAUNCH();
     return GS_OK;

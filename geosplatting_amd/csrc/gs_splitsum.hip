@@ -6,8 +6,8 @@
 //   _CubeMapMip fwd / bwd         rfstudio/graphics/_mesh/_texture.py:199-226
 // Launch shapes are re-derived for wave64: one thread per output texel in 64x4 blocks over a flat texel
 // index (the reference uses 8x8 blocks over (x,y,face)); the diffuse backward is formulated as a gather
-// over input texels (no atomics, deterministic); the specular backward scatters with hardware fp32
-// atomics like the reference.
+// over input texels (no atomics, deterministic); the specular backward is a gather too (lobe membership is symmetric),
+// so the whole prefilter backward is atomic-free and bit-reproducible.
 #include "gs_common.h"
 
 // Contraction OFF for the whole file: texel / LUT-cell / lobe-membership selection are discontinuous in the
@@ -131,18 +131,20 @@ extern "C" int gs_cubemap_mip_bwd(int R, const float* v_out, float* v_in, int ac
 
 // ---------------------------------------------------------------------------------------------------
 // diffuse: out[o] = sum_i cubemap[i] * clamp(N_o . L_i, 0, 0.999) * area_i / 3.141592
+// One 256-thread block per output texel; the 6*R*R inputs are strided over the threads and block-reduced
+// (the reference runs one thread per output over all inputs: 1 536 threads only at R=16 -- 6 blocks on a
+// 256-CU chip).  BWD is the same gather with the roles of input/output swapped (no atomics).
 template <bool BWD>
 __global__ void __launch_bounds__(256)
 diffuse_kernel(int R, const float* __restrict__ src, float* __restrict__ dst, int accumulate)
 {
     const int n = 6 * R * R;
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= n) return;
+    const int o = blockIdx.x;
     const int ox = o % R, oy = (o / R) % R, os = o / (R * R);
     float A[3]; cube_to_dir(ox, oy, os, R, A);
     const float pa_o = pixel_area(ox, oy, R);
     float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
-    for (int i = 0; i < n; ++i) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int x = i % R, y = (i / R) % R, s = i / (R * R);
         float B[3]; cube_to_dir(x, y, s, R, B);
         const float costheta = fminf(fmaxf(dot3(A, B), 0.0f), 0.999f);
@@ -151,14 +153,23 @@ diffuse_kernel(int R, const float* __restrict__ src, float* __restrict__ dst, in
         const float* t = src + (size_t)i * 3;
         c0 += t[0] * w; c1 += t[1] * w; c2 += t[2] * w;
     }
-    float* p = dst + (size_t)o * 3;
-    if (accumulate) { p[0] += c0; p[1] += c1; p[2] += c2; } else { p[0] = c0; p[1] = c1; p[2] = c2; }
+    c0 = gs_wave_sum(c0); c1 = gs_wave_sum(c1); c2 = gs_wave_sum(c2);
+    __shared__ float s_part[4][3];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_part[wave][0] = c0; s_part[wave][1] = c1; s_part[wave][2] = c2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+        for (int w = 0; w < 4; ++w) { r0 += s_part[w][0]; r1 += s_part[w][1]; r2 += s_part[w][2]; }
+        float* p = dst + (size_t)o * 3;
+        if (accumulate) { p[0] += r0; p[1] += r1; p[2] += r2; } else { p[0] = r0; p[1] = r1; p[2] = r2; }
+    }
 }
 
 extern "C" int gs_diffuse_cubemap_fwd(int R, const float* cubemap, float* out, void* stream)
 {
     GS_CHECK_ARG(R >= 1 && R <= 64, "diffuse prefilter expects the 16^2 level (R <= 64)");
-    hipLaunchKernelGGL(diffuse_kernel<false>, dim3(gs_cdiv(6 * R * R, 256)), dim3(256), 0, (hipStream_t)stream, R,
+    hipLaunchKernelGGL(diffuse_kernel<false>, dim3(6 * R * R), dim3(256), 0, (hipStream_t)stream, R,
                        cubemap, out, 0);
     GS_CHECK_LAUNCH();
     return GS_OK;
@@ -166,7 +177,7 @@ extern "C" int gs_diffuse_cubemap_fwd(int R, const float* cubemap, float* out, v
 extern "C" int gs_diffuse_cubemap_bwd(int R, const float* v_out, float* v_cubemap, int accumulate, void* stream)
 {
     GS_CHECK_ARG(R >= 1 && R <= 64, "diffuse prefilter expects the 16^2 level (R <= 64)");
-    hipLaunchKernelGGL(diffuse_kernel<true>, dim3(gs_cdiv(6 * R * R, 256)), dim3(256), 0, (hipStream_t)stream, R,
+    hipLaunchKernelGGL(diffuse_kernel<true>, dim3(6 * R * R), dim3(256), 0, (hipStream_t)stream, R,
                        v_out, v_cubemap, accumulate);
     GS_CHECK_LAUNCH();
     return GS_OK;
@@ -223,28 +234,35 @@ extern "C" int gs_specular_bounds(int R, float costheta_cutoff, float* bounds, v
     return GS_OK;
 }
 
+// One thread per texel t.  FWD: t is the OUTPUT texel (VNR = dir_t) and gathers the input texels of its lobe.
+// BWD: t is the INPUT texel (L = dir_t) and gathers the OUTPUT texels whose lobe contains it -- lobe
+// membership dot(L,VNR) >= cutoff is symmetric and the per-texel AABB table is a function of the direction
+// only, so bounds[t] serves both roles.  The pair weight w(o,i) is evaluated with exactly the forward's
+// operands (VNR = output direction, pixel_area of the input texel), which makes the backward the exact
+// adjoint of the forward WITHOUT atomics (the reference scatters with atomicAdd, cubemap.cu:300-350).
 template <bool BWD>
 __global__ void __launch_bounds__(256)
-specular_kernel(int R, const float* __restrict__ cubemap, const float* __restrict__ bounds,
-                const float* __restrict__ v_out, float roughness, float cutoff, float* __restrict__ out,
-                float* __restrict__ v_cubemap)
+specular_kernel(int R, const float* __restrict__ src /*cubemap (fwd) | v_out rgb (bwd)*/,
+                const float* __restrict__ bounds, float roughness, float cutoff, float* __restrict__ dst,
+                int accumulate)
 {
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= 6 * R * R) return;
-    const int px = o % R, py = (o / R) % R, pz = o / (R * R);
-    float VNR[3]; cube_to_dir(px, py, pz, R, VNR);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 6 * R * R) return;
+    const int px = t % R, py = (t / R) % R, pz = t / (R * R);
+    float own[3]; cube_to_dir(px, py, pz, R, own);
+    const float own_area = pixel_area(px, py, R);
     const float alpha = roughness * roughness;
     const float alphaSqr = alpha * alpha;
     float wsum = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-    if (BWD) { g0 = v_out[(size_t)o * 3]; g1 = v_out[(size_t)o * 3 + 1]; g2 = v_out[(size_t)o * 3 + 2]; }
     for (int s = 0; s < 6; ++s) {
-        const float4 b = *reinterpret_cast<const float4*>(bounds + (size_t)o * 24 + s * 4);
+        const float4 b = *reinterpret_cast<const float4*>(bounds + (size_t)t * 24 + s * 4);
         const int xmin = (int)b.x, xmax = (int)b.y, ymin = (int)b.z, ymax = (int)b.w;
         if (xmin > xmax) continue;
         for (int y = ymin; y <= ymax; ++y)
             for (int x = xmin; x <= xmax; ++x) {
-                float L[3]; cube_to_dir(x, y, s, R, L);
+                float other[3]; cube_to_dir(x, y, s, R, other);
+                const float* L = BWD ? own : other;
+                const float* VNR = BWD ? other : own;
                 const float ldv = dot3(L, VNR);
                 if (ldv >= cutoff) {
                     float Hv[3] = { L[0] + VNR[0], L[1] + VNR[1], L[2] + VNR[2] };
@@ -252,20 +270,20 @@ specular_kernel(int R, const float* __restrict__ cubemap, const float* __restric
                     if (hl > 0.0f) { Hv[0] /= hl; Hv[1] /= hl; Hv[2] /= hl; } else { Hv[0] = Hv[1] = Hv[2] = 0.0f; }
                     const float wiDotN = fmaxf(ldv, 0.0f);
                     const float VNRDotH = fmaxf(dot3(VNR, Hv), 0.0f);
-                    const float w = wiDotN * ndfGGX(alphaSqr, VNRDotH) * pixel_area(x, y, R) / 4.0f;
+                    const float area = BWD ? own_area : pixel_area(x, y, R);
+                    const float w = wiDotN * ndfGGX(alphaSqr, VNRDotH) * area / 4.0f;
                     const size_t ti = (((size_t)s * R + y) * R + x) * 3;
-                    if (BWD) {
-                        gs_atomic_add(v_cubemap + ti, g0 * w);
-                        gs_atomic_add(v_cubemap + ti + 1, g1 * w);
-                        gs_atomic_add(v_cubemap + ti + 2, g2 * w);
-                    } else {
-                        c0 += cubemap[ti] * w; c1 += cubemap[ti + 1] * w; c2 += cubemap[ti + 2] * w;
-                        wsum += w;
-                    }
+                    c0 += src[ti] * w; c1 += src[ti + 1] * w; c2 += src[ti + 2] * w;
+                    wsum += w;
                 }
             }
     }
-    if (!BWD) *reinterpret_cast<float4*>(out + (size_t)o * 4) = make_float4(c0, c1, c2, wsum);
+    if (BWD) {
+        float* p = dst + (size_t)t * 3;
+        if (accumulate) { p[0] += c0; p[1] += c1; p[2] += c2; } else { p[0] = c0; p[1] = c1; p[2] = c2; }
+    } else {
+        *reinterpret_cast<float4*>(dst + (size_t)t * 4) = make_float4(c0, c1, c2, wsum);
+    }
 }
 
 extern "C" int gs_specular_cubemap_fwd(int R, const float* cubemap, const float* bounds, float roughness,
@@ -273,7 +291,7 @@ extern "C" int gs_specular_cubemap_fwd(int R, const float* cubemap, const float*
 {
     GS_CHECK_ARG(R >= 1, "bad R");
     hipLaunchKernelGGL(specular_kernel<false>, dim3(gs_cdiv(6 * R * R, 256)), dim3(256), 0, (hipStream_t)stream, R,
-                       cubemap, bounds, nullptr, roughness, costheta_cutoff, out, nullptr);
+                       cubemap, bounds, roughness, costheta_cutoff, out, 0);
     GS_CHECK_LAUNCH();
     return GS_OK;
 }
@@ -282,10 +300,8 @@ extern "C" int gs_specular_cubemap_bwd(int R, const float* bounds, const float* 
                                        float costheta_cutoff, float* v_cubemap, int accumulate, void* stream)
 {
     GS_CHECK_ARG(R >= 1, "bad R");
-    hipStream_t s = (hipStream_t)stream;
-    if (!accumulate) GS_CHECK_HIP(hipMemsetAsync(v_cubemap, 0, sizeof(float) * 18 * (size_t)R * R, s));
-    hipLaunchKernelGGL(specular_kernel<true>, dim3(gs_cdiv(6 * R * R, 256)), dim3(256), 0, s, R, nullptr, bounds,
-                       v_out_rgb, roughness, costheta_cutoff, nullptr, v_cubemap);
+    hipLaunchKernelGGL(specular_kernel<true>, dim3(gs_cdiv(6 * R * R, 256)), dim3(256), 0, (hipStream_t)stream, R,
+                       v_out_rgb, bounds, roughness, costheta_cutoff, v_cubemap, accumulate);
     GS_CHECK_LAUNCH();
     return GS_OK;
 }

@@ -16,7 +16,7 @@ from torch import Tensor
 from . import _lib as L
 
 _META_KEYS = ("gaussian_ids_i32", "radii", "means2d", "depths", "conics", "compensations", "opacities", "colors",
-              "tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets", "last_ids")
+              "tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets", "last_ids", "raster_ws")
 
 
 def _forward_stages(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Tensor,
@@ -60,12 +60,14 @@ def _forward_stages(means: Tensor, quats: Tensor, scales: Tensor, opacities: Ten
 
     render = torch.empty(H, W, D, dtype=f32, device=dev); alphas = torch.empty(H, W, dtype=f32, device=dev)
     last_ids = torch.empty(H, W, dtype=i32, device=dev)
+    rws_bytes = lib.gs_raster_ws_bytes(L.i64(I), W, H, tile_size)
+    rws = torch.empty(rws_bytes, dtype=torch.uint8, device=dev)     # record stream: written here, read by the backward
     L.check(lib.gs_raster_fwd(W, H, tile_size, D, L.ptr(means2d), L.ptr(conics), L.ptr(opac_p), L.ptr(colors_p),
                               L.ptr(background), L.i64(I), L.ptr(offsets), L.ptr(flat_s), L.ptr(render), L.ptr(alphas),
-                              L.ptr(last_ids), st), "gs_raster_fwd")
+                              L.ptr(last_ids), L.ptr(rws), C.c_size_t(rws_bytes), st), "gs_raster_fwd")
     state = dict(gaussian_ids_i32=gids, radii=radii, means2d=means2d, depths=depths, conics=conics,
                  compensations=comps, opacities=opac_p, colors=colors_p, tiles_per_gauss=tpg, isect_ids=ids_s,
-                 flatten_ids=flat_s, isect_offsets=offsets, last_ids=last_ids)
+                 flatten_ids=flat_s, isect_offsets=offsets, last_ids=last_ids, raster_ws=rws)
     return render, alphas, state, V, I
 
 
@@ -99,11 +101,11 @@ class _Rasterize(torch.autograd.Function):
         v_m2d = torch.empty(V, 2, dtype=f32, device=dev); v_con = torch.empty(V, 3, dtype=f32, device=dev)
         v_col = torch.empty(V, D, dtype=f32, device=dev); v_op = torch.empty(V, dtype=f32, device=dev)
         s = L.stream()
-        L.check(lib.gs_raster_bwd(W, H, tile_size, D, V, L.ptr(st["means2d"]), L.ptr(st["conics"]),
-                                  L.ptr(st["opacities"]), L.ptr(st["colors"]), L.ptr(background), L.i64(I),
-                                  L.ptr(st["isect_offsets"]), L.ptr(st["flatten_ids"]), L.ptr(alphas),
-                                  L.ptr(st["last_ids"]), L.ptr(v_render), L.ptr(v_alphas), L.ptr(v_m2d), L.ptr(v_con),
-                                  L.ptr(v_col), L.ptr(v_op), s), "gs_raster_bwd")
+        rws = st["raster_ws"]
+        L.check(lib.gs_raster_bwd(W, H, tile_size, D, V, L.ptr(st["colors"]), L.ptr(background), L.i64(I),
+                                  L.ptr(st["isect_offsets"]), L.ptr(alphas), L.ptr(st["last_ids"]), L.ptr(v_render),
+                                  L.ptr(v_alphas), L.ptr(v_m2d), L.ptr(v_con), L.ptr(v_col), L.ptr(v_op), L.ptr(rws),
+                                  C.c_size_t(rws.numel()), s), "gs_raster_bwd")
         g_means = torch.empty(N, 3, dtype=f32, device=dev); g_quats = torch.empty(N, 4, dtype=f32, device=dev)
         g_scales = torch.empty(N, 3, dtype=f32, device=dev); g_opac = torch.empty(N, dtype=f32, device=dev)
         g_colors = torch.empty(N, D, dtype=f32, device=dev)

@@ -234,33 +234,63 @@ extern "C" int gs_specular_bounds(int R, float costheta_cutoff, float* bounds, v
     return GS_OK;
 }
 
-// One thread per texel t.  FWD: t is the OUTPUT texel (VNR = dir_t) and gathers the input texels of its lobe.
+// Per-texel table {dir.xyz, pixel_area}: depends on R only, cached by the host across steps.  It removes the
+// normalisation (3 correctly-rounded divisions + sqrt) and the four atanf of pixel_area from every (output,
+// input) pair of the lobe loops; values are bit-identical to calling cube_to_dir / pixel_area in place.
+__global__ void __launch_bounds__(256)
+dir_table_kernel(int R, float4* __restrict__ table)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 6 * R * R) return;
+    const int px = t % R, py = (t / R) % R, pz = t / (R * R);
+    float d[3]; cube_to_dir(px, py, pz, R, d);
+    table[t] = make_float4(d[0], d[1], d[2], pixel_area(px, py, R));
+}
+
+extern "C" int gs_cube_dir_table(int R, float* table, void* stream)
+{
+    GS_CHECK_ARG(R >= 1 && table != nullptr, "bad R/table");
+    hipLaunchKernelGGL(dir_table_kernel, dim3(gs_cdiv(6 * R * R, 256)), dim3(256), 0, (hipStream_t)stream, R, (float4*)table);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
+// One WAVE per texel t (4 texels per 256-thread block); the 64 lanes tile each face's AABB in 8x8 patches.
+// FWD: t is the OUTPUT texel (VNR = dir_t) and gathers the input texels of its lobe.
 // BWD: t is the INPUT texel (L = dir_t) and gathers the OUTPUT texels whose lobe contains it -- lobe
 // membership dot(L,VNR) >= cutoff is symmetric and the per-texel AABB table is a function of the direction
 // only, so bounds[t] serves both roles.  The pair weight w(o,i) is evaluated with exactly the forward's
 // operands (VNR = output direction, pixel_area of the input texel), which makes the backward the exact
 // adjoint of the forward WITHOUT atomics (the reference scatters with atomicAdd, cubemap.cu:300-350).
+// (The reference runs one THREAD per output texel: 1 536 threads at the 16^2 level that each walk the whole
+// cube map.  One wave per texel keeps >= 1 536 waves in flight at every level.)
 template <bool BWD>
 __global__ void __launch_bounds__(256)
 specular_kernel(int R, const float* __restrict__ src /*cubemap (fwd) | v_out rgb (bwd)*/,
-                const float* __restrict__ bounds, float roughness, float cutoff, float* __restrict__ dst,
-                int accumulate)
+                const float* __restrict__ bounds, const float4* __restrict__ table, float roughness, float cutoff,
+                float* __restrict__ dst, int accumulate)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= 6 * R * R) return;
-    const int px = t % R, py = (t / R) % R, pz = t / (R * R);
-    float own[3]; cube_to_dir(px, py, pz, R, own);
-    const float own_area = pixel_area(px, py, R);
+    const float4 own4 = table[t];
+    const float own[3] = { own4.x, own4.y, own4.z };
+    const float own_area = own4.w;
     const float alpha = roughness * roughness;
     const float alphaSqr = alpha * alpha;
+    const int lx = lane & 7, ly = lane >> 3;
     float wsum = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
     for (int s = 0; s < 6; ++s) {
         const float4 b = *reinterpret_cast<const float4*>(bounds + (size_t)t * 24 + s * 4);
         const int xmin = (int)b.x, xmax = (int)b.y, ymin = (int)b.z, ymax = (int)b.w;
         if (xmin > xmax) continue;
-        for (int y = ymin; y <= ymax; ++y)
-            for (int x = xmin; x <= xmax; ++x) {
-                float other[3]; cube_to_dir(x, y, s, R, other);
+        for (int by = ymin; by <= ymax; by += 8)
+            for (int bx = xmin; bx <= xmax; bx += 8) {
+                const int x = bx + lx, y = by + ly;
+                if (x > xmax || y > ymax) continue;
+                const size_t ti = ((size_t)s * R + y) * R + x;
+                const float4 o4 = table[ti];
+                const float other[3] = { o4.x, o4.y, o4.z };
                 const float* L = BWD ? own : other;
                 const float* VNR = BWD ? other : own;
                 const float ldv = dot3(L, VNR);
@@ -270,38 +300,42 @@ specular_kernel(int R, const float* __restrict__ src /*cubemap (fwd) | v_out rgb
                     if (hl > 0.0f) { Hv[0] /= hl; Hv[1] /= hl; Hv[2] /= hl; } else { Hv[0] = Hv[1] = Hv[2] = 0.0f; }
                     const float wiDotN = fmaxf(ldv, 0.0f);
                     const float VNRDotH = fmaxf(dot3(VNR, Hv), 0.0f);
-                    const float area = BWD ? own_area : pixel_area(x, y, R);
+                    const float area = BWD ? own_area : o4.w;
                     const float w = wiDotN * ndfGGX(alphaSqr, VNRDotH) * area / 4.0f;
-                    const size_t ti = (((size_t)s * R + y) * R + x) * 3;
-                    c0 += src[ti] * w; c1 += src[ti + 1] * w; c2 += src[ti + 2] * w;
+                    c0 += src[ti * 3] * w; c1 += src[ti * 3 + 1] * w; c2 += src[ti * 3 + 2] * w;
                     wsum += w;
                 }
             }
     }
-    if (BWD) {
-        float* p = dst + (size_t)t * 3;
-        if (accumulate) { p[0] += c0; p[1] += c1; p[2] += c2; } else { p[0] = c0; p[1] = c1; p[2] = c2; }
-    } else {
-        *reinterpret_cast<float4*>(dst + (size_t)t * 4) = make_float4(c0, c1, c2, wsum);
+    c0 = gs_wave_sum(c0); c1 = gs_wave_sum(c1); c2 = gs_wave_sum(c2);
+    if (!BWD) wsum = gs_wave_sum(wsum);
+    if (lane == 0) {
+        if (BWD) {
+            float* p = dst + (size_t)t * 3;
+            if (accumulate) { p[0] += c0; p[1] += c1; p[2] += c2; } else { p[0] = c0; p[1] = c1; p[2] = c2; }
+        } else {
+            *reinterpret_cast<float4*>(dst + (size_t)t * 4) = make_float4(c0, c1, c2, wsum);
+        }
     }
 }
 
-extern "C" int gs_specular_cubemap_fwd(int R, const float* cubemap, const float* bounds, float roughness,
-                                       float costheta_cutoff, float* out, void* stream)
+extern "C" int gs_specular_cubemap_fwd(int R, const float* cubemap, const float* bounds, const float* dir_table,
+                                       float roughness, float costheta_cutoff, float* out, void* stream)
 {
-    GS_CHECK_ARG(R >= 1, "bad R");
-    hipLaunchKernelGGL(specular_kernel<false>, dim3(gs_cdiv(6 * R * R, 256)), dim3(256), 0, (hipStream_t)stream, R,
-                       cubemap, bounds, roughness, costheta_cutoff, out, 0);
+    GS_CHECK_ARG(R >= 1 && dir_table != nullptr, "bad R / dir_table");
+    hipLaunchKernelGGL(specular_kernel<false>, dim3(gs_cdiv(6 * R * R, 4)), dim3(256), 0, (hipStream_t)stream, R,
+                       cubemap, bounds, (const float4*)dir_table, roughness, costheta_cutoff, out, 0);
     GS_CHECK_LAUNCH();
     return GS_OK;
 }
 
-extern "C" int gs_specular_cubemap_bwd(int R, const float* bounds, const float* v_out_rgb, float roughness,
-                                       float costheta_cutoff, float* v_cubemap, int accumulate, void* stream)
+extern "C" int gs_specular_cubemap_bwd(int R, const float* bounds, const float* dir_table, const float* v_out_rgb,
+                                       float roughness, float costheta_cutoff, float* v_cubemap, int accumulate,
+                                       void* stream)
 {
-    GS_CHECK_ARG(R >= 1, "bad R");
-    hipLaunchKernelGGL(specular_kernel<true>, dim3(gs_cdiv(6 * R * R, 256)), dim3(256), 0, (hipStream_t)stream, R,
-                       v_out_rgb, bounds, roughness, costheta_cutoff, v_cubemap, accumulate);
+    GS_CHECK_ARG(R >= 1 && dir_table != nullptr, "bad R / dir_table");
+    hipLaunchKernelGGL(specular_kernel<true>, dim3(gs_cdiv(6 * R * R, 4)), dim3(256), 0, (hipStream_t)stream, R,
+                       v_out_rgb, bounds, (const float4*)dir_table, roughness, costheta_cutoff, v_cubemap, accumulate);
     GS_CHECK_LAUNCH();
     return GS_OK;
 }

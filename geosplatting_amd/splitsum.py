@@ -47,6 +47,19 @@ def specular_bounds(res: int, roughness: float, cutoff: float, device: torch.dev
     return _bounds_cache[key]
 
 
+_dir_table_cache: Dict[Tuple[int, int], Tensor] = {}
+
+
+def dir_table(res: int, device: torch.device) -> Tensor:
+    """[6,R,R,4] = (unit direction, pixel_area) of every texel; a function of R only, cached like the bounds."""
+    key = (res, device.index or 0)
+    if key not in _dir_table_cache:
+        t = torch.empty(6, res, res, 4, dtype=torch.float32, device=device)
+        L.check(L.lib().gs_cube_dir_table(res, L.ptr(t), L.stream()), "gs_cube_dir_table")
+        _dir_table_cache[key] = t
+    return _dir_table_cache[key]
+
+
 # ----------------------------------------------------------------------------- autograd pieces
 class _CubeMapMip(torch.autograd.Function):
     """rfstudio/graphics/_mesh/_texture.py:199-226"""
@@ -97,7 +110,8 @@ class _SpecularCubemap(torch.autograd.Function):
         cubemap = cubemap.contiguous()
         R = cubemap.shape[1]
         raw = torch.empty(6, R, R, 4, dtype=torch.float32, device=cubemap.device)
-        L.check(L.lib().gs_specular_cubemap_fwd(R, L.ptr(cubemap), L.ptr(bounds), L.f32(roughness),
+        table = dir_table(R, cubemap.device)
+        L.check(L.lib().gs_specular_cubemap_fwd(R, L.ptr(cubemap), L.ptr(bounds), L.ptr(table), L.f32(roughness),
                                                 L.f32(costheta_cutoff), L.ptr(raw), L.stream()),
                 "gs_specular_cubemap_fwd")
         wsum = raw[..., 3:]
@@ -111,7 +125,8 @@ class _SpecularCubemap(torch.autograd.Function):
         roughness, ct = ctx.cfg
         v = (dout / wsum).contiguous()             # wsum does not depend on the cubemap
         g = torch.empty_like(v)
-        L.check(L.lib().gs_specular_cubemap_bwd(v.shape[1], L.ptr(bounds), L.ptr(v), L.f32(roughness), L.f32(ct),
+        table = dir_table(v.shape[1], v.device)
+        L.check(L.lib().gs_specular_cubemap_bwd(v.shape[1], L.ptr(bounds), L.ptr(table), L.ptr(v), L.f32(roughness), L.f32(ct),
                                                 L.ptr(g), 0, L.stream()), "gs_specular_cubemap_bwd")
         return g, None, None, None
 

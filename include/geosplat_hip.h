@@ -178,12 +178,15 @@ int gs_diffuse_cubemap_fwd(int R, const float* cubemap, float* out, void* stream
 int gs_diffuse_cubemap_bwd(int R, const float* v_out, float* v_cubemap, int accumulate, void* stream);
 /* bounds[6,R,R,24] (float-encoded ints, layout of the reference). */
 int gs_specular_bounds(int R, float costheta_cutoff, float* bounds, void* stream);
+/* table[6,R,R,4] = {unit direction xyz, pixel_area}: depends on R only -- compute once, reuse every step. */
+int gs_cube_dir_table(int R, float* table, void* stream);
 /* out[6,R,R,4] = (sum rgb*w, sum w) */
-int gs_specular_cubemap_fwd(int R, const float* cubemap, const float* bounds, float roughness,
-                            float costheta_cutoff, float* out, void* stream);
-/* v_out_rgb[6,R,R,3] = gradient w.r.t. the un-normalised rgb sums; v_cubemap written (or accumulated). */
-int gs_specular_cubemap_bwd(int R, const float* bounds, const float* v_out_rgb, float roughness,
-                            float costheta_cutoff, float* v_cubemap, int accumulate, void* stream);
+int gs_specular_cubemap_fwd(int R, const float* cubemap, const float* bounds, const float* dir_table,
+                            float roughness, float costheta_cutoff, float* out, void* stream);
+/* v_out_rgb[6,R,R,3] = gradient w.r.t. the un-normalised rgb sums; v_cubemap written (or accumulated).
+ * Atomic-free gather (lobe membership is symmetric). */
+int gs_specular_cubemap_bwd(int R, const float* bounds, const float* dir_table, const float* v_out_rgb,
+                            float roughness, float costheta_cutoff, float* v_cubemap, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

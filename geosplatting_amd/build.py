@@ -11,7 +11,9 @@ LIB = os.path.join(HERE, "libgeosplat_hip.so")
 SOURCES = ["gs_project.hip", "gs_sort.hip", "gs_raster.hip", "gs_shade.hip", "gs_splitsum.hip"]
 HEADERS = ["gs_common.h", "gs_cube.h", os.path.join("..", "..", "include", "geosplat_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
-         "-ffp-contract=fast-honor-pragmas", "-Wno-unused-result"]
+         "-ffp-contract=fast-honor-pragmas", "-Wno-unused-result",
+         # one lane commits per-Gaussian sums: the wave-uniform atomic optimiser (mbcnt/bcnt/mul per atomic) only adds work
+         "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 
 
 def _stale() -> bool:

@@ -54,6 +54,55 @@ __device__ __forceinline__ float gs_wave_sum(float v)
     return gs_readlane(v, 63);
 }
 
+// ---- butterfly reduce-scatter over a wave --------------------------------------------------------------
+// Sums NV per-lane values over the 64 lanes in ~3*NV/2 + 6 VALU ops instead of 6*NV: at every stage a lane
+// hands HALF of its values to its partner and keeps the other half, so the value count halves while the
+// partial sums double (DPP row_mirror, row_half_mirror, quad_perm xor2, quad_perm xor1 -- each fused into
+// the add), then two cross-row exchanges.  Afterwards lane l (every row holds the same totals) owns the total
+// of value index  16*q + 8*(l&1) + 4*((l>>1)&1) + 2*((l>>2)&1) + ((l>>3)&1)  in out[q].
+template <int CTRL>
+__device__ __forceinline__ float gs_dpp_take(float give)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), CTRL, 0xf, 0xf, true));
+}
+
+template <int N, int CTRL>
+__device__ __forceinline__ void gs_bfly_stage(const float* in, float* out, bool own_hi)
+{
+    // pairs (in[2z], in[2z+1]) -> out[z]; a lane with own_hi keeps the odd member and gives the even one
+#pragma unroll
+    for (int z = 0; z < (N + 1) / 2; ++z) {
+        const float lo = in[2 * z];
+        const float hi = (2 * z + 1 < N) ? in[2 * z + 1] : 0.0f;
+        const float keep = own_hi ? hi : lo;
+        const float give = own_hi ? lo : hi;
+        out[z] = keep + gs_dpp_take<CTRL>(give);
+    }
+}
+
+template <int NV>
+struct GsBfly {
+    static constexpr int N1 = (NV + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2;
+    // value index owned by this lane in out[q]
+    __device__ static __forceinline__ int owned_index(int lane, int q)
+    {
+        return 16 * q + 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
+    }
+    __device__ static __forceinline__ void reduce(const float (&v)[NV], float (&out)[N4], int lane)
+    {
+        float a[N1], b[N2], c[N3];
+        gs_bfly_stage<NV, 0x140>(v, a, (lane & 8) != 0);     // row_mirror       i <-> 15-i
+        gs_bfly_stage<N1, 0x141>(a, b, (lane & 4) != 0);     // row_half_mirror  i <-> 7-i (within 8)
+        gs_bfly_stage<N2, 0x4E>(b, c, (lane & 2) != 0);      // quad_perm [2,3,0,1]
+        gs_bfly_stage<N3, 0xB1>(c, out, (lane & 1) != 0);    // quad_perm [1,0,3,2]
+#pragma unroll
+        for (int q = 0; q < N4; ++q) {                       // rows: xor 16, xor 32 through the LDS crossbar
+            out[q] += __shfl_xor(out[q], 16, 64);
+            out[q] += __shfl_xor(out[q], 32, 64);
+        }
+    }
+};
+
 __device__ __forceinline__ int gs_lane_id() { return (int)(threadIdx.x & 63); }
 
 // fp32 atomic add that lowers to the hardware global_atomic_add_f32 (no CAS loop)

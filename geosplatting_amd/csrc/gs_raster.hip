@@ -239,6 +239,24 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
     }
     float T = T_final;
 
+    // per-lane commit slot of the butterfly reduction: value index -> (array, component, stride)
+    //   0,1 = v_means2d.xy   2,3,4 = v_conics   5 = v_opacities   6.. = v_colors[k]
+    constexpr int NV = 6 + CD;
+    using Bfly = GsBfly<NV>;
+    float* slot_ptr[Bfly::N4];
+    int slot_stride[Bfly::N4];
+#pragma unroll
+    for (int q = 0; q < Bfly::N4; ++q) {
+        const int vi = Bfly::owned_index(lane, q);
+        float* p = nullptr; int st = 0;
+        if (vi < 2)            { p = v_means2d + vi;        st = 2; }
+        else if (vi < 5)       { p = v_conics + (vi - 2);   st = 3; }
+        else if (vi == 5)      { p = v_opacities;           st = 1; }
+        else if (vi - 6 < D)   { p = v_colors + (vi - 6);   st = D; }
+        if (lane >= 16) p = nullptr;                         // row 0 commits
+        slot_ptr[q] = p; slot_stride[q] = st;
+    }
+
     int top = bin_final;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) top = max(top, __shfl_xor(top, off, 64));
@@ -286,52 +304,41 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
 #pragma unroll
             for (int k = 0; k < CD; ++k) gcol[k] = gs_readlane(col[k], j);
 
-            float p_xy0 = 0.f, p_xy1 = 0.f, p_c0 = 0.f, p_c1 = 0.f, p_c2 = 0.f, p_o = 0.f;
-            float p_col[CD];
+            float part[NV];
 #pragma unroll
-            for (int k = 0; k < CD; ++k) p_col[k] = 0.0f;
+            for (int k = 0; k < NV; ++k) part[k] = 0.0f;
             if (valid) {
-                const float ra = 1.0f / (1.0f - alpha);
+                const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);
                 T *= ra;
                 const float fac = alpha * T;
                 float v_alpha = 0.0f;
 #pragma unroll
                 for (int k = 0; k < CD; ++k) {
-                    p_col[k] = fac * v_rc[k];
+                    part[6 + k] = fac * v_rc[k];
                     v_alpha += (gcol[k] * T - buffer[k] * ra) * v_rc[k];
                 }
                 v_alpha += T_final * ra * v_a;
                 if (background) v_alpha += -T_final * ra * bg_dot;
                 if (go * vis <= 0.999f) {
                     const float v_sigma = -go * vis * v_alpha;
-                    p_c0 = 0.5f * v_sigma * dx * dx;
-                    p_c1 = v_sigma * dx * dy;
-                    p_c2 = 0.5f * v_sigma * dy * dy;
-                    p_xy0 = v_sigma * ((2.0f * ga) * dx + gb * dy);
-                    p_xy1 = v_sigma * (gb * dx + (2.0f * gc) * dy);
-                    p_o = vis * v_alpha;
+                    part[2] = 0.5f * v_sigma * dx * dx;
+                    part[3] = v_sigma * dx * dy;
+                    part[4] = 0.5f * v_sigma * dy * dy;
+                    part[0] = v_sigma * ((2.0f * ga) * dx + gb * dy);
+                    part[1] = v_sigma * (gb * dx + (2.0f * gc) * dy);
+                    part[5] = vis * v_alpha;
                 }
 #pragma unroll
                 for (int k = 0; k < CD; ++k) buffer[k] += gcol[k] * fac;
             }
-            // wave reduction, one lane commits
-            p_xy0 = gs_wave_sum(p_xy0); p_xy1 = gs_wave_sum(p_xy1);
-            p_c0 = gs_wave_sum(p_c0); p_c1 = gs_wave_sum(p_c1); p_c2 = gs_wave_sum(p_c2);
-            p_o = gs_wave_sum(p_o);
-#pragma unroll
-            for (int k = 0; k < CD; ++k) p_col[k] = gs_wave_sum(p_col[k]);
+            // butterfly reduce-scatter over the wave; the 6+D totals land in distinct lanes of row 0, which
+            // commit them with ONE atomic instruction
+            float tot[Bfly::N4];
+            Bfly::reduce(part, tot, lane);
             const int gj = gs_readlane(g, j);
-            if (lane == 0) {
-                gs_atomic_add(v_means2d + 2 * (size_t)gj, p_xy0);
-                gs_atomic_add(v_means2d + 2 * (size_t)gj + 1, p_xy1);
-                gs_atomic_add(v_conics + 3 * (size_t)gj, p_c0);
-                gs_atomic_add(v_conics + 3 * (size_t)gj + 1, p_c1);
-                gs_atomic_add(v_conics + 3 * (size_t)gj + 2, p_c2);
-                gs_atomic_add(v_opacities + gj, p_o);
 #pragma unroll
-                for (int k = 0; k < CD; ++k)
-                    if (k < D) gs_atomic_add(v_colors + (size_t)gj * D + k, p_col[k]);
-            }
+            for (int q = 0; q < Bfly::N4; ++q)
+                if (slot_ptr[q]) gs_atomic_add(slot_ptr[q] + (size_t)gj * slot_stride[q], tot[q]);
         }
     }
 }

@@ -197,7 +197,7 @@ __device__ __forceinline__ void cube_scatter_lds(float* lds, const CubeFp& fp, c
 // 160 KB LDS).  2 M Gaussians send ~13 M atomics at the 4 608 floats of the 16^2 level alone: in HBM/L2 that
 // serialises per address (5.5 ms per view measured); in LDS it is a ds_add_f32 and the block flushes its
 // copy once at the end.
-#define GS_SHADE_BWD_BLOCK 512
+#define GS_SHADE_BWD_BLOCK 1024
 __global__ void __launch_bounds__(GS_SHADE_BWD_BLOCK)
 shade_bwd_kernel(int N, const float* __restrict__ means, const float* __restrict__ normals,
                  const float* __restrict__ kd, const float* __restrict__ ks, const float* __restrict__ cam_pos,

@@ -1,0 +1,87 @@
+"""No-GPU checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/geosplat_hip.h
+declares (and nothing is declared that is not exported), and the product path fails LOUDLY without a GPU /
+without the library -- it never falls back to the oracle or to PyTorch."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "geosplat_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from geosplatting_amd import _lib
+    lib = _lib.lib()
+    decl = _declared()
+    assert len(decl) >= 20
+    for name in decl:
+        assert hasattr(lib, name), f"{name} declared in geosplat_hip.h but not exported"
+    assert sorted(_lib.SYMBOLS) == decl
+    assert lib.gs_version() >= 100
+    assert lib.gs_last_error() is not None
+
+
+def test_argument_validation_without_gpu():
+    """Entry points validate arguments before touching the device (no compute, no GPU needed)."""
+    from geosplatting_amd import _lib
+    lib = _lib.lib()
+    assert lib.gs_project_ws_bytes(0) > 0 and lib.gs_project_ws_bytes(1 << 21) >= 4 * 8 * (1 << 13)
+    assert lib.gs_raster_ws_bytes(ctypes.c_int64(1000), 800, 800, 16) >= 3 * 16 * 1000 + 4 * 2500
+    rc = lib.gs_raster_fwd(0, 0, 16, 3, None, None, None, None, None, ctypes.c_int64(0), None, None, None, None, None,
+                           None, ctypes.c_size_t(0), None)
+    assert rc == -1 and b"bad image size" in lib.gs_last_error()
+    rc = lib.gs_raster_fwd(16, 16, 8, 3, None, None, None, None, None, ctypes.c_int64(0), None, None, None, None, None,
+                           None, ctypes.c_size_t(0), None)
+    assert rc == -1 and b"tile_size" in lib.gs_last_error()
+    rc = lib.gs_shade_fwd(1, None, None, None, None, None, ctypes.c_float(0.1), ctypes.c_float(1.0), 7, None, None, None)
+    assert rc == -1
+
+
+def test_ops_refuse_cpu_tensors():
+    import geosplatting_amd as gs
+    from geosplatting_amd._lib import GeoSplatHipError
+    z = torch.zeros(1, 3)
+    with pytest.raises(GeoSplatHipError, match="GPU only"):
+        gs.rasterization(z, torch.ones(1, 4), z + 1, torch.ones(1), z, torch.eye(4)[None], torch.eye(3)[None], 16, 16)
+    with pytest.raises(GeoSplatHipError):
+        gs.as_splitsum(torch.rand(6, 64, 64, 3))
+    with pytest.raises(GeoSplatHipError):
+        gs.tone_map(torch.rand(4, 4, 4), torch.tensor(1.0))
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """With the .so absent the import of an op must raise -- no silent CPU path."""
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import geosplatting_amd._lib as L\n"
+        "L.LIB_PATH = %r\n"
+        "try:\n"
+        "    L.lib()\n"
+        "except L.GeoSplatHipError as e:\n"
+        "    print('RAISED', 'no CPU' in str(e))\n" % (ROOT, str(tmp_path / "nope.so")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert "RAISED True" in out.stdout, out.stdout + out.stderr
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "geosplatting_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), fn
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    # bench.py may use the oracle only inside cpu_baseline()
+    body = bench.split("def cpu_baseline")[1].split("\ndef ")[0]
+    assert "import oracle" in body
+    rest = bench.replace(body, "")
+    assert "import oracle" not in rest

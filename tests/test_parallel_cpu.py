@@ -1,0 +1,74 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the view sharding and the flat gradient bucket
+all-reduce exactly as bench.py / RenderStep use them (the rendering itself needs a GPU and is replaced by a
+deterministic per-view gradient)."""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _fake_view_grads(view, shapes):
+    g = torch.Generator().manual_seed(1000 + view)
+    return {k: torch.randn(*v, generator=g) for k, v in shapes.items()}
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from geosplatting_amd.parallel import GradBucket, init_distributed_from_env, shard_views
+    r, w, dev = init_distributed_from_env("cpu")
+    assert (r, w) == (rank, world) and dev.type == "cpu"
+    shapes = {"means": (37, 3), "quats": (37, 4), "ks": (37, 2), "cubemap": (6, 4, 4, 3), "exposure": (1,)}
+    views = shard_views(8, rank, world)
+    assert views == list(range(rank, 8, world))
+    local = {k: torch.zeros(*v) for k, v in shapes.items()}
+    for v in views:
+        for k, g in _fake_view_grads(v, shapes).items():
+            local[k] += g
+    local["ks"] = None                                   # a parameter without gradient on this rank -> zeros
+    bucket = GradBucket(shapes, dev)
+    bucket.pack(local)
+    wait = bucket.all_reduce(async_op=True)
+    wait()
+    out = {k: v.clone() for k, v in bucket.unpack().items()}
+    torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    shapes = {"means": (37, 3), "quats": (37, 4), "ks": (37, 2), "cubemap": (6, 4, 4, 3), "exposure": (1,)}
+    want = {k: torch.zeros(*v) for k, v in shapes.items()}
+    for view in range(8):
+        for k, g in _fake_view_grads(view, shapes).items():
+            want[k] += g
+    want["ks"].zero_()
+    outs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
+    for k in shapes:
+        assert torch.allclose(outs[0][k], want[k], atol=1e-5), k
+        assert torch.equal(outs[0][k], outs[1][k]), k            # every rank holds the identical sum
+
+
+def test_bucket_layout_single_process():
+    from geosplatting_amd.parallel import GradBucket, shard_views
+    shapes = {"a": (5, 3), "b": (1,), "c": (2, 2, 2)}
+    b = GradBucket(shapes, torch.device("cpu"))
+    assert b.numel % 64 == 0 and all(o % 64 == 0 for o in b.offsets.values())
+    b.pack({"a": torch.ones(5, 3), "b": torch.tensor(2.0), "c": None})
+    assert b.all_reduce() is None                         # no process group -> no-op
+    u = b.unpack()
+    assert u["a"].sum() == 15 and u["b"].item() == 2 and u["c"].abs().sum() == 0
+    assert [shard_views(8, r, 8) for r in range(8)] == [[r] for r in range(8)]
+    assert shard_views(3, 2, 4) == [2] and shard_views(3, 3, 4) == []

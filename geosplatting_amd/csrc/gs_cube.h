@@ -150,6 +150,49 @@ __device__ void cube_fetch(const float* __restrict__ tex, int R, const float* d,
     }
 }
 
+// ---- wave-aggregated texel-gradient scatter ---------------------------------------------------------------
+// Neighbouring Gaussians of a surface reflect into the same few texels of the coarse pyramid levels, so the
+// 64 lanes of a wave would send many fp32 atomics at identical addresses (the L2 serialises them: 1.26 ms of
+// the 1.3 ms shading backward at 2 M Gaussians).  Lanes that target the SAME address are summed in registers
+// (leader loop: broadcast the first pending address, ballot the matches, DPP-reduce, one lane commits);
+// incoherent lanes fall back to plain atomics after GS_AGG_ROUNDS leaders.
+#define GS_AGG_ROUNDS 6
+__device__ __forceinline__ void wave_agg_add3(float* p /* nullptr = nothing to add */, float v0, float v1, float v2)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    unsigned long long key = (unsigned long long)p;
+    unsigned long long remaining = __ballot(p != nullptr);
+    int singles = 0;
+    for (int round = 0; round < GS_AGG_ROUNDS && remaining != 0ull && singles < 2; ++round) {
+        const int leader = __builtin_ctzll(remaining);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key, leader);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key >> 32), leader);
+        const unsigned long long k = ((unsigned long long)hi << 32) | lo;
+        const bool same = (key == k);
+        const unsigned long long m = __ballot(same);
+        const float s0 = gs_wave_sum(same ? v0 : 0.0f);
+        const float s1 = gs_wave_sum(same ? v1 : 0.0f);
+        const float s2 = gs_wave_sum(same ? v2 : 0.0f);
+        if (lane == leader) { gs_atomic_add(p, s0); gs_atomic_add(p + 1, s1); gs_atomic_add(p + 2, s2); }
+        if (same) key = 0ull;
+        remaining &= ~m;
+        singles = (__popcll(m) == 1) ? singles + 1 : 0;
+    }
+    if (key != 0ull) { gs_atomic_add(p, v0); gs_atomic_add(p + 1, v1); gs_atomic_add(p + 2, v2); }
+}
+
+// all 64 lanes of the wave must call this together (lanes without work pass valid == false)
+__device__ __forceinline__ void cube_scatter_wave(float* grad_tex, const CubeFp& fp, const float* g, float scale, bool valid)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool on = valid && fp.valid && fp.idx[i] >= 0 && grad_tex != nullptr;
+        const float w = on ? scale * fp.w[i] : 0.0f;
+        float* p = on ? grad_tex + (size_t)fp.idx[i] * 3 : nullptr;
+        wave_agg_add3(p, g[0] * w, g[1] * w, g[2] * w);
+    }
+}
+
 __device__ __forceinline__ void cube_scatter(float* __restrict__ grad_tex, const CubeFp& fp, const float* g, float scale)
 {
     if (!fp.valid) return;
@@ -158,7 +201,11 @@ __device__ __forceinline__ void cube_scatter(float* __restrict__ grad_tex, const
         if (fp.idx[i] < 0) continue;
         const float w = scale * fp.w[i];
         float* p = grad_tex + (size_t)fp.idx[i] * 3;
+#ifndef GS_EXPERIMENT_NO_GLOBAL_TEXEL_ATOMICS      /* timing experiment only (scripts/shade_bwd_experiment.py) */
         gs_atomic_add(p, g[0] * w); gs_atomic_add(p + 1, g[1] * w); gs_atomic_add(p + 2, g[2] * w);
+#else
+        if (w == 123456.0f) p[0] = g[0];
+#endif
     }
 }
 

@@ -25,6 +25,21 @@
 #define GS_TILE 16
 #define GS_ALPHA_MIN (1.0f / 255.0f)
 
+// Diagnostic build only (scripts/raster_stats.py compiles this file with -DGS_RASTER_STATS into a scratch .so):
+// counts wave-batches, ballot survivors and evaluated/valid lane-pairs.  Never defined in the product library.
+#ifdef GS_RASTER_STATS
+__device__ unsigned long long g_raster_stats[8];
+extern "C" int gs_raster_stats_read(unsigned long long* host8, int reset)
+{
+    if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_raster_stats), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_raster_stats), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#define GS_STAT(i, v) do { const unsigned long long _sv = (unsigned long long)(v); if ((threadIdx.x & 63) == 0) atomicAdd(&g_raster_stats[i], _sv); } while (0)
+#else
+#define GS_STAT(i, v) do { } while (0)
+#endif
+
 // extent of {alpha >= 1/255} for a Gaussian, conservatively inflated; returns false if it can never reach
 __device__ __forceinline__ bool alpha_extent(float ca, float cb, float cc, float o, float& hx, float& hy)
 {
@@ -97,6 +112,21 @@ struct Batch {
     float4 r0, r1, r2;
 };
 
+// Bounding rectangle (pixel-centre coordinates) of the ACTIVE lanes of an 8x8 quadrant wave (lane = y*8 + x),
+// from the 64-bit activity ballot with scalar bit operations only.  Most pixels of a quadrant saturate early
+// while a few stragglers keep the wave walking its list: culling against the stragglers' rectangle instead
+// of the whole quadrant removes almost all survivors of the late batches (exact: inactive lanes ignore them).
+__device__ __forceinline__ void active_rect(unsigned long long act, int qx0, int qy0, float& rx0, float& rx1,
+                                            float& ry0, float& ry1)
+{
+    unsigned cols = (unsigned)(act | (act >> 32));
+    cols |= cols >> 16; cols |= cols >> 8; cols &= 0xffu;
+    const int xmin = __builtin_ctz(cols), xmax = 31 - __builtin_clz(cols);
+    const int ymin = __builtin_ctzll(act) >> 3, ymax = (63 - __builtin_clzll(act)) >> 3;
+    rx0 = (float)(qx0 + xmin) + 0.5f; rx1 = (float)(qx0 + xmax) + 0.5f;
+    ry0 = (float)(qy0 + ymin) + 0.5f; ry1 = (float)(qy0 + ymax) + 0.5f;
+}
+
 __device__ __forceinline__ Batch load_batch(const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                                             const float4* __restrict__ rec2, int idx, bool in_range)
 {
@@ -123,8 +153,6 @@ raster_fwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
     const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
     const bool inside = pxi < W && pyi < H;
     const float px = (float)pxi + 0.5f, py = (float)pyi + 0.5f;
-    const float rx0 = (float)qx0 + 0.5f, rx1 = (float)qx0 + 7.5f;
-    const float ry0 = (float)qy0 + 0.5f, ry1 = (float)qy0 + 7.5f;
 
     const int start = offsets[tile];
     const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
@@ -138,7 +166,10 @@ raster_fwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
 
     Batch nxt = load_batch(rec0, rec1, rec2, start + lane, start + lane < end);
     for (int base = start; base < end; base += 64) {
-        if (__ballot(!done) == 0ull) break;
+        const unsigned long long act = __ballot(!done);
+        if (act == 0ull) break;
+        float rx0, rx1, ry0, ry1;
+        active_rect(act, qx0, qy0, rx0, rx1, ry0, ry1);
         const Batch cur = nxt;
         {   // prefetch the next 64 records while this batch is composited
             const int nidx = base + 64 + lane;
@@ -148,6 +179,7 @@ raster_fwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
         const float hc = cur.r1.x, op = cur.r1.y, hx = cur.r1.z, hy = cur.r1.w;
         const bool hit = (hx >= 0.0f) && (mx + hx >= rx0) && (mx - hx <= rx1) && (my + hy >= ry0) && (my - hy <= ry1);
         unsigned long long mask = __ballot(hit);
+        GS_STAT(0, 1); GS_STAT(1, __popcll(mask));
         if (mask == 0ull) continue;
         float col[CD];
         if (CD <= 3) {
@@ -175,6 +207,7 @@ raster_fwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
             const bool stop = ok && next_T <= 1e-4f;
             const bool acc = ok && !stop;
             done = done || stop;
+            GS_STAT(2, __popcll(__ballot(ok)));
             if (__ballot(acc) != 0ull) {
                 const float vis = acc ? alpha * T : 0.0f;
 #pragma unroll
@@ -212,8 +245,6 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
     const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
     const bool inside = pxi < W && pyi < H;
     const float px = (float)pxi + 0.5f, py = (float)pyi + 0.5f;
-    const float rx0 = (float)qx0 + 0.5f, rx1 = (float)qx0 + 7.5f;
-    const float ry0 = (float)qy0 + 0.5f, ry1 = (float)qy0 + 7.5f;
 
     const int start = offsets[tile];
     const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
@@ -264,6 +295,10 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
 
     Batch nxt = load_batch(rec0, rec1, rec2, top - lane, top - lane >= start);
     for (; top >= start; top -= 64) {
+        // lanes whose last composited entry lies at or after this batch's lowest index can be valid in it
+        const unsigned long long act = __ballot(bin_final >= top - 63);
+        float rx0, rx1, ry0, ry1;
+        active_rect(act, qx0, qy0, rx0, rx1, ry0, ry1);
         const Batch cur = nxt;
         {
             const int nidx = top - 64 - lane;
@@ -274,6 +309,7 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
         const int g = __float_as_int(cur.r2.w);
         const bool hit = (hx >= 0.0f) && (mx + hx >= rx0) && (mx - hx <= rx1) && (my + hy >= ry0) && (my - hy <= ry1);
         unsigned long long mask = __ballot(hit);
+        GS_STAT(4, 1); GS_STAT(5, __popcll(mask));
         if (mask == 0ull) continue;
         float col[CD];
         if (CD <= 3) {
@@ -299,6 +335,7 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
             const float alpha = fminf(0.999f, go * vis);
             const bool valid = (idxj <= bin_final) && sigma >= 0.0f && alpha >= GS_ALPHA_MIN;
             if (__ballot(valid) == 0ull) continue;
+            GS_STAT(6, 1); GS_STAT(7, __popcll(__ballot(valid)));
 
             float gcol[CD];
 #pragma unroll

@@ -209,18 +209,35 @@ shade_bwd_kernel(int N, const float* __restrict__ means, const float* __restrict
     for (int i = threadIdx.x; i < eg.lds_floats; i += blockDim.x) s_grad[i] = 0.0f;
     __syncthreads();
     const float cp[3] = { cam_pos[0], cam_pos[1], cam_pos[2] };
-    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    // wave-uniform trip count: every lane of a wave reaches the wave-aggregated scatter together
+    const int n_iter = (N + (int)(gridDim.x * blockDim.x) - 1) / (int)(gridDim.x * blockDim.x);
+    for (int it = 0; it < n_iter; ++it) {
+        const int n = it * (int)(gridDim.x * blockDim.x) + blockIdx.x * blockDim.x + threadIdx.x;
+        const bool live = n < N;
+        bool scatter = false;              // this lane has texel gradients to commit
+        ShadeTmp t;
+        float v_ls[3] = { 0, 0, 0 }, v_ld[3] = { 0, 0, 0 };
+        if (live) {
         const float mean[3] = { means[3 * (size_t)n], means[3 * (size_t)n + 1], means[3 * (size_t)n + 2] };
         const float normal[3] = { normals[3 * (size_t)n], normals[3 * (size_t)n + 1], normals[3 * (size_t)n + 2] };
         const float kdn[3] = { kd[3 * (size_t)n], kd[3 * (size_t)n + 1], kd[3 * (size_t)n + 2] };
         const float2 ks2 = *reinterpret_cast<const float2*>(ks + 2 * (size_t)n);
         const float ksn[2] = { ks2.x, ks2.y };
         const float g[3] = { v_colors[3 * (size_t)n], v_colors[3 * (size_t)n + 1], v_colors[3 * (size_t)n + 2] };
-        ShadeTmp t;
+        if (g[0] == 0.0f && g[1] == 0.0f && g[2] == 0.0f) {
+            // Gaussian that reached no pixel (culled, hidden behind the opaque front layer, ...): every gradient
+            // of the shading is exactly zero -- skip the texture taps and the texel atomics
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                v_means[3 * (size_t)n + k] = 0.0f; v_normals[3 * (size_t)n + k] = 0.0f; v_kd[3 * (size_t)n + k] = 0.0f;
+            }
+            *reinterpret_cast<float2*>(v_ks + 2 * (size_t)n) = make_float2(0.0f, 0.0f);
+        } else {
         float color[3];
         shade_one<true>(mean, normal, kdn, ksn, cp, min_roughness, max_metallic, mode, env, color, t);
+        scatter = true;
 
-        float v_diff[3] = { 0, 0, 0 }, v_ls[3] = { 0, 0, 0 }, v_rf[3] = { 0, 0, 0 }, v_ld[3] = { 0, 0, 0 };
+        float v_diff[3] = { 0, 0, 0 }, v_rf[3] = { 0, 0, 0 };
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             if (mode == GS_MODE_PBR)          { v_diff[c] = g[c]; v_ls[c] = g[c] * t.refl_c[c]; v_rf[c] = g[c] * t.ls.out[c]; }
@@ -275,17 +292,23 @@ shade_bwd_kernel(int N, const float* __restrict__ means, const float* __restrict
         }
         *reinterpret_cast<float2*>(v_ks + 2 * (size_t)n) = make_float2(v_rough * (1.0f - min_roughness), v_metal * max_metallic);
 
+        }   // non-zero upstream gradient
+        }   // live
+        // ---- texel gradients: LDS-private copies for the small levels, wave-aggregated atomics for the rest
         if (mode != GS_MODE_DIFFUSE) {
-            const float w0 = (t.ls.l1 < 0) ? 1.0f : 1.0f - t.ls.f;
-            if (eg.lds_level[t.ls.l0] >= 0) cube_scatter_lds(s_grad + eg.lds_level[t.ls.l0], t.ls.fp0, v_ls, w0);
-            else                            cube_scatter(eg.levels[t.ls.l0], t.ls.fp0, v_ls, w0);
-            if (t.ls.l1 >= 0) {
-                if (eg.lds_level[t.ls.l1] >= 0) cube_scatter_lds(s_grad + eg.lds_level[t.ls.l1], t.ls.fp1, v_ls, t.ls.f);
-                else                            cube_scatter(eg.levels[t.ls.l1], t.ls.fp1, v_ls, t.ls.f);
-            }
+            const int l0 = scatter ? t.ls.l0 : 0, l1 = scatter ? t.ls.l1 : -1;
+            const float w0 = (l1 < 0) ? 1.0f : 1.0f - t.ls.f;
+            const bool lds0 = scatter && eg.lds_level[l0] >= 0;
+            if (lds0) cube_scatter_lds(s_grad + eg.lds_level[l0], t.ls.fp0, v_ls, w0);
+            cube_scatter_wave(scatter && !lds0 ? eg.levels[l0] : nullptr, t.ls.fp0, v_ls, w0, scatter && !lds0);
+            const bool has1 = scatter && l1 >= 0;
+            const bool lds1 = has1 && eg.lds_level[has1 ? l1 : 0] >= 0;
+            if (lds1) cube_scatter_lds(s_grad + eg.lds_level[l1], t.ls.fp1, v_ls, t.ls.f);
+            cube_scatter_wave(has1 && !lds1 ? eg.levels[l1] : nullptr, t.ls.fp1, v_ls, t.ls.f, has1 && !lds1);
         } else {
-            if (eg.lds_base >= 0) cube_scatter_lds(s_grad + eg.lds_base, t.ld_fp, v_ld, 1.0f);
-            else                  cube_scatter(eg.base, t.ld_fp, v_ld, 1.0f);
+            const bool ldsb = scatter && eg.lds_base >= 0;
+            if (ldsb) cube_scatter_lds(s_grad + eg.lds_base, t.ld_fp, v_ld, 1.0f);
+            cube_scatter_wave(scatter && !ldsb ? eg.base : nullptr, t.ld_fp, v_ld, 1.0f, scatter && !ldsb);
         }
     }
     // ---- flush the private copies

@@ -1,0 +1,31 @@
+"""Diagnostic: compile gs_raster.hip with -DGS_RASTER_STATS into a scratch library and count wave-batches,
+ballot survivors and valid lane-pairs of the compositor at the bench workload."""
+import ctypes as C, os, subprocess, sys, math
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import geosplatting_amd.build as B
+so = "/tmp/libgeosplat_stats.so"
+srcs = [os.path.join(B.CSRC, s) for s in B.SOURCES]
+subprocess.check_call(["/opt/rocm/bin/hipcc", *B.FLAGS, "-DGS_RASTER_STATS", "-shared", "-o", so, *srcs])
+import geosplatting_amd._lib as L
+L.LIB_PATH = so
+import geosplatting_amd as gs, geosplatting_amd.synthetic as syn
+lib = L.lib()
+level = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+dev = torch.device("cuda:0")
+sc = syn.sphere_scene(level, seed=1, cubemap_res=64)
+cam = syn.blender_cameras(8)[0]
+sp = sc.splats.to(dev)
+colors = torch.rand(sp.num, 3, device=dev, requires_grad=True)
+buf = (C.c_ulonglong * 8)()
+lib.gs_raster_stats_read(buf, 1)
+r, a, meta = gs.rasterization(sp.means, sp.quats, sp.scales.exp(), torch.sigmoid(sp.opacities).squeeze(-1), colors,
+                              cam.view_matrix.to(dev)[None], cam.intrinsic_matrix.to(dev)[None], 800, 800)
+(r.sum() + a.sum()).backward()
+torch.cuda.synchronize()
+lib.gs_raster_stats_read(buf, 0)
+v = list(buf)
+I = meta["flatten_ids"].numel()
+print(f"I={I}  fwd: wave-batches {v[0]}  survivors {v[1]} ({v[1]/max(v[0],1):.1f}/batch)  ok lane-pairs {v[2]} ({v[2]/max(v[1],1):.1f}/survivor)")
+print(f"       bwd: wave-batches {v[4]}  survivors {v[5]} ({v[5]/max(v[4],1):.1f}/batch)  reduced hits {v[6]}  valid lane-pairs {v[7]} ({v[7]/max(v[6],1):.1f}/hit)")

@@ -319,6 +319,190 @@ specular_kernel(int R, const float* __restrict__ src /*cubemap (fwd) | v_out rgb
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Cached pair weights.  w(o,i) depends on (R, roughness, cutoff) only -- never on the cubemap -- and the cubemap
+// is re-filtered every training step.  With 288 GB of HBM the weights are worth keeping: for every texel t the
+// 8x8 patches of its face AABBs are stored as 64 contiguous floats in the traversal order of specular_kernel
+// (0 outside the lobe / outside the AABB).  Applying the filter then is a pure stream: one coalesced 256-byte
+// weight read per patch plus L2-resident texel gathers -- HBM-bound instead of division/sqrt-bound -- and the
+// numbers are bit-identical to the direct kernel because the same kernel code fills the table.
+// Two tables per level: forward (t = output texel) and backward (t = input texel, see specular_kernel<BWD>).
+__global__ void __launch_bounds__(256)
+specular_patch_count_kernel(int R, const float* __restrict__ bounds, int32_t* __restrict__ counts)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 6 * R * R) return;
+    int n = 0;
+    for (int s = 0; s < 6; ++s) {
+        const float4 b = *reinterpret_cast<const float4*>(bounds + (size_t)t * 24 + s * 4);
+        const int xmin = (int)b.x, xmax = (int)b.y, ymin = (int)b.z, ymax = (int)b.w;
+        if (xmin > xmax) continue;
+        n += ((xmax - xmin) / 8 + 1) * ((ymax - ymin) / 8 + 1);
+    }
+    counts[t] = n;
+}
+
+extern "C" int gs_specular_patch_count(int R, const float* bounds, int32_t* counts, void* stream)
+{
+    GS_CHECK_ARG(R >= 1, "bad R");
+    hipLaunchKernelGGL(specular_patch_count_kernel, dim3(gs_cdiv(6 * R * R, 256)), dim3(256), 0, (hipStream_t)stream, R,
+                       bounds, counts);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
+// MODE 0: fill the weight table (and wsum in the forward orientation); MODE 1: apply a filled table.
+template <bool BWD, int MODE>
+__global__ void __launch_bounds__(256)
+specular_table_kernel(int R, const float* __restrict__ src, const float* __restrict__ bounds,
+                      const float4* __restrict__ table, const int64_t* __restrict__ patch_offsets,
+                      float roughness, float cutoff, float* __restrict__ weights, float* __restrict__ wsum_out,
+                      float* __restrict__ dst, int dst_stride, int accumulate, int32_t* __restrict__ patch_desc)
+{
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= 6 * R * R) return;
+    const int lx = lane & 7, ly = lane >> 3;
+    float own[3] = { 0.f, 0.f, 0.f }, own_area = 0.0f, alphaSqr = 0.0f;
+    if (MODE == 0) {
+        const float4 own4 = table[t];
+        own[0] = own4.x; own[1] = own4.y; own[2] = own4.z; own_area = own4.w;
+        const float alpha = roughness * roughness;
+        alphaSqr = alpha * alpha;
+    }
+    float* wp = weights + (size_t)patch_offsets[t] * 64 + lane;
+    int32_t* dp = (MODE == 0 && patch_desc) ? patch_desc + patch_offsets[t] : nullptr;
+    float wsum = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    for (int s = 0; s < 6; ++s) {
+        const float4 b = *reinterpret_cast<const float4*>(bounds + (size_t)t * 24 + s * 4);
+        const int xmin = (int)b.x, xmax = (int)b.y, ymin = (int)b.z, ymax = (int)b.w;
+        if (xmin > xmax) continue;
+        for (int by = ymin; by <= ymax; by += 8)
+            for (int bx = xmin; bx <= xmax; bx += 8, wp += 64) {
+                const int x = bx + lx, y = by + ly;
+                const bool in_box = (x <= xmax && y <= ymax);
+                const size_t ti = ((size_t)s * R + y) * R + x;
+                if (MODE == 0) {
+                    float w = 0.0f;
+                    if (in_box) {
+                        const float4 o4 = table[ti];
+                        const float other[3] = { o4.x, o4.y, o4.z };
+                        const float* L = BWD ? own : other;
+                        const float* VNR = BWD ? other : own;
+                        const float ldv = dot3(L, VNR);
+                        if (ldv >= cutoff) {
+                            float Hv[3] = { L[0] + VNR[0], L[1] + VNR[1], L[2] + VNR[2] };
+                            const float hl = sqrtf(dot3(Hv, Hv));
+                            if (hl > 0.0f) { Hv[0] /= hl; Hv[1] /= hl; Hv[2] /= hl; } else { Hv[0] = Hv[1] = Hv[2] = 0.0f; }
+                            const float wiDotN = fmaxf(ldv, 0.0f);
+                            const float VNRDotH = fmaxf(dot3(VNR, Hv), 0.0f);
+                            const float area = BWD ? own_area : o4.w;
+                            w = wiDotN * ndfGGX(alphaSqr, VNRDotH) * area / 4.0f;
+                        }
+                    }
+                    *wp = w;
+                    wsum += w;
+                    if (dp) { if (lane == 0) *dp = (s << 24) | (by << 12) | bx; ++dp; }
+                } else {
+                    const float w = *wp;
+                    if (w != 0.0f) { c0 += src[ti * 3] * w; c1 += src[ti * 3 + 1] * w; c2 += src[ti * 3 + 2] * w; }
+                }
+            }
+    }
+    if (MODE == 0) {
+        if (wsum_out) { wsum = gs_wave_sum(wsum); if (lane == 0) wsum_out[t] = wsum; }
+    } else {
+        c0 = gs_wave_sum(c0); c1 = gs_wave_sum(c1); c2 = gs_wave_sum(c2);
+        if (lane == 0) {
+            float* p = dst + (size_t)t * dst_stride;
+            if (accumulate) { p[0] += c0; p[1] += c1; p[2] += c2; } else { p[0] = c0; p[1] = c1; p[2] = c2; }
+        }
+    }
+}
+
+extern "C" int gs_specular_weights_build(int R, const float* bounds, const float* dir_table, const int64_t* patch_offsets,
+                                         float roughness, float costheta_cutoff, int backward, float* weights,
+                                         float* wsum, int32_t* patch_desc, void* stream)
+{
+    GS_CHECK_ARG(R >= 1 && R < 4096 && dir_table && patch_offsets && weights, "bad arguments");
+    const dim3 grid(gs_cdiv(6 * R * R, 4)), block(256);
+    if (backward)
+        hipLaunchKernelGGL((specular_table_kernel<true, 0>), grid, block, 0, (hipStream_t)stream, R, nullptr, bounds,
+                           (const float4*)dir_table, patch_offsets, roughness, costheta_cutoff, weights, wsum, nullptr, 0, 0, patch_desc);
+    else
+        hipLaunchKernelGGL((specular_table_kernel<false, 0>), grid, block, 0, (hipStream_t)stream, R, nullptr, bounds,
+                           (const float4*)dir_table, patch_offsets, roughness, costheta_cutoff, weights, wsum, nullptr, 0, 0, patch_desc);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
+// Streaming application of a weight table: the patches of texel t are a flat list (descriptor = face|by|bx),
+// so four patches' weights and texels are requested before any is consumed (memory-level parallelism; the direct
+// kernel's nested AABB loops serialise one patch's latency after the other).
+// SRC4: the source is float4-padded [6,R,R,4] -> ONE 16-byte load per lane and patch instead of three strided
+// dword gathers (the texture-addresser cycles of those gathers, not HBM, bounded the first version).
+template <bool SRC4>
+__global__ void __launch_bounds__(256)
+specular_apply_kernel(int R, const float* __restrict__ src, const int64_t* __restrict__ patch_offsets, int64_t total_patches,
+                      const int32_t* __restrict__ patch_desc, const float* __restrict__ weights,
+                      float* __restrict__ dst, int dst_stride, int accumulate)
+{
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = 6 * R * R;
+    if (t >= n) return;
+    const int lx = lane & 7, ly = lane >> 3;
+    const int64_t p0 = patch_offsets[t];
+    const int64_t p1 = (t + 1 < n) ? patch_offsets[t + 1] : total_patches;
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    for (int64_t p = p0; p < p1; p += 4) {
+        float w[4]; size_t ti[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool on = p + k < p1;
+            const int d = on ? patch_desc[p + k] : 0;
+            w[k] = on ? weights[(size_t)(p + k) * 64 + lane] : 0.0f;
+            const int s = d >> 24, by = (d >> 12) & 0xfff, bx = d & 0xfff;
+            ti[k] = (((size_t)s * R + (by + ly)) * R + (bx + lx)) * (SRC4 ? 4 : 3);
+        }
+        float v[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool nz = w[k] != 0.0f;
+            if (SRC4) {
+                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (nz) q = *reinterpret_cast<const float4*>(src + ti[k]);
+                v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z;
+            } else {
+                v[k][0] = nz ? src[ti[k]] : 0.0f; v[k][1] = nz ? src[ti[k] + 1] : 0.0f; v[k][2] = nz ? src[ti[k] + 2] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { c0 += v[k][0] * w[k]; c1 += v[k][1] * w[k]; c2 += v[k][2] * w[k]; }
+    }
+    c0 = gs_wave_sum(c0); c1 = gs_wave_sum(c1); c2 = gs_wave_sum(c2);
+    if (lane == 0) {
+        float* q = dst + (size_t)t * dst_stride;
+        if (accumulate) { q[0] += c0; q[1] += c1; q[2] += c2; } else { q[0] = c0; q[1] = c1; q[2] = c2; }
+    }
+}
+
+extern "C" int gs_specular_apply(int R, const float* src, int src_stride, const int64_t* patch_offsets,
+                                 int64_t total_patches, const int32_t* patch_desc, const float* weights, float* dst,
+                                 int dst_stride, int accumulate, void* stream)
+{
+    GS_CHECK_ARG(R >= 1 && src && patch_offsets && patch_desc && weights && dst && dst_stride >= 3, "bad arguments");
+    GS_CHECK_ARG(src_stride == 3 || src_stride == 4, "src_stride must be 3 or 4");
+    if (src_stride == 4)
+        hipLaunchKernelGGL(specular_apply_kernel<true>, dim3(gs_cdiv(6 * R * R, 4)), dim3(256), 0, (hipStream_t)stream, R, src,
+                           patch_offsets, total_patches, patch_desc, weights, dst, dst_stride, accumulate);
+    else
+        hipLaunchKernelGGL(specular_apply_kernel<false>, dim3(gs_cdiv(6 * R * R, 4)), dim3(256), 0, (hipStream_t)stream, R, src,
+                           patch_offsets, total_patches, patch_desc, weights, dst, dst_stride, accumulate);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
 extern "C" int gs_specular_cubemap_fwd(int R, const float* cubemap, const float* bounds, const float* dir_table,
                                        float roughness, float costheta_cutoff, float* out, void* stream)
 {

@@ -6,6 +6,7 @@ libgeosplat_hip.so; this file only owns tensors, the bounds cache and the autogr
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -60,6 +61,40 @@ def dir_table(res: int, device: torch.device) -> Tensor:
     return _dir_table_cache[key]
 
 
+_weights_cache: Dict[Tuple[int, float, float, int], Dict[str, Tensor]] = {}
+CACHE_PAIR_WEIGHTS = os.environ.get("GEOSPLAT_PREFILTER_CACHE", "1") != "0"
+
+
+def specular_weights(res: int, roughness: float, cutoff: float, device: torch.device) -> Dict[str, Tensor]:
+    """Cached pair weights of one pyramid level (forward + transposed orientation, ~10 GB in total for a 512^2
+    pyramid -- sized for the 288 GB of an MI355X).  They depend on (res, roughness, cutoff) only, while the cubemap
+    changes every training step."""
+    key = (res, float(roughness), float(cutoff), device.index or 0)
+    if key not in _weights_cache:
+        lib = L.lib()
+        ct, bounds = specular_bounds(res, roughness, cutoff, device)
+        table = dir_table(res, device)
+        n = 6 * res * res
+        counts = torch.empty(n, dtype=torch.int32, device=device)
+        L.check(lib.gs_specular_patch_count(res, L.ptr(bounds), L.ptr(counts), L.stream()), "gs_specular_patch_count")
+        csum = torch.cumsum(counts.long(), 0)
+        offsets = (csum - counts.long()).contiguous()
+        total = int(csum[-1].item())
+        desc = torch.empty(max(total, 1), dtype=torch.int32, device=device)
+        entry = {"offsets": offsets, "ct": ct, "bounds": bounds, "desc": desc, "total": total}
+        for name, bwd in (("fwd", 0), ("bwd", 1)):
+            w = torch.empty(max(total, 1) * 64, dtype=torch.float32, device=device)
+            wsum = torch.empty(n, dtype=torch.float32, device=device) if not bwd else None
+            L.check(lib.gs_specular_weights_build(res, L.ptr(bounds), L.ptr(table), L.ptr(offsets), L.f32(roughness), L.f32(ct),
+                                                  bwd, L.ptr(w), L.ptr(wsum), L.ptr(desc), L.stream()),
+                    "gs_specular_weights_build")
+            entry[name] = w
+            if wsum is not None:
+                entry["wsum"] = wsum.view(6, res, res, 1)
+        _weights_cache[key] = entry
+    return _weights_cache[key]
+
+
 # ----------------------------------------------------------------------------- autograd pieces
 class _CubeMapMip(torch.autograd.Function):
     """rfstudio/graphics/_mesh/_texture.py:199-226"""
@@ -103,7 +138,8 @@ class _DiffuseCubemap(torch.autograd.Function):
 
 
 class _SpecularCubemap(torch.autograd.Function):
-    """_specular_cubemap + the rgb/wsum normalisation (rfstudio/graphics/_mesh/_splitsum/_wrap.py:104-118,157)"""
+    """_specular_cubemap + the rgb/wsum normalisation (rfstudio/graphics/_mesh/_splitsum/_wrap.py:104-118,157).
+    Direct evaluation of the lobe weights (every call recomputes them)."""
 
     @staticmethod
     def forward(ctx, cubemap: Tensor, roughness: float, costheta_cutoff: float, bounds: Tensor) -> Tensor:
@@ -131,11 +167,40 @@ class _SpecularCubemap(torch.autograd.Function):
         return g, None, None, None
 
 
+class _SpecularCubemapCached(torch.autograd.Function):
+    """Same operator through the cached pair-weight tables (bit-identical weights, streamed instead of recomputed)."""
+
+    @staticmethod
+    def forward(ctx, cubemap: Tensor, res: int, roughness: float, cutoff: float) -> Tensor:
+        e = specular_weights(res, roughness, cutoff, cubemap.device)
+        src4 = torch.nn.functional.pad(cubemap, (0, 1)).contiguous()          # float4 texels: one 16-byte tap per lane
+        rgb = torch.empty(6, res, res, 3, dtype=torch.float32, device=cubemap.device)
+        L.check(L.lib().gs_specular_apply(res, L.ptr(src4), 4, L.ptr(e["offsets"]), L.i64(e["total"]), L.ptr(e["desc"]),
+                                          L.ptr(e["fwd"]), L.ptr(rgb), 3, 0, L.stream()), "gs_specular_apply")
+        ctx.cfg = (res, roughness, cutoff)
+        return rgb / e["wsum"]
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        res, roughness, cutoff = ctx.cfg
+        e = specular_weights(res, roughness, cutoff, dout.device)
+        v4 = torch.nn.functional.pad(dout / e["wsum"], (0, 1)).contiguous()
+        g = torch.empty_like(dout, memory_format=torch.contiguous_format)
+        L.check(L.lib().gs_specular_apply(res, L.ptr(v4), 4, L.ptr(e["offsets"]), L.i64(e["total"]), L.ptr(e["desc"]),
+                                          L.ptr(e["bwd"]), L.ptr(g), 3, 0, L.stream()), "gs_specular_apply")
+        return g, None, None, None
+
+
 def diffuse_cubemap(cubemap: Tensor) -> Tensor:
     return _DiffuseCubemap.apply(cubemap)
 
 
-def specular_cubemap(cubemap: Tensor, roughness: float, cutoff: float = 0.99) -> Tensor:
+def specular_cubemap(cubemap: Tensor, roughness: float, cutoff: float = 0.99, cached: Optional[bool] = None) -> Tensor:
+    """specular_cubemap of _wrap.py:138-157.  cached=True streams the pair weights from the per-level table
+    (default, GEOSPLAT_PREFILTER_CACHE=0 disables), cached=False recomputes them in the kernel."""
+    use_cache = CACHE_PAIR_WEIGHTS if cached is None else cached
+    if use_cache:
+        return _SpecularCubemapCached.apply(cubemap, int(cubemap.shape[1]), float(roughness), float(cutoff))
     ct, bounds = specular_bounds(cubemap.shape[1], roughness, cutoff, cubemap.device)
     return _SpecularCubemap.apply(cubemap, float(roughness), ct, bounds)
 

@@ -188,6 +188,22 @@ int gs_specular_cubemap_fwd(int R, const float* cubemap, const float* bounds, co
 int gs_specular_cubemap_bwd(int R, const float* bounds, const float* dir_table, const float* v_out_rgb,
                             float roughness, float costheta_cutoff, float* v_cubemap, int accumulate, void* stream);
 
+/* Cached pair weights of the specular prefilter (functions of R / roughness / cutoff only; the cubemap is
+ * re-filtered every step).  Per texel the 8x8 patches of its face AABBs are stored as 64 contiguous floats:
+ *   gs_specular_patch_count  -> counts[6*R*R] patches per texel; the caller builds patch_offsets[6*R*R] =
+ *                               exclusive cumsum (int64) and allocates weights[total_patches * 64];
+ *   gs_specular_weights_build-> fills weights (backward != 0: the transposed orientation used by the
+ *                               atomic-free backward gather) and, if wsum != NULL, wsum[6*R*R];
+ *   gs_specular_apply        -> dst[t*dst_stride + 0..2] (+)= sum_k weights[t][k] * src[texel_k][0..2]
+ *                               (flat patch list + descriptors: four patches in flight per wave). */
+int gs_specular_patch_count(int R, const float* bounds, int32_t* counts, void* stream);
+int gs_specular_weights_build(int R, const float* bounds, const float* dir_table, const int64_t* patch_offsets,
+                              float roughness, float costheta_cutoff, int backward, float* weights, float* wsum,
+                              int32_t* patch_desc /* [total_patches]: face<<24 | by<<12 | bx */, void* stream);
+int gs_specular_apply(int R, const float* src, int src_stride /* 3, or 4 = float4-padded texels (faster) */,
+                      const int64_t* patch_offsets, int64_t total_patches, const int32_t* patch_desc,
+                      const float* weights, float* dst, int dst_stride, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -103,6 +103,23 @@ def test_as_splitsum_fwd_bwd(cuda):
         assert torch.equal(a, b)
 
 
+def test_prefilter_cached_weights_equal_direct(cuda):
+    """The streamed pair-weight tables reproduce the direct lobe evaluation (same kernel code fills them)."""
+    import geosplatting_amd as gs
+    g = torch.Generator().manual_seed(4)
+    for R, rough in ((64, 0.08), (32, 0.29), (16, 1.0)):
+        c = torch.rand(6, R, R, 3, generator=g).to(cuda)
+        v = (torch.rand(6, R, R, 3, generator=g) - 0.5).to(cuda)
+        outs, grads = [], []
+        for cached in (False, True):
+            x = c.clone().requires_grad_(True)
+            y = gs.specular_cubemap(x, rough, cached=cached)
+            y.backward(v)
+            outs.append(y.detach()); grads.append(x.grad)
+        assert float((outs[0] - outs[1]).abs().max()) <= 2e-6 * float(outs[0].abs().max())
+        assert float((grads[0] - grads[1]).abs().max()) <= 2e-6 * float(grads[0].abs().max())
+
+
 def test_splat_end_to_end(cuda):
     """RenderableAttrs.splat: shade -> rasterize -> tone-map, forward image and all parameter gradients."""
     import geosplatting_amd as gs

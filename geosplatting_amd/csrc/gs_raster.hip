@@ -192,28 +192,44 @@ raster_fwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
             for (int k = 0; k < CD; ++k) col[k] = (hit && k < D) ? colors[(size_t)g * D + k] : 0.0f;
         }
 
-        while (mask) {
-            const int j = __builtin_ctzll(mask);
-            mask &= mask - 1ull;
+        // Two survivors per trip.  Phase A (geometry -> alpha) does not depend on the compositing state, phase B
+        // (T / done / pix recurrence) is short and branch-free: issuing A(j0), A(j1) before B(j0), B(j1) gives the
+        // in-order SIMD independent work to cover the dependent chain of B (the kernel was ~50 % issue-stalled).
+        auto phase_a = [&](int j, float& alpha, bool& pre) {
             const float gx = gs_readlane(mx, j), gy = gs_readlane(my, j);
             const float ga = gs_readlane(ha, j), gb = gs_readlane(cb, j), gc = gs_readlane(hc, j);
             const float go = gs_readlane(op, j);
             const float dx = gx - px, dy = gy - py;
             const float t0 = ga * dx, t1 = gc * dy, t2 = gb * dx;
             const float sigma = fmaf(t0, dx, fmaf(t1, dy, t2 * dy));
-            const float alpha = fminf(0.999f, go * __expf(-sigma));
-            const bool ok = !done && sigma >= 0.0f && alpha >= GS_ALPHA_MIN;
+            alpha = fminf(0.999f, go * __expf(-sigma));
+            pre = sigma >= 0.0f && alpha >= GS_ALPHA_MIN;
+        };
+        auto phase_b = [&](int j, float alpha, bool pre) {
+            const bool ok = !done && pre;
             const float next_T = T * (1.0f - alpha);
             const bool stop = ok && next_T <= 1e-4f;
             const bool acc = ok && !stop;
             done = done || stop;
             GS_STAT(2, __popcll(__ballot(ok)));
-            if (__ballot(acc) != 0ull) {
-                const float vis = acc ? alpha * T : 0.0f;
+            const float vis = acc ? alpha * T : 0.0f;
 #pragma unroll
-                for (int k = 0; k < CD; ++k) pix[k] = fmaf(gs_readlane(col[k], j), vis, pix[k]);
-                if (acc) { T = next_T; cur_idx = base + j; }
-            }
+            for (int k = 0; k < CD; ++k) pix[k] = fmaf(gs_readlane(col[k], j), vis, pix[k]);
+            T = acc ? next_T : T;
+            cur_idx = acc ? base + j : cur_idx;
+        };
+        while (mask) {
+            const int j0 = __builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            const bool has1 = mask != 0ull;
+            const int j1 = has1 ? __builtin_ctzll(mask) : j0;
+            mask &= mask - 1ull;                         // no-op when mask is already 0
+            float a0, a1; bool p0, p1;
+            phase_a(j0, a0, p0);
+            phase_a(j1, a1, p1);
+            p1 = p1 && has1;
+            phase_b(j0, a0, p0);
+            phase_b(j1, a1, p1);
         }
     }
 

@@ -31,7 +31,7 @@ class GsEnvGrad(C.Structure):
 SYMBOLS = [
     "gs_last_error", "gs_version", "gs_project_ws_bytes", "gs_project_fwd", "gs_isect_emit", "gs_sort_ws_bytes",
     "gs_isect_sort", "gs_isect_offsets", "gs_raster_ws_bytes", "gs_raster_fwd", "gs_raster_bwd", "gs_project_bwd", "gs_shade_fwd",
-    "gs_shade_bwd", "gs_tonemap_fwd", "gs_tonemap_bwd", "gs_cubemap_mip_fwd", "gs_cube_sample_linear",
+    "gs_shade_bwd_ws_bytes", "gs_shade_bwd", "gs_tonemap_fwd", "gs_tonemap_bwd", "gs_cubemap_mip_fwd", "gs_cube_sample_linear",
     "gs_cubemap_mip_bwd", "gs_diffuse_cubemap_fwd", "gs_diffuse_cubemap_bwd", "gs_specular_bounds", "gs_cube_dir_table",
     "gs_specular_cubemap_fwd", "gs_specular_cubemap_bwd", "gs_specular_patch_count", "gs_specular_weights_build",
     "gs_specular_apply",
@@ -58,6 +58,8 @@ def lib() -> C.CDLL:
         l.gs_project_ws_bytes.argtypes = [C.c_int]
         l.gs_sort_ws_bytes.restype = C.c_size_t
         l.gs_sort_ws_bytes.argtypes = [C.c_int64, C.c_int, C.c_int]
+        l.gs_shade_bwd_ws_bytes.restype = C.c_size_t
+        l.gs_shade_bwd_ws_bytes.argtypes = [C.c_void_p, C.c_int]
         l.gs_raster_ws_bytes.restype = C.c_size_t
         l.gs_raster_ws_bytes.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int]
         _lib = l

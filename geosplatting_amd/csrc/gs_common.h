@@ -105,5 +105,19 @@ struct GsBfly {
 
 __device__ __forceinline__ int gs_lane_id() { return (int)(threadIdx.x & 63); }
 
-// fp32 atomic add that lowers to the hardware global_atomic_add_f32 (no CAS loop)
+// fp32 atomic add that lowers to the hardware global_atomic_add_f32 (no CAS loop), agent (device) scope:
+// coherent across the 8 XCDs, i.e. executed at the memory side of the fabric (a 32-byte write-through per op).
 __device__ __forceinline__ void gs_atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+// XCD-LOCAL fp32 atomic add (workgroup scope: no sc1 -> resolved in this XCD's L2, the line stays cached).
+// ONLY valid on memory that no other XCD touches during the launch (per-XCD private accumulators).
+__device__ __forceinline__ void gs_atomic_add_xcd(float* p, float v)
+{
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// id of the XCD (accelerator complex die) this wave runs on, 0..7 on MI355X: HW_REG_XCC_ID (hwreg 20), bits [3:0]
+__device__ __forceinline__ int gs_xcc_id()
+{
+    return (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xf);
+}

@@ -157,6 +157,13 @@ __device__ void cube_fetch(const float* __restrict__ tex, int R, const float* d,
 // (leader loop: broadcast the first pending address, ballot the matches, DPP-reduce, one lane commits);
 // incoherent lanes fall back to plain atomics after GS_AGG_ROUNDS leaders.
 #define GS_AGG_ROUNDS 6
+template <bool XCD_LOCAL>
+__device__ __forceinline__ void gs_add_scoped(float* p, float v)
+{
+    if (XCD_LOCAL) gs_atomic_add_xcd(p, v); else gs_atomic_add(p, v);
+}
+
+template <bool XCD_LOCAL>
 __device__ __forceinline__ void wave_agg_add3(float* p /* nullptr = nothing to add */, float v0, float v1, float v2)
 {
     const int lane = (int)(threadIdx.x & 63);
@@ -173,15 +180,16 @@ __device__ __forceinline__ void wave_agg_add3(float* p /* nullptr = nothing to a
         const float s0 = gs_wave_sum(same ? v0 : 0.0f);
         const float s1 = gs_wave_sum(same ? v1 : 0.0f);
         const float s2 = gs_wave_sum(same ? v2 : 0.0f);
-        if (lane == leader) { gs_atomic_add(p, s0); gs_atomic_add(p + 1, s1); gs_atomic_add(p + 2, s2); }
+        if (lane == leader) { gs_add_scoped<XCD_LOCAL>(p, s0); gs_add_scoped<XCD_LOCAL>(p + 1, s1); gs_add_scoped<XCD_LOCAL>(p + 2, s2); }
         if (same) key = 0ull;
         remaining &= ~m;
         singles = (__popcll(m) == 1) ? singles + 1 : 0;
     }
-    if (key != 0ull) { gs_atomic_add(p, v0); gs_atomic_add(p + 1, v1); gs_atomic_add(p + 2, v2); }
+    if (key != 0ull) { gs_add_scoped<XCD_LOCAL>(p, v0); gs_add_scoped<XCD_LOCAL>(p + 1, v1); gs_add_scoped<XCD_LOCAL>(p + 2, v2); }
 }
 
 // all 64 lanes of the wave must call this together (lanes without work pass valid == false)
+template <bool XCD_LOCAL>
 __device__ __forceinline__ void cube_scatter_wave(float* grad_tex, const CubeFp& fp, const float* g, float scale, bool valid)
 {
 #pragma unroll
@@ -189,7 +197,7 @@ __device__ __forceinline__ void cube_scatter_wave(float* grad_tex, const CubeFp&
         const bool on = valid && fp.valid && fp.idx[i] >= 0 && grad_tex != nullptr;
         const float w = on ? scale * fp.w[i] : 0.0f;
         float* p = on ? grad_tex + (size_t)fp.idx[i] * 3 : nullptr;
-        wave_agg_add3(p, g[0] * w, g[1] * w, g[2] * w);
+        wave_agg_add3<XCD_LOCAL>(p, g[0] * w, g[1] * w, g[2] * w);
     }
 }
 

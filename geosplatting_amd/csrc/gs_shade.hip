@@ -34,6 +34,12 @@ struct EnvGradDev {
     int lds_base;
     int lds_level[GS_MAX_LEVELS];
     int lds_floats;
+    // per-XCD private accumulators for the levels that do not fit LDS (XCD-local atomics, reduced afterwards):
+    // copy x of level l lives at priv + x * priv_stride + priv_level[l] (floats); priv == nullptr -> device atomics
+    float* priv;
+    long long priv_stride;
+    long long priv_level[GS_MAX_LEVELS];
+    long long priv_base;
 };
 
 __device__ __forceinline__ void tex2d_linear_clamp2(const float* __restrict__ lut, int W, int H, float u, float v,
@@ -198,6 +204,7 @@ __device__ __forceinline__ void cube_scatter_lds(float* lds, const CubeFp& fp, c
 // serialises per address (5.5 ms per view measured); in LDS it is a ds_add_f32 and the block flushes its
 // copy once at the end.
 #define GS_SHADE_BWD_BLOCK 1024
+template <bool PRIV>
 __global__ void __launch_bounds__(GS_SHADE_BWD_BLOCK)
 shade_bwd_kernel(int N, const float* __restrict__ means, const float* __restrict__ normals,
                  const float* __restrict__ kd, const float* __restrict__ ks, const float* __restrict__ cam_pos,
@@ -208,6 +215,9 @@ shade_bwd_kernel(int N, const float* __restrict__ means, const float* __restrict
     extern __shared__ __attribute__((aligned(16))) float s_grad[];
     for (int i = threadIdx.x; i < eg.lds_floats; i += blockDim.x) s_grad[i] = 0.0f;
     __syncthreads();
+    // this block's XCD-private accumulator copy (device-scope fp32 atomics are resolved at the memory side of the
+    // fabric -- a 32-byte write-through each, 0.6 GB per view here; XCD-local ones stay in the 4 MiB L2)
+    float* const priv = PRIV ? eg.priv + (long long)gs_xcc_id() * eg.priv_stride : nullptr;
     const float cp[3] = { cam_pos[0], cam_pos[1], cam_pos[2] };
     // wave-uniform trip count: every lane of a wave reaches the wave-aggregated scatter together
     const int n_iter = (N + (int)(gridDim.x * blockDim.x) - 1) / (int)(gridDim.x * blockDim.x);
@@ -300,15 +310,18 @@ shade_bwd_kernel(int N, const float* __restrict__ means, const float* __restrict
             const float w0 = (l1 < 0) ? 1.0f : 1.0f - t.ls.f;
             const bool lds0 = scatter && eg.lds_level[l0] >= 0;
             if (lds0) cube_scatter_lds(s_grad + eg.lds_level[l0], t.ls.fp0, v_ls, w0);
-            cube_scatter_wave(scatter && !lds0 ? eg.levels[l0] : nullptr, t.ls.fp0, v_ls, w0, scatter && !lds0);
+            cube_scatter_wave<PRIV>(scatter && !lds0 ? (PRIV ? priv + eg.priv_level[l0] : eg.levels[l0]) : nullptr, t.ls.fp0,
+                                    v_ls, w0, scatter && !lds0);
             const bool has1 = scatter && l1 >= 0;
             const bool lds1 = has1 && eg.lds_level[has1 ? l1 : 0] >= 0;
             if (lds1) cube_scatter_lds(s_grad + eg.lds_level[l1], t.ls.fp1, v_ls, t.ls.f);
-            cube_scatter_wave(has1 && !lds1 ? eg.levels[l1] : nullptr, t.ls.fp1, v_ls, t.ls.f, has1 && !lds1);
+            cube_scatter_wave<PRIV>(has1 && !lds1 ? (PRIV ? priv + eg.priv_level[has1 ? l1 : 0] : eg.levels[l1]) : nullptr,
+                                    t.ls.fp1, v_ls, t.ls.f, has1 && !lds1);
         } else {
             const bool ldsb = scatter && eg.lds_base >= 0;
             if (ldsb) cube_scatter_lds(s_grad + eg.lds_base, t.ld_fp, v_ld, 1.0f);
-            cube_scatter_wave(scatter && !ldsb ? eg.base : nullptr, t.ld_fp, v_ld, 1.0f, scatter && !ldsb);
+            cube_scatter_wave<PRIV>(scatter && !ldsb ? (PRIV ? priv + eg.priv_base : eg.base) : nullptr, t.ld_fp, v_ld, 1.0f,
+                                    scatter && !ldsb);
         }
     }
     // ---- flush the private copies
@@ -328,6 +341,32 @@ shade_bwd_kernel(int N, const float* __restrict__ means, const float* __restrict
             if (v != 0.0f) gs_atomic_add(eg.levels[l] + i, v);
         }
     }
+}
+
+// dst[i] += sum over the 8 XCD-private copies (plain loads: the producer launch has ended, its L2s are written back)
+__global__ void __launch_bounds__(256)
+priv_reduce_kernel(long long n, int copies, const float* __restrict__ priv, long long stride, float* __restrict__ dst)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float acc = 0.0f;
+        for (int x = 0; x < copies; ++x) acc += priv[x * stride + i];
+        if (acc != 0.0f) dst[i] += acc;
+    }
+}
+
+#define GS_XCD_COPIES 8
+static size_t shade_bwd_priv_floats(const EnvDev& e, int mode, long long* level_off, long long* base_off)
+{
+    long long off = 0;
+    for (int l = 0; l < GS_MAX_LEVELS; ++l) level_off[l] = -1;
+    *base_off = -1;
+    if (mode == GS_MODE_DIFFUSE) {
+        if (e.base_res > 32) { *base_off = off; off += 18ll * e.base_res * e.base_res; }
+    } else {
+        for (int l = 0; l < e.L; ++l)
+            if (e.res[l] > 32) { level_off[l] = off; off += 18ll * e.res[l] * e.res[l]; }
+    }
+    return (size_t)((off + 63) / 64 * 64);
 }
 
 static int env_to_dev(const GsEnv* env, EnvDev& e)
@@ -357,10 +396,19 @@ extern "C" int gs_shade_fwd(int N, const float* means, const float* normals, con
     return GS_OK;
 }
 
+extern "C" size_t gs_shade_bwd_ws_bytes(const GsEnv* env, int mode)
+{
+    EnvDev e;
+    if (env_to_dev(env, e) != 0) return 0;
+    long long lo[GS_MAX_LEVELS], bo;
+    return shade_bwd_priv_floats(e, mode, lo, &bo) * sizeof(float) * GS_XCD_COPIES;
+}
+
 extern "C" int gs_shade_bwd(int N, const float* means, const float* normals, const float* kd, const float* ks,
                             const float* cam_pos, float min_roughness, float max_metallic, int mode,
                             const GsEnv* env, const float* v_colors, float* v_means, float* v_normals,
-                            float* v_kd, float* v_ks, const GsEnvGrad* env_grad, void* stream)
+                            float* v_kd, float* v_ks, const GsEnvGrad* env_grad, void* ws, size_t ws_bytes,
+                            void* stream)
 {
     GS_CHECK_ARG(N >= 0 && mode >= 0 && mode <= 2, "bad N or mode");
     EnvDev e;
@@ -386,16 +434,41 @@ extern "C" int gs_shade_bwd(int N, const float* means, const float* normals, con
         }
     }
     eg.lds_floats = used;
+    // XCD-private accumulators for the big levels (optional workspace)
+    const size_t priv_floats = shade_bwd_priv_floats(e, mode, eg.priv_level, &eg.priv_base);
+    const bool use_priv = ws != nullptr && priv_floats > 0;
+    if (use_priv && ws_bytes < priv_floats * sizeof(float) * GS_XCD_COPIES) { gs_set_error("gs_shade_bwd: workspace too small"); return GS_ENOSPC; }
+    eg.priv = use_priv ? (float*)ws : nullptr;
+    eg.priv_stride = (long long)priv_floats;
     if (N == 0) return GS_OK;
+    hipStream_t s = (hipStream_t)stream;
     const size_t lds_bytes = (size_t)used * sizeof(float);
-    GS_CHECK_HIP(hipFuncSetAttribute((const void*)shade_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     int blocks = gs_cdiv(N, GS_SHADE_BWD_BLOCK);
     const int max_blocks = used > 0 ? 256 : 2048;
     if (blocks > max_blocks) blocks = max_blocks;
-    hipLaunchKernelGGL(shade_bwd_kernel, dim3(blocks), dim3(GS_SHADE_BWD_BLOCK), lds_bytes, (hipStream_t)stream, N, means,
-                       normals, kd, ks, cam_pos, min_roughness, max_metallic, mode, e, v_colors, v_means, v_normals, v_kd,
-                       v_ks, eg);
-    GS_CHECK_LAUNCH();
+    if (use_priv) {
+        GS_CHECK_HIP(hipMemsetAsync(ws, 0, priv_floats * sizeof(float) * GS_XCD_COPIES, s));
+        GS_CHECK_HIP(hipFuncSetAttribute((const void*)shade_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(shade_bwd_kernel<true>, dim3(blocks), dim3(GS_SHADE_BWD_BLOCK), lds_bytes, s, N, means, normals, kd, ks,
+                           cam_pos, min_roughness, max_metallic, mode, e, v_colors, v_means, v_normals, v_kd, v_ks, eg);
+        GS_CHECK_LAUNCH();
+        // fold the 8 copies into the caller's gradient buffers, level by level
+        for (int l = -1; l < e.L; ++l) {
+            const long long off = l < 0 ? eg.priv_base : eg.priv_level[l];
+            if (off < 0) continue;
+            const int R = l < 0 ? e.base_res : e.res[l];
+            float* dst = l < 0 ? eg.base : eg.levels[l];
+            const long long n = 18ll * R * R;
+            hipLaunchKernelGGL(priv_reduce_kernel, dim3((int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, s, n,
+                               GS_XCD_COPIES, (const float*)ws + off, (long long)priv_floats, dst);
+            GS_CHECK_LAUNCH();
+        }
+    } else {
+        GS_CHECK_HIP(hipFuncSetAttribute((const void*)shade_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(shade_bwd_kernel<false>, dim3(blocks), dim3(GS_SHADE_BWD_BLOCK), lds_bytes, s, N, means, normals, kd, ks,
+                           cam_pos, min_roughness, max_metallic, mode, e, v_colors, v_means, v_normals, v_kd, v_ks, eg);
+        GS_CHECK_LAUNCH();
+    }
     return GS_OK;
 }
 

@@ -92,12 +92,17 @@ def init_distributed_from_env(device_type: str = "cuda"):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = "nccl" if device_type == "cuda" else "gloo"
     if device_type == "cuda":
+        # GEOSPLAT_DEBUG_SHARE_GPU=1: every rank on cuda:0 with the gloo backend -- lets a 1-GPU box exercise the
+        # multi-rank code path of bench.py end to end (never used for measurements)
+        if os.environ.get("GEOSPLAT_DEBUG_SHARE_GPU") == "1":
+            local, backend = 0, "gloo"
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
     else:
         device = torch.device("cpu")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if device_type == "cuda" else "gloo", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, device

@@ -151,13 +151,17 @@ int gs_shade_fwd(int N, const float* means, const float* normals, const float* k
                  const float* cam_pos, float min_roughness, float max_metallic, int mode,
                  const GsEnv* env /*host*/, float* colors, void* stream);
 
+/* Bytes of the optional workspace of gs_shade_bwd: 8 XCD-private copies of the texel-gradient levels that do
+ * not fit LDS (XCD-local atomics stay in L2; device-scope ones are 32-byte write-throughs to the fabric). */
+size_t gs_shade_bwd_ws_bytes(const GsEnv* env /*host*/, int mode);
+
 /* Recomputes the forward and chains v_colors[N,3].  v_means/v_normals/v_kd/v_ks are fully written;
- * texel gradients are ACCUMULATED into env_grad (fp32 atomics). */
+ * texel gradients are ACCUMULATED into env_grad.  ws may be NULL (plain device-scope atomics). */
 int gs_shade_bwd(int N, const float* means, const float* normals, const float* kd, const float* ks,
                  const float* cam_pos, float min_roughness, float max_metallic, int mode,
                  const GsEnv* env /*host*/, const float* v_colors,
                  float* v_means, float* v_normals, float* v_kd, float* v_ks,
-                 const GsEnvGrad* env_grad /*host*/, void* stream);
+                 const GsEnvGrad* env_grad /*host*/, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ S4 ----------------------------- */
 /* out[P,4] = tonemap(rgba[P,4] * exposure) ; exposure is a DEVICE scalar. */

@@ -66,11 +66,11 @@ def time_dominant_kernels(scene_state, iters):
     v_m2d = torch.empty(V, 2, dtype=f32, device=dev); v_con = torch.empty(V, 3, dtype=f32, device=dev)
     v_col = torch.empty(V, D, dtype=f32, device=dev); v_op = torch.empty(V, dtype=f32, device=dev)
     s = L.stream()
-    rws_bytes = lib.gs_raster_ws_bytes(L.i64(I), W, H, 16)
+    rws_bytes = lib.gs_raster_ws_bytes(L.i64(I), V, W, H, 16)
     rws = torch.empty(rws_bytes, dtype=torch.uint8, device=dev)
 
     def fwd():
-        L.check(lib.gs_raster_fwd(W, H, 16, D, L.ptr(st["means2d"]), L.ptr(st["conics"]), L.ptr(st["opacities"]),
+        L.check(lib.gs_raster_fwd(W, H, 16, D, V, L.ptr(st["means2d"]), L.ptr(st["conics"]), L.ptr(st["opacities"]),
                                   L.ptr(st["colors"]), None, L.i64(I), L.ptr(st["offsets"]), L.ptr(st["flatten_ids"]),
                                   L.ptr(render), L.ptr(alphas), L.ptr(last), L.ptr(rws), C.c_size_t(rws_bytes), s), "raster_fwd")
 

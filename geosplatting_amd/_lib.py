@@ -61,7 +61,7 @@ def lib() -> C.CDLL:
         l.gs_shade_bwd_ws_bytes.restype = C.c_size_t
         l.gs_shade_bwd_ws_bytes.argtypes = [C.c_void_p, C.c_int]
         l.gs_raster_ws_bytes.restype = C.c_size_t
-        l.gs_raster_ws_bytes.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int]
+        l.gs_raster_ws_bytes.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib = l
     return _lib
 

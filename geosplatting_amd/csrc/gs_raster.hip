@@ -81,6 +81,46 @@ build_stream_kernel(int n_isects, int D, const int32_t* __restrict__ flatten_ids
     rec2[i] = make_float4(c0, c1, c2, __int_as_float(g));
 }
 
+// Same stream from the PACKED per-visible records written by gs_pack_visible (3 aligned 16-byte gathers per
+// intersection instead of 8 scalar ones: the gather, not the 48-byte store, bounds this kernel).
+__global__ void __launch_bounds__(256)
+build_stream_packed_kernel(int n_isects, const int32_t* __restrict__ flatten_ids, const float4* __restrict__ vis0,
+                           const float4* __restrict__ vis1, const float4* __restrict__ vis2,
+                           float4* __restrict__ rec0, float4* __restrict__ rec1, float4* __restrict__ rec2)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_isects) return;
+    const int g = flatten_ids[i];
+    const float4 a = vis0[g], b = vis1[g];
+    float4 c = vis2[g];
+    c.w = __int_as_float(g);
+    rec0[i] = a; rec1[i] = b; rec2[i] = c;
+}
+
+// per-visible packing (coalesced): vis0 = {mx,my,0.5a,b}, vis1 = {0.5c,op,hx,hy}, vis2 = {c0,c1,c2,-}
+__global__ void __launch_bounds__(256)
+pack_visible_kernel(int V, int D, const float* __restrict__ means2d, const float* __restrict__ conics,
+                    const float* __restrict__ opacities, const float* __restrict__ colors,
+                    float4* __restrict__ vis0, float4* __restrict__ vis1, float4* __restrict__ vis2)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= V) return;
+    const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)g);
+    const float ca = conics[3 * (size_t)g], cb = conics[3 * (size_t)g + 1], cc = conics[3 * (size_t)g + 2];
+    const float op = opacities[g];
+    float hx = -1.0f, hy = -1.0f;
+    if (!alpha_extent(ca, cb, cc, op, hx, hy)) { hx = -1.0f; hy = -1.0f; }
+    vis0[g] = make_float4(m.x, m.y, 0.5f * ca, cb);
+    vis1[g] = make_float4(0.5f * cc, op, hx, hy);
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    if (D <= 3) {
+        c0 = colors[(size_t)g * D];
+        if (D > 1) c1 = colors[(size_t)g * D + 1];
+        if (D > 2) c2 = colors[(size_t)g * D + 2];
+    }
+    vis2[g] = make_float4(c0, c1, c2, 0.0f);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // LPT tile order: bucket tiles by floor(log2(count)) descending (single block).
 __global__ void __launch_bounds__(1024)
@@ -400,27 +440,33 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
 // workspace layout: [rec0 | rec1 | rec2 | tile_order], every segment 256-byte aligned
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-extern "C" size_t gs_raster_ws_bytes(int64_t n_isects, int W, int H, int tile_size)
+extern "C" size_t gs_raster_ws_bytes(int64_t n_isects, int V, int W, int H, int tile_size)
 {
     if (tile_size <= 0) return 0;
     const size_t tiles = (size_t)((W + tile_size - 1) / tile_size) * (size_t)((H + tile_size - 1) / tile_size);
     const size_t n = n_isects > 0 ? (size_t)n_isects : 1;
-    return 3 * align256(n * sizeof(float4)) + align256(tiles * sizeof(int32_t));
+    const size_t v = V > 0 ? (size_t)V : 1;
+    return 3 * align256(n * sizeof(float4)) + align256(tiles * sizeof(int32_t)) + 3 * align256(v * sizeof(float4));
 }
 
 struct RasterWs {
     float4 *rec0, *rec1, *rec2;
     int32_t* order;
+    float4 *vis0, *vis1, *vis2;     // scratch of the forward only
 };
-static RasterWs carve(void* ws, int64_t n_isects, int tiles)
+static RasterWs carve(void* ws, int64_t n_isects, int V, int tiles)
 {
     const size_t n = n_isects > 0 ? (size_t)n_isects : 1;
+    const size_t v = V > 0 ? (size_t)V : 1;
     char* p = (char*)ws;
     RasterWs r;
     r.rec0 = (float4*)p; p += align256(n * sizeof(float4));
     r.rec1 = (float4*)p; p += align256(n * sizeof(float4));
     r.rec2 = (float4*)p; p += align256(n * sizeof(float4));
-    r.order = (int32_t*)p;
+    r.order = (int32_t*)p; p += align256((size_t)tiles * sizeof(int32_t));
+    r.vis0 = (float4*)p; p += align256(v * sizeof(float4));
+    r.vis1 = (float4*)p; p += align256(v * sizeof(float4));
+    r.vis2 = (float4*)p;
     return r;
 }
 
@@ -437,7 +483,7 @@ static int launch_fwd(int W, int H, int D, const RasterWs& ws, const float* colo
     return GS_OK;
 }
 
-extern "C" int gs_raster_fwd(int W, int H, int tile_size, int D, const float* means2d, const float* conics,
+extern "C" int gs_raster_fwd(int W, int H, int tile_size, int D, int V, const float* means2d, const float* conics,
                              const float* opacities, const float* colors, const float* background,
                              int64_t n_isects, const int32_t* offsets, const int32_t* flatten_ids,
                              float* render, float* alphas, int32_t* last_ids, void* ws, size_t ws_bytes, void* stream)
@@ -447,13 +493,17 @@ extern "C" int gs_raster_fwd(int W, int H, int tile_size, int D, const float* me
     GS_CHECK_ARG(D >= 1 && D <= GS_MAX_CHANNELS, "1 <= D <= 32");
     GS_CHECK_ARG(n_isects >= 0 && n_isects < (1ll << 31), "n_isects must fit int32");
     GS_CHECK_ARG(ws != nullptr, "workspace must not be NULL");
-    if (ws_bytes < gs_raster_ws_bytes(n_isects, W, H, tile_size)) { gs_set_error("gs_raster_fwd: workspace too small"); return GS_ENOSPC; }
+    GS_CHECK_ARG(V >= 0, "bad V");
+    if (ws_bytes < gs_raster_ws_bytes(n_isects, V, W, H, tile_size)) { gs_set_error("gs_raster_fwd: workspace too small"); return GS_ENOSPC; }
     hipStream_t s = (hipStream_t)stream;
     const int tiles = ((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
-    const RasterWs r = carve(ws, n_isects, tiles);
-    if (n_isects > 0) {
-        hipLaunchKernelGGL(build_stream_kernel, dim3(gs_cdiv(n_isects, 256)), dim3(256), 0, s, (int)n_isects, D, flatten_ids,
-                           means2d, conics, opacities, colors, r.rec0, r.rec1, r.rec2);
+    const RasterWs r = carve(ws, n_isects, V, tiles);
+    if (n_isects > 0 && V > 0) {
+        hipLaunchKernelGGL(pack_visible_kernel, dim3(gs_cdiv(V, 256)), dim3(256), 0, s, V, D, means2d, conics, opacities, colors,
+                           r.vis0, r.vis1, r.vis2);
+        GS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(build_stream_packed_kernel, dim3(gs_cdiv(n_isects, 256)), dim3(256), 0, s, (int)n_isects, flatten_ids,
+                           r.vis0, r.vis1, r.vis2, r.rec0, r.rec1, r.rec2);
         GS_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, tiles, (int)n_isects, offsets, r.order);
@@ -491,7 +541,7 @@ extern "C" int gs_raster_bwd(int W, int H, int tile_size, int D, int V, const fl
     GS_CHECK_ARG(D >= 1 && D <= GS_MAX_CHANNELS, "1 <= D <= 32");
     GS_CHECK_ARG(n_isects >= 0 && n_isects < (1ll << 31), "n_isects must fit int32");
     GS_CHECK_ARG(ws != nullptr, "workspace (the stream written by gs_raster_fwd) must not be NULL");
-    if (ws_bytes < gs_raster_ws_bytes(n_isects, W, H, tile_size)) { gs_set_error("gs_raster_bwd: workspace too small"); return GS_ENOSPC; }
+    if (ws_bytes < gs_raster_ws_bytes(n_isects, V, W, H, tile_size)) { gs_set_error("gs_raster_bwd: workspace too small"); return GS_ENOSPC; }
     hipStream_t s = (hipStream_t)stream;
     if (V > 0) {
         GS_CHECK_HIP(hipMemsetAsync(v_means2d, 0, sizeof(float) * 2 * (size_t)V, s));
@@ -501,7 +551,7 @@ extern "C" int gs_raster_bwd(int W, int H, int tile_size, int D, int V, const fl
     }
     if (n_isects == 0 || V == 0) return GS_OK;
     const int tiles = ((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
-    const RasterWs r = carve((void*)ws, n_isects, tiles);
+    const RasterWs r = carve((void*)ws, n_isects, V, tiles);
 #define GS_BWD(CD) return launch_bwd<CD>(W, H, D, r, colors, background, n_isects, offsets, alphas, last_ids, v_render, v_alphas, v_means2d, v_conics, v_colors, v_opacities, s)
     if (D <= 3) GS_BWD(3);
     if (D <= 4) GS_BWD(4);

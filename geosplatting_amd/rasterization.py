@@ -60,9 +60,9 @@ def _forward_stages(means: Tensor, quats: Tensor, scales: Tensor, opacities: Ten
 
     render = torch.empty(H, W, D, dtype=f32, device=dev); alphas = torch.empty(H, W, dtype=f32, device=dev)
     last_ids = torch.empty(H, W, dtype=i32, device=dev)
-    rws_bytes = lib.gs_raster_ws_bytes(L.i64(I), W, H, tile_size)
+    rws_bytes = lib.gs_raster_ws_bytes(L.i64(I), V, W, H, tile_size)
     rws = torch.empty(rws_bytes, dtype=torch.uint8, device=dev)     # record stream: written here, read by the backward
-    L.check(lib.gs_raster_fwd(W, H, tile_size, D, L.ptr(means2d), L.ptr(conics), L.ptr(opac_p), L.ptr(colors_p),
+    L.check(lib.gs_raster_fwd(W, H, tile_size, D, V, L.ptr(means2d), L.ptr(conics), L.ptr(opac_p), L.ptr(colors_p),
                               L.ptr(background), L.i64(I), L.ptr(offsets), L.ptr(flat_s), L.ptr(render), L.ptr(alphas),
                               L.ptr(last_ids), L.ptr(rws), C.c_size_t(rws_bytes), st), "gs_raster_fwd")
     state = dict(gaussian_ids_i32=gids, radii=radii, means2d=means2d, depths=depths, conics=conics,

@@ -98,12 +98,12 @@ int gs_isect_offsets(int64_t n_isects, const int64_t* isect_ids_sorted, int n_ti
 /* ------------------------------------------------------------------ A5 / A6 ------------------------ */
 /* Bytes of the compositor workspace: the per-intersection record stream in sorted order (48 B each) plus the
  * longest-first tile order.  gs_raster_fwd WRITES it, gs_raster_bwd READS it (keep it alive in between). */
-size_t gs_raster_ws_bytes(int64_t n_isects, int W, int H, int tile_size);
+size_t gs_raster_ws_bytes(int64_t n_isects, int V, int W, int H, int tile_size);
 
 /* Front-to-back alpha compositing of the per-tile sorted lists.  colors: packed [V,D]; opacities: packed
  * (already multiplied by the compensation); background: nullable [D].
  * render [H,W,D], alphas [H,W], last_ids [H,W] (index into the sorted list of the last composited entry). */
-int gs_raster_fwd(int W, int H, int tile_size, int D, const float* means2d, const float* conics,
+int gs_raster_fwd(int W, int H, int tile_size, int D, int V, const float* means2d, const float* conics,
                   const float* opacities, const float* colors, const float* background,
                   int64_t n_isects, const int32_t* offsets, const int32_t* flatten_ids,
                   float* render, float* alphas, int32_t* last_ids, void* ws, size_t ws_bytes, void* stream);

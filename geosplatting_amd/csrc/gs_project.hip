@@ -459,7 +459,7 @@ project_bwd_kernel(int N, int V, int D, const float* __restrict__ means, const f
                    const float* __restrict__ v_depths, const float* __restrict__ v_conics,
                    const float* __restrict__ v_opacities_packed, const float* __restrict__ v_colors_packed,
                    float* __restrict__ v_means, float* __restrict__ v_quats, float* __restrict__ v_scales,
-                   float* __restrict__ v_opacities, float* __restrict__ v_colors)
+                   float* __restrict__ v_opacities, float* __restrict__ v_colors, int accumulate)
 {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
@@ -608,11 +608,22 @@ project_bwd_kernel(int N, int V, int D, const float* __restrict__ means, const f
 #pragma unroll
         for (int k = 0; k < 4; ++k) g_quat[k] = (vqn[k] - dotp * qn[k]) * inv;
     }
-    v_means[3 * (size_t)n] = g_mean[0]; v_means[3 * (size_t)n + 1] = g_mean[1]; v_means[3 * (size_t)n + 2] = g_mean[2];
-    *reinterpret_cast<float4*>(v_quats + 4 * (size_t)n) = make_float4(g_quat[0], g_quat[1], g_quat[2], g_quat[3]);
-    v_scales[3 * (size_t)n] = g_scale[0]; v_scales[3 * (size_t)n + 1] = g_scale[1]; v_scales[3 * (size_t)n + 2] = g_scale[2];
-    v_opacities[n] = g_op;
-    if (v_colors) {
+    if (accumulate) {          // += into persistent gradient buffers (several views per step); culled Gaussians add nothing
+        if (v >= 0) {
+            v_means[3 * (size_t)n] += g_mean[0]; v_means[3 * (size_t)n + 1] += g_mean[1]; v_means[3 * (size_t)n + 2] += g_mean[2];
+            float4 q = *reinterpret_cast<float4*>(v_quats + 4 * (size_t)n);
+            q.x += g_quat[0]; q.y += g_quat[1]; q.z += g_quat[2]; q.w += g_quat[3];
+            *reinterpret_cast<float4*>(v_quats + 4 * (size_t)n) = q;
+            v_scales[3 * (size_t)n] += g_scale[0]; v_scales[3 * (size_t)n + 1] += g_scale[1]; v_scales[3 * (size_t)n + 2] += g_scale[2];
+            v_opacities[n] += g_op;
+        }
+    } else {
+        v_means[3 * (size_t)n] = g_mean[0]; v_means[3 * (size_t)n + 1] = g_mean[1]; v_means[3 * (size_t)n + 2] = g_mean[2];
+        *reinterpret_cast<float4*>(v_quats + 4 * (size_t)n) = make_float4(g_quat[0], g_quat[1], g_quat[2], g_quat[3]);
+        v_scales[3 * (size_t)n] = g_scale[0]; v_scales[3 * (size_t)n + 1] = g_scale[1]; v_scales[3 * (size_t)n + 2] = g_scale[2];
+        v_opacities[n] = g_op;
+    }
+    if (v_colors) {             // per-view quantity (feeds the shading backward): always a plain write
         for (int k = 0; k < D; ++k) v_colors[(size_t)n * D + k] = (v >= 0) ? v_colors_packed[(size_t)v * D + k] : 0.0f;
     }
 }
@@ -623,14 +634,14 @@ extern "C" int gs_project_bwd(int N, int V, int D, const float* means, const flo
                               const float* compensations, const float* v_means2d, const float* v_depths,
                               const float* v_conics, const float* v_opacities_packed, const float* v_colors_packed,
                               float* v_means, float* v_quats, float* v_scales, float* v_opacities, float* v_colors,
-                              void* stream)
+                              int accumulate, void* stream)
 {
     GS_CHECK_ARG(N >= 0 && V >= 0 && V <= N, "bad sizes");
     if (N == 0) return GS_OK;
     hipLaunchKernelGGL(project_bwd_kernel, dim3(gs_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, N, V, D, means,
                        quats, scales, opacities, viewmat, K, W, H, eps2d, gaussian_ids, conics, compensations,
                        v_means2d, v_depths, v_conics, v_opacities_packed, v_colors_packed, v_means, v_quats,
-                       v_scales, v_opacities, v_colors);
+                       v_scales, v_opacities, v_colors, accumulate);
     GS_CHECK_LAUNCH();
     return GS_OK;
 }

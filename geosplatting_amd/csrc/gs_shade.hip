@@ -210,7 +210,7 @@ shade_bwd_kernel(int N, const float* __restrict__ means, const float* __restrict
                  const float* __restrict__ kd, const float* __restrict__ ks, const float* __restrict__ cam_pos,
                  float min_roughness, float max_metallic, int mode, EnvDev env, const float* __restrict__ v_colors,
                  float* __restrict__ v_means, float* __restrict__ v_normals, float* __restrict__ v_kd,
-                 float* __restrict__ v_ks, EnvGradDev eg)
+                 float* __restrict__ v_ks, EnvGradDev eg, int accumulate)
 {
     extern __shared__ __attribute__((aligned(16))) float s_grad[];
     for (int i = threadIdx.x; i < eg.lds_floats; i += blockDim.x) s_grad[i] = 0.0f;
@@ -239,9 +239,9 @@ shade_bwd_kernel(int N, const float* __restrict__ means, const float* __restrict
             // of the shading is exactly zero -- skip the texture taps and the texel atomics
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                v_means[3 * (size_t)n + k] = 0.0f; v_normals[3 * (size_t)n + k] = 0.0f; v_kd[3 * (size_t)n + k] = 0.0f;
+                if (!accumulate) { v_means[3 * (size_t)n + k] = 0.0f; v_normals[3 * (size_t)n + k] = 0.0f; v_kd[3 * (size_t)n + k] = 0.0f; }
             }
-            *reinterpret_cast<float2*>(v_ks + 2 * (size_t)n) = make_float2(0.0f, 0.0f);
+            if (!accumulate) *reinterpret_cast<float2*>(v_ks + 2 * (size_t)n) = make_float2(0.0f, 0.0f);
         } else {
         float color[3];
         shade_one<true>(mean, normal, kdn, ksn, cp, min_roughness, max_metallic, mode, env, color, t);
@@ -294,13 +294,25 @@ shade_bwd_kernel(int N, const float* __restrict__ means, const float* __restrict
 #pragma unroll
             for (int k = 0; k < 3; ++k) o_mean[k] = -((v_wo[k] - t.wo[k] * dot) / l);
         }
+        if (accumulate) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            v_means[3 * (size_t)n + k] = o_mean[k];
-            v_normals[3 * (size_t)n + k] = v_n[k];
-            v_kd[3 * (size_t)n + k] = o_kd[k];
+            for (int k = 0; k < 3; ++k) {
+                v_means[3 * (size_t)n + k] += o_mean[k];
+                v_normals[3 * (size_t)n + k] += v_n[k];
+                v_kd[3 * (size_t)n + k] += o_kd[k];
+            }
+            float2 o = *reinterpret_cast<float2*>(v_ks + 2 * (size_t)n);
+            o.x += v_rough * (1.0f - min_roughness); o.y += v_metal * max_metallic;
+            *reinterpret_cast<float2*>(v_ks + 2 * (size_t)n) = o;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                v_means[3 * (size_t)n + k] = o_mean[k];
+                v_normals[3 * (size_t)n + k] = v_n[k];
+                v_kd[3 * (size_t)n + k] = o_kd[k];
+            }
+            *reinterpret_cast<float2*>(v_ks + 2 * (size_t)n) = make_float2(v_rough * (1.0f - min_roughness), v_metal * max_metallic);
         }
-        *reinterpret_cast<float2*>(v_ks + 2 * (size_t)n) = make_float2(v_rough * (1.0f - min_roughness), v_metal * max_metallic);
 
         }   // non-zero upstream gradient
         }   // live
@@ -407,8 +419,8 @@ extern "C" size_t gs_shade_bwd_ws_bytes(const GsEnv* env, int mode)
 extern "C" int gs_shade_bwd(int N, const float* means, const float* normals, const float* kd, const float* ks,
                             const float* cam_pos, float min_roughness, float max_metallic, int mode,
                             const GsEnv* env, const float* v_colors, float* v_means, float* v_normals,
-                            float* v_kd, float* v_ks, const GsEnvGrad* env_grad, void* ws, size_t ws_bytes,
-                            void* stream)
+                            float* v_kd, float* v_ks, const GsEnvGrad* env_grad, int accumulate, void* ws,
+                            size_t ws_bytes, void* stream)
 {
     GS_CHECK_ARG(N >= 0 && mode >= 0 && mode <= 2, "bad N or mode");
     EnvDev e;
@@ -450,7 +462,7 @@ extern "C" int gs_shade_bwd(int N, const float* means, const float* normals, con
         GS_CHECK_HIP(hipMemsetAsync(ws, 0, priv_floats * sizeof(float) * GS_XCD_COPIES, s));
         GS_CHECK_HIP(hipFuncSetAttribute((const void*)shade_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         hipLaunchKernelGGL(shade_bwd_kernel<true>, dim3(blocks), dim3(GS_SHADE_BWD_BLOCK), lds_bytes, s, N, means, normals, kd, ks,
-                           cam_pos, min_roughness, max_metallic, mode, e, v_colors, v_means, v_normals, v_kd, v_ks, eg);
+                           cam_pos, min_roughness, max_metallic, mode, e, v_colors, v_means, v_normals, v_kd, v_ks, eg, accumulate);
         GS_CHECK_LAUNCH();
         // fold the 8 copies into the caller's gradient buffers, level by level
         for (int l = -1; l < e.L; ++l) {
@@ -466,7 +478,7 @@ extern "C" int gs_shade_bwd(int N, const float* means, const float* normals, con
     } else {
         GS_CHECK_HIP(hipFuncSetAttribute((const void*)shade_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         hipLaunchKernelGGL(shade_bwd_kernel<false>, dim3(blocks), dim3(GS_SHADE_BWD_BLOCK), lds_bytes, s, N, means, normals, kd, ks,
-                           cam_pos, min_roughness, max_metallic, mode, e, v_colors, v_means, v_normals, v_kd, v_ks, eg);
+                           cam_pos, min_roughness, max_metallic, mode, e, v_colors, v_means, v_normals, v_kd, v_ks, eg, accumulate);
         GS_CHECK_LAUNCH();
     }
     return GS_OK;
@@ -539,11 +551,11 @@ extern "C" int gs_tonemap_fwd(int64_t P, int mode, const float* rgba, const floa
 }
 
 extern "C" int gs_tonemap_bwd(int64_t P, int mode, const float* rgba, const float* exposure, const float* v_out,
-                              float* v_rgba, float* v_exposure, void* stream)
+                              float* v_rgba, float* v_exposure, int accumulate, void* stream)
 {
     GS_CHECK_ARG(P >= 0 && mode >= 0 && mode <= 2, "bad P or mode");
     hipStream_t s = (hipStream_t)stream;
-    GS_CHECK_HIP(hipMemsetAsync(v_exposure, 0, sizeof(float), s));
+    if (!accumulate) GS_CHECK_HIP(hipMemsetAsync(v_exposure, 0, sizeof(float), s));
     if (P == 0) return GS_OK;
     const int blocks = (int)((P + 255) / 256 < 1024 ? (P + 255) / 256 : 1024);
     hipLaunchKernelGGL(tonemap_bwd_kernel, dim3(blocks), dim3(256), 0, s, P, mode, (const float4*)rgba, exposure,

@@ -18,9 +18,13 @@ from typing import Callable, Dict, List, Optional, Sequence
 import torch
 from torch import Tensor
 
+import ctypes as C
+
+from . import _lib as L
 from .cameras import Camera
 from .parallel import GradBucket
-from .shading import RenderableAttrs
+from .rasterization import _forward_stages
+from .shading import _MODE, _TONE, RenderableAttrs, _make_env, get_fg_lut
 from .splitsum import TextureSplitSum, as_splitsum
 from .synthetic import SplatSet
 
@@ -44,17 +48,120 @@ class PathParams:
 
 class RenderStep:
     def __init__(self, params: PathParams, min_roughness: float = 0.1, max_metallic: float = 1.0, mode: str = "pbr",
-                 tone_type: str = "naive", prefilter: bool = True):
+                 tone_type: str = "naive", prefilter: bool = True, fused: bool = True):
         self.p = params
         self.min_roughness, self.max_metallic, self.mode, self.tone_type = min_roughness, max_metallic, mode, tone_type
         self.prefilter = prefilter
+        self.fused = fused
         self.bucket = GradBucket(params.shapes(), params.means.device)
         self._static_env: Optional[TextureSplitSum] = None
+        self._cam_cache: Dict[int, tuple] = {}
+
+    # ------------------------------------------------------------------------------------------------- fused path
+    def _camera_tensors(self, cam: Camera):
+        key = id(cam)
+        if key not in self._cam_cache:
+            dev = self.p.means.device
+            self._cam_cache[key] = (cam.view_matrix.to(dev).contiguous(), cam.intrinsic_matrix.to(dev).contiguous(),
+                                    cam.c2w[:, 3].to(dev).contiguous())
+        return self._cam_cache[key]
+
+    def _step_fused(self, cameras, upstream, all_reduce, keep_images):
+        """Same arithmetic as the autograd path, driven directly through the C-ABI: every per-view backward ADDS into
+        the flat gradient bucket (accumulate flags of gs_project_bwd / gs_shade_bwd / gs_tonemap_bwd), the exp /
+        sigmoid activations of GSplatter.render_rgba (rfstudio/model/gsplat.py:336-339) are applied once per step and
+        chained once per step (their Jacobians do not depend on the view), and the prefilter backward runs once on the
+        texel gradients summed over the views."""
+        lib = L.lib()
+        p = self.p
+        dev = p.means.device
+        N = p.means.shape[0]
+        f32 = torch.float32
+        st = L.stream
+        mode, tone = _MODE[self.mode], _TONE[self.tone_type]
+        cubemap = p.cubemap.detach().requires_grad_(self.prefilter)
+        if self.prefilter:
+            env = as_splitsum(cubemap)
+        else:
+            if self._static_env is None:
+                with torch.no_grad():
+                    self._static_env = as_splitsum(p.cubemap)
+            env = self._static_env
+        env_d = TextureSplitSum(env.base.detach(), [l.detach().contiguous() for l in env.levels], env.min_roughness,
+                                env.max_roughness)
+        lut = get_fg_lut(dev)
+        e = _make_env(lut, env_d)
+        g_base = torch.zeros_like(env_d.base); g_levels = [torch.zeros_like(l) for l in env_d.levels]
+        eg = L.GsEnvGrad(); eg.base = g_base.data_ptr()
+        for i, g in enumerate(g_levels):
+            eg.levels[i] = g.data_ptr()
+        ws_bytes = lib.gs_shade_bwd_ws_bytes(C.byref(e), mode)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+
+        scales_act = p.scales.detach().exp()
+        opac_act = torch.sigmoid(p.opacities.detach()).squeeze(-1).contiguous()
+        self.bucket.flat.zero_()
+        b = self.bucket.unpack()
+        g_scales_act = torch.zeros(N, 3, dtype=f32, device=dev); g_opac_act = torch.zeros(N, dtype=f32, device=dev)
+        colors = torch.empty(N, 3, dtype=f32, device=dev); g_colors = torch.empty(N, 3, dtype=f32, device=dev)
+        exposure = p.exposure.detach().reshape(1).contiguous()
+        means, quats = p.means.detach(), p.quats.detach()
+        normals, kd, ks = p.normals.detach(), p.kd.detach(), p.ks.detach()
+        images = []
+        for i, cam in enumerate(cameras):
+            vm, K, cam_pos = self._camera_tensors(cam)
+            W, H = cam.width, cam.height
+            L.check(lib.gs_shade_fwd(N, L.ptr(means), L.ptr(normals), L.ptr(kd), L.ptr(ks), L.ptr(cam_pos),
+                                     L.f32(self.min_roughness), L.f32(self.max_metallic), mode, C.byref(e), L.ptr(colors),
+                                     st()), "gs_shade_fwd")
+            render, alphas, s, V, I = _forward_stages(means, quats, scales_act, opac_act, colors, vm, K, W, H, 16, 0.3, 0.01,
+                                                      1e10, 0.0, None)
+            rgba = torch.cat((render, alphas.unsqueeze(-1)), dim=-1)
+            img = torch.empty_like(rgba)
+            P = W * H
+            L.check(lib.gs_tonemap_fwd(L.i64(P), tone, L.ptr(rgba), L.ptr(exposure), L.ptr(img), st()), "gs_tonemap_fwd")
+            v_img = upstream(i, img).contiguous()
+            v_rgba = torch.empty_like(rgba)
+            L.check(lib.gs_tonemap_bwd(L.i64(P), tone, L.ptr(rgba), L.ptr(exposure), L.ptr(v_img), L.ptr(v_rgba),
+                                       L.ptr(b["exposure"]), 1, st()), "gs_tonemap_bwd")
+            v_render = v_rgba[..., :3].contiguous(); v_alpha = v_rgba[..., 3].contiguous()
+            v_m2d = torch.empty(V, 2, dtype=f32, device=dev); v_con = torch.empty(V, 3, dtype=f32, device=dev)
+            v_col = torch.empty(V, 3, dtype=f32, device=dev); v_op = torch.empty(V, dtype=f32, device=dev)
+            rws = s["raster_ws"]
+            L.check(lib.gs_raster_bwd(W, H, 16, 3, V, L.ptr(s["colors"]), None, L.i64(I), L.ptr(s["isect_offsets"]),
+                                      L.ptr(alphas), L.ptr(s["last_ids"]), L.ptr(v_render), L.ptr(v_alpha), L.ptr(v_m2d),
+                                      L.ptr(v_con), L.ptr(v_col), L.ptr(v_op), L.ptr(rws), C.c_size_t(rws.numel()), st()),
+                    "gs_raster_bwd")
+            L.check(lib.gs_project_bwd(N, V, 3, L.ptr(means), L.ptr(quats), L.ptr(scales_act), L.ptr(opac_act), L.ptr(vm),
+                                       L.ptr(K), W, H, L.f32(0.3), L.ptr(s["gaussian_ids_i32"]), L.ptr(s["conics"]),
+                                       L.ptr(s["compensations"]), L.ptr(v_m2d), None, L.ptr(v_con), L.ptr(v_op), L.ptr(v_col),
+                                       L.ptr(b["means"]), L.ptr(b["quats"]), L.ptr(g_scales_act), L.ptr(g_opac_act),
+                                       L.ptr(g_colors), 1, st()), "gs_project_bwd")
+            L.check(lib.gs_shade_bwd(N, L.ptr(means), L.ptr(normals), L.ptr(kd), L.ptr(ks), L.ptr(cam_pos),
+                                     L.f32(self.min_roughness), L.f32(self.max_metallic), mode, C.byref(e), L.ptr(g_colors),
+                                     L.ptr(b["means"]), L.ptr(b["normals"]), L.ptr(b["kd"]), L.ptr(b["ks"]), C.byref(eg), 1,
+                                     L.ptr(ws) if ws_bytes else None, C.c_size_t(ws_bytes), st()), "gs_shade_bwd")
+            if keep_images:
+                images.append(img)
+        # chain the once-per-step activations and the prefilter
+        torch.mul(g_scales_act, scales_act, out=b["scales"])
+        b["opacities"].copy_((g_opac_act * opac_act * (1.0 - opac_act)).unsqueeze(-1))
+        if self.prefilter:
+            outs = [env.base] + list(env.levels)
+            gouts = [g_base] + g_levels
+            keep = [(o, g) for o, g in zip(outs, gouts) if o.requires_grad]
+            torch.autograd.backward([o for o, _ in keep], [g for _, g in keep])
+            b["cubemap"].copy_(cubemap.grad)
+        if all_reduce:
+            self.bucket.all_reduce()
+        return b, (images if keep_images else None)
 
     def __call__(self, cameras: List[Camera], upstream: Callable[[int, Tensor], Tensor], all_reduce: bool = True,
                  keep_images: bool = False):
         """Forward + backward for `cameras`; `upstream(i, image)` returns d(loss)/d(image) for local view i.
         Returns (grads dict of views into the flat bucket, images or None)."""
+        if self.fused and self.mode == "pbr":
+            return self._step_fused(cameras, upstream, all_reduce, keep_images)
         p = self.p
         leaves = {k: v.detach().requires_grad_(True) for k, v in p.named().items()}
         if self.prefilter:

@@ -113,7 +113,7 @@ class _Rasterize(torch.autograd.Function):
                                    L.ptr(K), W, H, L.f32(eps2d), L.ptr(st["gaussian_ids_i32"]), L.ptr(st["conics"]),
                                    L.ptr(st["compensations"]), L.ptr(v_m2d), None, L.ptr(v_con), L.ptr(v_op),
                                    L.ptr(v_col), L.ptr(g_means), L.ptr(g_quats), L.ptr(g_scales), L.ptr(g_opac),
-                                   L.ptr(g_colors), s), "gs_project_bwd")
+                                   L.ptr(g_colors), 0, s), "gs_project_bwd")
         return (g_means, g_quats, g_scales, g_opac, g_colors) + (None,) * 10
 
 

@@ -118,14 +118,16 @@ int gs_raster_bwd(int W, int H, int tile_size, int D, int V, const float* colors
 
 /* ------------------------------------------------------------------ A7 ----------------------------- */
 /* Projection backward + gather backward; dense outputs [N,*] are fully written (zeros for culled
- * Gaussians) -- no caller-side zeroing needed.  v_depths nullable. */
+ * Gaussians) -- no caller-side zeroing needed -- or, with accumulate != 0, ADDED to v_means / v_quats /
+ * v_scales / v_opacities (several views per step share one gradient buffer; v_colors is always written).
+ * v_depths nullable. */
 int gs_project_bwd(int N, int V, int D, const float* means, const float* quats, const float* scales,
                    const float* opacities, const float* viewmat, const float* K, int W, int H, float eps2d,
                    const int32_t* gaussian_ids, const float* conics, const float* compensations,
                    const float* v_means2d, const float* v_depths, const float* v_conics,
                    const float* v_opacities_packed, const float* v_colors_packed,
                    float* v_means, float* v_quats, float* v_scales, float* v_opacities, float* v_colors,
-                   void* stream);
+                   int accumulate, void* stream);
 
 /* ------------------------------------------------------------------ S1..S3 ------------------------- */
 /* Split-sum pyramid description (host struct, device pointers inside). */
@@ -155,20 +157,21 @@ int gs_shade_fwd(int N, const float* means, const float* normals, const float* k
  * not fit LDS (XCD-local atomics stay in L2; device-scope ones are 32-byte write-throughs to the fabric). */
 size_t gs_shade_bwd_ws_bytes(const GsEnv* env /*host*/, int mode);
 
-/* Recomputes the forward and chains v_colors[N,3].  v_means/v_normals/v_kd/v_ks are fully written;
- * texel gradients are ACCUMULATED into env_grad.  ws may be NULL (plain device-scope atomics). */
+/* Recomputes the forward and chains v_colors[N,3].  v_means/v_normals/v_kd/v_ks are fully written (or added
+ * to when accumulate != 0); texel gradients are always ACCUMULATED into env_grad.  ws may be NULL (plain
+ * device-scope atomics). */
 int gs_shade_bwd(int N, const float* means, const float* normals, const float* kd, const float* ks,
                  const float* cam_pos, float min_roughness, float max_metallic, int mode,
                  const GsEnv* env /*host*/, const float* v_colors,
                  float* v_means, float* v_normals, float* v_kd, float* v_ks,
-                 const GsEnvGrad* env_grad /*host*/, void* ws, size_t ws_bytes, void* stream);
+                 const GsEnvGrad* env_grad /*host*/, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ S4 ----------------------------- */
 /* out[P,4] = tonemap(rgba[P,4] * exposure) ; exposure is a DEVICE scalar. */
 int gs_tonemap_fwd(int64_t P, int mode, const float* rgba, const float* exposure, float* out, void* stream);
-/* v_exposure: device scalar, zeroed by the call then accumulated. */
+/* v_exposure: device scalar, zeroed by the call (accumulate == 0) then accumulated into. */
 int gs_tonemap_bwd(int64_t P, int mode, const float* rgba, const float* exposure, const float* v_out,
-                   float* v_rgba, float* v_exposure, void* stream);
+                   float* v_rgba, float* v_exposure, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------ S5 ----------------------------- */
 int gs_cubemap_mip_fwd(int R, int C, const float* in, float* out, void* stream);

@@ -88,6 +88,16 @@ struct GsBfly {
     {
         return 16 * q + 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
     }
+    // rows only: every 16-lane DPP row ends with ITS partial totals (no cross-row exchange) -- the caller lets
+    // each row that had contributing lanes commit its own partial sums
+    __device__ static __forceinline__ void reduce_rows(const float (&v)[NV], float (&out)[N4], int lane)
+    {
+        float a[N1], b[N2], c[N3];
+        gs_bfly_stage<NV, 0x140>(v, a, (lane & 8) != 0);
+        gs_bfly_stage<N1, 0x141>(a, b, (lane & 4) != 0);
+        gs_bfly_stage<N2, 0x4E>(b, c, (lane & 2) != 0);
+        gs_bfly_stage<N3, 0xB1>(c, out, (lane & 1) != 0);
+    }
     __device__ static __forceinline__ void reduce(const float (&v)[NV], float (&out)[N4], int lane)
     {
         float a[N1], b[N2], c[N3];

@@ -24,6 +24,10 @@
 
 #define GS_TILE 16
 #define GS_ALPHA_MIN (1.0f / 255.0f)
+#ifndef GS_BWD_ROW_COMMIT
+#define GS_BWD_ROW_COMMIT 0      // 1 = every DPP row commits its own partial sums (no cross-row exchange): measured 2.2x SLOWER --
+                                 // the kernel sits at the memory-side atomic request rate (~4 requests per survivor already)
+#endif
 
 // Diagnostic build only (scripts/raster_stats.py compiles this file with -DGS_RASTER_STATS into a scratch .so):
 // counts wave-batches, ballot survivors and evaluated/valid lane-pairs.  Never defined in the product library.
@@ -340,7 +344,7 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
         else if (vi < 5)       { p = v_conics + (vi - 2);   st = 3; }
         else if (vi == 5)      { p = v_opacities;           st = 1; }
         else if (vi - 6 < D)   { p = v_colors + (vi - 6);   st = D; }
-        if (lane >= 16) p = nullptr;                         // row 0 commits
+        if (!GS_BWD_ROW_COMMIT && lane >= 16) p = nullptr;   // row 0 commits
         slot_ptr[q] = p; slot_stride[q] = st;
     }
 
@@ -390,8 +394,9 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
             const float vis = __expf(-sigma);
             const float alpha = fminf(0.999f, go * vis);
             const bool valid = (idxj <= bin_final) && sigma >= 0.0f && alpha >= GS_ALPHA_MIN;
-            if (__ballot(valid) == 0ull) continue;
-            GS_STAT(6, 1); GS_STAT(7, __popcll(__ballot(valid)));
+            const unsigned long long vmask = __ballot(valid);
+            if (vmask == 0ull) continue;
+            GS_STAT(6, 1); GS_STAT(7, __popcll(vmask));
 
             float gcol[CD];
 #pragma unroll
@@ -427,11 +432,18 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
             // butterfly reduce-scatter over the wave; the 6+D totals land in distinct lanes of row 0, which
             // commit them with ONE atomic instruction
             float tot[Bfly::N4];
-            Bfly::reduce(part, tot, lane);
             const int gj = gs_readlane(g, j);
+            bool commit = true;
+            if (GS_BWD_ROW_COMMIT) {
+                // each 16-lane row that had valid lanes commits its own partial sums: no cross-row exchange
+                Bfly::reduce_rows(part, tot, lane);
+                commit = ((vmask >> (lane & 48)) & 0xffffull) != 0ull;
+            } else {
+                Bfly::reduce(part, tot, lane);
+            }
 #pragma unroll
             for (int q = 0; q < Bfly::N4; ++q)
-                if (slot_ptr[q]) gs_atomic_add(slot_ptr[q] + (size_t)gj * slot_stride[q], tot[q]);
+                if (slot_ptr[q] && commit) gs_atomic_add(slot_ptr[q] + (size_t)gj * slot_stride[q], tot[q]);
         }
     }
 }

@@ -63,8 +63,7 @@ def time_dominant_kernels(scene_state, iters):
     render = torch.empty(H, W, D, dtype=f32, device=dev); alphas = torch.empty(H, W, dtype=f32, device=dev)
     last = torch.empty(H, W, dtype=torch.int32, device=dev)
     v_render = torch.rand(H, W, D, device=dev) * 2 - 1; v_alpha = torch.rand(H, W, device=dev) * 2 - 1
-    v_m2d = torch.empty(V, 2, dtype=f32, device=dev); v_con = torch.empty(V, 3, dtype=f32, device=dev)
-    v_col = torch.empty(V, D, dtype=f32, device=dev); v_op = torch.empty(V, dtype=f32, device=dev)
+    v_packed = torch.empty(V, lib.gs_raster_grad_stride(D), dtype=f32, device=dev)
     s = L.stream()
     rws_bytes = lib.gs_raster_ws_bytes(L.i64(I), V, W, H, 16)
     rws = torch.empty(rws_bytes, dtype=torch.uint8, device=dev)
@@ -76,8 +75,8 @@ def time_dominant_kernels(scene_state, iters):
 
     def bwd():
         L.check(lib.gs_raster_bwd(W, H, 16, D, V, L.ptr(st["colors"]), None, L.i64(I), L.ptr(st["offsets"]),
-                                  L.ptr(alphas), L.ptr(last), L.ptr(v_render), L.ptr(v_alpha), L.ptr(v_m2d), L.ptr(v_con),
-                                  L.ptr(v_col), L.ptr(v_op), L.ptr(rws), C.c_size_t(rws_bytes), s), "raster_bwd")
+                                  L.ptr(alphas), L.ptr(last), L.ptr(v_render), L.ptr(v_alpha), L.ptr(v_packed),
+                                  L.ptr(rws), C.c_size_t(rws_bytes), s), "raster_bwd")
     out = {}
     for name, fn in (("raster_fwd_kernel", fwd), ("raster_bwd_kernel", bwd)):
         fn(); torch.cuda.synchronize()

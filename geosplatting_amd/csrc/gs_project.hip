@@ -455,9 +455,8 @@ project_bwd_kernel(int N, int V, int D, const float* __restrict__ means, const f
                    const float* __restrict__ scales, const float* __restrict__ opacities,
                    const float* __restrict__ viewmat, const float* __restrict__ K, int W, int H, float eps2d,
                    const int32_t* __restrict__ gaussian_ids, const float* __restrict__ conics,
-                   const float* __restrict__ compensations, const float* __restrict__ v_means2d,
-                   const float* __restrict__ v_depths, const float* __restrict__ v_conics,
-                   const float* __restrict__ v_opacities_packed, const float* __restrict__ v_colors_packed,
+                   const float* __restrict__ compensations, const float* __restrict__ v_packed, int rec_stride,
+                   const float* __restrict__ v_depths,
                    float* __restrict__ v_means, float* __restrict__ v_quats, float* __restrict__ v_scales,
                    float* __restrict__ v_opacities, float* __restrict__ v_colors, int accumulate)
 {
@@ -471,7 +470,8 @@ project_bwd_kernel(int N, int V, int D, const float* __restrict__ means, const f
         const float4 q4 = *reinterpret_cast<const float4*>(quats + 4 * (size_t)n);
         const float scale[3] = { scales[3 * (size_t)n], scales[3 * (size_t)n + 1], scales[3 * (size_t)n + 2] };
         const float comp = compensations[v];
-        const float v_op = v_opacities_packed[v];
+        const float* __restrict__ rec = v_packed + (size_t)v * rec_stride;   // {xy(2), conic(3), opacity, colors(D)}
+        const float v_op = rec[5];
         g_op = v_op * comp;
         const float v_comp = v_op * opacities[n];
 
@@ -504,7 +504,7 @@ project_bwd_kernel(int N, int V, int D, const float* __restrict__ means, const f
 
         // conic = inverse(cov2d_blur): v_cov2d = -conic * v_conic_mat * conic
         const float ia = conics[3 * (size_t)v], ib = conics[3 * (size_t)v + 1], ic = conics[3 * (size_t)v + 2];
-        const float ga = v_conics[3 * (size_t)v], gb = 0.5f * v_conics[3 * (size_t)v + 1], gc = v_conics[3 * (size_t)v + 2];
+        const float ga = rec[2], gb = 0.5f * rec[3], gc = rec[4];
         const float p00 = ia * ga + ib * gb, p01 = ia * gb + ib * gc;
         const float p10 = ib * ga + ic * gb, p11 = ib * gb + ic * gc;
         float G[4] = { -(p00 * ia + p01 * ib), -(p00 * ib + p01 * ic), -(p10 * ia + p11 * ib), -(p10 * ib + p11 * ic) };
@@ -550,7 +550,7 @@ project_bwd_kernel(int N, int V, int D, const float* __restrict__ means, const f
 #pragma unroll
             for (int j = 0; j < 3; ++j)
                 v_J[i * 3 + j] = (G[i * 2 + 0] * JCt[j] + G[i * 2 + 1] * JCt[3 + j]) + (G[i] * JC[j] + G[2 + i] * JC[3 + j]);
-        const float vm2x = v_means2d[2 * (size_t)v], vm2y = v_means2d[2 * (size_t)v + 1];
+        const float vm2x = rec[0], vm2y = rec[1];
         float v_mc[3];
         v_mc[0] = cam.fx * rz * vm2x;
         v_mc[1] = cam.fy * rz * vm2y;
@@ -624,15 +624,14 @@ project_bwd_kernel(int N, int V, int D, const float* __restrict__ means, const f
         v_opacities[n] = g_op;
     }
     if (v_colors) {             // per-view quantity (feeds the shading backward): always a plain write
-        for (int k = 0; k < D; ++k) v_colors[(size_t)n * D + k] = (v >= 0) ? v_colors_packed[(size_t)v * D + k] : 0.0f;
+        for (int k = 0; k < D; ++k) v_colors[(size_t)n * D + k] = (v >= 0) ? v_packed[(size_t)v * rec_stride + 6 + k] : 0.0f;
     }
 }
 
 extern "C" int gs_project_bwd(int N, int V, int D, const float* means, const float* quats, const float* scales,
                               const float* opacities, const float* viewmat, const float* K, int W, int H,
                               float eps2d, const int32_t* gaussian_ids, const float* conics,
-                              const float* compensations, const float* v_means2d, const float* v_depths,
-                              const float* v_conics, const float* v_opacities_packed, const float* v_colors_packed,
+                              const float* compensations, const float* v_packed, const float* v_depths,
                               float* v_means, float* v_quats, float* v_scales, float* v_opacities, float* v_colors,
                               int accumulate, void* stream)
 {
@@ -640,7 +639,7 @@ extern "C" int gs_project_bwd(int N, int V, int D, const float* means, const flo
     if (N == 0) return GS_OK;
     hipLaunchKernelGGL(project_bwd_kernel, dim3(gs_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, N, V, D, means,
                        quats, scales, opacities, viewmat, K, W, H, eps2d, gaussian_ids, conics, compensations,
-                       v_means2d, v_depths, v_conics, v_opacities_packed, v_colors_packed, v_means, v_quats,
+                       v_packed, ((6 + D) + 15) / 16 * 16, v_depths, v_means, v_quats,
                        v_scales, v_opacities, v_colors, accumulate);
     GS_CHECK_LAUNCH();
     return GS_OK;

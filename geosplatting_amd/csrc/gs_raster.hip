@@ -295,8 +295,7 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
                   const int32_t* __restrict__ offsets,
                   const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
                   const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-                  float* __restrict__ v_means2d, float* __restrict__ v_conics, float* __restrict__ v_colors,
-                  float* __restrict__ v_opacities)
+                  float* __restrict__ v_packed, int rec_stride)
 {
     const int tile = tile_order[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -330,23 +329,21 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
     }
     float T = T_final;
 
-    // per-lane commit slot of the butterfly reduction: value index -> (array, component, stride)
-    //   0,1 = v_means2d.xy   2,3,4 = v_conics   5 = v_opacities   6.. = v_colors[k]
+    // per-lane commit slot of the butterfly reduction.  The per-Gaussian gradients form ONE packed record
+    //   v_packed[g][0..1] = v_means2d, [2..4] = v_conics, [5] = v_opacities, [6..6+D) = v_colors   (stride: 64-byte multiple)
+    // so that the 6+D atomics of a survivor fall into one or two cache lines: the memory side merges them into
+    // 1-2 requests instead of 4 (separate arrays), and this kernel sits at the atomic REQUEST rate of the fabric.
     constexpr int NV = 6 + CD;
     using Bfly = GsBfly<NV>;
     float* slot_ptr[Bfly::N4];
-    int slot_stride[Bfly::N4];
 #pragma unroll
     for (int q = 0; q < Bfly::N4; ++q) {
         const int vi = Bfly::owned_index(lane, q);
-        float* p = nullptr; int st = 0;
-        if (vi < 2)            { p = v_means2d + vi;        st = 2; }
-        else if (vi < 5)       { p = v_conics + (vi - 2);   st = 3; }
-        else if (vi == 5)      { p = v_opacities;           st = 1; }
-        else if (vi - 6 < D)   { p = v_colors + (vi - 6);   st = D; }
+        float* p = (vi < 6 + D) ? v_packed + vi : nullptr;
         if (!GS_BWD_ROW_COMMIT && lane >= 16) p = nullptr;   // row 0 commits
-        slot_ptr[q] = p; slot_stride[q] = st;
+        slot_ptr[q] = p;
     }
+    const int slot_stride_all = rec_stride;
 
     int top = bin_final;
 #pragma unroll
@@ -443,7 +440,7 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
             }
 #pragma unroll
             for (int q = 0; q < Bfly::N4; ++q)
-                if (slot_ptr[q] && commit) gs_atomic_add(slot_ptr[q] + (size_t)gj * slot_stride[q], tot[q]);
+                if (slot_ptr[q] && commit) gs_atomic_add(slot_ptr[q] + (size_t)gj * slot_stride_all, tot[q]);
         }
     }
 }
@@ -532,21 +529,22 @@ extern "C" int gs_raster_fwd(int W, int H, int tile_size, int D, int V, const fl
 template <int CD>
 static int launch_bwd(int W, int H, int D, const RasterWs& ws, const float* colors, const float* background,
                       int64_t n_isects, const int32_t* offsets, const float* alphas, const int32_t* last_ids,
-                      const float* v_render, const float* v_alphas, float* v_means2d, float* v_conics, float* v_colors,
-                      float* v_opacities, hipStream_t s)
+                      const float* v_render, const float* v_alphas, float* v_packed, int rec_stride, hipStream_t s)
 {
     const int tile_w = (W + GS_TILE - 1) / GS_TILE, tile_h = (H + GS_TILE - 1) / GS_TILE;
     hipLaunchKernelGGL(raster_bwd_kernel<CD>, dim3(tile_w * tile_h), dim3(256), 0, s, W, H, tile_w, tile_w * tile_h, D,
                        ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, (int)n_isects, offsets, alphas, last_ids,
-                       v_render, v_alphas, v_means2d, v_conics, v_colors, v_opacities);
+                       v_render, v_alphas, v_packed, rec_stride);
     GS_CHECK_LAUNCH();
     return GS_OK;
 }
 
+extern "C" int gs_raster_grad_stride(int D) { return ((6 + D) + 15) / 16 * 16; }
+
 extern "C" int gs_raster_bwd(int W, int H, int tile_size, int D, int V, const float* colors, const float* background,
                              int64_t n_isects, const int32_t* offsets, const float* alphas, const int32_t* last_ids,
-                             const float* v_render, const float* v_alphas, float* v_means2d, float* v_conics,
-                             float* v_colors, float* v_opacities, const void* ws, size_t ws_bytes, void* stream)
+                             const float* v_render, const float* v_alphas, float* v_packed, const void* ws,
+                             size_t ws_bytes, void* stream)
 {
     GS_CHECK_ARG(W > 0 && H > 0 && V >= 0, "bad sizes");
     GS_CHECK_ARG(tile_size == GS_TILE, "only tile_size=16 is built (rfstudio/model/gsplat.py:30)");
@@ -555,16 +553,12 @@ extern "C" int gs_raster_bwd(int W, int H, int tile_size, int D, int V, const fl
     GS_CHECK_ARG(ws != nullptr, "workspace (the stream written by gs_raster_fwd) must not be NULL");
     if (ws_bytes < gs_raster_ws_bytes(n_isects, V, W, H, tile_size)) { gs_set_error("gs_raster_bwd: workspace too small"); return GS_ENOSPC; }
     hipStream_t s = (hipStream_t)stream;
-    if (V > 0) {
-        GS_CHECK_HIP(hipMemsetAsync(v_means2d, 0, sizeof(float) * 2 * (size_t)V, s));
-        GS_CHECK_HIP(hipMemsetAsync(v_conics, 0, sizeof(float) * 3 * (size_t)V, s));
-        GS_CHECK_HIP(hipMemsetAsync(v_colors, 0, sizeof(float) * (size_t)D * (size_t)V, s));
-        GS_CHECK_HIP(hipMemsetAsync(v_opacities, 0, sizeof(float) * (size_t)V, s));
-    }
+    const int rec_stride = gs_raster_grad_stride(D);
+    if (V > 0) GS_CHECK_HIP(hipMemsetAsync(v_packed, 0, sizeof(float) * (size_t)rec_stride * (size_t)V, s));
     if (n_isects == 0 || V == 0) return GS_OK;
     const int tiles = ((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
     const RasterWs r = carve((void*)ws, n_isects, V, tiles);
-#define GS_BWD(CD) return launch_bwd<CD>(W, H, D, r, colors, background, n_isects, offsets, alphas, last_ids, v_render, v_alphas, v_means2d, v_conics, v_colors, v_opacities, s)
+#define GS_BWD(CD) return launch_bwd<CD>(W, H, D, r, colors, background, n_isects, offsets, alphas, last_ids, v_render, v_alphas, v_packed, rec_stride, s)
     if (D <= 3) GS_BWD(3);
     if (D <= 4) GS_BWD(4);
     if (D <= 8) GS_BWD(8);

@@ -125,16 +125,14 @@ class RenderStep:
             L.check(lib.gs_tonemap_bwd(L.i64(P), tone, L.ptr(rgba), L.ptr(exposure), L.ptr(v_img), L.ptr(v_rgba),
                                        L.ptr(b["exposure"]), 1, st()), "gs_tonemap_bwd")
             v_render = v_rgba[..., :3].contiguous(); v_alpha = v_rgba[..., 3].contiguous()
-            v_m2d = torch.empty(V, 2, dtype=f32, device=dev); v_con = torch.empty(V, 3, dtype=f32, device=dev)
-            v_col = torch.empty(V, 3, dtype=f32, device=dev); v_op = torch.empty(V, dtype=f32, device=dev)
+            v_packed = torch.empty(V, lib.gs_raster_grad_stride(3), dtype=f32, device=dev)
             rws = s["raster_ws"]
             L.check(lib.gs_raster_bwd(W, H, 16, 3, V, L.ptr(s["colors"]), None, L.i64(I), L.ptr(s["isect_offsets"]),
-                                      L.ptr(alphas), L.ptr(s["last_ids"]), L.ptr(v_render), L.ptr(v_alpha), L.ptr(v_m2d),
-                                      L.ptr(v_con), L.ptr(v_col), L.ptr(v_op), L.ptr(rws), C.c_size_t(rws.numel()), st()),
-                    "gs_raster_bwd")
+                                      L.ptr(alphas), L.ptr(s["last_ids"]), L.ptr(v_render), L.ptr(v_alpha), L.ptr(v_packed),
+                                      L.ptr(rws), C.c_size_t(rws.numel()), st()), "gs_raster_bwd")
             L.check(lib.gs_project_bwd(N, V, 3, L.ptr(means), L.ptr(quats), L.ptr(scales_act), L.ptr(opac_act), L.ptr(vm),
                                        L.ptr(K), W, H, L.f32(0.3), L.ptr(s["gaussian_ids_i32"]), L.ptr(s["conics"]),
-                                       L.ptr(s["compensations"]), L.ptr(v_m2d), None, L.ptr(v_con), L.ptr(v_op), L.ptr(v_col),
+                                       L.ptr(s["compensations"]), L.ptr(v_packed), None,
                                        L.ptr(b["means"]), L.ptr(b["quats"]), L.ptr(g_scales_act), L.ptr(g_opac_act),
                                        L.ptr(g_colors), 1, st()), "gs_project_bwd")
             L.check(lib.gs_shade_bwd(N, L.ptr(means), L.ptr(normals), L.ptr(kd), L.ptr(ks), L.ptr(cam_pos),

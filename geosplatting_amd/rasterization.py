@@ -98,22 +98,20 @@ class _Rasterize(torch.autograd.Function):
         f32 = torch.float32
         v_render = torch.zeros(H, W, D, dtype=f32, device=dev) if v_render is None else v_render.contiguous()
         v_alphas = torch.zeros(H, W, dtype=f32, device=dev) if v_alphas is None else v_alphas.contiguous()
-        v_m2d = torch.empty(V, 2, dtype=f32, device=dev); v_con = torch.empty(V, 3, dtype=f32, device=dev)
-        v_col = torch.empty(V, D, dtype=f32, device=dev); v_op = torch.empty(V, dtype=f32, device=dev)
+        stride = lib.gs_raster_grad_stride(D)
+        v_packed = torch.empty(V, stride, dtype=f32, device=dev)      # {v_means2d, v_conics, v_opacity, v_colors} per Gaussian
         s = L.stream()
         rws = st["raster_ws"]
         L.check(lib.gs_raster_bwd(W, H, tile_size, D, V, L.ptr(st["colors"]), L.ptr(background), L.i64(I),
                                   L.ptr(st["isect_offsets"]), L.ptr(alphas), L.ptr(st["last_ids"]), L.ptr(v_render),
-                                  L.ptr(v_alphas), L.ptr(v_m2d), L.ptr(v_con), L.ptr(v_col), L.ptr(v_op), L.ptr(rws),
-                                  C.c_size_t(rws.numel()), s), "gs_raster_bwd")
+                                  L.ptr(v_alphas), L.ptr(v_packed), L.ptr(rws), C.c_size_t(rws.numel()), s), "gs_raster_bwd")
         g_means = torch.empty(N, 3, dtype=f32, device=dev); g_quats = torch.empty(N, 4, dtype=f32, device=dev)
         g_scales = torch.empty(N, 3, dtype=f32, device=dev); g_opac = torch.empty(N, dtype=f32, device=dev)
         g_colors = torch.empty(N, D, dtype=f32, device=dev)
         L.check(lib.gs_project_bwd(N, V, D, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opacities), L.ptr(viewmat),
                                    L.ptr(K), W, H, L.f32(eps2d), L.ptr(st["gaussian_ids_i32"]), L.ptr(st["conics"]),
-                                   L.ptr(st["compensations"]), L.ptr(v_m2d), None, L.ptr(v_con), L.ptr(v_op),
-                                   L.ptr(v_col), L.ptr(g_means), L.ptr(g_quats), L.ptr(g_scales), L.ptr(g_opac),
-                                   L.ptr(g_colors), 0, s), "gs_project_bwd")
+                                   L.ptr(st["compensations"]), L.ptr(v_packed), None, L.ptr(g_means), L.ptr(g_quats),
+                                   L.ptr(g_scales), L.ptr(g_opac), L.ptr(g_colors), 0, s), "gs_project_bwd")
         return (g_means, g_quats, g_scales, g_opac, g_colors) + (None,) * 10
 
 

@@ -108,24 +108,29 @@ int gs_raster_fwd(int W, int H, int tile_size, int D, int V, const float* means2
                   int64_t n_isects, const int32_t* offsets, const int32_t* flatten_ids,
                   float* render, float* alphas, int32_t* last_ids, void* ws, size_t ws_bytes, void* stream);
 
-/* Stored-state backward (uses alphas + last_ids + the workspace of the forward).  Output gradients [V,*] are
- * zeroed by the call and accumulated with one fp32 atomic per (wave, Gaussian).  colors is only read when
+/* Floats per packed per-Gaussian gradient record written by gs_raster_bwd: (6 + D) rounded up to 16. */
+int gs_raster_grad_stride(int D);
+
+/* Stored-state backward (uses alphas + last_ids + the workspace of the forward).  The per-visible-Gaussian
+ * gradients come out as ONE packed record per Gaussian (one or two cache lines, so the 6+D fp32 atomics of a
+ * survivor merge into 1-2 memory-side requests):
+ *     v_packed[g*stride + 0..1] = v_means2d   [2..4] = v_conics   [5] = v_opacities   [6..6+D) = v_colors
+ * with stride = gs_raster_grad_stride(D); the buffer [V*stride] is zeroed by the call.  colors is only read when
  * D > 3 (for D <= 3 the colours travel inside the record stream). */
 int gs_raster_bwd(int W, int H, int tile_size, int D, int V, const float* colors, const float* background,
                   int64_t n_isects, const int32_t* offsets, const float* alphas, const int32_t* last_ids,
-                  const float* v_render, const float* v_alphas, float* v_means2d, float* v_conics,
-                  float* v_colors, float* v_opacities, const void* ws, size_t ws_bytes, void* stream);
+                  const float* v_render, const float* v_alphas, float* v_packed, const void* ws, size_t ws_bytes,
+                  void* stream);
 
 /* ------------------------------------------------------------------ A7 ----------------------------- */
-/* Projection backward + gather backward; dense outputs [N,*] are fully written (zeros for culled
- * Gaussians) -- no caller-side zeroing needed -- or, with accumulate != 0, ADDED to v_means / v_quats /
- * v_scales / v_opacities (several views per step share one gradient buffer; v_colors is always written).
- * v_depths nullable. */
+/* Projection backward + gather backward from the packed records of gs_raster_bwd; dense outputs [N,*] are fully
+ * written (zeros for culled Gaussians) -- no caller-side zeroing needed -- or, with accumulate != 0, ADDED to
+ * v_means / v_quats / v_scales / v_opacities (several views per step share one gradient buffer; v_colors is always
+ * written).  v_depths nullable. */
 int gs_project_bwd(int N, int V, int D, const float* means, const float* quats, const float* scales,
                    const float* opacities, const float* viewmat, const float* K, int W, int H, float eps2d,
                    const int32_t* gaussian_ids, const float* conics, const float* compensations,
-                   const float* v_means2d, const float* v_depths, const float* v_conics,
-                   const float* v_opacities_packed, const float* v_colors_packed,
+                   const float* v_packed, const float* v_depths,
                    float* v_means, float* v_quats, float* v_scales, float* v_opacities, float* v_colors,
                    int accumulate, void* stream);
 

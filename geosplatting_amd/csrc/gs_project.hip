@@ -631,15 +631,15 @@ project_bwd_kernel(int N, int V, int D, const float* __restrict__ means, const f
 extern "C" int gs_project_bwd(int N, int V, int D, const float* means, const float* quats, const float* scales,
                               const float* opacities, const float* viewmat, const float* K, int W, int H,
                               float eps2d, const int32_t* gaussian_ids, const float* conics,
-                              const float* compensations, const float* v_packed, const float* v_depths,
-                              float* v_means, float* v_quats, float* v_scales, float* v_opacities, float* v_colors,
+                              const float* compensations, const float* v_packed, int rec_stride,
+                              const float* v_depths, float* v_means, float* v_quats, float* v_scales, float* v_opacities, float* v_colors,
                               int accumulate, void* stream)
 {
     GS_CHECK_ARG(N >= 0 && V >= 0 && V <= N, "bad sizes");
     if (N == 0) return GS_OK;
     hipLaunchKernelGGL(project_bwd_kernel, dim3(gs_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, N, V, D, means,
                        quats, scales, opacities, viewmat, K, W, H, eps2d, gaussian_ids, conics, compensations,
-                       v_packed, ((6 + D) + 15) / 16 * 16, v_depths, v_means, v_quats,
+                       v_packed, rec_stride > 0 ? rec_stride : ((6 + D) + 15) / 16 * 16, v_depths, v_means, v_quats,
                        v_scales, v_opacities, v_colors, accumulate);
     GS_CHECK_LAUNCH();
     return GS_OK;

@@ -132,7 +132,7 @@ class RenderStep:
                                       L.ptr(rws), C.c_size_t(rws.numel()), st()), "gs_raster_bwd")
             L.check(lib.gs_project_bwd(N, V, 3, L.ptr(means), L.ptr(quats), L.ptr(scales_act), L.ptr(opac_act), L.ptr(vm),
                                        L.ptr(K), W, H, L.f32(0.3), L.ptr(s["gaussian_ids_i32"]), L.ptr(s["conics"]),
-                                       L.ptr(s["compensations"]), L.ptr(v_packed), None,
+                                       L.ptr(s["compensations"]), L.ptr(v_packed), 0, None,
                                        L.ptr(b["means"]), L.ptr(b["quats"]), L.ptr(g_scales_act), L.ptr(g_opac_act),
                                        L.ptr(g_colors), 1, st()), "gs_project_bwd")
             L.check(lib.gs_shade_bwd(N, L.ptr(means), L.ptr(normals), L.ptr(kd), L.ptr(ks), L.ptr(cam_pos),

@@ -19,18 +19,21 @@ _META_KEYS = ("gaussian_ids_i32", "radii", "means2d", "depths", "conics", "compe
               "tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets", "last_ids", "raster_ws")
 
 
-def _forward_stages(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Tensor,
+def _forward_stages(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Optional[Tensor],
                     viewmat: Tensor, K: Tensor, W: int, H: int, tile_size: int, eps2d: float, near: float,
-                    far: float, radius_clip: float, background: Optional[Tensor]):
+                    far: float, radius_clip: float, background: Optional[Tensor], depth_channel: bool = False):
+    """A1..A5 through the C-ABI.  depth_channel appends the camera-space depth of every visible Gaussian as one
+    more composited channel (gsplat render modes 'D' / 'ED' / 'RGB+D' / 'RGB+ED'; colors may be None for 'D'/'ED')."""
     lib = L.lib()
     dev = means.device
-    N, D = means.shape[0], colors.shape[1]
+    N, D = means.shape[0], (0 if colors is None else colors.shape[1])
     tw, th = (W + tile_size - 1) // tile_size, (H + tile_size - 1) // tile_size
     i32, f32 = torch.int32, torch.float32
     gids = torch.empty(N, dtype=i32, device=dev); radii = torch.empty(N, dtype=i32, device=dev)
     means2d = torch.empty(N, 2, dtype=f32, device=dev); depths = torch.empty(N, dtype=f32, device=dev)
     conics = torch.empty(N, 3, dtype=f32, device=dev); comps = torch.empty(N, dtype=f32, device=dev)
-    opac_p = torch.empty(N, dtype=f32, device=dev); colors_p = torch.empty(N, D, dtype=f32, device=dev)
+    opac_p = torch.empty(N, dtype=f32, device=dev)
+    colors_p = torch.empty(N, D, dtype=f32, device=dev) if D > 0 else None
     tpg = torch.empty(N, dtype=i32, device=dev); cum = torch.empty(N, dtype=torch.int64, device=dev)
     ws_bytes = lib.gs_project_ws_bytes(N)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -45,7 +48,12 @@ def _forward_stages(means: Tensor, quats: Tensor, scales: Tensor, opacities: Ten
     if V < 0 or I < 0 or I >= 2 ** 31:
         raise L.GeoSplatHipError(f"bad intersection count V={V} I={I}")
     gids, radii, means2d, depths = gids[:V], radii[:V], means2d[:V], depths[:V]
-    conics, comps, opac_p, colors_p, tpg, cum = conics[:V], comps[:V], opac_p[:V], colors_p[:V], tpg[:V], cum[:V]
+    conics, comps, opac_p, tpg, cum = conics[:V], comps[:V], opac_p[:V], tpg[:V], cum[:V]
+    colors_p = colors_p[:V] if colors_p is not None else None
+    if depth_channel:
+        colors_p = depths.unsqueeze(-1).clone() if colors_p is None else torch.cat((colors_p, depths.unsqueeze(-1)), dim=1)
+        D = D + 1
+    colors_p = colors_p.contiguous()
 
     ids = torch.empty(I, dtype=torch.int64, device=dev); flat = torch.empty(I, dtype=i32, device=dev)
     ids_s = torch.empty(I, dtype=torch.int64, device=dev); flat_s = torch.empty(I, dtype=i32, device=dev)
@@ -74,13 +82,14 @@ def _forward_stages(means: Tensor, quats: Tensor, scales: Tensor, opacities: Ten
 class _Rasterize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, colors, viewmat, K, background, W, H, tile_size, eps2d, near, far,
-                radius_clip):
+                radius_clip, depth_channel):
         means, quats, scales = means.contiguous(), quats.contiguous(), scales.contiguous()
-        opacities, colors = opacities.contiguous(), colors.contiguous()
+        opacities = opacities.contiguous()
+        colors = colors.contiguous() if colors is not None else None
         viewmat, K = viewmat.contiguous(), K.contiguous()
         render, alphas, st, V, I = _forward_stages(means, quats, scales, opacities, colors, viewmat, K, W, H, tile_size,
-                                                   eps2d, near, far, radius_clip, background)
-        ctx.cfg = (W, H, tile_size, eps2d, V, I)
+                                                   eps2d, near, far, radius_clip, background, depth_channel)
+        ctx.cfg = (W, H, tile_size, eps2d, V, I, depth_channel)
         ctx.save_for_backward(means, quats, scales, opacities, colors, viewmat, K, background, alphas,
                               *[st[k] for k in _META_KEYS])
         outs = (render, alphas) + tuple(st[k] for k in _META_KEYS)
@@ -90,11 +99,13 @@ class _Rasterize(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_render, v_alphas, *_unused):
         lib = L.lib()
-        W, H, tile_size, eps2d, V, I = ctx.cfg
+        W, H, tile_size, eps2d, V, I, depth_channel = ctx.cfg
         (means, quats, scales, opacities, colors, viewmat, K, background, alphas, *meta) = ctx.saved_tensors
         st = dict(zip(_META_KEYS, meta))
         dev = means.device
-        N, D = means.shape[0], colors.shape[1]
+        N = means.shape[0]
+        Dc = 0 if colors is None else colors.shape[1]       # input colour channels
+        D = Dc + (1 if depth_channel else 0)                # composited channels
         f32 = torch.float32
         v_render = torch.zeros(H, W, D, dtype=f32, device=dev) if v_render is None else v_render.contiguous()
         v_alphas = torch.zeros(H, W, dtype=f32, device=dev) if v_alphas is None else v_alphas.contiguous()
@@ -107,12 +118,13 @@ class _Rasterize(torch.autograd.Function):
                                   L.ptr(v_alphas), L.ptr(v_packed), L.ptr(rws), C.c_size_t(rws.numel()), s), "gs_raster_bwd")
         g_means = torch.empty(N, 3, dtype=f32, device=dev); g_quats = torch.empty(N, 4, dtype=f32, device=dev)
         g_scales = torch.empty(N, 3, dtype=f32, device=dev); g_opac = torch.empty(N, dtype=f32, device=dev)
-        g_colors = torch.empty(N, D, dtype=f32, device=dev)
-        L.check(lib.gs_project_bwd(N, V, D, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opacities), L.ptr(viewmat),
+        g_colors = torch.empty(N, Dc, dtype=f32, device=dev) if Dc > 0 else None
+        v_depths = v_packed[:, 6 + Dc].contiguous() if depth_channel else None   # grad of the appended depth channel
+        L.check(lib.gs_project_bwd(N, V, Dc, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opacities), L.ptr(viewmat),
                                    L.ptr(K), W, H, L.f32(eps2d), L.ptr(st["gaussian_ids_i32"]), L.ptr(st["conics"]),
-                                   L.ptr(st["compensations"]), L.ptr(v_packed), None, L.ptr(g_means), L.ptr(g_quats),
-                                   L.ptr(g_scales), L.ptr(g_opac), L.ptr(g_colors), 0, s), "gs_project_bwd")
-        return (g_means, g_quats, g_scales, g_opac, g_colors) + (None,) * 10
+                                   L.ptr(st["compensations"]), L.ptr(v_packed), stride, L.ptr(v_depths), L.ptr(g_means),
+                                   L.ptr(g_quats), L.ptr(g_scales), L.ptr(g_opac), L.ptr(g_colors), 0, s), "gs_project_bwd")
+        return (g_means, g_quats, g_scales, g_opac, g_colors) + (None,) * 11
 
 
 def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Tensor, viewmats: Tensor,
@@ -128,23 +140,33 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
         raise ValueError("exactly one camera per call (rfstudio/model/gsplat.py:293 asserts cameras.shape == (1,))")
     if sh_degree is not None:
         raise NotImplementedError("sh_degree must be None (the reference passes sh_degree=None, geosplat uses sh_degree=0)")
-    if render_mode != "RGB":
-        raise NotImplementedError("render_mode 'RGB' only (depth modes are a SURVEY section 8f 'next' row)")
+    if render_mode not in ("RGB", "D", "ED", "RGB+D", "RGB+ED"):
+        raise ValueError(f"unknown render_mode {render_mode!r}")
     if rasterize_mode != "antialiased":
         raise NotImplementedError("rasterize_mode 'antialiased' only (rfstudio/model/geosplat.py:796)")
     if sparse_grad or absgrad:
         raise NotImplementedError("sparse_grad / absgrad are False on the reference path")
     N = means.shape[0]
     assert means.shape == (N, 3) and quats.shape == (N, 4) and scales.shape == (N, 3) and opacities.shape == (N,)
-    assert colors.dim() == 2 and colors.shape[0] == N
+    depth_channel = render_mode != "RGB"
+    if render_mode in ("D", "ED"):
+        colors = None                                    # upstream ignores colours in the depth-only modes
+    else:
+        assert colors.dim() == 2 and colors.shape[0] == N
     bg = None
     if backgrounds is not None:
         bg = backgrounds.reshape(-1).contiguous().float()
-        assert bg.shape[0] == colors.shape[1]
-    outs = _Rasterize.apply(means.float(), quats.float(), scales.float(), opacities.float(), colors.float(),
+        if depth_channel:                                # upstream pads the background of the depth channel with 0
+            bg = torch.cat((bg, bg.new_zeros(1))) if colors is not None else bg.new_zeros(1)
+        assert bg.shape[0] == (0 if colors is None else colors.shape[1]) + (1 if depth_channel else 0)
+    outs = _Rasterize.apply(means.float(), quats.float(), scales.float(), opacities.float(),
+                            None if colors is None else colors.float(),
                             viewmats.reshape(4, 4).float(), Ks.reshape(3, 3).float(), bg, int(width), int(height),
-                            int(tile_size), float(eps2d), float(near_plane), float(far_plane), float(radius_clip))
+                            int(tile_size), float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
+                            depth_channel)
     render, alphas = outs[0], outs[1]
+    if render_mode in ("ED", "RGB+ED"):                  # expected depth = accumulated depth / alpha (rfstudio/model/gsplat.py:151-172)
+        render = torch.cat((render[..., :-1], render[..., -1:] / alphas.unsqueeze(-1).clamp(min=1e-10)), dim=-1)
     st = dict(zip(_META_KEYS, outs[2:]))
     tw, th = (width + tile_size - 1) // tile_size, (height + tile_size - 1) // tile_size
     V = st["radii"].shape[0]

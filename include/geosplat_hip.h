@@ -130,7 +130,7 @@ int gs_raster_bwd(int W, int H, int tile_size, int D, int V, const float* colors
 int gs_project_bwd(int N, int V, int D, const float* means, const float* quats, const float* scales,
                    const float* opacities, const float* viewmat, const float* K, int W, int H, float eps2d,
                    const int32_t* gaussian_ids, const float* conics, const float* compensations,
-                   const float* v_packed, const float* v_depths,
+                   const float* v_packed, int rec_stride /* 0 = gs_raster_grad_stride(D) */, const float* v_depths,
                    float* v_means, float* v_quats, float* v_scales, float* v_opacities, float* v_colors,
                    int accumulate, void* stream);
 

@@ -135,13 +135,64 @@ def test_empty_inputs(cuda):
         assert meta["flatten_ids"].numel() == 0 and meta["gaussian_ids"].numel() == 0
 
 
+@pytest.mark.parametrize("mode", ["ED", "RGB+D"])
+def test_depth_render_modes(cuda, mode):
+    """render_mode 'ED' (GSplatter.render_depth, rfstudio/model/gsplat.py:151-172) and 'RGB+D': the camera-space depth
+    is composited as one more channel; gradients reach means/quats/scales through v_depths."""
+    import geosplatting_amd as gs
+    sp, cam = random_case(3000, 96, view=1, seed=5)
+    means, quats, scales, opac = activated(sp)
+    opac = np.clip(opac * 5, 0, 0.9).astype(np.float32)
+    colors = sp.colors.numpy()
+    W = H = 96
+    vm, K = cam.view_matrix.numpy(), cam.intrinsic_matrix.numpy()
+    proj = oracle.project_fwd(means, quats, scales, vm, K, W, H)
+    depth_full = np.zeros((means.shape[0], 1), np.float32)
+    depth_full[proj["gaussian_ids"], 0] = proj["depths"]
+    col_ref = depth_full if mode == "ED" else np.concatenate([colors, depth_full], 1)
+    ref = oracle.rasterization(means, quats, scales, opac, col_ref, vm, K, W, H)
+    t = lambda a: torch.tensor(a, device=cuda, requires_grad=True)
+    tm, tq, ts, to, tc = t(means), t(quats), t(scales), t(opac), t(colors)
+    render, alpha, meta = gs.rasterization(tm, tq, ts, to, tc, torch.tensor(vm, device=cuda)[None],
+                                           torch.tensor(K, device=cuda)[None], W, H, render_mode=mode)
+    amb = ref["ambiguous"]
+    want = ref["render"].copy()
+    if mode == "ED":
+        want = want / np.clip(ref["alphas"][..., None], 1e-10, None)
+    assert render.shape == (1, H, W, col_ref.shape[1])
+    assert rel_err(render[0].detach().cpu().numpy()[~amb], want[~amb]) < 1e-4
+    # gradient through the depth channel: compare d(sum accumulated depth)/d(means) with the oracle chain
+    if mode == "RGB+D":
+        g = torch.Generator().manual_seed(2)
+        vr = (torch.rand(H, W, 4, generator=g) * 2 - 1); vr[torch.tensor(amb)] = 0
+        (render[0] * vr.to(cuda)).sum().backward()
+        rb = oracle.raster_bwd(W, H, 16, ref["means2d"], ref["conics"], ref["opacities"], ref["colors"],
+                               ref["isect_offsets"].reshape(-1), ref["flatten_ids"], ref["alphas"], ref["last_ids"],
+                               vr.numpy(), np.zeros((H, W), np.float32))
+        v_m2d, v_con, v_col, v_op = rb
+        gref = oracle.project_bwd(means, quats, scales, opac, vm, K, W, H, ref["gaussian_ids"], ref["conics"],
+                                  ref["compensations"], v_m2d, v_con, v_op, v_col[:, :3], v_depths=v_col[:, 3])
+        assert rel_err(tm.grad.cpu().numpy(), gref[0]) < 1e-4
+        assert rel_err(tc.grad.cpu().numpy(), gref[4]) < 1e-4
+
+
+def test_deferred_14_channels(cuda):
+    """D = 14 as in the reference's deferred call (rfstudio/model/geosplat.py:276-295)."""
+    sp, cam = random_case(2500, 80, view=3, seed=9)
+    means, quats, scales, opac = activated(sp)
+    colors = torch.rand(2500, 14, generator=torch.Generator().manual_seed(1)).numpy()
+    _run_case(cuda, means, quats, scales, np.clip(opac * 4, 0, 0.9).astype(np.float32), colors, cam)
+
+
 def test_error_behaviour(cuda):
     import geosplatting_amd as gs
     z = torch.zeros(1, 3, device=cuda)
     args = (z, torch.ones(1, 4, device=cuda), z + 1, torch.ones(1, device=cuda), z, torch.eye(4, device=cuda)[None],
             torch.eye(3, device=cuda)[None], 16, 16)
+    with pytest.raises(ValueError):
+        gs.rasterization(*args, render_mode="bogus")
     with pytest.raises(NotImplementedError):
-        gs.rasterization(*args, render_mode="ED")
+        gs.rasterization(*args, rasterize_mode="classic")
     with pytest.raises(ValueError):
         gs.rasterization(z, torch.ones(1, 4, device=cuda), z + 1, torch.ones(1, device=cuda), z,
                          torch.eye(4, device=cuda).repeat(2, 1, 1), torch.eye(3, device=cuda).repeat(2, 1, 1), 16, 16)

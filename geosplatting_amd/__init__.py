@@ -10,7 +10,7 @@ raises if that library is missing -- there is no CPU or PyTorch fallback path.
 """
 from .cameras import Camera, intrinsic_matrix, lookat_c2w, orbit_cameras, view_matrix  # noqa: F401
 from .rasterization import rasterization  # noqa: F401
-from .shading import RenderableAttrs, get_fg_lut, render_rgba, shade, tone_map  # noqa: F401
+from .shading import RenderableAttrs, get_fg_lut, render_depth, render_rgb, render_rgba, shade, tone_map  # noqa: F401
 from .splitsum import TextureSplitSum, as_splitsum, diffuse_cubemap, specular_cubemap  # noqa: F401
 
 __version__ = "0.1.0"

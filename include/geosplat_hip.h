@@ -216,6 +216,19 @@ int gs_specular_apply(int R, const float* src, int src_stride /* 3, or 4 = float
                       const int64_t* patch_offsets, int64_t total_patches, const int32_t* patch_desc,
                       const float* weights, float* dst, int dst_stride, int accumulate, void* stream);
 
+/* ------------------------------------------------------------------ M1: MGAdapter (mesh -> Gaussians) */
+/* rfstudio/model/geosplat.py:378-472 (MGAdapter.make, default ratios): every face -> 6 flat Gaussians (two rings
+ * of three).  Output rows are part-major like the reference's Splats.cat: row = part * F + face, N = 6 F.
+ *   means[N,3]; scales[N,3] log-scales (third = -10); quats[N,4] wxyz; normals[N,3] interpolated shading normals.
+ * faces[F,3] int64 vertex indices; vertices[V,3]; vnormals[V,3].  Opacities are the constant logit(0.99). */
+int gs_mgadapter_fwd(int F, const float* vertices, const int64_t* faces, const float* vnormals,
+                     float* means, float* scales, float* quats, float* normals, void* stream);
+/* v_vertices[V,3], v_vnormals[V,3] are WRITTEN (zeroed by the call, then accumulated with fp32 atomics).
+ * v_normals may be NULL (no gradient through the shading normals). */
+int gs_mgadapter_bwd(int F, int V, const float* vertices, const int64_t* faces, const float* vnormals,
+                     const float* v_means, const float* v_scales, const float* v_quats, const float* v_normals,
+                     float* v_vertices, float* v_vnormals, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -198,12 +198,13 @@ def test_error_behaviour(cuda):
                          torch.eye(4, device=cuda).repeat(2, 1, 1), torch.eye(3, device=cuda).repeat(2, 1, 1), 16, 16)
 
 
-def test_full_size_properties(cuda):
-    """BASELINE size (491 520 surface splats, 800x800): size-independent properties -- sortedness of keys,
+@pytest.mark.parametrize("level", [6, 7])
+def test_full_size_properties(cuda, level):
+    """BASELINE sizes (491 520 and 1 966 080 surface splats, 800x800): size-independent properties -- sortedness of keys,
     stability (flatten_ids ascending inside equal keys), offsets monotone and consistent, alpha in [0,1],
     colour linearity of the compositor, and a sub-sampled oracle check of projection outputs."""
     import geosplatting_amd as gs
-    sc, cam = sphere_case(6, 800)
+    sc, cam = sphere_case(level, 800)
     means, quats, scales, opac = activated(sc.splats)
     N = sc.splats.num
     g = torch.Generator().manual_seed(7)

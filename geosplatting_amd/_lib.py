@@ -34,7 +34,8 @@ SYMBOLS = [
     "gs_shade_bwd_ws_bytes", "gs_shade_bwd", "gs_tonemap_fwd", "gs_tonemap_bwd", "gs_cubemap_mip_fwd", "gs_cube_sample_linear",
     "gs_cubemap_mip_bwd", "gs_diffuse_cubemap_fwd", "gs_diffuse_cubemap_bwd", "gs_specular_bounds", "gs_cube_dir_table",
     "gs_specular_cubemap_fwd", "gs_specular_cubemap_bwd", "gs_specular_patch_count", "gs_specular_weights_build",
-    "gs_specular_apply", "gs_mgadapter_fwd", "gs_mgadapter_bwd",
+    "gs_specular_apply", "gs_mgadapter_fwd", "gs_mgadapter_bwd", "gs_vertex_normals_fwd",
+    "gs_vertex_normals_bwd",
 ]
 
 _lib: Optional[C.CDLL] = None

@@ -224,6 +224,88 @@ mgadapter_bwd_kernel(int F, const float* __restrict__ vertices, const int64_t* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// compute_vertex_normals_(fix=True) (rfstudio/graphics/_mesh/_triangle_mesh.py:588-613): area-weighted face normals
+// scatter-added to the three corners, then normalised; |n| <= 1e-10 -> (0,0,1).
+__global__ void __launch_bounds__(256)
+vnormal_scatter_kernel(int F, const float* __restrict__ vertices, const int64_t* __restrict__ faces, float* __restrict__ raw)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    int64_t vid[3]; float P[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        vid[i] = faces[3 * (size_t)f + i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) P[i][k] = vertices[3 * vid[i] + k];
+    }
+    float e1[3], e2[3], fn[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { e1[k] = P[1][k] - P[0][k]; e2[k] = P[2][k] - P[0][k]; }
+    cross3(e1, e2, fn);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gs_atomic_add(raw + 3 * vid[i] + k, fn[k]);
+}
+
+__global__ void __launch_bounds__(256)
+vnormal_normalize_kernel(int V, const float* __restrict__ raw, float* __restrict__ vnormals)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const float x = raw[3 * v], y = raw[3 * v + 1], z = raw[3 * v + 2];
+    const float l = sqrtf(x * x + y * y + z * z);
+    const bool ok = l > 1e-10f;
+    const float lc = fmaxf(l, 1e-10f);
+    vnormals[3 * v] = ok ? x / lc : 0.0f; vnormals[3 * v + 1] = ok ? y / lc : 0.0f; vnormals[3 * v + 2] = ok ? z / lc : 1.0f;
+}
+
+// v_raw = (g - n (n.g)) / |raw| per vertex (zero where the fixing constant was used)
+__global__ void __launch_bounds__(256)
+vnormal_bwd_vertex_kernel(int V, const float* __restrict__ raw, const float* __restrict__ v_vnormals, float* __restrict__ v_raw)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const float x = raw[3 * v], y = raw[3 * v + 1], z = raw[3 * v + 2];
+    const float l = sqrtf(x * x + y * y + z * z);
+    float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+    if (l > 1e-10f) {
+        const float nx = x / l, ny = y / l, nz = z / l;
+        const float ax = v_vnormals[3 * v], ay = v_vnormals[3 * v + 1], az = v_vnormals[3 * v + 2];
+        const float d = nx * ax + ny * ay + nz * az;
+        gx = (ax - nx * d) / l; gy = (ay - ny * d) / l; gz = (az - nz * d) / l;
+    }
+    v_raw[3 * v] = gx; v_raw[3 * v + 1] = gy; v_raw[3 * v + 2] = gz;
+}
+
+// per face: g = sum of its corners' v_raw; fn = e1 x e2 -> v_e1 = e2 x g, v_e2 = g x e1
+__global__ void __launch_bounds__(256)
+vnormal_bwd_face_kernel(int F, const float* __restrict__ vertices, const int64_t* __restrict__ faces,
+                        const float* __restrict__ v_raw, float* __restrict__ v_vertices)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    int64_t vid[3]; float P[3][3]; float g[3] = { 0.0f, 0.0f, 0.0f };
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        vid[i] = faces[3 * (size_t)f + i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { P[i][k] = vertices[3 * vid[i] + k]; g[k] += v_raw[3 * vid[i] + k]; }
+    }
+    float e1[3], e2[3], g1[3], g2[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { e1[k] = P[1][k] - P[0][k]; e2[k] = P[2][k] - P[0][k]; }
+    cross3(e2, g, g1);
+    cross3(g, e1, g2);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        gs_atomic_add(v_vertices + 3 * vid[1] + k, g1[k]);
+        gs_atomic_add(v_vertices + 3 * vid[2] + k, g2[k]);
+        gs_atomic_add(v_vertices + 3 * vid[0] + k, -(g1[k] + g2[k]));
+    }
+}
+
 extern "C" int gs_mgadapter_fwd(int F, const float* vertices, const int64_t* faces, const float* vnormals,
                                 float* means, float* scales, float* quats, float* normals, void* stream)
 {
@@ -246,6 +328,33 @@ extern "C" int gs_mgadapter_bwd(int F, int V, const float* vertices, const int64
     if (F == 0) return GS_OK;
     hipLaunchKernelGGL(mgadapter_bwd_kernel, dim3(gs_cdiv(F, 256)), dim3(256), 0, s, F, vertices, faces, vnormals, v_means,
                        v_scales, v_quats, v_normals, v_vertices, v_vnormals);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
+extern "C" int gs_vertex_normals_fwd(int F, int V, const float* vertices, const int64_t* faces, float* raw,
+                                     float* vnormals, void* stream)
+{
+    GS_CHECK_ARG(F >= 0 && V >= 0, "bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    if (V == 0) return GS_OK;
+    GS_CHECK_HIP(hipMemsetAsync(raw, 0, sizeof(float) * 3 * (size_t)V, s));
+    if (F > 0) hipLaunchKernelGGL(vnormal_scatter_kernel, dim3(gs_cdiv(F, 256)), dim3(256), 0, s, F, vertices, faces, raw);
+    hipLaunchKernelGGL(vnormal_normalize_kernel, dim3(gs_cdiv(V, 256)), dim3(256), 0, s, V, raw, vnormals);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
+extern "C" int gs_vertex_normals_bwd(int F, int V, const float* vertices, const int64_t* faces, const float* raw,
+                                     const float* v_vnormals, float* v_raw, float* v_vertices, int accumulate,
+                                     void* stream)
+{
+    GS_CHECK_ARG(F >= 0 && V >= 0, "bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    if (V == 0) return GS_OK;
+    if (!accumulate) GS_CHECK_HIP(hipMemsetAsync(v_vertices, 0, sizeof(float) * 3 * (size_t)V, s));
+    hipLaunchKernelGGL(vnormal_bwd_vertex_kernel, dim3(gs_cdiv(V, 256)), dim3(256), 0, s, V, raw, v_vnormals, v_raw);
+    if (F > 0) hipLaunchKernelGGL(vnormal_bwd_face_kernel, dim3(gs_cdiv(F, 256)), dim3(256), 0, s, F, vertices, faces, v_raw, v_vertices);
     GS_CHECK_LAUNCH();
     return GS_OK;
 }

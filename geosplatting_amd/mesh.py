@@ -50,6 +50,34 @@ class _MGAdapter(torch.autograd.Function):
         return gv, None, gn
 
 
+class _VertexNormals(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vertices: Tensor, faces: Tensor):
+        _lib.require_cuda(vertices, faces)
+        if faces.dtype != torch.int64 or faces.ndim != 2 or faces.shape[1] != 3:
+            raise _lib.GeoSplatHipError("faces must be int64 [F,3]")
+        v = vertices.detach().contiguous().float(); f = faces.contiguous()
+        raw = torch.empty_like(v); vn = torch.empty_like(v)
+        _lib.check(_lib.lib().gs_vertex_normals_fwd(f.shape[0], v.shape[0], _lib.ptr(v), _lib.ptr(f), _lib.ptr(raw),
+                                                    _lib.ptr(vn), _lib.stream()), "gs_vertex_normals_fwd")
+        ctx.save_for_backward(v, f, raw)
+        return vn
+
+    @staticmethod
+    def backward(ctx, v_vn):
+        v, f, raw = ctx.saved_tensors
+        gv = torch.empty_like(v); scratch = torch.empty_like(v)
+        _lib.check(_lib.lib().gs_vertex_normals_bwd(f.shape[0], v.shape[0], _lib.ptr(v), _lib.ptr(f), _lib.ptr(raw),
+                                                    _lib.ptr(v_vn.contiguous().float()), _lib.ptr(scratch),
+                                                    _lib.ptr(gv), 0, _lib.stream()), "gs_vertex_normals_bwd")
+        return gv, None
+
+
+def vertex_normals(vertices: Tensor, faces: Tensor) -> Tensor:
+    """TriangleMesh.compute_vertex_normals(fix=True) (rfstudio/graphics/_mesh/_triangle_mesh.py:588-613)."""
+    return _VertexNormals.apply(vertices, faces)
+
+
 def mesh_to_splats(vertices: Tensor, faces: Tensor, vnormals: Tensor) -> Tuple[SplatSet, Tensor]:
     """MGAdapter.make (rfstudio/model/geosplat.py:426-472): returns (splats with colours = shading normals,
     shading_normals[6F,3]); row = part * F + face."""

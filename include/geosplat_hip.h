@@ -229,6 +229,15 @@ int gs_mgadapter_bwd(int F, int V, const float* vertices, const int64_t* faces, 
                      const float* v_means, const float* v_scales, const float* v_quats, const float* v_normals,
                      float* v_vertices, float* v_vnormals, void* stream);
 
+/* compute_vertex_normals_(fix=True), rfstudio/graphics/_mesh/_triangle_mesh.py:588-613: area-weighted vertex normals.
+ * raw[V,3] = un-normalised sums (saved for the backward); |raw| <= 1e-10 -> (0,0,1) with zero gradient.
+ * bwd: v_raw[V,3] scratch; v_vertices[V,3] written, or accumulated into when accumulate != 0 (so that it can be
+ * chained onto gs_mgadapter_bwd's v_vertices). */
+int gs_vertex_normals_fwd(int F, int V, const float* vertices, const int64_t* faces, float* raw, float* vnormals,
+                          void* stream);
+int gs_vertex_normals_bwd(int F, int V, const float* vertices, const int64_t* faces, const float* raw,
+                          const float* v_vnormals, float* v_raw, float* v_vertices, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

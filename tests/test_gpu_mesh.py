@@ -104,3 +104,36 @@ def test_mgadapter_feeds_render_path():
     assert alpha.max().item() > 0.9
     (render.sum() + alpha.sum()).backward()
     assert torch.isfinite(vc.grad).all() and vc.grad.abs().max().item() > 0
+
+
+def test_vertex_normals_golden_and_gradient():
+    """compute_vertex_normals(fix=True): golden from the real TriangleMesh, gradient vs float64 autograd, chained
+    mesh -> normals -> Gaussians"""
+    from geosplatting_amd.mesh import mesh_to_splats, vertex_normals
+    g = np.load(os.path.join(GOLD, "ref_mgadapter.npz"))
+    v = torch.tensor(g["vertices"]).cuda(); f = torch.tensor(g["faces"]).cuda()
+    assert np.allclose(vertex_normals(v, f).cpu().numpy(), g["vnormals"], atol=1e-6)
+
+    gen = torch.Generator().manual_seed(5)
+    v, f = syn.icosphere(3)
+    v = v + 0.02 * torch.randn(v.shape, generator=gen)
+    N = 6 * f.shape[0]
+    gm, gs, gq, gn = (torch.randn(N, w, generator=gen) for w in (3, 3, 4, 3))
+    vc = v.cuda().requires_grad_(True)
+    sp, nrm = mesh_to_splats(vc, f.cuda(), vertex_normals(vc, f.cuda()))
+    ((sp.means * gm.cuda()).sum() + (sp.scales * gs.cuda()).sum() + (sp.quats * gq.cuda()).sum()
+     + (nrm * gn.cuda()).sum()).backward()
+    vd = v.double().requires_grad_(True)
+    sp_ref, nrm_ref = syn.mesh_to_splats(vd, f, syn.vertex_normals(vd, f))
+    sign = torch.sign((sp.quats.detach().cpu().double() * sp_ref.quats.detach()).sum(-1, keepdim=True))
+    ((sp_ref.means * gm).sum() + (sp_ref.scales * gs).sum() + (sp_ref.quats * sign * gq).sum()
+     + (nrm_ref * gn).sum()).backward()
+    assert (nrm.detach().cpu().double() - nrm_ref.detach()).abs().max().item() < 2e-6
+    err = (vc.grad.cpu().double() - vd.grad).abs().max().item() / vd.grad.abs().max().item()
+    assert err < 1e-4, err
+    # an isolated vertex gets the fixing constant (0,0,1) and no gradient
+    v2 = torch.cat([v, torch.zeros(1, 3)], 0).cuda().requires_grad_(True)
+    n2 = vertex_normals(v2, f.cuda())
+    assert n2[-1].tolist() == [0.0, 0.0, 1.0]
+    n2.sum().backward()
+    assert v2.grad[-1].abs().max().item() == 0.0

@@ -238,6 +238,22 @@ int gs_vertex_normals_fwd(int F, int V, const float* vertices, const int64_t* fa
 int gs_vertex_normals_bwd(int F, int V, const float* vertices, const int64_t* faces, const float* raw,
                           const float* v_vnormals, float* v_raw, float* v_vertices, int accumulate, void* stream);
 
+/* ------------------------------------------------------------------ L1: loss side (per view) ------- */
+/* rfstudio/trainer/geosplat_trainer.py:171-195 for one view, value AND gradient in one call:
+ *   x = rgb + (1-alpha) train_bg;  y = lin(gt) mask + (1-mask) train_bg;  mask = gt alpha
+ *   loss = ssim_lambda (1 - SSIM(y,x)) + (1 - ssim_lambda) L1(x,y) + mask_weight mean((mask-alpha)^2)
+ * SSIM = torchmetrics structural_similarity_index_measure defaults (11x11 Gaussian, sigma 1.5; loss/photometric_loss.py:73-112).
+ *   rgb[H,W,3] linear (the path's tone-mapped output), alpha[H,W], gt_rgba[H,W,4] (sRGB colours when gt_is_srgb != 0:
+ *   srgb2rgb of graphics/_images.py:287-311 is applied inside), train_bg[H,W,3] (the caller's torch.rand_like),
+ *   metric_bg[3] device or NULL (background of the sRGB PSNR metric, :191-195).
+ *   out[6] device = {loss, 1-ssim, l1, mask_mse, mse_srgb, psnr_srgb}  (unscaled)
+ *   v_rgb[H,W,3], v_alpha[H,W] = grad_scale * d loss / d(rgb, alpha)  (both NULL: value only).
+ * W, H must exceed 10.  Deterministic (fixed-order reduction). */
+size_t gs_photo_loss_ws_bytes(int W, int H);
+int gs_photo_loss(int W, int H, const float* rgb, const float* alpha, const float* gt_rgba, int gt_is_srgb,
+                  const float* train_bg, const float* metric_bg, float ssim_lambda, float mask_weight,
+                  float grad_scale, float* out, float* v_rgb, float* v_alpha, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

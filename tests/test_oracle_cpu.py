@@ -303,3 +303,35 @@ def test_as_splitsum_shapes_and_energy():
     assert all(np.isfinite(l).all() for l in levels) and np.isfinite(base).all()
     # prefiltering is an average: stays within the range of the input
     assert levels[0].min() >= cube.min() - 1e-4 and levels[0].max() <= cube.max() + 1e-4
+
+
+# ----------------------------------------------------------------------------- loss side (section 8f rank 2)
+def test_golden_loss_glue():
+    """oracle/loss_ref.view_loss == the reference's own SSIML1Loss / PSNRLoss / image-space conversions composed as
+    geosplat_trainer.py:171-195 (tests/golden/ref_loss.npz, scripts/make_golden_loss.py)"""
+    from oracle import loss_ref
+    g = gold("ref_loss.npz")
+    t = lambda k: torch.tensor(g[k])
+    assert np.allclose(loss_ref.rgb2srgb(t("rgb")).numpy(), g["rgb2srgb"][..., :3], atol=1e-7)
+    assert np.allclose(loss_ref.srgb2rgb(t("gt_rgba")[..., :3]).numpy(), g["srgb2rgb"][..., :3], atol=1e-7)
+    out = loss_ref.view_loss(t("rgb"), t("alpha"), t("gt_rgba"), t("train_bg"), metric_bg=t("bg_color"))
+    assert abs(float(out["loss"]) - float(g["loss"])) < 1e-6
+    assert abs(float(out["ssim_loss"]) * 0.2 + float(out["l1"]) * 0.8 - float(g["ssim_l1"])) < 1e-6
+    assert abs(float(out["psnr"]) - float(g["psnr"])) < 1e-4
+
+
+def test_ssim_restatement_vs_scipy():
+    """independent formulation of the torchmetrics SSIM: scipy separable filters with reflect borders + crop"""
+    from scipy.ndimage import correlate1d
+    from oracle import loss_ref
+    rng = np.random.default_rng(3)
+    a = rng.random((1, 3, 37, 45)); b = np.clip(a + 0.2 * rng.standard_normal(a.shape), 0, 1)
+    w = loss_ref.gaussian_window(11, 1.5, torch.float64).numpy()
+    blur = lambda z: correlate1d(correlate1d(z, w, axis=-1, mode="mirror"), w, axis=-2, mode="mirror")
+    mu_a, mu_b = blur(a), blur(b)
+    va = np.maximum(blur(a * a) - mu_a ** 2, 0); vb = np.maximum(blur(b * b) - mu_b ** 2, 0); cab = blur(a * b) - mu_a * mu_b
+    s = ((2 * mu_a * mu_b + 1e-4) * (2 * cab + 9e-4)) / ((mu_a ** 2 + mu_b ** 2 + 1e-4) * (va + vb + 9e-4))
+    expect = s[..., 5:-5, 5:-5].mean()
+    got = float(loss_ref.ssim_torchmetrics(torch.tensor(a), torch.tensor(b))[0])
+    assert abs(got - expect) < 1e-12
+    assert abs(float(loss_ref.ssim_torchmetrics(torch.tensor(a), torch.tensor(a))[0]) - 1.0) < 1e-12

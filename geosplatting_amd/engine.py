@@ -197,6 +197,41 @@ class RenderStep:
         return self.bucket.unpack(), (images if keep_images else None)
 
 
+class MeshStep:
+    """mesh -> Gaussians -> render -> backward to the mesh: the geometry half of the reference's stage-1 loop
+    (GeoSplatter.get_gaussians_from_mesh, rfstudio/model/geosplat.py:620-672, then render_report) with the
+    FlexiCubes extraction and the hash-grid field replaced by explicit leaves:
+    `vertices` [V,3] and per-Gaussian `kd` [6F,3] / `ks` [6F,2].  Per step:
+        vertex normals -> MGAdapter (HIP, mesh.py) -> RenderStep (fused C-ABI path, per-Gaussian gradient bucket,
+        all-reduce at that cut) -> MGAdapter backward -> vertex-normal backward -> d loss / d vertices."""
+
+    def __init__(self, vertices: Tensor, faces: Tensor, kd: Tensor, ks: Tensor, cubemap: Tensor, exposure: Tensor,
+                 **render_kwargs):
+        from .mesh import mesh_to_splats, vertex_normals
+        self._m2s, self._vn = mesh_to_splats, vertex_normals
+        self.vertices, self.faces, self.kd, self.ks, self.cubemap, self.exposure = vertices, faces, kd, ks, cubemap, exposure
+        self.render_kwargs = render_kwargs
+        self.step: Optional[RenderStep] = None
+
+    def __call__(self, cameras: List[Camera], upstream: Callable[[int, Tensor], Tensor], all_reduce: bool = True,
+                 keep_images: bool = False):
+        v = self.vertices.detach().requires_grad_(True)
+        sp, nrm = self._m2s(v, self.faces, self._vn(v, self.faces))
+        params = PathParams(sp.means.detach(), sp.scales.detach(), sp.quats.detach(), sp.opacities.detach(), nrm.detach(),
+                            self.kd.detach(), self.ks.detach(), self.cubemap.detach(), self.exposure.detach())
+        if self.step is None:
+            self.step = RenderStep(params, **self.render_kwargs)
+        else:
+            self.step.p = params
+        grads, images = self.step(cameras, upstream, all_reduce=all_reduce, keep_images=keep_images)
+        # shading normals == splat colours of the adapter: their gradient rides on `nrm`
+        torch.autograd.backward([sp.means, sp.scales, sp.quats, nrm],
+                                [grads["means"], grads["scales"], grads["quats"], grads["normals"]])
+        out = {"vertices": v.grad, "kd": grads["kd"], "ks": grads["ks"], "cubemap": grads["cubemap"],
+               "exposure": grads["exposure"]}
+        return out, images
+
+
 def params_from_scene(scene, device, exposure: float = 1.0) -> PathParams:
     sp: SplatSet = scene.splats
     d = lambda t: t.to(device).contiguous()

@@ -73,3 +73,30 @@ def photo_loss_and_grad(rgb: Tensor, alpha: Tensor, gt_rgba: Tensor, train_bg: T
     grad_scale (e.g. 1 / number of views, geosplat_trainer.py:180)."""
     return _photo_loss_raw(rgb, alpha, gt_rgba, train_bg, metric_bg, gt_is_srgb, ssim_lambda,
                            5.0 if use_mask_loss else 0.0, grad_scale, True)
+
+
+class TrainerUpstream:
+    """`upstream(i, image)` callback for engine.RenderStep: the trainer's per-view loss
+    (geosplat_trainer.py:171-180, mean over the views of the step) evaluated on the GPU; hands back d(loss)/d(image)
+    and keeps the per-view values in `.out` ([num_local_views, 6] device tensor, no host sync)."""
+
+    def __init__(self, gt_rgba, num_views_total: int, metric_bg: Optional[Tensor] = None, gt_is_srgb: bool = True,
+                 ssim_lambda: float = 0.2, use_mask_loss: bool = True, seed: int = 0):
+        self.gt = gt_rgba                              # sequence of [H,W,4] device tensors, local views in order
+        self.scale = 1.0 / float(num_views_total)
+        self.metric_bg, self.gt_is_srgb, self.ssim_lambda, self.use_mask_loss = metric_bg, gt_is_srgb, ssim_lambda, use_mask_loss
+        self.gen = torch.Generator(device=gt_rgba[0].device).manual_seed(seed)
+        self.out = torch.zeros(len(gt_rgba), 6, device=gt_rgba[0].device)
+
+    def __call__(self, i: int, image: Tensor) -> Tensor:
+        img = image.reshape(image.shape[-3], image.shape[-2], 4)
+        rgb = img[..., :3].contiguous(); alpha = img[..., 3:].contiguous()
+        bg = torch.rand(rgb.shape, generator=self.gen, device=rgb.device)
+        out, v_rgb, v_alpha = photo_loss_and_grad(rgb, alpha, self.gt[i], bg, grad_scale=self.scale, metric_bg=self.metric_bg,
+                                                  gt_is_srgb=self.gt_is_srgb, ssim_lambda=self.ssim_lambda,
+                                                  use_mask_loss=self.use_mask_loss)
+        self.out[i] = out
+        return torch.cat((v_rgb, v_alpha), dim=-1).reshape(image.shape)
+
+    def mean_loss(self) -> Tensor:
+        return self.out[:, 0].sum() * self.scale

@@ -441,6 +441,17 @@ extern "C" int gs_specular_weights_build(int R, const float* bounds, const float
 // kernel's nested AABB loops serialise one patch's latency after the other).
 // SRC4: the source is float4-padded [6,R,R,4] -> ONE 16-byte load per lane and patch instead of three strided
 // dword gathers (the texture-addresser cycles of those gathers, not HBM, bounded the first version).
+#ifndef GS_APPLY_XCD
+#define GS_APPLY_XCD 1
+#endif
+#ifndef GS_APPLY_NT
+#define GS_APPLY_NT 1
+#endif
+#if GS_APPLY_NT
+#define GS_STREAM_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define GS_STREAM_LOAD(p) (*(p))
+#endif
 #ifndef GS_APPLY_UNROLL
 #define GS_APPLY_UNROLL 8          // patches in flight per wave (4 -> 8: +x% on the 256^2 / 512^2 levels)
 #endif
@@ -451,7 +462,19 @@ specular_apply_kernel(int R, const float* __restrict__ src, const int64_t* __res
                       float* __restrict__ dst, int dst_stride, int accumulate)
 {
     const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // XCD-aware order: workgroups go round-robin over the 8 XCDs, so XCD x takes the x-th contiguous eighth of the
+    // texels -- its private L2 then holds "its" part of the source cubemap (neighbouring texels tap the same patches);
+    // the weights are a pure stream and bypass the cache (together +5 %).
+    // Measured dead ends (scripts/apply_experiment.py): 16 texels per wave as one flat prefetched patch list (-30 %),
+    // next-batch prefetch in this kernel (-10 %), 16 patches in flight (-15 %): all lose occupancy to registers; the
+    // kernel streams 2.2-2.9 TB/s and is latency x occupancy bound (2.9-3.5 TB/s even without the texel taps).
+#if GS_APPLY_XCD
+    const int per = gridDim.x / 8;
+    const int grp = (blockIdx.x % 8) * per + blockIdx.x / 8;
+#else
+    const int grp = blockIdx.x;
+#endif
+    const int t = grp * 4 + (threadIdx.x >> 6);
     const int n = 6 * R * R;
     if (t >= n) return;
     const int lx = lane & 7, ly = lane >> 3;
@@ -464,7 +487,7 @@ specular_apply_kernel(int R, const float* __restrict__ src, const int64_t* __res
         for (int k = 0; k < GS_APPLY_UNROLL; ++k) {
             const bool on = p + k < p1;
             const int d = on ? patch_desc[p + k] : 0;
-            w[k] = on ? weights[(size_t)(p + k) * 64 + lane] : 0.0f;
+            w[k] = on ? GS_STREAM_LOAD(weights + (size_t)(p + k) * 64 + lane) : 0.0f;
             const int s = d >> 24, by = (d >> 12) & 0xfff, bx = d & 0xfff;
             ti[k] = (((size_t)s * R + (by + ly)) * R + (bx + lx)) * (SRC4 ? 4 : 3);
         }
@@ -496,11 +519,12 @@ extern "C" int gs_specular_apply(int R, const float* src, int src_stride, const 
 {
     GS_CHECK_ARG(R >= 1 && src && patch_offsets && patch_desc && weights && dst && dst_stride >= 3, "bad arguments");
     GS_CHECK_ARG(src_stride == 3 || src_stride == 4, "src_stride must be 3 or 4");
+    const int groups = (gs_cdiv(6 * R * R, 4) + 7) / 8 * 8;           // multiple of 8: one contiguous share per XCD
     if (src_stride == 4)
-        hipLaunchKernelGGL(specular_apply_kernel<true>, dim3(gs_cdiv(6 * R * R, 4)), dim3(256), 0, (hipStream_t)stream, R, src,
+        hipLaunchKernelGGL(specular_apply_kernel<true>, dim3(groups), dim3(256), 0, (hipStream_t)stream, R, src,
                            patch_offsets, total_patches, patch_desc, weights, dst, dst_stride, accumulate);
     else
-        hipLaunchKernelGGL(specular_apply_kernel<false>, dim3(gs_cdiv(6 * R * R, 4)), dim3(256), 0, (hipStream_t)stream, R, src,
+        hipLaunchKernelGGL(specular_apply_kernel<false>, dim3(groups), dim3(256), 0, (hipStream_t)stream, R, src,
                            patch_offsets, total_patches, patch_desc, weights, dst, dst_stride, accumulate);
     GS_CHECK_LAUNCH();
     return GS_OK;

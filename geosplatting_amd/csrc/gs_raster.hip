@@ -88,24 +88,25 @@ build_stream_kernel(int n_isects, int D, const int32_t* __restrict__ flatten_ids
 // Same stream from the PACKED per-visible records written by gs_pack_visible (3 aligned 16-byte gathers per
 // intersection instead of 8 scalar ones: the gather, not the 48-byte store, bounds this kernel).
 __global__ void __launch_bounds__(256)
-build_stream_packed_kernel(int n_isects, const int32_t* __restrict__ flatten_ids, const float4* __restrict__ vis0,
-                           const float4* __restrict__ vis1, const float4* __restrict__ vis2,
+build_stream_packed_kernel(int n_isects, const int32_t* __restrict__ flatten_ids, const float4* __restrict__ vis,
                            float4* __restrict__ rec0, float4* __restrict__ rec1, float4* __restrict__ rec2)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_isects) return;
     const int g = flatten_ids[i];
-    const float4 a = vis0[g], b = vis1[g];
-    float4 c = vis2[g];
+    const float4* v = vis + 4 * (size_t)g;          // one 64-byte record = one cache line per gathered Gaussian
+    const float4 a = v[0], b = v[1];
+    float4 c = v[2];
     c.w = __int_as_float(g);
     rec0[i] = a; rec1[i] = b; rec2[i] = c;
 }
 
-// per-visible packing (coalesced): vis0 = {mx,my,0.5a,b}, vis1 = {0.5c,op,hx,hy}, vis2 = {c0,c1,c2,-}
+// per-visible packing: ONE 64-byte record per Gaussian {mx,my,0.5a,b | 0.5c,op,hx,hy | c0,c1,c2,- | pad} so that the
+// stream build gathers one cache line per intersection (three separate arrays cost three sector fetches)
 __global__ void __launch_bounds__(256)
 pack_visible_kernel(int V, int D, const float* __restrict__ means2d, const float* __restrict__ conics,
                     const float* __restrict__ opacities, const float* __restrict__ colors,
-                    float4* __restrict__ vis0, float4* __restrict__ vis1, float4* __restrict__ vis2)
+                    float4* __restrict__ vis)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= V) return;
@@ -114,15 +115,16 @@ pack_visible_kernel(int V, int D, const float* __restrict__ means2d, const float
     const float op = opacities[g];
     float hx = -1.0f, hy = -1.0f;
     if (!alpha_extent(ca, cb, cc, op, hx, hy)) { hx = -1.0f; hy = -1.0f; }
-    vis0[g] = make_float4(m.x, m.y, 0.5f * ca, cb);
-    vis1[g] = make_float4(0.5f * cc, op, hx, hy);
+    vis[4 * (size_t)g] = make_float4(m.x, m.y, 0.5f * ca, cb);
+    vis[4 * (size_t)g + 1] = make_float4(0.5f * cc, op, hx, hy);
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
     if (D <= 3) {
         c0 = colors[(size_t)g * D];
         if (D > 1) c1 = colors[(size_t)g * D + 1];
         if (D > 2) c2 = colors[(size_t)g * D + 2];
     }
-    vis2[g] = make_float4(c0, c1, c2, 0.0f);
+    vis[4 * (size_t)g + 2] = make_float4(c0, c1, c2, 0.0f);
+    vis[4 * (size_t)g + 3] = make_float4(0.f, 0.f, 0.f, 0.f);     // full-line write (a partial line costs a read-modify-write)
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -455,13 +457,13 @@ extern "C" size_t gs_raster_ws_bytes(int64_t n_isects, int V, int W, int H, int 
     const size_t tiles = (size_t)((W + tile_size - 1) / tile_size) * (size_t)((H + tile_size - 1) / tile_size);
     const size_t n = n_isects > 0 ? (size_t)n_isects : 1;
     const size_t v = V > 0 ? (size_t)V : 1;
-    return 3 * align256(n * sizeof(float4)) + align256(tiles * sizeof(int32_t)) + 3 * align256(v * sizeof(float4));
+    return 3 * align256(n * sizeof(float4)) + align256(tiles * sizeof(int32_t)) + align256(4 * v * sizeof(float4));
 }
 
 struct RasterWs {
     float4 *rec0, *rec1, *rec2;
     int32_t* order;
-    float4 *vis0, *vis1, *vis2;     // scratch of the forward only
+    float4* vis;                    // scratch of the forward only: 64-byte per-visible records
 };
 static RasterWs carve(void* ws, int64_t n_isects, int V, int tiles)
 {
@@ -473,9 +475,7 @@ static RasterWs carve(void* ws, int64_t n_isects, int V, int tiles)
     r.rec1 = (float4*)p; p += align256(n * sizeof(float4));
     r.rec2 = (float4*)p; p += align256(n * sizeof(float4));
     r.order = (int32_t*)p; p += align256((size_t)tiles * sizeof(int32_t));
-    r.vis0 = (float4*)p; p += align256(v * sizeof(float4));
-    r.vis1 = (float4*)p; p += align256(v * sizeof(float4));
-    r.vis2 = (float4*)p;
+    r.vis = (float4*)p;
     return r;
 }
 
@@ -509,10 +509,10 @@ extern "C" int gs_raster_fwd(int W, int H, int tile_size, int D, int V, const fl
     const RasterWs r = carve(ws, n_isects, V, tiles);
     if (n_isects > 0 && V > 0) {
         hipLaunchKernelGGL(pack_visible_kernel, dim3(gs_cdiv(V, 256)), dim3(256), 0, s, V, D, means2d, conics, opacities, colors,
-                           r.vis0, r.vis1, r.vis2);
+                           r.vis);
         GS_CHECK_LAUNCH();
         hipLaunchKernelGGL(build_stream_packed_kernel, dim3(gs_cdiv(n_isects, 256)), dim3(256), 0, s, (int)n_isects, flatten_ids,
-                           r.vis0, r.vis1, r.vis2, r.rec0, r.rec1, r.rec2);
+                           r.vis, r.rec0, r.rec1, r.rec2);
         GS_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, tiles, (int)n_isects, offsets, r.order);

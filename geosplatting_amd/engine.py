@@ -23,7 +23,7 @@ import ctypes as C
 from . import _lib as L
 from .cameras import Camera
 from .parallel import GradBucket
-from .rasterization import _forward_stages
+from .rasterization import _bin_stage, _composite_stage, _forward_stages, _project_stage
 from .shading import _MODE, _TONE, RenderableAttrs, _make_env, get_fg_lut
 from .splitsum import TextureSplitSum, as_splitsum
 from .synthetic import SplatSet
@@ -56,6 +56,8 @@ class RenderStep:
         self.bucket = GradBucket(params.shapes(), params.means.device)
         self._static_env: Optional[TextureSplitSum] = None
         self._cam_cache: Dict[int, tuple] = {}
+        self._side_stream = None
+        self._tail_stream = None
 
     # ------------------------------------------------------------------------------------------------- fused path
     def _camera_tensors(self, cam: Camera):
@@ -103,19 +105,60 @@ class RenderStep:
         self.bucket.flat.zero_()
         b = self.bucket.unpack()
         g_scales_act = torch.zeros(N, 3, dtype=f32, device=dev); g_opac_act = torch.zeros(N, dtype=f32, device=dev)
-        colors = torch.empty(N, 3, dtype=f32, device=dev); g_colors = torch.empty(N, 3, dtype=f32, device=dev)
         exposure = p.exposure.detach().reshape(1).contiguous()
         means, quats = p.means.detach(), p.quats.detach()
         normals, kd, ks = p.normals.detach(), p.kd.detach(), p.ks.detach()
         images = []
+
+        # Two HIP streams per step.  The side stream runs the memory/latency-bound front of every view (shading,
+        # projection, intersection emit, radix sort, tile offsets: ~0.8 ms), the main stream the VALU-bound compositor
+        # forward/backward and the gradient kernels (~2.8 ms): issued one to two views ahead, the front of view i+1
+        # overlaps the compositor of view i on the CUs instead of queueing behind it, and the host's wait for the
+        # (V, I) counts of a view never stalls the main stream.
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream
+        if side is None:
+            side = self._side_stream = torch.cuda.Stream(device=dev)
+        tail = self._tail_stream
+        if tail is None:
+            tail = self._tail_stream = torch.cuda.Stream(device=dev)
+        side.wait_stream(main)                               # prefilter pyramid, activations, zeroed buckets
+        tail.wait_stream(main)
+
+        def start_view(cam):                                 # S1-S3 + A1; (V, I) travel to the host asynchronously
+            vm, K, cam_pos = self._camera_tensors(cam)
+            with torch.cuda.stream(side):
+                col = torch.empty(N, 3, dtype=f32, device=dev)
+                L.check(lib.gs_shade_fwd(N, L.ptr(means), L.ptr(normals), L.ptr(kd), L.ptr(ks), L.ptr(cam_pos),
+                                         L.f32(self.min_roughness), L.f32(self.max_metallic), mode, C.byref(e), L.ptr(col),
+                                         st()), "gs_shade_fwd")
+                pr = _project_stage(means, quats, scales_act, opac_act, col, vm, K, cam.width, cam.height, 16, 0.3, 0.01,
+                                    1e10, 0.0)
+            return pr, col
+
+        def bin_view(item):                                  # A2-A4 on the side stream (host waits for that view's counts)
+            pr, col = item
+            with torch.cuda.stream(side):
+                state, V, I, D, whs = _bin_stage(pr)
+                ev = torch.cuda.Event(); ev.record(side)
+            for t in list(state.values()) + [col] + list(pr.bufs):
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(main)                    # allocated on the side stream, consumed on the main one
+            return state, V, I, D, whs, ev, col
+
+        n_views = len(cameras)
+        proj = [start_view(cameras[j]) for j in range(min(2, n_views))]      # prologue: A(0), A(1), B1(0)
+        binned = bin_view(proj.pop(0)) if n_views else None
         for i, cam in enumerate(cameras):
             vm, K, cam_pos = self._camera_tensors(cam)
             W, H = cam.width, cam.height
-            L.check(lib.gs_shade_fwd(N, L.ptr(means), L.ptr(normals), L.ptr(kd), L.ptr(ks), L.ptr(cam_pos),
-                                     L.f32(self.min_roughness), L.f32(self.max_metallic), mode, C.byref(e), L.ptr(colors),
-                                     st()), "gs_shade_fwd")
-            render, alphas, s, V, I = _forward_stages(means, quats, scales_act, opac_act, colors, vm, K, W, H, 16, 0.3, 0.01,
-                                                      1e10, 0.0, None)
+            state, V, I, D, whs, ev, colors = binned
+            main.wait_event(ev)
+            render, alphas, s, V, I = _composite_stage(state, V, I, D, whs, None)
+            # keep the side stream two views ahead: A(i+2), then B1(i+1)
+            if i + 2 < n_views:
+                proj.append(start_view(cameras[i + 2]))
+            binned = bin_view(proj.pop(0)) if i + 1 < n_views else None
             rgba = torch.cat((render, alphas.unsqueeze(-1)), dim=-1)
             img = torch.empty_like(rgba)
             P = W * H
@@ -130,17 +173,27 @@ class RenderStep:
             L.check(lib.gs_raster_bwd(W, H, 16, 3, V, L.ptr(s["colors"]), None, L.i64(I), L.ptr(s["isect_offsets"]),
                                       L.ptr(alphas), L.ptr(s["last_ids"]), L.ptr(v_render), L.ptr(v_alpha), L.ptr(v_packed),
                                       L.ptr(rws), C.c_size_t(rws.numel()), st()), "gs_raster_bwd")
-            L.check(lib.gs_project_bwd(N, V, 3, L.ptr(means), L.ptr(quats), L.ptr(scales_act), L.ptr(opac_act), L.ptr(vm),
-                                       L.ptr(K), W, H, L.f32(0.3), L.ptr(s["gaussian_ids_i32"]), L.ptr(s["conics"]),
-                                       L.ptr(s["compensations"]), L.ptr(v_packed), 0, None,
-                                       L.ptr(b["means"]), L.ptr(b["quats"]), L.ptr(g_scales_act), L.ptr(g_opac_act),
-                                       L.ptr(g_colors), 1, st()), "gs_project_bwd")
-            L.check(lib.gs_shade_bwd(N, L.ptr(means), L.ptr(normals), L.ptr(kd), L.ptr(ks), L.ptr(cam_pos),
-                                     L.f32(self.min_roughness), L.f32(self.max_metallic), mode, C.byref(e), L.ptr(g_colors),
-                                     L.ptr(b["means"]), L.ptr(b["normals"]), L.ptr(b["kd"]), L.ptr(b["ks"]), C.byref(eg), 1,
-                                     L.ptr(ws) if ws_bytes else None, C.c_size_t(ws_bytes), st()), "gs_shade_bwd")
+            # gradient tail of the view (A7 + S1-S3 backward: HBM / atomic-rate bound) on a third stream, so that it
+            # overlaps the VALU-bound compositor of the next view; the tail kernels of successive views stay in order
+            # on that stream (they accumulate into the same gradient buffers)
+            ev_r = torch.cuda.Event(); ev_r.record(main)
+            g_colors = torch.empty(N, 3, dtype=f32, device=dev)
+            with torch.cuda.stream(tail):
+                tail.wait_event(ev_r)
+                L.check(lib.gs_project_bwd(N, V, 3, L.ptr(means), L.ptr(quats), L.ptr(scales_act), L.ptr(opac_act), L.ptr(vm),
+                                           L.ptr(K), W, H, L.f32(0.3), L.ptr(s["gaussian_ids_i32"]), L.ptr(s["conics"]),
+                                           L.ptr(s["compensations"]), L.ptr(v_packed), 0, None,
+                                           L.ptr(b["means"]), L.ptr(b["quats"]), L.ptr(g_scales_act), L.ptr(g_opac_act),
+                                           L.ptr(g_colors), 1, st()), "gs_project_bwd")
+                L.check(lib.gs_shade_bwd(N, L.ptr(means), L.ptr(normals), L.ptr(kd), L.ptr(ks), L.ptr(cam_pos),
+                                         L.f32(self.min_roughness), L.f32(self.max_metallic), mode, C.byref(e), L.ptr(g_colors),
+                                         L.ptr(b["means"]), L.ptr(b["normals"]), L.ptr(b["kd"]), L.ptr(b["ks"]), C.byref(eg), 1,
+                                         L.ptr(ws) if ws_bytes else None, C.c_size_t(ws_bytes), st()), "gs_shade_bwd")
+            for t in (v_packed, g_colors, s["gaussian_ids_i32"], s["conics"], s["compensations"]):
+                t.record_stream(tail)
             if keep_images:
                 images.append(img)
+        main.wait_stream(tail)
         # chain the once-per-step activations and the prefilter
         torch.mul(g_scales_act, scales_act, out=b["scales"])
         b["opacities"].copy_((g_opac_act * opac_act * (1.0 - opac_act)).unsqueeze(-1))

@@ -19,15 +19,22 @@ _META_KEYS = ("gaussian_ids_i32", "radii", "means2d", "depths", "conics", "compe
               "tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets", "last_ids", "raster_ws")
 
 
-def _forward_stages(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Optional[Tensor],
-                    viewmat: Tensor, K: Tensor, W: int, H: int, tile_size: int, eps2d: float, near: float,
-                    far: float, radius_clip: float, background: Optional[Tensor], depth_channel: bool = False):
-    """A1..A5 through the C-ABI.  depth_channel appends the camera-space depth of every visible Gaussian as one
-    more composited channel (gsplat render modes 'D' / 'ED' / 'RGB+D' / 'RGB+ED'; colors may be None for 'D'/'ED')."""
+class _Projected:
+    """Outputs of the projection stage (A1 + A1' + A2 count) of one view, with the (V, I) counts on their way to a
+    pinned host buffer.  Nothing here blocks: `counts()` waits for the copy only when the sizes are needed, so a
+    caller can launch the projection of view i+1 before it finishes view i (engine.RenderStep does)."""
+    __slots__ = ("args", "bufs", "host_counts", "event", "D")
+
+
+_pinned_pool = []
+
+
+def _project_stage(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Optional[Tensor],
+                   viewmat: Tensor, K: Tensor, W: int, H: int, tile_size: int, eps2d: float, near: float,
+                   far: float, radius_clip: float) -> _Projected:
     lib = L.lib()
     dev = means.device
     N, D = means.shape[0], (0 if colors is None else colors.shape[1])
-    tw, th = (W + tile_size - 1) // tile_size, (H + tile_size - 1) // tile_size
     i32, f32 = torch.int32, torch.float32
     gids = torch.empty(N, dtype=i32, device=dev); radii = torch.empty(N, dtype=i32, device=dev)
     means2d = torch.empty(N, 2, dtype=f32, device=dev); depths = torch.empty(N, dtype=f32, device=dev)
@@ -44,7 +51,31 @@ def _forward_stages(means: Tensor, quats: Tensor, scales: Tensor, opacities: Ten
                                L.f32(radius_clip), L.ptr(gids), L.ptr(radii), L.ptr(means2d), L.ptr(depths),
                                L.ptr(conics), L.ptr(comps), L.ptr(opac_p), L.ptr(colors_p), L.ptr(tpg), L.ptr(cum),
                                None, L.ptr(ws), C.c_size_t(ws_bytes), L.ptr(counts), st), "gs_project_fwd")
-    V, I = (int(x) for x in counts.cpu().tolist())          # the one host sync of the forward (as upstream)
+    pr = _Projected()
+    pr.host_counts = _pinned_pool.pop() if _pinned_pool else torch.empty(2, dtype=torch.int64).pin_memory()
+    pr.host_counts.copy_(counts, non_blocking=True)          # 16 bytes, asynchronous
+    pr.event = torch.cuda.Event()
+    pr.event.record()
+    pr.bufs = (gids, radii, means2d, depths, conics, comps, opac_p, colors_p, tpg, cum, counts)
+    pr.args = (W, H, tile_size)
+    pr.D = D
+    return pr
+
+
+def _bin_stage(pr: _Projected, depth_channel: bool = False):
+    """A2 emit, A3 sort, A4 offsets for a projected view; waits for its (V, I) -- the one host sync of the forward
+    (as upstream).  Returns the state dict without the compositor outputs."""
+    lib = L.lib()
+    W, H, tile_size = pr.args
+    gids, radii, means2d, depths, conics, comps, opac_p, colors_p, tpg, cum, _ = pr.bufs
+    dev = means2d.device
+    D = pr.D
+    tw, th = (W + tile_size - 1) // tile_size, (H + tile_size - 1) // tile_size
+    i32 = torch.int32
+    st = L.stream()
+    pr.event.synchronize()
+    V, I = (int(x) for x in pr.host_counts.tolist())
+    _pinned_pool.append(pr.host_counts)
     if V < 0 or I < 0 or I >= 2 ** 31:
         raise L.GeoSplatHipError(f"bad intersection count V={V} I={I}")
     gids, radii, means2d, depths = gids[:V], radii[:V], means2d[:V], depths[:V]
@@ -65,18 +96,42 @@ def _forward_stages(means: Tensor, quats: Tensor, scales: Tensor, opacities: Ten
                               C.c_size_t(sort_bytes), st), "gs_isect_sort")
     offsets = torch.empty(th * tw, dtype=i32, device=dev)
     L.check(lib.gs_isect_offsets(L.i64(I), L.ptr(ids_s), tw * th, L.ptr(offsets), st), "gs_isect_offsets")
+    state = dict(gaussian_ids_i32=gids, radii=radii, means2d=means2d, depths=depths, conics=conics,
+                 compensations=comps, opacities=opac_p, colors=colors_p, tiles_per_gauss=tpg, isect_ids=ids_s,
+                 flatten_ids=flat_s, isect_offsets=offsets)
+    return state, V, I, D, (W, H, tile_size)
 
+
+def _composite_stage(state, V: int, I: int, D: int, whs, background: Optional[Tensor]):
+    """A5 (stream build + compositor) on the current stream."""
+    lib = L.lib()
+    W, H, tile_size = whs
+    dev = state["means2d"].device
+    i32, f32 = torch.int32, torch.float32
     render = torch.empty(H, W, D, dtype=f32, device=dev); alphas = torch.empty(H, W, dtype=f32, device=dev)
     last_ids = torch.empty(H, W, dtype=i32, device=dev)
     rws_bytes = lib.gs_raster_ws_bytes(L.i64(I), V, W, H, tile_size)
     rws = torch.empty(rws_bytes, dtype=torch.uint8, device=dev)     # record stream: written here, read by the backward
-    L.check(lib.gs_raster_fwd(W, H, tile_size, D, V, L.ptr(means2d), L.ptr(conics), L.ptr(opac_p), L.ptr(colors_p),
-                              L.ptr(background), L.i64(I), L.ptr(offsets), L.ptr(flat_s), L.ptr(render), L.ptr(alphas),
-                              L.ptr(last_ids), L.ptr(rws), C.c_size_t(rws_bytes), st), "gs_raster_fwd")
-    state = dict(gaussian_ids_i32=gids, radii=radii, means2d=means2d, depths=depths, conics=conics,
-                 compensations=comps, opacities=opac_p, colors=colors_p, tiles_per_gauss=tpg, isect_ids=ids_s,
-                 flatten_ids=flat_s, isect_offsets=offsets, last_ids=last_ids, raster_ws=rws)
+    L.check(lib.gs_raster_fwd(W, H, tile_size, D, V, L.ptr(state["means2d"]), L.ptr(state["conics"]),
+                              L.ptr(state["opacities"]), L.ptr(state["colors"]), L.ptr(background), L.i64(I),
+                              L.ptr(state["isect_offsets"]), L.ptr(state["flatten_ids"]), L.ptr(render), L.ptr(alphas),
+                              L.ptr(last_ids), L.ptr(rws), C.c_size_t(rws_bytes), L.stream()), "gs_raster_fwd")
+    state = dict(state, last_ids=last_ids, raster_ws=rws)
     return render, alphas, state, V, I
+
+
+def _raster_stage(pr: _Projected, background: Optional[Tensor], depth_channel: bool = False):
+    state, V, I, D, whs = _bin_stage(pr, depth_channel)
+    return _composite_stage(state, V, I, D, whs, background)
+
+
+def _forward_stages(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Optional[Tensor],
+                    viewmat: Tensor, K: Tensor, W: int, H: int, tile_size: int, eps2d: float, near: float,
+                    far: float, radius_clip: float, background: Optional[Tensor], depth_channel: bool = False):
+    """A1..A5 through the C-ABI.  depth_channel appends the camera-space depth of every visible Gaussian as one
+    more composited channel (gsplat render modes 'D' / 'ED' / 'RGB+D' / 'RGB+ED'; colors may be None for 'D'/'ED')."""
+    pr = _project_stage(means, quats, scales, opacities, colors, viewmat, K, W, H, tile_size, eps2d, near, far, radius_clip)
+    return _raster_stage(pr, background, depth_channel)
 
 
 class _Rasterize(torch.autograd.Function):

@@ -448,6 +448,15 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Occupancy cap of the two compositor kernels: they use no LDS, so a dynamic LDS request of 160 KB / 4 limits a CU to
+// FOUR resident 256-thread blocks (4 waves per SIMD instead of 8).  Measured on the bench workload: backward
+// 1.48 -> 1.19 ms, forward 0.68 -> 0.64 ms per view (3 blocks: same; 2 blocks: back to 1.49 ms; wave priorities for
+// the long tiles: no effect).  The walks are serial dependency chains bound by VALU issue; four waves per SIMD already
+// saturate it, the other four only stretch every chain, delay the long tiles and thrash the scalar/vector L1s -- and
+// the freed wave slots let the memory-bound kernels of the engine's other two streams co-reside.
+#define GS_RASTER_BLOCKS_PER_CU 4
+static size_t gs_raster_lds_pad() { return (size_t)(160 * 1024 / GS_RASTER_BLOCKS_PER_CU) - 1024; }
+
 // workspace layout: [rec0 | rec1 | rec2 | tile_order], every segment 256-byte aligned
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -485,7 +494,7 @@ static int launch_fwd(int W, int H, int D, const RasterWs& ws, const float* colo
                       hipStream_t s)
 {
     const int tile_w = (W + GS_TILE - 1) / GS_TILE, tile_h = (H + GS_TILE - 1) / GS_TILE;
-    hipLaunchKernelGGL(raster_fwd_kernel<CD>, dim3(tile_w * tile_h), dim3(256), 0, s, W, H, tile_w, tile_w * tile_h, D,
+    hipLaunchKernelGGL(raster_fwd_kernel<CD>, dim3(tile_w * tile_h), dim3(256), gs_raster_lds_pad(), s, W, H, tile_w, tile_w * tile_h, D,
                        ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, (int)n_isects, offsets, render, alphas,
                        last_ids);
     GS_CHECK_LAUNCH();
@@ -532,7 +541,7 @@ static int launch_bwd(int W, int H, int D, const RasterWs& ws, const float* colo
                       const float* v_render, const float* v_alphas, float* v_packed, int rec_stride, hipStream_t s)
 {
     const int tile_w = (W + GS_TILE - 1) / GS_TILE, tile_h = (H + GS_TILE - 1) / GS_TILE;
-    hipLaunchKernelGGL(raster_bwd_kernel<CD>, dim3(tile_w * tile_h), dim3(256), 0, s, W, H, tile_w, tile_w * tile_h, D,
+    hipLaunchKernelGGL(raster_bwd_kernel<CD>, dim3(tile_w * tile_h), dim3(256), gs_raster_lds_pad(), s, W, H, tile_w, tile_w * tile_h, D,
                        ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, (int)n_isects, offsets, alphas, last_ids,
                        v_render, v_alphas, v_packed, rec_stride);
     GS_CHECK_LAUNCH();

@@ -191,6 +191,18 @@ def main():
         kbytes = {"raster_fwd_kernel": 40 * I + 20 * P, "raster_bwd_kernel": 40 * I + 24 * P + 36 * V}
         achieved = kbytes[dom] / (kt[dom] * 1e-3) / 1e9
         view_bytes = algorithmic_bytes_per_view(N, V, I, P, E)
+        # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes (scripts/run_pmc.sh ->
+        # scripts/pmc_summary.py: FETCH_SIZE x 2 (gfx950 under-count of wide reads) + WRITE_SIZE, KiB -> bytes) on this
+        # same workload and committed under profiles/; counters cannot be read inside this process
+        traffic, traffic_src = None, None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath) and args.level == 7 and args.res == 800:
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj[dom + "<3>"]["hbm_bytes"]
+                traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, per launch)"
+            except Exception:
+                traffic = None
         result = {
             "metric": "fwd+bwd views/sec at 2M Gaussians, 800x800",
             "value": views_per_s, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -202,7 +214,7 @@ def main():
                        "N": N, "V": V, "I": I, "P": P, "views_per_step_per_gpu": args.views,
                        "parallelism": f"dp{world} (views sharded, flat RCCL all-reduce of grads)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": kt, "algorithmic_bytes": kbytes[dom],
                          "note": "compositor kernels are FP32-VALU/exp bound (SURVEY 8d); HBM fraction reported as the contract asks"},
             "view_roofline": {"algorithmic_bytes_per_view": view_bytes,

@@ -501,10 +501,8 @@ static int launch_fwd(int W, int H, int D, const RasterWs& ws, const float* colo
     return GS_OK;
 }
 
-extern "C" int gs_raster_fwd(int W, int H, int tile_size, int D, int V, const float* means2d, const float* conics,
-                             const float* opacities, const float* colors, const float* background,
-                             int64_t n_isects, const int32_t* offsets, const int32_t* flatten_ids,
-                             float* render, float* alphas, int32_t* last_ids, void* ws, size_t ws_bytes, void* stream)
+static int raster_check(const char* who, int W, int H, int tile_size, int D, int V, int64_t n_isects, const void* ws,
+                        size_t ws_bytes)
 {
     GS_CHECK_ARG(W > 0 && H > 0, "bad image size");
     GS_CHECK_ARG(tile_size == GS_TILE, "only tile_size=16 is built (rfstudio/model/gsplat.py:30)");
@@ -512,7 +510,18 @@ extern "C" int gs_raster_fwd(int W, int H, int tile_size, int D, int V, const fl
     GS_CHECK_ARG(n_isects >= 0 && n_isects < (1ll << 31), "n_isects must fit int32");
     GS_CHECK_ARG(ws != nullptr, "workspace must not be NULL");
     GS_CHECK_ARG(V >= 0, "bad V");
-    if (ws_bytes < gs_raster_ws_bytes(n_isects, V, W, H, tile_size)) { gs_set_error("gs_raster_fwd: workspace too small"); return GS_ENOSPC; }
+    if (ws_bytes < gs_raster_ws_bytes(n_isects, V, W, H, tile_size)) { gs_set_error("%s: workspace too small", who); return GS_ENOSPC; }
+    return GS_OK;
+}
+
+// A5 preparation: per-visible records, the sorted record stream and the longest-first tile order (HBM-bound; a caller
+// that overlaps streams runs it next to the sort, away from the VALU-bound compositor).
+extern "C" int gs_raster_prepare(int W, int H, int tile_size, int D, int V, const float* means2d, const float* conics,
+                                 const float* opacities, const float* colors, int64_t n_isects, const int32_t* offsets,
+                                 const int32_t* flatten_ids, void* ws, size_t ws_bytes, void* stream)
+{
+    const int rc = raster_check("gs_raster_prepare", W, H, tile_size, D, V, n_isects, ws, ws_bytes);
+    if (rc != GS_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int tiles = ((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
     const RasterWs r = carve(ws, n_isects, V, tiles);
@@ -526,6 +535,19 @@ extern "C" int gs_raster_fwd(int W, int H, int tile_size, int D, int V, const fl
     }
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, tiles, (int)n_isects, offsets, r.order);
     GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
+// A5 proper on a prepared workspace
+extern "C" int gs_raster_composite(int W, int H, int tile_size, int D, int V, const float* colors, const float* background,
+                                   int64_t n_isects, const int32_t* offsets, float* render, float* alphas,
+                                   int32_t* last_ids, const void* ws, size_t ws_bytes, void* stream)
+{
+    const int rc = raster_check("gs_raster_composite", W, H, tile_size, D, V, n_isects, ws, ws_bytes);
+    if (rc != GS_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles = ((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
+    const RasterWs r = carve((void*)ws, n_isects, V, tiles);
 #define GS_FWD(CD) return launch_fwd<CD>(W, H, D, r, colors, background, n_isects, offsets, render, alphas, last_ids, s)
     if (D <= 3) GS_FWD(3);
     if (D <= 4) GS_FWD(4);
@@ -533,6 +555,18 @@ extern "C" int gs_raster_fwd(int W, int H, int tile_size, int D, int V, const fl
     if (D <= 16) GS_FWD(16);
     GS_FWD(32);
 #undef GS_FWD
+}
+
+extern "C" int gs_raster_fwd(int W, int H, int tile_size, int D, int V, const float* means2d, const float* conics,
+                             const float* opacities, const float* colors, const float* background,
+                             int64_t n_isects, const int32_t* offsets, const int32_t* flatten_ids,
+                             float* render, float* alphas, int32_t* last_ids, void* ws, size_t ws_bytes, void* stream)
+{
+    const int rc = gs_raster_prepare(W, H, tile_size, D, V, means2d, conics, opacities, colors, n_isects, offsets, flatten_ids,
+                                     ws, ws_bytes, stream);
+    if (rc != GS_OK) return rc;
+    return gs_raster_composite(W, H, tile_size, D, V, colors, background, n_isects, offsets, render, alphas, last_ids, ws,
+                               ws_bytes, stream);
 }
 
 template <int CD>

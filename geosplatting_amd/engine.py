@@ -23,7 +23,7 @@ import ctypes as C
 from . import _lib as L
 from .cameras import Camera
 from .parallel import GradBucket
-from .rasterization import _bin_stage, _composite_stage, _forward_stages, _project_stage
+from .rasterization import _bin_stage, _composite_stage, _forward_stages, _prepare_stage, _project_stage
 from .shading import _MODE, _TONE, RenderableAttrs, _make_env, get_fg_lut
 from .splitsum import TextureSplitSum, as_splitsum
 from .synthetic import SplatSet
@@ -140,6 +140,7 @@ class RenderStep:
             pr, col = item
             with torch.cuda.stream(side):
                 state, V, I, D, whs = _bin_stage(pr)
+                state = _prepare_stage(state, V, I, D, whs)  # record stream: HBM-bound, belongs on this stream too
                 ev = torch.cuda.Event(); ev.record(side)
             for t in list(state.values()) + [col] + list(pr.bufs):
                 if isinstance(t, torch.Tensor):

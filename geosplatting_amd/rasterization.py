@@ -102,21 +102,34 @@ def _bin_stage(pr: _Projected, depth_channel: bool = False):
     return state, V, I, D, (W, H, tile_size)
 
 
+def _prepare_stage(state, V: int, I: int, D: int, whs):
+    """A5 preparation (per-visible records, sorted record stream, tile order) on the current stream."""
+    lib = L.lib()
+    W, H, tile_size = whs
+    rws_bytes = lib.gs_raster_ws_bytes(L.i64(I), V, W, H, tile_size)
+    rws = torch.empty(rws_bytes, dtype=torch.uint8, device=state["means2d"].device)   # written here, read by fwd AND bwd
+    L.check(lib.gs_raster_prepare(W, H, tile_size, D, V, L.ptr(state["means2d"]), L.ptr(state["conics"]),
+                                  L.ptr(state["opacities"]), L.ptr(state["colors"]), L.i64(I),
+                                  L.ptr(state["isect_offsets"]), L.ptr(state["flatten_ids"]), L.ptr(rws),
+                                  C.c_size_t(rws_bytes), L.stream()), "gs_raster_prepare")
+    return dict(state, raster_ws=rws)
+
+
 def _composite_stage(state, V: int, I: int, D: int, whs, background: Optional[Tensor]):
-    """A5 (stream build + compositor) on the current stream."""
+    """A5 proper (the compositor) on the current stream; prepares the workspace first if the caller has not."""
     lib = L.lib()
     W, H, tile_size = whs
     dev = state["means2d"].device
     i32, f32 = torch.int32, torch.float32
+    if "raster_ws" not in state:
+        state = _prepare_stage(state, V, I, D, whs)
+    rws = state["raster_ws"]
     render = torch.empty(H, W, D, dtype=f32, device=dev); alphas = torch.empty(H, W, dtype=f32, device=dev)
     last_ids = torch.empty(H, W, dtype=i32, device=dev)
-    rws_bytes = lib.gs_raster_ws_bytes(L.i64(I), V, W, H, tile_size)
-    rws = torch.empty(rws_bytes, dtype=torch.uint8, device=dev)     # record stream: written here, read by the backward
-    L.check(lib.gs_raster_fwd(W, H, tile_size, D, V, L.ptr(state["means2d"]), L.ptr(state["conics"]),
-                              L.ptr(state["opacities"]), L.ptr(state["colors"]), L.ptr(background), L.i64(I),
-                              L.ptr(state["isect_offsets"]), L.ptr(state["flatten_ids"]), L.ptr(render), L.ptr(alphas),
-                              L.ptr(last_ids), L.ptr(rws), C.c_size_t(rws_bytes), L.stream()), "gs_raster_fwd")
-    state = dict(state, last_ids=last_ids, raster_ws=rws)
+    L.check(lib.gs_raster_composite(W, H, tile_size, D, V, L.ptr(state["colors"]), L.ptr(background), L.i64(I),
+                                    L.ptr(state["isect_offsets"]), L.ptr(render), L.ptr(alphas), L.ptr(last_ids),
+                                    L.ptr(rws), C.c_size_t(rws.numel()), L.stream()), "gs_raster_composite")
+    state = dict(state, last_ids=last_ids)
     return render, alphas, state, V, I
 
 

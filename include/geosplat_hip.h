@@ -108,6 +108,16 @@ int gs_raster_fwd(int W, int H, int tile_size, int D, int V, const float* means2
                   int64_t n_isects, const int32_t* offsets, const int32_t* flatten_ids,
                   float* render, float* alphas, int32_t* last_ids, void* ws, size_t ws_bytes, void* stream);
 
+/* The two halves of gs_raster_fwd for a caller that spreads a view over several streams: gs_raster_prepare fills
+ * the workspace (per-visible records, sorted record stream, tile order: HBM-bound), gs_raster_composite runs the
+ * compositor on it (VALU-bound).  gs_raster_fwd == prepare followed by composite on one stream. */
+int gs_raster_prepare(int W, int H, int tile_size, int D, int V, const float* means2d, const float* conics,
+                      const float* opacities, const float* colors, int64_t n_isects, const int32_t* offsets,
+                      const int32_t* flatten_ids, void* ws, size_t ws_bytes, void* stream);
+int gs_raster_composite(int W, int H, int tile_size, int D, int V, const float* colors, const float* background,
+                        int64_t n_isects, const int32_t* offsets, float* render, float* alphas, int32_t* last_ids,
+                        const void* ws, size_t ws_bytes, void* stream);
+
 /* Floats per packed per-Gaussian gradient record written by gs_raster_bwd: (6 + D) rounded up to 16. */
 int gs_raster_grad_stride(int D);
 

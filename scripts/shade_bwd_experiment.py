@@ -6,7 +6,7 @@ import torch
 import geosplatting_amd.build as B
 variant = sys.argv[1] if len(sys.argv) > 1 else "base"
 so = f"/tmp/libgeosplat_{variant}.so"
-flags = list(B.FLAGS) + (["-DGS_EXPERIMENT_NO_GLOBAL_TEXEL_ATOMICS"] if variant == "noatom" else [])
+flags = list(B.FLAGS) + (["-DGS_EXPERIMENT_NO_GLOBAL_TEXEL_ATOMICS"] if variant == "noatom" else []) + sys.argv[2:]
 subprocess.check_call(["/opt/rocm/bin/hipcc", *flags, "-shared", "-o", so, *[os.path.join(B.CSRC, s) for s in B.SOURCES]])
 import geosplatting_amd._lib as L
 L.LIB_PATH = so

@@ -195,17 +195,19 @@ class RenderStep:
             if keep_images:
                 images.append(img)
         main.wait_stream(tail)
-        # chain the once-per-step activations and the prefilter
+        # chain the once-per-step activations; the per-Gaussian gradients are now final, so their all-reduce (RCCL on
+        # the communication stream) overlaps the prefilter backward, whose cubemap gradient is reduced afterwards
         torch.mul(g_scales_act, scales_act, out=b["scales"])
         b["opacities"].copy_((g_opac_act * opac_act * (1.0 - opac_act)).unsqueeze(-1))
+        start_head, finish = self.bucket.all_reduce_split("cubemap") if all_reduce else ((lambda: None), (lambda: None))
+        start_head()
         if self.prefilter:
             outs = [env.base] + list(env.levels)
             gouts = [g_base] + g_levels
             keep = [(o, g) for o, g in zip(outs, gouts) if o.requires_grad]
             torch.autograd.backward([o for o, _ in keep], [g for _, g in keep])
             b["cubemap"].copy_(cubemap.grad)
-        if all_reduce:
-            self.bucket.all_reduce()
+        finish()
         return b, (images if keep_images else None)
 
     def __call__(self, cameras: List[Camera], upstream: Callable[[int, Tensor], Tensor], all_reduce: bool = True,

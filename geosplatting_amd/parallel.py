@@ -82,6 +82,36 @@ class GradBucket:
             self.flat.div_(dist.get_world_size())
         return (lambda: None) if async_op else None
 
+    def all_reduce_split(self, first_of_tail: str):
+        """Two-phase sum for a step whose last gradients arrive late (the cubemap gradient comes out of the prefilter
+        backward, the per-Gaussian gradients are complete before it): returns (start_head, finish).  `start_head()`
+        launches the all-reduce of everything BEFORE segment `first_of_tail` on the communication stream -- it then
+        overlaps the prefilter backward -- and `finish()` reduces the tail segments and joins the streams."""
+        cut = self.offsets[first_of_tail]
+        head, tail = self.flat[:cut], self.flat[cut:]
+        active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if not active:
+            return (lambda: None), (lambda: None)
+        cs = self.comm_stream
+
+        def start_head():
+            if cs is not None:
+                cs.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(cs):
+                    dist.all_reduce(head, op=dist.ReduceOp.SUM)
+            else:
+                dist.all_reduce(head, op=dist.ReduceOp.SUM)
+
+        def finish():
+            if cs is not None:
+                cs.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(cs):
+                    dist.all_reduce(tail, op=dist.ReduceOp.SUM)
+                torch.cuda.current_stream().wait_stream(cs)
+            else:
+                dist.all_reduce(tail, op=dist.ReduceOp.SUM)
+        return start_head, finish
+
     def unpack(self) -> Dict[str, Tensor]:
         return {k: self.view(k) for k in self.names}
 

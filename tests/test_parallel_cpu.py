@@ -40,6 +40,14 @@ def _worker(rank, world, port, out_dir):
     wait = bucket.all_reduce(async_op=True)
     wait()
     out = {k: v.clone() for k, v in bucket.unpack().items()}
+    # the two-phase reduction RenderStep uses (per-Gaussian head first, cubemap + exposure tail later) gives the same sums
+    bucket.pack(local)
+    start_head, finish = bucket.all_reduce_split("cubemap")
+    start_head()
+    assert torch.allclose(bucket.view("means"), out["means"]) and not torch.allclose(bucket.view("cubemap"), out["cubemap"])
+    finish()
+    for k, v in bucket.unpack().items():
+        assert torch.allclose(v, out[k]), k
     torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

@@ -1,0 +1,365 @@
+// gs_hashgrid.hip -- SURVEY section 8f rank 3: the multi-resolution hash encoding that produces kd / ks / z per
+// Gaussian upstream of the path (rfstudio/model/components/encoding.py:87-241, used at rfstudio/model/geosplat.py:482-520,
+// 644-672).  The reference's default backend is tinycudann (CUDA only); what a ROCm user of the reference runs is its
+// own `backend='torch'` branch (`pytorch_fwd`, :187-229), and THAT is the semantics restated here (and pinned by
+// golden vectors generated from it): every level is hashed (no dense coarse levels), x01 = x/2 + 1/2,
+// scaled = x01 * floor(min_res * growth^l), corners = {ceil, floor} per axis, weights = (scaled - floor) for the
+// CEIL corner, hash = ((x * 1) xor (y * 2654435761) xor (z * 805459861)) mod T  (+ l * T), products in int64.
+//
+// Forward: one thread per point loops over the levels (all lanes of a wave are on the same 2^log2_T-entry slice of the
+// table at the same time: L2-resident) and writes its L*F contiguous outputs.
+// Backward: table gradients are fp32 atomics -- the scatter is irregular by construction (a hash) -- with the
+// F = 2 features of a corner committed by two ADJACENT lanes of one instruction (one memory-side request instead of
+// two, see gs_cube.h); the position gradient flows through the interpolation offsets only (ceil/floor are constant).
+#include "gs_common.h"
+
+#pragma clang fp contract(off)   // cell indices must round exactly like the reference (x * 0.5 + 0.5, then * scaling)
+
+#define GS_HG_MAX_LEVELS 32
+
+struct HgLevels {
+    float scaling[GS_HG_MAX_LEVELS];
+};
+
+__device__ __forceinline__ unsigned hg_hash(int x, int y, int z, unsigned mask, unsigned log2_T)
+{
+    // torch: int32 coords * int64 primes, xor, then python-style modulo by T (a power of two): the low log2_T bits of
+    // the two's-complement xor -- identical for negative products
+    const long long h = (long long)x ^ ((long long)y * 2654435761ll) ^ ((long long)z * 805459861ll);
+    (void)log2_T;
+    return (unsigned)((unsigned long long)h & (unsigned long long)mask);
+}
+
+template <int F>
+__global__ void __launch_bounds__(256)
+hashgrid_fwd_kernel(int N, int L, unsigned log2_T, HgLevels lv, const float* __restrict__ x, const float* __restrict__ table,
+                    float* __restrict__ out)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const unsigned T = 1u << log2_T, mask = T - 1u;
+    const float p[3] = { x[3 * (size_t)n] * 0.5f + 0.5f, x[3 * (size_t)n + 1] * 0.5f + 0.5f, x[3 * (size_t)n + 2] * 0.5f + 0.5f };
+    for (int l = 0; l < L; ++l) {
+        const float s = lv.scaling[l];
+        int c[3], f[3]; float o[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float sc = p[k] * s;
+            c[k] = (int)ceilf(sc); f[k] = (int)floorf(sc);
+            o[k] = sc - (float)f[k];
+        }
+        const float* tl = table + (size_t)l * T * F;
+        float acc[F];
+#pragma unroll
+        for (int q = 0; q < F; ++q) acc[q] = 0.0f;
+        // corner (bx, by, bz): b = 1 -> ceil with weight o, b = 0 -> floor with weight 1 - o; accumulated in the
+        // reference's order: x pairs, then y, then z (f_03, f_12, f_56, f_47 -> f0312, f4756 -> value)
+        float fx[2][2][F];                                  // [by][bz][feature] after the x interpolation
+#pragma unroll
+        for (int by = 0; by < 2; ++by)
+#pragma unroll
+            for (int bz = 0; bz < 2; ++bz) {
+                const int yy = by ? c[1] : f[1], zz = bz ? c[2] : f[2];
+                const float* pc = tl + (size_t)hg_hash(c[0], yy, zz, mask, log2_T) * F;
+                const float* pf = tl + (size_t)hg_hash(f[0], yy, zz, mask, log2_T) * F;
+#pragma unroll
+                for (int q = 0; q < F; ++q) fx[by][bz][q] = pc[q] * o[0] + pf[q] * (1.0f - o[0]);
+            }
+#pragma unroll
+        for (int q = 0; q < F; ++q) {
+            const float z1 = fx[1][1][q] * o[1] + fx[0][1][q] * (1.0f - o[1]);      // bz = 1 (ceil z): f0312
+            const float z0 = fx[1][0][q] * o[1] + fx[0][0][q] * (1.0f - o[1]);      // bz = 0:          f4756
+            acc[q] = z1 * o[2] + z0 * (1.0f - o[2]);
+        }
+#pragma unroll
+        for (int q = 0; q < F; ++q) out[(size_t)n * L * F + (size_t)l * F + q] = acc[q];
+    }
+}
+
+template <int F, bool PRIV>
+__global__ void __launch_bounds__(256)
+hashgrid_bwd_kernel(int N, int L, unsigned log2_T, HgLevels lv, const float* __restrict__ x, const float* __restrict__ table,
+                    const float* __restrict__ v_out, float table_grad_scale, float* __restrict__ v_table,
+                    float* __restrict__ v_x)
+{
+    // PRIV: v_table points at 8 private copies, one per XCD; the atomics are workgroup-scope (resolved in this XCD's
+    // L2, the line stays cached) because no other XCD touches the copy during the launch
+    if (PRIV) v_table += (size_t)gs_xcc_id() * ((size_t)L << log2_T) * F;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = n < N;
+    const unsigned T = 1u << log2_T, mask = T - 1u;
+    float p[3] = { 0.f, 0.f, 0.f };
+    if (live) { p[0] = x[3 * (size_t)n] * 0.5f + 0.5f; p[1] = x[3 * (size_t)n + 1] * 0.5f + 0.5f; p[2] = x[3 * (size_t)n + 2] * 0.5f + 0.5f; }
+    float gx[3] = { 0.f, 0.f, 0.f };
+    const int lane = threadIdx.x & 63;
+    for (int l = 0; l < L; ++l) {
+        const float s = lv.scaling[l];
+        int c[3], f[3]; float o[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float sc = p[k] * s;
+            c[k] = (int)ceilf(sc); f[k] = (int)floorf(sc);
+            o[k] = sc - (float)f[k];
+        }
+        float g[F];
+#pragma unroll
+        for (int q = 0; q < F; ++q) g[q] = live ? v_out[(size_t)n * L * F + (size_t)l * F + q] : 0.0f;
+        const float* tl = table + (size_t)l * T * F;
+        float* gl = v_table + (size_t)l * T * F;
+        float do_[3] = { 0.f, 0.f, 0.f };                      // d value / d o[k], summed over features with g
+#pragma unroll
+        for (int bx = 0; bx < 2; ++bx)
+#pragma unroll
+            for (int by = 0; by < 2; ++by)
+#pragma unroll
+                for (int bz = 0; bz < 2; ++bz) {
+                    const unsigned h = hg_hash(bx ? c[0] : f[0], by ? c[1] : f[1], bz ? c[2] : f[2], mask, log2_T);
+                    const float wx = bx ? o[0] : 1.0f - o[0], wy = by ? o[1] : 1.0f - o[1], wz = bz ? o[2] : 1.0f - o[2];
+                    const float w = wx * wy * wz;
+                    float dotg = 0.0f;
+                    if (live && v_x) {
+#pragma unroll
+                        for (int q = 0; q < F; ++q) dotg += tl[(size_t)h * F + q] * g[q];
+                    }
+                    do_[0] += (bx ? 1.0f : -1.0f) * wy * wz * dotg;
+                    do_[1] += (by ? 1.0f : -1.0f) * wx * wz * dotg;
+                    do_[2] += (bz ? 1.0f : -1.0f) * wx * wy * dotg;
+                    // table gradient: the F features of this corner go out from F adjacent lanes of one instruction
+                    // (F = 2: lanes 2j, 2j+1 serve source lane j, then lanes serve source lane 32 + j)
+                    float* dst = live ? gl + (size_t)h * F : nullptr;
+                    float cv[F];
+#pragma unroll
+                    for (int q = 0; q < F; ++q) cv[q] = g[q] * w * table_grad_scale;
+                    // Points arrive in mesh order, so on the coarse levels most lanes of a wave fall into the same few
+                    // cells: while at least a quarter of the remaining lanes share the leader's row, sum them in the
+                    // wave and let the leader carry the total (up to 4 rounds); the fine levels skip this after one test.
+                    {
+                        unsigned long long remaining = __ballot(dst != nullptr);
+                        for (int round = 0; round < 4 && remaining != 0ull; ++round) {
+                            const int leader = __builtin_ctzll(remaining);
+                            const unsigned hl = (unsigned)__builtin_amdgcn_readlane((int)h, leader);
+                            const bool same = dst != nullptr && h == hl;
+                            const unsigned long long m = __ballot(same);
+                            if (__popcll(m) * 4 < __popcll(remaining)) break;
+                            float tot[F];
+#pragma unroll
+                            for (int q = 0; q < F; ++q) tot[q] = gs_wave_sum(same ? cv[q] : 0.0f);
+                            if (same) {
+                                if (lane == leader) {
+#pragma unroll
+                                    for (int q = 0; q < F; ++q) cv[q] = tot[q];
+                                } else {
+                                    dst = nullptr;                       // folded into the leader
+                                }
+                            }
+                            remaining &= ~m;
+                        }
+                    }
+                    const unsigned long long key = (unsigned long long)dst;
+#pragma unroll
+                    for (int half = 0; half < F; ++half) {
+                        const int src = (64 * half + lane) / F, ch = (64 * half + lane) - F * src;
+                        const int sa = src << 2;
+                        const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(sa, (int)(unsigned)key);
+                        const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(sa, (int)(unsigned)(key >> 32));
+                        float val = 0.0f;
+#pragma unroll
+                        for (int q = 0; q < F; ++q) {
+                            const float t = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sa, __builtin_bit_cast(int, cv[q])));
+                            val = (ch == q) ? t : val;
+                        }
+                        float* d2 = (float*)(((unsigned long long)hi << 32) | lo);
+                        if (d2 != nullptr) { if (PRIV) gs_atomic_add_xcd(d2 + ch, val); else gs_atomic_add(d2 + ch, val); }
+                    }
+                }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gx[k] += do_[k] * s * 0.5f;             // o = x01 * s - floor, x01 = x / 2 + 1/2
+    }
+    if (live && v_x) { v_x[3 * (size_t)n] = gx[0]; v_x[3 * (size_t)n + 1] = gx[1]; v_x[3 * (size_t)n + 2] = gx[2]; }
+}
+
+static int hg_check(int N, int L, int F, int log2_T)
+{
+    GS_CHECK_ARG(N >= 0, "bad N");
+    GS_CHECK_ARG(L >= 1 && L <= GS_HG_MAX_LEVELS, "1 <= num_levels <= 32");
+    GS_CHECK_ARG(F == 2, "features_per_level = 2 is built (rfstudio/model/geosplat.py:485-518)");
+    GS_CHECK_ARG(log2_T >= 1 && log2_T <= 28, "bad log2_hashmap_size");
+    return GS_OK;
+}
+
+extern "C" int gs_hashgrid_fwd(int N, int L, int F, int log2_T, const float* scalings_host, const float* x,
+                               const float* table, float* out, void* stream)
+{
+    const int rc = hg_check(N, L, F, log2_T);
+    if (rc != GS_OK) return rc;
+    if (N == 0) return GS_OK;
+    HgLevels lv;
+    for (int l = 0; l < GS_HG_MAX_LEVELS; ++l) lv.scaling[l] = l < L ? scalings_host[l] : 0.0f;
+    hipLaunchKernelGGL(hashgrid_fwd_kernel<2>, dim3(gs_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, N, L, (unsigned)log2_T, lv,
+                       x, table, out);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Atomic-free table gradient (the default): fp32 atomics of this GPU are executed at the memory side (~15 G requests/s,
+// whatever their scope), and the hash makes 8 * L * N of them -- 12.8 ms for 2 M points.  Instead every workgroup OWNS
+// one 128 KB slab of one level's table (16384 rows x 2 features) in LDS, walks ALL points, recomputes the 8 corner
+// hashes and keeps the contributions that fall into its slab (ds_add_f32), then writes the slab with plain stores:
+// 16x redundant hashing (VALU is idle anyway) buys the removal of every global atomic.  L * (T / 16384) workgroups =
+// 256 at the GaussianField configuration, one per CU.  v_out is first transposed to level-major so that a workgroup
+// streams 8 contiguous bytes per point.
+#define GS_HG_SLAB_ROWS 16384
+
+__global__ void __launch_bounds__(256)
+hashgrid_transpose_kernel(int N, int LF, const float* __restrict__ v_out, float* __restrict__ v_lm)
+{
+    // v_out [N][L*2] -> v_lm [L][N][2]; one thread per (point, level)
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int L = LF / 2;
+    if (i >= (size_t)N * L) return;
+    const size_t n = i / L; const int l = (int)(i - n * L);
+    const float2 v = *reinterpret_cast<const float2*>(v_out + n * LF + 2 * l);
+    *reinterpret_cast<float2*>(v_lm + ((size_t)l * N + n) * 2) = v;
+}
+
+__global__ void __launch_bounds__(1024)
+hashgrid_bwd_slab_kernel(int N, int L, unsigned log2_T, HgLevels lv, int slabs_per_level, int parts, const float* __restrict__ x,
+                         const float* __restrict__ v_lm, float table_grad_scale, float* __restrict__ v_table, int accumulate)
+{
+    extern __shared__ float slab[];                                  // [rows][2]
+    const unsigned T = 1u << log2_T, mask = T - 1u;
+    const int rows = (int)min((unsigned)GS_HG_SLAB_ROWS, T);
+    const int b = blockIdx.x;
+    const int part = b % parts, sl = (b / parts) % slabs_per_level, l = b / (parts * slabs_per_level);
+    for (int i = threadIdx.x; i < rows * 2; i += blockDim.x) slab[i] = 0.0f;
+    __syncthreads();
+    const float s = lv.scaling[l];
+    const float* g_l = v_lm + (size_t)l * N * 2;
+    const unsigned row0 = (unsigned)sl * (unsigned)rows;
+    const int n_lo = (int)((long long)N * part / parts), n_hi = (int)((long long)N * (part + 1) / parts);
+    for (int n = n_lo + (int)threadIdx.x; n < n_hi; n += (int)blockDim.x) {
+        const float2 g = *reinterpret_cast<const float2*>(g_l + 2 * (size_t)n);
+        if (g.x == 0.0f && g.y == 0.0f) continue;
+        int c[3], f[3]; float o[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float sc = (x[3 * (size_t)n + k] * 0.5f + 0.5f) * s;
+            c[k] = (int)ceilf(sc); f[k] = (int)floorf(sc);
+            o[k] = sc - (float)f[k];
+        }
+#pragma unroll
+        for (int bx = 0; bx < 2; ++bx)
+#pragma unroll
+            for (int by = 0; by < 2; ++by)
+#pragma unroll
+                for (int bz = 0; bz < 2; ++bz) {
+                    const unsigned h = hg_hash(bx ? c[0] : f[0], by ? c[1] : f[1], bz ? c[2] : f[2], mask, log2_T);
+                    const unsigned r = h - row0;
+                    if (r < (unsigned)rows) {
+                        const float w = (bx ? o[0] : 1.0f - o[0]) * (by ? o[1] : 1.0f - o[1]) * (bz ? o[2] : 1.0f - o[2]) * table_grad_scale;
+                        atomicAdd(&slab[2 * r], g.x * w);            // (wave pre-aggregation of equal rows was measured: 20 % slower)
+                        atomicAdd(&slab[2 * r + 1], g.y * w);
+                    }
+                }
+    }
+    __syncthreads();
+    float* dst = v_table + ((size_t)l * T + row0) * 2;
+    if (parts == 1) {
+        for (int i = threadIdx.x; i < rows * 2; i += blockDim.x) dst[i] = accumulate ? dst[i] + slab[i] : slab[i];
+    } else {                                                         // small tables only: several workgroups share a slab
+        for (int i = threadIdx.x; i < rows * 2; i += blockDim.x) if (slab[i] != 0.0f) gs_atomic_add(dst + i, slab[i]);
+    }
+}
+
+// position gradient only (no table gradient): one thread per point
+template <int F>
+__global__ void __launch_bounds__(256)
+hashgrid_bwd_x_kernel(int N, int L, unsigned log2_T, HgLevels lv, const float* __restrict__ x, const float* __restrict__ table,
+                      const float* __restrict__ v_out, float* __restrict__ v_x)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const unsigned T = 1u << log2_T, mask = T - 1u;
+    const float p[3] = { x[3 * (size_t)n] * 0.5f + 0.5f, x[3 * (size_t)n + 1] * 0.5f + 0.5f, x[3 * (size_t)n + 2] * 0.5f + 0.5f };
+    float gx[3] = { 0.f, 0.f, 0.f };
+    for (int l = 0; l < L; ++l) {
+        const float s = lv.scaling[l];
+        int c[3], f[3]; float o[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float sc = p[k] * s;
+            c[k] = (int)ceilf(sc); f[k] = (int)floorf(sc);
+            o[k] = sc - (float)f[k];
+        }
+        float g[F];
+#pragma unroll
+        for (int q = 0; q < F; ++q) g[q] = v_out[(size_t)n * L * F + (size_t)l * F + q];
+        const float* tl = table + (size_t)l * T * F;
+        float do_[3] = { 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int bx = 0; bx < 2; ++bx)
+#pragma unroll
+            for (int by = 0; by < 2; ++by)
+#pragma unroll
+                for (int bz = 0; bz < 2; ++bz) {
+                    const unsigned h = hg_hash(bx ? c[0] : f[0], by ? c[1] : f[1], bz ? c[2] : f[2], mask, log2_T);
+                    const float wx = bx ? o[0] : 1.0f - o[0], wy = by ? o[1] : 1.0f - o[1], wz = bz ? o[2] : 1.0f - o[2];
+                    float dotg = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < F; ++q) dotg += tl[(size_t)h * F + q] * g[q];
+                    do_[0] += (bx ? 1.0f : -1.0f) * wy * wz * dotg;
+                    do_[1] += (by ? 1.0f : -1.0f) * wx * wz * dotg;
+                    do_[2] += (bz ? 1.0f : -1.0f) * wx * wy * dotg;
+                }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gx[k] += do_[k] * s * 0.5f;
+    }
+    v_x[3 * (size_t)n] = gx[0]; v_x[3 * (size_t)n + 1] = gx[1]; v_x[3 * (size_t)n + 2] = gx[2];
+}
+
+extern "C" size_t gs_hashgrid_bwd_ws_bytes(int N, int L, int F)
+{
+    return sizeof(float) * (size_t)(N > 0 ? N : 1) * (size_t)L * (size_t)F;     // level-major copy of v_out
+}
+
+extern "C" int gs_hashgrid_bwd(int N, int L, int F, int log2_T, const float* scalings_host, const float* x,
+                               const float* table, const float* v_out, float table_grad_scale, float* v_table,
+                               int accumulate, float* v_x, void* ws, size_t ws_bytes, void* stream)
+{
+    const int rc = hg_check(N, L, F, log2_T);
+    if (rc != GS_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)L * ((size_t)1 << log2_T) * F;
+    HgLevels lv;
+    for (int l = 0; l < GS_HG_MAX_LEVELS; ++l) lv.scaling[l] = l < L ? scalings_host[l] : 0.0f;
+    const bool slabs = ws != nullptr && ws_bytes >= gs_hashgrid_bwd_ws_bytes(N, L, F);
+    if (N == 0) {
+        if (!accumulate) GS_CHECK_HIP(hipMemsetAsync(v_table, 0, sizeof(float) * n, s));
+        return GS_OK;
+    }
+    if (!slabs) {
+        // fallback without workspace: per-point kernel with memory-side atomics (4-5x slower at 2 M points)
+        if (!accumulate) GS_CHECK_HIP(hipMemsetAsync(v_table, 0, sizeof(float) * n, s));
+        hipLaunchKernelGGL((hashgrid_bwd_kernel<2, false>), dim3(gs_cdiv(N, 256)), dim3(256), 0, s, N, L, (unsigned)log2_T, lv, x, table,
+                           v_out, table_grad_scale, v_table, v_x);
+        GS_CHECK_LAUNCH();
+        return GS_OK;
+    }
+    float* v_lm = (float*)ws;
+    hipLaunchKernelGGL(hashgrid_transpose_kernel, dim3(gs_cdiv((int64_t)N * L, 256)), dim3(256), 0, s, N, L * F, v_out, v_lm);
+    const unsigned T = 1u << log2_T;
+    const int rows = (int)(T < GS_HG_SLAB_ROWS ? T : GS_HG_SLAB_ROWS);
+    const int slabs_per_level = (int)(T / (unsigned)rows);
+    int parts = 1;
+    while (L * slabs_per_level * parts < 192 && parts < 64) parts *= 2;    // small tables: split the points to fill the CUs
+    if (parts > 1 && !accumulate) GS_CHECK_HIP(hipMemsetAsync(v_table, 0, sizeof(float) * n, s));
+    const size_t lds = sizeof(float) * 2 * (size_t)rows;
+    GS_CHECK_HIP(hipFuncSetAttribute((const void*)hashgrid_bwd_slab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(hashgrid_bwd_slab_kernel, dim3(L * slabs_per_level * parts), dim3(1024), lds, s, N, L, (unsigned)log2_T, lv,
+                       slabs_per_level, parts, x, v_lm, table_grad_scale, v_table, accumulate);
+    if (v_x) hipLaunchKernelGGL(hashgrid_bwd_x_kernel<2>, dim3(gs_cdiv(N, 256)), dim3(256), 0, s, N, L, (unsigned)log2_T, lv, x, table,
+                                v_out, v_x);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}

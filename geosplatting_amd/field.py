@@ -1,0 +1,107 @@
+"""Hash-grid field encoder on the GPU: `HashEncoding` of
+rfstudio/model/components/encoding.py:87-241 with its `backend='torch'` semantics (the branch a ROCm user of the
+reference runs -- tinycudann is CUDA-only), as used for kd / ks / z per Gaussian at rfstudio/model/geosplat.py:482-520,
+644-672.  The encoding (gather / interpolate / scatter) is hand-written HIP (csrc/gs_hashgrid.hip); the 32-wide MLP
+behind it is two or three plain GEMMs and goes to the BLAS library through torch.  No CPU path.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+from torch import Tensor
+
+import ctypes as C
+
+from . import _lib
+
+
+def level_scalings(num_levels: int = 16, min_res: int = 16, max_res: int = 1024) -> Tensor:
+    """encoding.py:124-132: floor(min_res * growth^l), evaluated with the same torch expression as the reference so
+    that the float32 values (and with them every cell index) are identical."""
+    levels = torch.arange(num_levels)
+    growth = np.exp((np.log(max_res) - np.log(min_res)) / (num_levels - 1)) if num_levels > 1 else 1
+    return torch.floor(min_res * growth ** levels)
+
+
+class _HashGrid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, table: Tensor, scalings: Sequence[float], log2_T: int, table_grad_scale: float):
+        _lib.require_cuda(x, table)
+        L = len(scalings)
+        if x.ndim != 2 or x.shape[1] != 3:
+            raise _lib.GeoSplatHipError("hash_encode expects x [N,3]")
+        if table.ndim != 2 or table.shape[0] != L * (1 << log2_T):
+            raise _lib.GeoSplatHipError(f"hash table must be [{L} * 2^{log2_T}, F]")
+        xd = x.detach().contiguous().float(); td = table.detach().contiguous().float()
+        N, F = xd.shape[0], td.shape[1]
+        out = torch.empty(N, L * F, device=xd.device)
+        sc = (C.c_float * L)(*[float(s) for s in scalings])
+        _lib.check(_lib.lib().gs_hashgrid_fwd(N, L, F, log2_T, sc, _lib.ptr(xd), _lib.ptr(td), _lib.ptr(out), _lib.stream()),
+                   "gs_hashgrid_fwd")
+        ctx.save_for_backward(xd, td)
+        ctx.cfg = (tuple(float(s) for s in scalings), log2_T, float(table_grad_scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, v_out: Tensor):
+        xd, td = ctx.saved_tensors
+        scalings, log2_T, tgs = ctx.cfg
+        L = len(scalings)
+        N, F = xd.shape[0], td.shape[1]
+        v_table = torch.empty_like(td)
+        v_x = torch.empty_like(xd) if ctx.needs_input_grad[0] else None
+        sc = (C.c_float * L)(*scalings)
+        use_slabs = os.environ.get("GEOSPLAT_HASHGRID_SLABS", "1") != "0"       # 0: per-point kernel with fp32 atomics
+        nbytes = _lib.lib().gs_hashgrid_bwd_ws_bytes(N, L, F) if use_slabs else 0
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=xd.device) if nbytes else None
+        _lib.check(_lib.lib().gs_hashgrid_bwd(N, L, F, log2_T, sc, _lib.ptr(xd), _lib.ptr(td), _lib.ptr(v_out.contiguous().float()),
+                                              _lib.f32(tgs), _lib.ptr(v_table), 0, _lib.ptr(v_x), _lib.ptr(ws),
+                                              C.c_size_t(nbytes), _lib.stream()), "gs_hashgrid_bwd")
+        return v_x, v_table, None, None, None
+
+
+def hash_encode(x: Tensor, table: Tensor, scalings: Tensor, log2_hashmap_size: int,
+                grad_scaling: Optional[float] = None) -> Tensor:
+    """`HashEncoding.pytorch_fwd` wrapped in the grad-scaling trick of `HashEncoding.__call__` (encoding.py:231-240):
+    features [N, L*F]; with grad_scaling the TABLE gradient is multiplied by it, the input gradient is unchanged."""
+    return _HashGrid.apply(x, table, [float(s) for s in scalings.tolist()], int(log2_hashmap_size),
+                           1.0 if grad_scaling is None else float(grad_scaling))
+
+
+class HashEncoding:
+    """Mirror of the reference's HashEncoding + MLP pair (same field names): `enc(x)` = mlp(hash features)."""
+
+    def __init__(self, mlp_layers: Sequence[int], activation: str = "none", num_levels: int = 16, min_res: int = 16,
+                 max_res: int = 1024, log2_hashmap_size: int = 19, features_per_level: int = 2,
+                 hash_init_scale: float = 0.001, grad_scaling: Optional[float] = None, device="cuda", seed: int = 0):
+        if features_per_level != 2:
+            raise NotImplementedError("features_per_level = 2 (rfstudio/model/geosplat.py:485-518)")
+        if activation not in ("none", "sigmoid"):
+            raise NotImplementedError(activation)
+        g = torch.Generator().manual_seed(seed)
+        self.num_levels, self.log2_hashmap_size, self.grad_scaling, self.activation = num_levels, log2_hashmap_size, grad_scaling, activation
+        self.scalings = level_scalings(num_levels, min_res, max_res)
+        T = 2 ** log2_hashmap_size
+        self.hash_table = ((torch.rand(T * num_levels, features_per_level, generator=g) * 2 - 1) * hash_init_scale).to(device).requires_grad_(True)
+        dims = [num_levels * features_per_level] + list(mlp_layers[1:])
+        self.weights: List[Tensor] = []
+        for i, o in zip(dims[:-1], dims[1:]):
+            w = torch.empty(o, i)
+            torch.nn.init.kaiming_uniform_(w, nonlinearity="relu", generator=g)     # MLP initialization='kaiming-uniform', bias=False
+            self.weights.append(w.to(device).requires_grad_(True))
+
+    def parameters(self) -> List[Tensor]:
+        return [self.hash_table] + self.weights
+
+    def __call__(self, x: Tensor) -> Tensor:
+        f = hash_encode(x, self.hash_table, self.scalings, self.log2_hashmap_size, self.grad_scaling)
+        for i, w in enumerate(self.weights):
+            f = torch.nn.functional.linear(f, w)
+            if i < len(self.weights) - 1:
+                f = torch.relu(f)
+            elif self.activation == "sigmoid":
+                f = f.sigmoid()
+        return f

@@ -264,6 +264,21 @@ int gs_photo_loss(int W, int H, const float* rgb, const float* alpha, const floa
                   const float* train_bg, const float* metric_bg, float ssim_lambda, float mask_weight,
                   float grad_scale, float* out, float* v_rgb, float* v_alpha, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------ F1: hash-grid encoding --------- */
+/* HashEncoding, `backend='torch'` semantics (rfstudio/model/components/encoding.py:187-229): every level hashed,
+ * x in [-1,1]^3 -> x/2+1/2, scalings[l] = floor(min_res * growth^l) (host array of L floats, computed by the caller
+ * exactly as encoding.py:124-132 does), corners {ceil, floor}, hash = (x ^ y*2654435761 ^ z*805459861) mod 2^log2_T.
+ *   x[N,3]; table[L * 2^log2_T, F]; out[N, L*F].  F must be 2 (rfstudio/model/geosplat.py:485-518).
+ * bwd: v_table (+)= table_grad_scale * d/dtable (written, or added to when accumulate != 0; table_grad_scale
+ *      carries the reference's grad_scaling trick, encoding.py:231-240), v_x[N,3] written (may be NULL). */
+int gs_hashgrid_fwd(int N, int L, int F, int log2_T, const float* scalings_host, const float* x, const float* table,
+                    float* out, void* stream);
+size_t gs_hashgrid_bwd_ws_bytes(int N, int L, int F);         /* level-major copy of v_out */
+int gs_hashgrid_bwd(int N, int L, int F, int log2_T, const float* scalings_host, const float* x, const float* table,
+                    const float* v_out, float table_grad_scale, float* v_table, int accumulate, float* v_x,
+                    void* ws /* with it: atomic-free LDS-slab kernel; NULL: per-point kernel with fp32 atomics */,
+                    size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

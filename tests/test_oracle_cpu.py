@@ -335,3 +335,39 @@ def test_ssim_restatement_vs_scipy():
     got = float(loss_ref.ssim_torchmetrics(torch.tensor(a), torch.tensor(b))[0])
     assert abs(got - expect) < 1e-12
     assert abs(float(loss_ref.ssim_torchmetrics(torch.tensor(a), torch.tensor(a))[0]) - 1.0) < 1e-12
+
+
+# ----------------------------------------------------------------------------- hash-grid field (section 8f rank 3)
+def _hashgrid_golden():
+    g = gold("ref_hashgrid.npz")
+    tb = torch.Generator().manual_seed(0)
+    torch.manual_seed(int(g["b_table_seed"]))
+    b_table = torch.rand(16 * 2 ** int(g["b_log2"]), 2) * 2 - 1        # the generator script draws it the same way
+    return g, b_table
+
+
+def test_golden_hashgrid_restatement():
+    """oracle/field_ref == outputs of the reference's own HashEncoding (torch backend) + MLP code"""
+    from oracle import field_ref
+    g, b_table = _hashgrid_golden()
+    assert np.array_equal(field_ref.level_scalings(16, 16, 4096).numpy(), g["a_scalings"])
+    for tag, table in (("a", torch.tensor(g["a_table"])), ("b", b_table)):
+        x = torch.tensor(g[f"{tag}_x"]).requires_grad_(True)
+        t = table.clone().requires_grad_(True)
+        f = field_ref.encode(x, t, torch.tensor(g[f"{tag}_scalings"]), int(g[f"{tag}_log2"]))
+        assert np.allclose(f.detach().numpy(), g[f"{tag}_feats"], atol=1e-6), tag
+        (f * torch.tensor(g[f"{tag}_g"])).sum().backward()
+        assert np.allclose(x.grad.numpy(), g[f"{tag}_v_x"], rtol=1e-4, atol=1e-4 * np.abs(g[f"{tag}_v_x"]).max()), tag
+        rows = torch.tensor(g[f"{tag}_touched"])
+        assert np.allclose(t.grad[rows].numpy(), g[f"{tag}_v_table_touched"], atol=1e-5), tag
+        mask = torch.ones(t.shape[0], dtype=torch.bool); mask[rows] = False
+        assert t.grad[mask].abs().max().item() == 0.0
+    # full call: grad-scaling trick + MLP
+    x = torch.tensor(g["a_x"][:256]).requires_grad_(True)
+    t = torch.tensor(g["a_table"]).requires_grad_(True)
+    y = field_ref.hash_encoding(x, t, torch.tensor(g["a_scalings"]), int(g["a_log2"]),
+                                [torch.tensor(g["c_w0"]), torch.tensor(g["c_w1"]), torch.tensor(g["c_w2"])], "sigmoid", 16.0)
+    assert np.allclose(y.detach().numpy(), g["c_y"], atol=1e-6)
+    (y * torch.tensor(g["c_gy"])).sum().backward()
+    assert np.allclose(x.grad.numpy(), g["c_v_x"], rtol=1e-4, atol=1e-4 * np.abs(g["c_v_x"]).max())
+    assert np.allclose(t.grad[torch.tensor(g["c_touched"])].numpy(), g["c_v_table_touched"], atol=1e-5)

@@ -455,8 +455,14 @@ extern "C" int gs_specular_weights_build(int R, const float* bounds, const float
 #ifndef GS_APPLY_UNROLL
 #define GS_APPLY_UNROLL 8          // patches in flight per wave (4 -> 8: +x% on the 256^2 / 512^2 levels)
 #endif
+#ifndef GS_APPLY_WAVES
+#define GS_APPLY_WAVES 4            // texels (waves) per workgroup
+#endif
+#ifndef GS_APPLY_LDS
+#define GS_APPLY_LDS 0              // dynamic LDS request (occupancy cap experiment)
+#endif
 template <bool SRC4>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * GS_APPLY_WAVES)
 specular_apply_kernel(int R, const float* __restrict__ src, const int64_t* __restrict__ patch_offsets, int64_t total_patches,
                       const int32_t* __restrict__ patch_desc, const float* __restrict__ weights,
                       float* __restrict__ dst, int dst_stride, int accumulate)
@@ -474,7 +480,7 @@ specular_apply_kernel(int R, const float* __restrict__ src, const int64_t* __res
 #else
     const int grp = blockIdx.x;
 #endif
-    const int t = grp * 4 + (threadIdx.x >> 6);
+    const int t = grp * GS_APPLY_WAVES + (threadIdx.x >> 6);
     const int n = 6 * R * R;
     if (t >= n) return;
     const int lx = lane & 7, ly = lane >> 3;
@@ -519,12 +525,12 @@ extern "C" int gs_specular_apply(int R, const float* src, int src_stride, const 
 {
     GS_CHECK_ARG(R >= 1 && src && patch_offsets && patch_desc && weights && dst && dst_stride >= 3, "bad arguments");
     GS_CHECK_ARG(src_stride == 3 || src_stride == 4, "src_stride must be 3 or 4");
-    const int groups = (gs_cdiv(6 * R * R, 4) + 7) / 8 * 8;           // multiple of 8: one contiguous share per XCD
+    const int groups = (gs_cdiv(6 * R * R, GS_APPLY_WAVES) + 7) / 8 * 8;   // multiple of 8: one contiguous share per XCD
     if (src_stride == 4)
-        hipLaunchKernelGGL(specular_apply_kernel<true>, dim3(groups), dim3(256), 0, (hipStream_t)stream, R, src,
+        hipLaunchKernelGGL(specular_apply_kernel<true>, dim3(groups), dim3(64 * GS_APPLY_WAVES), GS_APPLY_LDS, (hipStream_t)stream, R, src,
                            patch_offsets, total_patches, patch_desc, weights, dst, dst_stride, accumulate);
     else
-        hipLaunchKernelGGL(specular_apply_kernel<false>, dim3(groups), dim3(256), 0, (hipStream_t)stream, R, src,
+        hipLaunchKernelGGL(specular_apply_kernel<false>, dim3(groups), dim3(64 * GS_APPLY_WAVES), GS_APPLY_LDS, (hipStream_t)stream, R, src,
                            patch_offsets, total_patches, patch_desc, weights, dst, dst_stride, accumulate);
     GS_CHECK_LAUNCH();
     return GS_OK;

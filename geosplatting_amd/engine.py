@@ -12,6 +12,7 @@ Order of work per step (all on the current HIP stream, kernels in libgeosplat_hi
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Sequence
 
@@ -25,7 +26,7 @@ from .cameras import Camera
 from .parallel import GradBucket
 from .rasterization import _bin_stage, _composite_stage, _forward_stages, _prepare_stage, _project_stage
 from .shading import _MODE, _TONE, RenderableAttrs, _make_env, get_fg_lut
-from .splitsum import TextureSplitSum, as_splitsum
+from .splitsum import CACHE_PAIR_WEIGHTS, TextureSplitSum, as_splitsum, as_splitsum_backward
 from .synthetic import SplatSet
 
 PARAM_NAMES = ("means", "scales", "quats", "opacities", "normals", "kd", "ks", "cubemap", "exposure")
@@ -58,6 +59,7 @@ class RenderStep:
         self._cam_cache: Dict[int, tuple] = {}
         self._side_stream = None
         self._tail_stream = None
+        self._pre_stream = None
 
     # ------------------------------------------------------------------------------------------------- fused path
     def _camera_tensors(self, cam: Camera):
@@ -81,9 +83,16 @@ class RenderStep:
         f32 = torch.float32
         st = L.stream
         mode, tone = _MODE[self.mode], _TONE[self.tone_type]
-        cubemap = p.cubemap.detach().requires_grad_(self.prefilter)
+        # explicit prefilter backward (as_splitsum_backward) instead of autograd: it can then be split in two halves and
+        # the first half placed on its own stream, under the compositor of the remaining views
+        explicit_pre = self.prefilter and CACHE_PAIR_WEIGHTS
+        cubemap = p.cubemap.detach().requires_grad_(self.prefilter and not explicit_pre)
         if self.prefilter:
-            env = as_splitsum(cubemap)
+            if explicit_pre:
+                with torch.no_grad():
+                    env = as_splitsum(cubemap)
+            else:
+                env = as_splitsum(cubemap)
         else:
             if self._static_env is None:
                 with torch.no_grad():
@@ -93,10 +102,20 @@ class RenderStep:
                                 env.max_roughness)
         lut = get_fg_lut(dev)
         e = _make_env(lut, env_d)
-        g_base = torch.zeros_like(env_d.base); g_levels = [torch.zeros_like(l) for l in env_d.levels]
-        eg = L.GsEnvGrad(); eg.base = g_base.data_ptr()
-        for i, g in enumerate(g_levels):
-            eg.levels[i] = g.data_ptr()
+        # texel-gradient accumulators.  Two sets (views [0, n/2) and [n/2, n)) with the first half's prefilter backward
+        # on its own stream under the remaining compositor work was measured: 30.4 vs 28.7 ms per step -- the backward is
+        # linear, so splitting it doubles its 2.4 ms and the overlap does not pay that back.  One set.
+        n_sets = 2 if (explicit_pre and len(cameras) >= 4 and os.environ.get("GEOSPLAT_SPLIT_PREFILTER_BWD") == "1") else 1
+        g_sets = []
+        for _ in range(n_sets):
+            gb = torch.zeros_like(env_d.base); gl = [torch.zeros_like(l) for l in env_d.levels]
+            egs = L.GsEnvGrad(); egs.base = gb.data_ptr()
+            for i, g in enumerate(gl):
+                egs.levels[i] = g.data_ptr()
+            g_sets.append((gb, gl, egs))
+        g_base, g_levels, eg = g_sets[0]
+        half = (len(cameras) + 1) // 2 if n_sets == 2 else len(cameras)
+        g_cube_first = None
         ws_bytes = lib.gs_shade_bwd_ws_bytes(C.byref(e), mode)
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
 
@@ -179,6 +198,7 @@ class RenderStep:
             # on that stream (they accumulate into the same gradient buffers)
             ev_r = torch.cuda.Event(); ev_r.record(main)
             g_colors = torch.empty(N, 3, dtype=f32, device=dev)
+            eg = g_sets[0 if i < half else n_sets - 1][2]
             with torch.cuda.stream(tail):
                 tail.wait_event(ev_r)
                 L.check(lib.gs_project_bwd(N, V, 3, L.ptr(means), L.ptr(quats), L.ptr(scales_act), L.ptr(opac_act), L.ptr(vm),
@@ -192,6 +212,16 @@ class RenderStep:
                                          L.ptr(ws) if ws_bytes else None, C.c_size_t(ws_bytes), st()), "gs_shade_bwd")
             for t in (v_packed, g_colors, s["gaussian_ids_i32"], s["conics"], s["compensations"]):
                 t.record_stream(tail)
+            if n_sets == 2 and i == half - 1:
+                # the first half of the texel gradients is complete: its prefilter backward (2.4 ms, latency-bound
+                # streaming) runs on its own stream under the compositor of the remaining views
+                pre = self._pre_stream
+                if pre is None:
+                    pre = self._pre_stream = torch.cuda.Stream(device=dev)
+                pre.wait_stream(tail)
+                with torch.cuda.stream(pre):
+                    g_cube_first = as_splitsum_backward(g_sets[0][0], g_sets[0][1], min_roughness=env.min_roughness,
+                                                        max_roughness=env.max_roughness)
             if keep_images:
                 images.append(img)
         main.wait_stream(tail)
@@ -201,7 +231,16 @@ class RenderStep:
         b["opacities"].copy_((g_opac_act * opac_act * (1.0 - opac_act)).unsqueeze(-1))
         start_head, finish = self.bucket.all_reduce_split("cubemap") if all_reduce else ((lambda: None), (lambda: None))
         start_head()
-        if self.prefilter:
+        if self.prefilter and explicit_pre:
+            gb, gl, _ = g_sets[n_sets - 1]
+            g_cube = as_splitsum_backward(gb, gl, min_roughness=env.min_roughness, max_roughness=env.max_roughness)
+            if g_cube_first is not None:
+                main.wait_stream(self._pre_stream)
+                g_cube_first.record_stream(main)
+                torch.add(g_cube, g_cube_first, out=b["cubemap"])
+            else:
+                b["cubemap"].copy_(g_cube)
+        elif self.prefilter:
             outs = [env.base] + list(env.levels)
             gouts = [g_base] + g_levels
             keep = [(o, g) for o, g in zip(outs, gouts) if o.requires_grad]

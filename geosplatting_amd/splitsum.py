@@ -258,6 +258,38 @@ class TextureSplitSum:
         return cls(base, split_mipmaps(mipmaps, num_mipmaps), float(min_roughness), float(max_roughness))
 
 
+def as_splitsum_backward(g_base: Tensor, g_levels: List[Tensor], *, cutoff: float = 0.99, min_roughness: float = 0.08,
+                         max_roughness: float = 0.5) -> Tensor:
+    """Explicit backward of `as_splitsum` on the CURRENT stream (no autograd graph, so a caller can place it on any HIP
+    stream -- the autograd engine would run it on the stream of the forward): texel gradients of the base map and of
+    the n levels -> gradient of the cubemap.  Same kernels as the autograd path."""
+    n = len(g_levels)
+    roughs = [(idx / (n - 2)) * (max_roughness - min_roughness) + min_roughness for idx in range(n - 1)] + [1.0]
+    g_mips = []
+    for gl, rough in zip(g_levels, roughs):
+        res = gl.shape[1]
+        if CACHE_PAIR_WEIGHTS:
+            e = specular_weights(res, rough, cutoff, gl.device)
+            v4 = torch.nn.functional.pad(gl / e["wsum"], (0, 1)).contiguous()
+            g = torch.empty(6, res, res, 3, dtype=torch.float32, device=gl.device)
+            L.check(L.lib().gs_specular_apply(res, L.ptr(v4), 4, L.ptr(e["offsets"]), L.i64(e["total"]), L.ptr(e["desc"]),
+                                              L.ptr(e["bwd"]), L.ptr(g), 3, 0, L.stream()), "gs_specular_apply")
+        else:
+            raise L.GeoSplatHipError("as_splitsum_backward needs the cached pair weights (GEOSPLAT_PREFILTER_CACHE=1)")
+        g_mips.append(g)
+    gd = g_base.contiguous()
+    gdb = torch.empty_like(gd)
+    L.check(L.lib().gs_diffuse_cubemap_bwd(gd.shape[1], L.ptr(gd), L.ptr(gdb), 0, L.stream()), "gs_diffuse_cubemap_bwd")
+    g_mips[-1] = g_mips[-1] + gdb
+    for idx in range(n - 1, 0, -1):
+        dout = g_mips[idx].contiguous()
+        R = dout.shape[1]
+        up = torch.empty(6, 2 * R, 2 * R, 3, dtype=torch.float32, device=dout.device)
+        L.check(L.lib().gs_cubemap_mip_bwd(R, L.ptr(dout), L.ptr(up), 0, L.stream()), "gs_cubemap_mip_bwd")
+        g_mips[idx - 1] = g_mips[idx - 1] + up
+    return g_mips[0]
+
+
 def as_splitsum(cubemap: Tensor, *, cutoff: float = 0.99, min_resolution: int = 16, min_roughness: float = 0.08,
                 max_roughness: float = 0.5) -> TextureSplitSum:
     """TextureCubeMap.as_splitsum (rfstudio/graphics/_mesh/_texture.py:530-557); differentiable w.r.t. cubemap."""

@@ -246,7 +246,11 @@ __device__ __forceinline__ void wave_commit6(float* pa, float* pb, const float (
         float val = x[0];
 #pragma unroll
         for (int c = 1; c < 6; ++c) val = (ch == c) ? x[c] : val;
+#ifndef GS_EXPERIMENT_NO_GLOBAL_TEXEL_ATOMICS
         if (base != nullptr) gs_add_scoped<XCD_LOCAL>(base + c3, val);
+#else
+        if (base != nullptr && val == 123456.0f) base[c3] = val;      /* timing experiment only */
+#endif
     }
 }
 

@@ -25,7 +25,7 @@ from . import _lib as L
 from .cameras import Camera
 from .parallel import GradBucket
 from .rasterization import _bin_stage, _composite_stage, _forward_stages, _prepare_stage, _project_stage
-from .shading import _MODE, _TONE, RenderableAttrs, _make_env, get_fg_lut
+from .shading import _MODE, _TONE, RenderableAttrs, _make_env, get_fg_lut, shade_private_copies
 from .splitsum import CACHE_PAIR_WEIGHTS, TextureSplitSum, as_splitsum, as_splitsum_backward
 from .synthetic import SplatSet
 
@@ -116,7 +116,7 @@ class RenderStep:
         g_base, g_levels, eg = g_sets[0]
         half = (len(cameras) + 1) // 2 if n_sets == 2 else len(cameras)
         g_cube_first = None
-        ws_bytes = lib.gs_shade_bwd_ws_bytes(C.byref(e), mode)
+        ws_bytes = lib.gs_shade_bwd_ws_bytes(C.byref(e), mode) if shade_private_copies() else 0
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
 
         scales_act = p.scales.detach().exp()

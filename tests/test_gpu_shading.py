@@ -18,9 +18,10 @@ def _random_env(seed=3, res=(64, 32, 16)):
     return base, levels
 
 
-@pytest.mark.parametrize("mode", ["pbr", "diffuse", "specular"])
-def test_shade_fwd_bwd(cuda, mode):
+@pytest.mark.parametrize("mode,priv", [("pbr", "0"), ("diffuse", "0"), ("specular", "0"), ("pbr", "1")])
+def test_shade_fwd_bwd(cuda, mode, priv, monkeypatch):
     import geosplatting_amd as gs
+    monkeypatch.setenv("GEOSPLAT_SHADE_PRIV", priv)       # "1": texel gradients through the eight XCD-private copies
     sc, cam = sphere_case(3, 64)
     N = sc.splats.num
     base, levels = _random_env()

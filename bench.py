@@ -111,13 +111,29 @@ def cpu_baseline(scene, cam, res, budget_note):
                            base, levels)
     m = oracle.rasterization(means, quats, scales, opac, col, vm, K, res, res)
     rgba = np.concatenate([m["render"], m["alphas"][..., None]], -1)
-    oracle.tonemap_fwd(rgba, 1.0, "naive")
+    img_ref = oracle.tonemap_fwd(rgba, 1.0, "naive")
     v_rgba, _ = oracle.tonemap_bwd(rgba, 1.0, v, "naive")
     gr = oracle.rasterization_bwd(means, quats, scales, opac, col, vm, K, res, res, m, v_rgba[..., :3], v_rgba[..., 3])
     oracle.shade_bwd(means, scene.normals.numpy(), scene.kd.numpy(), scene.ks.numpy(), cam.c2w[:, 3].numpy(), lut, base,
                      levels, gr["v_colors"])
     dt = time.time() - t0
-    return {"value": 1.0 / dt, "unit": "views/s", "cores": cores, "kind": "port",
+    # "PSNR vs ref" half of the metric: the HIP path on the same view / same pyramid against the oracle's image
+    parity = None
+    try:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        with torch.no_grad():
+            env = gs.TextureSplitSum(torch.from_numpy(base).to(dev), [torch.from_numpy(l).to(dev) for l in levels])
+            attrs = gs.RenderableAttrs(kd=scene.kd.to(dev), ks=scene.ks.to(dev), normals=scene.normals.to(dev))
+            img = attrs.splat(sp.to(dev), [cam], exposure=torch.tensor(1.0, device=dev), envmap=env, min_roughness=0.1,
+                              max_metallic=1.0).reshape(res, res, 4).cpu().numpy()
+        ref = np.asarray(img_ref, dtype=np.float64).reshape(res, res, 4)
+        mse = float(np.mean((img[..., :3].astype(np.float64) - ref[..., :3]) ** 2))
+        parity = {"psnr_vs_oracle_db": (10.0 * math.log10(1.0 / mse) if mse > 0 else float("inf")),
+                  "rgb_max_abs_err": float(np.abs(img[..., :3] - ref[..., :3]).max()),
+                  "view": "the cpu_baseline view, tone-mapped RGB, peak 1.0"}
+    except Exception as e:                              # never take the bench line down
+        parity = {"psnr_vs_oracle_db": None, "error": str(e)}
+    return {"parity": parity, "value": 1.0 / dt, "unit": "views/s", "cores": cores, "kind": "port",
             "sample": f"1 view fwd+bwd (shade+project+bin+sort+composite+tonemap and backward; prefilter excluded), "
                       f"N={means.shape[0]}, {res}x{res}, oracle/libgs_oracle.so with OpenMP on {cores} host threads; {budget_note}",
             "pairs_fwd": m["pairs"], "V": int(len(m["gaussian_ids"])), "I": int(len(m["flatten_ids"]))}
@@ -223,7 +239,9 @@ def main():
         }
         if not args.no_cpu_baseline:
             try:
-                result["cpu_baseline"] = cpu_baseline(scene, cam, args.res, "bounded to one view")
+                cb = cpu_baseline(scene, cam, args.res, "bounded to one view")
+                result["parity"] = cb.pop("parity")
+                result["cpu_baseline"] = cb
             except Exception as e:       # the baseline must never take the bench line down
                 result["cpu_baseline"] = {"value": None, "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
                                           "sample": f"failed: {e}"}

@@ -105,3 +105,45 @@ class HashEncoding:
             elif self.activation == "sigmoid":
                 f = f.sigmoid()
         return f
+
+
+class GaussianField:
+    """Mirror of rfstudio's GaussianField (rfstudio/model/geosplat.py:482-520) with its three default encoders and of
+    `get_gaussians_from_face` (:620-672, the MGAdapter branch used by GeoSplatter): mesh -> Gaussians, with kd / ks
+    from the hash-grid field at the Gaussian centres and a learned offset of the centres against the face normal.
+    Every stage is a HIP op of this package (vertex normals, MGAdapter, hash encoding) or a library GEMM."""
+
+    def __init__(self, device="cuda", log2_hashmap_size: int = 18, max_res: int = 4096, seed: int = 0):
+        common = dict(max_res=max_res, log2_hashmap_size=log2_hashmap_size, grad_scaling=16.0, device=device)
+        self.kd_enc = HashEncoding([-1, 32, 32, 3], activation="sigmoid", seed=seed, **common)
+        self.ks_enc = HashEncoding([-1, 32, 2], activation="none", seed=seed + 1, **common)
+        self.z_enc = HashEncoding([-1, 32, 1], activation="none", seed=seed + 2, **common)
+
+    def parameters(self) -> List[Tensor]:
+        return self.kd_enc.parameters() + self.ks_enc.parameters() + self.z_enc.parameters()
+
+    def get_gaussians_from_face(self, vertices: Tensor, faces: Tensor, kd_perturb_std: float = 0.0,
+                                ks_perturb_std: float = 0.0, *, scale: float, initial_guess: Tensor):
+        """Returns (SplatSet with the shifted means, RenderableAttrs, offsets[6F,3])."""
+        from .mesh import mesh_to_splats, vertex_normals
+        from .shading import RenderableAttrs
+        from .synthetic import SplatSet
+        splats, shading_normals = mesh_to_splats(vertices, faces, vertex_normals(vertices, faces))
+        with torch.no_grad():                                  # MGAdapter.make: offsets = n.detach() * sqrt(area.detach())
+            p = vertices[faces]
+            fn = torch.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0], dim=-1)
+            ln = fn.norm(dim=-1, keepdim=True)
+            area = ln.clamp(min=1e-10) / 2
+            n = torch.where(ln < 1e-6, torch.tensor([0.0, 0.0, 1.0], device=fn.device), fn / ln.clamp_min(1e-6))
+            offsets = (n * area.sqrt()).repeat(6, 1)
+        means = (splats.means / scale).clamp(-1, 1)
+        offsets = offsets * self.z_enc(means.detach()).sigmoid()
+        shifted = splats.means - offsets
+        kd_jitter = ks_jitter = None
+        if kd_perturb_std > 0:
+            kd_jitter = self.kd_enc((means + torch.randn_like(means) * kd_perturb_std).clamp(-1, 1))
+        if ks_perturb_std > 0:
+            ks_jitter = (self.ks_enc((means + torch.randn_like(means) * ks_perturb_std).clamp(-1, 1)) + initial_guess).sigmoid()
+        attrs = RenderableAttrs(kd=self.kd_enc(means), ks=(self.ks_enc(means) + initial_guess).sigmoid(), normals=shading_normals,
+                                kd_jitter=kd_jitter, ks_jitter=ks_jitter)
+        return SplatSet(shifted, splats.scales, splats.quats, splats.opacities, splats.colors), attrs, offsets

@@ -91,3 +91,55 @@ def test_hashgrid_vs_float64_and_properties():
         hash_encode(x, table, sc, log2)                                  # CPU tensors: no CPU path
     with pytest.raises(_lib.GeoSplatHipError):
         hash_encode(xc, tc[:100], sc, log2)                              # wrong table size
+
+
+def test_gaussian_field_from_mesh():
+    """GaussianField.get_gaussians_from_face: field outputs == the CPU restatement with the same parameters; one full
+    iteration mesh -> field -> splat -> trainer loss reaches every leaf (hash tables, MLP weights, vertices)"""
+    import geosplatting_amd as gs
+    from geosplatting_amd import synthetic as syn
+    from geosplatting_amd.field import GaussianField
+    from geosplatting_amd.loss import photo_loss
+    dev = torch.device("cuda")
+    v, f = syn.icosphere(3, radius=0.7)
+    v = v.to(dev).requires_grad_(True); f = f.to(dev)
+    fld = GaussianField(device=dev, log2_hashmap_size=14, seed=4)
+    with torch.no_grad():
+        for enc in (fld.kd_enc, fld.ks_enc, fld.z_enc):
+            enc.hash_table.mul_(300.0)                       # O(0.3) features so that the outputs are not all sigmoid(0)
+    guess = torch.tensor([0.5, -0.5], device=dev)
+    sp, attrs, offsets = fld.get_gaussians_from_face(v, f, 0.05, 0.05, scale=1.0, initial_guess=guess)
+    N = 6 * f.shape[0]
+    assert sp.means.shape == (N, 3) and attrs.kd.shape == (N, 3) and attrs.ks.shape == (N, 2) and offsets.shape == (N, 3)
+    assert attrs.kd_jitter.shape == (N, 3) and attrs.ks_jitter.shape == (N, 2)
+    # field outputs against the restatement (fp32, same tables / weights)
+    # (the centres come from the HIP adapter itself: at resolution 4096 a 1e-7 difference in a centre moves the cell
+    #  offset by 4e-4, so the encoders must see bit-identical inputs on both sides)
+    from geosplatting_amd.mesh import mesh_to_splats, vertex_normals
+    with torch.no_grad():
+        sp0, _ = mesh_to_splats(v.detach(), f, vertex_normals(v.detach(), f))
+    sp0 = sp0.to("cpu")
+    means = sp0.means.clamp(-1, 1)
+    for enc, got, act, post in ((fld.kd_enc, attrs.kd, "sigmoid", lambda t: t),
+                                (fld.ks_enc, attrs.ks, "none", lambda t: (t + guess.cpu()).sigmoid())):
+        ref = post(field_ref.hash_encoding(means, enc.hash_table.detach().cpu(), enc.scalings, enc.log2_hashmap_size,
+                                           [w.detach().cpu() for w in enc.weights], act, 16.0))
+        assert (got.detach().cpu() - ref).abs().max().item() < 2e-5
+    z = field_ref.hash_encoding(means, fld.z_enc.hash_table.detach().cpu(), fld.z_enc.scalings, 14,
+                                [w.detach().cpu() for w in fld.z_enc.weights], "none", 16.0).sigmoid()
+    assert (sp.means.detach().cpu() - (sp0.means - offsets.detach().cpu())).abs().max().item() < 1e-6
+    pc = v.detach().cpu()[f.cpu()]
+    area = torch.cross(pc[:, 1] - pc[:, 0], pc[:, 2] - pc[:, 0], dim=-1).norm(dim=-1) / 2
+    want = (area.sqrt().repeat(6) * z.squeeze(-1))                       # |offset| = sqrt(face area) * sigmoid(z field)
+    assert (offsets.detach().cpu().norm(dim=-1) - want).abs().max().item() < 1e-5
+    # one iteration through render + loss
+    cam = syn.blender_cameras(1, 128, 128)[0]
+    env = gs.as_splitsum(syn.make_cubemap(64).to(dev))
+    img = attrs.splat(sp, [cam], exposure=torch.tensor(1.0, device=dev), envmap=env, min_roughness=0.1, max_metallic=1.0)
+    img = img.reshape(128, 128, 4)
+    gt = torch.cat([torch.rand(128, 128, 3, device=dev), torch.ones(128, 128, 1, device=dev)], -1)
+    loss, _ = photo_loss(img[..., :3], img[..., 3:], gt, torch.rand(128, 128, 3, device=dev))
+    (loss + 0.1 * (attrs.kd - attrs.kd_jitter).abs().mean()).backward()
+    assert torch.isfinite(v.grad).all() and v.grad.abs().max().item() > 0
+    for p_ in fld.kd_enc.parameters() + fld.ks_enc.parameters() + fld.z_enc.parameters():
+        assert p_.grad is not None and torch.isfinite(p_.grad).all() and p_.grad.abs().max().item() > 0

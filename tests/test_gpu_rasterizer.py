@@ -232,3 +232,18 @@ def test_full_size_properties(cuda, level):
     assert np.array_equal(meta["gaussian_ids"].cpu().numpy(), ref["gaussian_ids"].astype(np.int64))
     assert np.array_equal(meta["radii"].cpu().numpy(), ref["radii"])
     assert np.array_equal(meta["means2d"].cpu().numpy(), ref["means2d"])
+
+
+@pytest.mark.parametrize("seed", [0, 3, 6, 9])
+def test_seeded_random_scenes(cuda, seed):
+    """anisotropic random splats with varied opacity, odd resolutions, optional background (scripts/stress_parity.py
+    runs the same generator over many more seeds)"""
+    g = torch.Generator().manual_seed(100 + seed)
+    res = [64, 96, 128, 200][seed // 2 % 4]
+    sp, cam = random_case([500, 2000, 5000][seed % 3], res, view=seed % 4, seed=seed + 7)
+    sp.scales = sp.scales + torch.randn(sp.scales.shape, generator=g) * 0.5
+    sp.opacities = torch.logit(torch.rand(sp.opacities.shape, generator=g) * 0.9 + 0.05)
+    means, quats, scales, opac = activated(sp)
+    colors = torch.rand(sp.num, 3, generator=g).numpy()
+    bg = None if seed % 3 else np.array([0.2, 0.5, 0.9], np.float32)
+    _run_case(cuda, means, quats, scales, opac, colors, cam, background=bg)

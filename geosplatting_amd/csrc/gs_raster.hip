@@ -193,7 +193,7 @@ raster_fwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
                   float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids)
 {
     const int tile = tile_order[blockIdx.x];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPR
     const int tx = tile % tile_w, ty = tile / tile_w;
     const int qx0 = tx * GS_TILE + (wave & 1) * 8, qy0 = ty * GS_TILE + (wave >> 1) * 8;
     const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
@@ -300,7 +300,7 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
                   float* __restrict__ v_packed, int rec_stride)
 {
     const int tile = tile_order[blockIdx.x];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPR
     const int tx = tile % tile_w, ty = tile / tile_w;
     const int qx0 = tx * GS_TILE + (wave & 1) * 8, qy0 = ty * GS_TILE + (wave >> 1) * 8;
     const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);

@@ -480,7 +480,9 @@ specular_apply_kernel(int R, const float* __restrict__ src, const int64_t* __res
 #else
     const int grp = blockIdx.x;
 #endif
-    const int t = grp * GS_APPLY_WAVES + (threadIdx.x >> 6);
+    // t is wave-uniform: telling the compiler so (readfirstlane) turns the offset / descriptor loads into scalar loads
+    // and the patch address arithmetic into SALU work
+    const int t = __builtin_amdgcn_readfirstlane(grp * GS_APPLY_WAVES + (int)(threadIdx.x >> 6));
     const int n = 6 * R * R;
     if (t >= n) return;
     const int lx = lane & 7, ly = lane >> 3;

@@ -453,7 +453,7 @@ extern "C" int gs_specular_weights_build(int R, const float* bounds, const float
 #define GS_STREAM_LOAD(p) (*(p))
 #endif
 #ifndef GS_APPLY_UNROLL
-#define GS_APPLY_UNROLL 8          // patches in flight per wave (4 -> 8: +x% on the 256^2 / 512^2 levels)
+#define GS_APPLY_UNROLL 12         // patches in flight per wave (4 -> 8 -> 12; 16 loses occupancy to registers)
 #endif
 #ifndef GS_APPLY_WAVES
 #define GS_APPLY_WAVES 4            // texels (waves) per workgroup
@@ -490,14 +490,14 @@ specular_apply_kernel(int R, const float* __restrict__ src, const int64_t* __res
     const int64_t p1 = (t + 1 < n) ? patch_offsets[t + 1] : total_patches;
     float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
     for (int64_t p = p0; p < p1; p += GS_APPLY_UNROLL) {
-        float w[GS_APPLY_UNROLL]; size_t ti[GS_APPLY_UNROLL];
+        float w[GS_APPLY_UNROLL]; unsigned ti[GS_APPLY_UNROLL];     // 32-bit element offsets: the source is < 4 G floats
 #pragma unroll
         for (int k = 0; k < GS_APPLY_UNROLL; ++k) {
             const bool on = p + k < p1;
             const int d = on ? patch_desc[p + k] : 0;
             w[k] = on ? GS_STREAM_LOAD(weights + (size_t)(p + k) * 64 + lane) : 0.0f;
             const int s = d >> 24, by = (d >> 12) & 0xfff, bx = d & 0xfff;
-            ti[k] = (((size_t)s * R + (by + ly)) * R + (bx + lx)) * (SRC4 ? 4 : 3);
+            ti[k] = (unsigned)(((s * R + (by + ly)) * R + (bx + lx)) * (SRC4 ? 4 : 3));
         }
         float v[GS_APPLY_UNROLL][3];
 #pragma unroll

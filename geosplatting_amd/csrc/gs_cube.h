@@ -71,7 +71,7 @@ __device__ void cube_footprint(const float* d, int R, CubeFp& fp)
     const float ac = fabsf(comp3(d, m.c));
     fp.valid = (ac > 0.0f) && isfinite(ac);
     fp.face = s;
-    if (!fp.valid) return;
+    if (!fp.valid) { fp.idx[0] = fp.idx[1] = fp.idx[2] = fp.idx[3] = 0; return; }
     const float inv = 1.0f / ac;
     const float xn = m.sx * comp3(d, m.a) * inv, yn = m.sy * comp3(d, m.b) * inv;
     fp.inv_c = inv; fp.xn = xn; fp.yn = yn;
@@ -108,18 +108,24 @@ template <bool WITH_GRAD>
 __device__ void cube_fetch(const float* __restrict__ tex, int R, const float* d, float* out, float* dd, CubeFp& fp)
 {
     cube_footprint(d, R, fp);
-    if (!fp.valid) {
-        out[0] = out[1] = out[2] = 0.0f;
-        if (WITH_GRAD) { for (int i = 0; i < 9; ++i) dd[i] = 0.0f; }
-        return;
-    }
+    // BRANCH-FREE loads: a load under a condition makes the compiler drain vmcnt at the join, which turned the 8 taps of a
+    // trilinear sample into 8 sequential L2 round trips.  Invalid footprints and the missing corner texel read element 0
+    // and are zeroed by selects afterwards.
+    const bool valid = fp.valid;
+    bool ok[4]; int safe[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ok[i] = valid && fp.idx[i] >= 0; safe[i] = ok[i] ? fp.idx[i] : 0; }
     float t[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float* p = tex + (size_t)safe[i] * 3;
+        t[i][0] = p[0]; t[i][1] = p[1]; t[i][2] = p[2];
+    }
     bool has_miss = false;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        if (fp.idx[i] < 0) { has_miss = true; t[i][0] = t[i][1] = t[i][2] = 0.0f; continue; }
-        const float* p = tex + (size_t)fp.idx[i] * 3;
-        t[i][0] = p[0]; t[i][1] = p[1]; t[i][2] = p[2];
+        if (!ok[i]) { t[i][0] = t[i][1] = t[i][2] = 0.0f; }
+        has_miss = has_miss || (valid && fp.idx[i] < 0);
     }
     if (has_miss) {
 #pragma unroll
@@ -128,6 +134,11 @@ __device__ void cube_fetch(const float* __restrict__ tex, int R, const float* d,
 #pragma unroll
             for (int i = 0; i < 4; ++i) if (fp.idx[i] < 0) t[i][c] = s;
         }
+    }
+    if (!valid) {
+        out[0] = out[1] = out[2] = 0.0f;
+        if (WITH_GRAD) { for (int i = 0; i < 9; ++i) dd[i] = 0.0f; }
+        return;
     }
     const FaceMap m = c_faces[fp.face];
     const float sgn_c = comp3(d, m.c) < 0.0f ? -1.0f : 1.0f;

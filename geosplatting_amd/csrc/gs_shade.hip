@@ -98,19 +98,18 @@ __device__ void cube_mip_fetch(const EnvDev& env, const float* d, float bias, Mi
 {
     const int L = env.L;
     const float lam = fminf(fmaxf(bias, 0.0f), (float)(L - 1));
-    const int l0 = (int)floorf(lam);
-    if (l0 >= L - 1) {
-        s.l0 = L - 1; s.l1 = -1; s.f = 0.0f;
-        cube_fetch<WITH_GRAD>(env.levels[L - 1], env.res[L - 1], d, s.out, s.dd, s.fp0);
-        s.dmip[0] = s.dmip[1] = s.dmip[2] = 0.0f;
-        return;
-    }
-    const float f = lam - (float)l0;
+    // no early-out for the last level (a branch would serialise the texel loads of the two fetches): it samples level
+    // L-1 twice with f = 0, which gives bit-identical results
+    const int lf = (int)floorf(lam);
+    const bool last = lf >= L - 1;
+    const int l0 = last ? L - 1 : lf;
+    const int l1 = last ? L - 1 : lf + 1;
+    const float f = last ? 0.0f : lam - (float)l0;
     float c0[3], c1[3], dd0[9], dd1[9];
     cube_fetch<WITH_GRAD>(env.levels[l0], env.res[l0], d, c0, dd0, s.fp0);
-    cube_fetch<WITH_GRAD>(env.levels[l0 + 1], env.res[l0 + 1], d, c1, dd1, s.fp1);
-    s.l0 = l0; s.l1 = l0 + 1; s.f = f;
-    const bool clamped = (bias < 0.0f || bias > (float)(L - 1));
+    cube_fetch<WITH_GRAD>(env.levels[l1], env.res[l1], d, c1, dd1, s.fp1);
+    s.l0 = l0; s.l1 = last ? -1 : l1; s.f = f;
+    const bool clamped = last || (bias < 0.0f || bias > (float)(L - 1));
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         s.out[c] = c0[c] + f * (c1[c] - c0[c]);

@@ -35,7 +35,7 @@ def test_argument_validation_without_gpu():
     """Entry points validate arguments before touching the device (no compute, no GPU needed)."""
     from geosplatting_amd import _lib
     lib = _lib.lib()
-    assert lib.gs_project_ws_bytes(0) > 0 and lib.gs_project_ws_bytes(1 << 21) >= 4 * 8 * (1 << 13)
+    assert lib.gs_project_ws_bytes(0) > 0 and lib.gs_project_ws_bytes(1 << 21) >= 4 * 8 * (1 << 11)
     assert lib.gs_raster_ws_bytes(ctypes.c_int64(1000), 500, 800, 800, 16) >= 3 * 16 * 1000 + 4 * 2500 + 3 * 16 * 500
     rc = lib.gs_raster_fwd(0, 0, 16, 3, 0, None, None, None, None, None, ctypes.c_int64(0), None, None, None, None, None,
                            None, ctypes.c_size_t(0), None)

@@ -443,9 +443,11 @@ extern "C" int gs_isect_offsets(int64_t n_isects, const int64_t* isect_ids_sorte
 // A7: projection backward + gather backward.  One thread per INPUT Gaussian so that the dense [N,*]
 // gradients are written coalesced and exactly once (culled Gaussians get zeros, no memset pass); the
 // packed slot comes from a binary search in the ascending gaussian_ids list (log2(V) L2-resident probes).
-__device__ __forceinline__ int find_slot(const int32_t* __restrict__ gids, int V, int n)
+__device__ __forceinline__ int find_slot(const int32_t* __restrict__ gids, int V, int N, int n)
 {
-    int lo = 0, hi = V;
+    // gids is ascending and holds V of the N indices, so the slot of n lies in [n - (N - V), n]: the search collapses to
+    // zero probes when every Gaussian is visible and to log2(N - V + 1) dependent L2 probes otherwise (was log2 V = 21)
+    int lo = max(0, n - (N - V)), hi = min(n + 1, V);
     while (lo < hi) {
         int mid = (lo + hi) >> 1;
         if (gids[mid] < n) lo = mid + 1; else hi = mid;
@@ -465,7 +467,7 @@ project_bwd_kernel(int N, int V, int D, const float* __restrict__ means, const f
 {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    const int v = find_slot(gaussian_ids, V, n);
+    const int v = find_slot(gaussian_ids, V, N, n);
     float g_mean[3] = { 0, 0, 0 }, g_quat[4] = { 0, 0, 0, 0 }, g_scale[3] = { 0, 0, 0 }, g_op = 0.0f;
     if (v >= 0) {
         const GsCam cam = load_cam(viewmat, K);

@@ -210,12 +210,13 @@ def main():
         # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes (scripts/run_pmc.sh ->
         # scripts/pmc_summary.py: FETCH_SIZE x 2 (gfx950 under-count of wide reads) + WRITE_SIZE, KiB -> bytes) on this
         # same workload and committed under profiles/; counters cannot be read inside this process
-        traffic, traffic_src = None, None
+        traffic, traffic_src, valu_insts = None, None, None
         tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
         if os.path.exists(tpath) and args.level == 7 and args.res == 800:
             try:
                 tj = json.load(open(tpath))
                 traffic = tj[dom + "<3>"]["hbm_bytes"]
+                valu_insts = tj[dom + "<3>"].get("valu_wave_instructions")
                 traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, per launch)"
             except Exception:
                 traffic = None
@@ -232,6 +233,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": kt, "algorithmic_bytes": kbytes[dom],
+                         # the binding resource of this kernel is FP32 VALU issue, not HBM: wave64 instructions (PMC
+                         # SQ_INSTS_VALU, same passes) x 4 cycles on a SIMD16 / (time x 1024 SIMDs x 2.4 GHz)
+                         "valu": None if valu_insts is None else {
+                             "wave_instructions": valu_insts,
+                             "issue_frac": valu_insts * 4.0 / (kt[dom] * 1e-3 * 1024 * 2.4e9)},
                          "note": "compositor kernels are FP32-VALU/exp bound (SURVEY 8d); HBM fraction reported as the contract asks"},
             "view_roofline": {"algorithmic_bytes_per_view": view_bytes,
                               "achieved_GBs": view_bytes * views_per_s / world / 1e9,

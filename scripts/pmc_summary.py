@@ -24,6 +24,11 @@ for k in sorted(vals):
     if f and w:
         fb = 2.0 * 1024.0 * sum(f) / len(f); wb = 1024.0 * sum(w) / len(w)
         traffic[short] = {"fetch_bytes_corrected": fb, "write_bytes": wb, "hbm_bytes": fb + wb}
+        vi = vals[k].get("SQ_INSTS_VALU"); at = vals[k].get("TCC_ATOMIC_sum")
+        if vi:
+            traffic[short]["valu_wave_instructions"] = sum(vi) / len(vi)
+        if at:
+            traffic[short]["atomic_requests"] = sum(at) / len(at)
         lines.append(f"    -> HBM traffic per launch: fetch {fb / 1e6:.1f} MB (FETCH_SIZE KiB x 2, gfx950 correction) + write {wb / 1e6:.1f} MB")
 out = "\n".join(lines)
 if len(sys.argv) > 2:

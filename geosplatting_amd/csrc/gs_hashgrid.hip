@@ -8,9 +8,11 @@
 //
 // Forward: one thread per point loops over the levels (all lanes of a wave are on the same 2^log2_T-entry slice of the
 // table at the same time: L2-resident) and writes its L*F contiguous outputs.
-// Backward: table gradients are fp32 atomics -- the scatter is irregular by construction (a hash) -- with the
-// F = 2 features of a corner committed by two ADJACENT lanes of one instruction (one memory-side request instead of
-// two, see gs_cube.h); the position gradient flows through the interpolation offsets only (ceil/floor are constant).
+// Backward (default, with a workspace): ATOMIC-FREE table gradient -- each workgroup owns a 128 KB LDS slab of one level
+// and keeps the contributions of all points that hash into it (hashgrid_bwd_slab_kernel below); the position gradient
+// is a separate per-point kernel and flows through the interpolation offsets only (ceil/floor are constant).
+// Without a workspace: per-point kernel with fp32 atomics (the F = 2 features of a corner committed by two ADJACENT
+// lanes of one instruction = one memory-side request), 2.6x slower at 2 M points.
 #include "gs_common.h"
 
 #pragma clang fp contract(off)   // cell indices must round exactly like the reference (x * 0.5 + 0.5, then * scaling)

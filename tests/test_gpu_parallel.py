@@ -1,0 +1,56 @@
+"""N > 1 path on the GPU: two ranks share cuda:0 over gloo (GEOSPLAT_DEBUG_SHARE_GPU=1, the same switch bench.py honours)
+and run engine.RenderStep -- fused C-ABI drivers on three streams, view sharding, two-phase gradient all-reduce -- on
+their views; the reduced gradients must equal a single-process step over all the views."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_VIEWS, RES, LEVEL = 4, 160, 3
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _step(dev, views, all_reduce):
+    import geosplatting_amd.synthetic as syn
+    from geosplatting_amd.engine import RenderStep, params_from_scene
+    sc = syn.sphere_scene(LEVEL, seed=2, cubemap_res=64)
+    cams = syn.blender_cameras(N_VIEWS, RES, RES)
+    step = RenderStep(params_from_scene(sc, dev, exposure=1.1))
+    ups = {i: (torch.rand(RES, RES, 4, generator=torch.Generator().manual_seed(50 + i)) * 2 - 1).to(dev) for i in range(N_VIEWS)}
+    local = [cams[i] for i in views]
+    grads, _ = step(local, lambda j, img: ups[views[j]].reshape(img.shape), all_reduce=all_reduce)
+    torch.cuda.synchronize()
+    return {k: v.detach().cpu().clone() for k, v in grads.items()}
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      GEOSPLAT_DEBUG_SHARE_GPU="1")
+    import torch.distributed as dist
+    from geosplatting_amd.parallel import init_distributed_from_env, shard_views
+    r, w, dev = init_distributed_from_env("cuda")
+    g = _step(dev, shard_views(N_VIEWS, r, w), all_reduce=True)
+    torch.save(g, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_single_process(tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(2)]
+    want = _step(torch.device("cuda", 0), list(range(N_VIEWS)), all_reduce=False)
+    for k, w in want.items():
+        scale = w.abs().max().item() + 1e-30
+        for r in range(2):
+            err = (got[r][k] - w).abs().max().item() / scale
+            assert err < 2e-5, (k, r, err)            # different summation order over the views, nothing else
+        assert torch.equal(got[0][k], got[1][k]), k   # both ranks hold the same reduced buffer

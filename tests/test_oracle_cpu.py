@@ -371,3 +371,35 @@ def test_golden_hashgrid_restatement():
     (y * torch.tensor(g["c_gy"])).sum().backward()
     assert np.allclose(x.grad.numpy(), g["c_v_x"], rtol=1e-4, atol=1e-4 * np.abs(g["c_v_x"]).max())
     assert np.allclose(t.grad[torch.tensor(g["c_touched"])].numpy(), g["c_v_table_touched"], atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["rand4", "rand6", "rand567", "blob10", "blob_plain"])
+def test_golden_flexicubes_restatement(tag):
+    """oracle/flexicubes_ref.py (tables derived by rule, index formulation of its own) against the reference's own
+    dual_marching_cubes / compute_entropy outputs and autograd gradients (scripts/make_golden_flexicubes.py)."""
+    from oracle import flexicubes_ref as O
+    g = np.load(os.path.join(GOLD, "ref_flexicubes.npz"))
+    res = tuple(int(r) for r in g[f"{tag}.res"])
+    ins = {k: torch.from_numpy(g[f"{tag}.in.{k}"]).requires_grad_(True)
+           for k in ("vertices", "sdf", "alpha", "beta", "gamma") if f"{tag}.in.{k}" in g}
+    v, f, L = O.extract(ins["vertices"], ins["sdf"], res, ins.get("alpha"), ins.get("beta"), ins.get("gamma"))
+    ent = O.entropy(ins["sdf"], res)
+    assert torch.equal(f, torch.from_numpy(g[f"{tag}.out.faces"]))                      # index work: bit-exact
+    assert torch.equal(v.detach(), torch.from_numpy(g[f"{tag}.out.vertices"]))
+    assert torch.equal(L.detach(), torch.from_numpy(g[f"{tag}.out.L_dev"]))
+    np.testing.assert_allclose(ent.item(), g[f"{tag}.out.entropy"], rtol=1e-6)
+    ((v * torch.from_numpy(g[f"{tag}.cot.vertices"])).sum() + (L * torch.from_numpy(g[f"{tag}.cot.L_dev"])).sum()
+     + 0.7 * ent).backward()
+    for k, t in ins.items():
+        ref = g[f"{tag}.grad.{k}"]
+        np.testing.assert_allclose(t.grad.numpy(), ref, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(ref).max()))
+
+
+def test_flexicubes_tables_cover_all_cases():
+    from oracle import flexicubes_ref as O
+    dmc, nvd, chk = O.tables()
+    for c in range(256):
+        crossing = sorted(i for i, (a, b) in enumerate(O.CUBE_EDGES) if (c >> a & 1) != (c >> b & 1))
+        assert sorted(e for p in dmc[c] for e in p) == crossing          # every crossing edge in exactly one patch
+        assert all(3 <= len(p) <= 7 for p in dmc[c]) and len(dmc[c]) <= 4
+    assert int(chk[:, 0].sum()) == 36 and all(chk[c, 4] == 255 - c for c in range(256) if chk[c, 0])

@@ -8,11 +8,14 @@ Public surface (mirrors the reference's two call boundaries, SURVEY.md section 8
   mesh_to_splats(vertices, faces, vn)     == MGAdapter.make, rfstudio/model/geosplat.py:426-472 (section 8f rank 1)
   photo_loss(rgb, alpha, gt, bg)          == per-view trainer loss, rfstudio/trainer/geosplat_trainer.py:171-195 (rank 2)
   HashEncoding / hash_encode              == HashEncoding backend='torch', rfstudio/model/components/encoding.py:87-241 (rank 3)
+  FlexiCubes / get_geometry               == FlexiCubes.dual_marching_cubes / compute_entropy, rfstudio/graphics/_mesh/_flexicubes.py:369-802,
+                                             GeoSplatter.get_geometry rfstudio/model/geosplat.py:751-769 (rank 4)
 Every op calls hand-written HIP kernels in libgeosplat_hip.so through the C-ABI of include/geosplat_hip.h and
 raises if that library is missing -- there is no CPU or PyTorch fallback path.
 """
 from .cameras import Camera, intrinsic_matrix, lookat_c2w, orbit_cameras, view_matrix  # noqa: F401
 from .field import HashEncoding, hash_encode  # noqa: F401
+from .flexicubes import FlexiCubes, get_geometry  # noqa: F401
 from .loss import photo_loss  # noqa: F401
 from .mesh import mesh_to_splats, vertex_normals  # noqa: F401
 from .rasterization import rasterization  # noqa: F401

@@ -279,6 +279,38 @@ int gs_hashgrid_bwd(int N, int L, int F, int log2_T, const float* scalings_host,
                     void* ws /* with it: atomic-free LDS-slab kernel; NULL: per-point kernel with fp32 atomics */,
                     size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------ X1: FlexiCubes extraction ------ */
+/* FlexiCubes.dual_marching_cubes(grad_func=None) + compute_entropy on the regular grid of FlexiCubes.from_resolution
+ * (rfstudio/graphics/_mesh/_flexicubes.py:397-457, 559-713, 715-802; caller rfstudio/model/geosplat.py:751-769).
+ * Grid: cube n = i0 + R0 (i1 + R1 i2); grid vertex id = i0 + (R0+1) (i1 + (R1+1) i2); cube corner k adds bit j of k to ij
+ * (exactly the `indices` from_resolution builds, which are therefore not passed).
+ *   vertices[Vg,3], sdf[Vg]; raw alpha[C,8] / beta[C,12] / gamma[C] or NULL (the tanh / sigmoid * weight_scale
+ *   activations of :608-624 are applied inside); sdf_eps < 0 means None.
+ * Step 1  gs_flexicubes_count: classifies cubes and grid edges into `ws`, writes counts[8] (device int64) =
+ *         {surface cubes N, dual vertices Q, (patch,edge) pairs K, surface edges E, quads, flipped quads, 0, 0}.
+ *         The caller reads them (the reference's own .item() syncs) and allocates the outputs.
+ * Step 2  gs_flexicubes_fwd: out_vertices[Q + quads, 3] (dual vertices, then one centre vertex per quad),
+ *         out_faces[4 * quads, 3] int64, L_dev[K] -- vertex / face / row numbering identical to the reference's.
+ * Step 3  gs_flexicubes_bwd: cotangents v_out_vertices[Q+quads,3], v_L_dev[K] (or NULL) -> g_vertices[Vg,3], g_sdf[Vg],
+ *         g_alpha[C,8], g_beta[C,12], g_gamma[C] (w.r.t. the RAW weights; NULL iff the weight was NULL), all overwritten.
+ *         g_vd_scratch: 3*Q floats.  `ws` must still hold what step 1 left for the same sdf.
+ * gs_flexicubes_entropy_fwd/bwd: compute_entropy (:715-725) of the same sdf (needs step 1's `ws`); out[1]; bwd adds
+ *         v_out[0] * d/dsdf into g_sdf (overwrites when accumulate == 0). */
+size_t gs_flexicubes_ws_bytes(int R0, int R1, int R2);
+int gs_flexicubes_count(int R0, int R1, int R2, const float* sdf, void* ws, size_t ws_bytes, int64_t* counts, void* stream);
+int gs_flexicubes_fwd(int R0, int R1, int R2, const float* vertices, const float* sdf, const float* alpha,
+                      const float* beta, const float* gamma, float weight_scale, float sdf_eps, const void* ws,
+                      size_t ws_bytes, int64_t Q, int64_t num_quads, int64_t K, float* out_vertices, int64_t* out_faces,
+                      float* L_dev, void* stream);
+int gs_flexicubes_bwd(int R0, int R1, int R2, const float* vertices, const float* sdf, const float* alpha,
+                      const float* beta, const float* gamma, float weight_scale, float sdf_eps, const void* ws,
+                      size_t ws_bytes, int64_t Q, int64_t num_quads, int64_t K, const float* out_vertices,
+                      const float* v_out_vertices, const float* v_L_dev, float* g_vd_scratch, float* g_vertices,
+                      float* g_sdf, float* g_alpha, float* g_beta, float* g_gamma, void* stream);
+int gs_flexicubes_entropy_fwd(int R0, int R1, int R2, const float* sdf, void* ws, size_t ws_bytes, float* out, void* stream);
+int gs_flexicubes_entropy_bwd(int R0, int R1, int R2, const float* sdf, const void* ws, size_t ws_bytes, const float* v_out,
+                              float* g_sdf, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -453,7 +453,7 @@ extern "C" int gs_specular_weights_build(int R, const float* bounds, const float
 #define GS_STREAM_LOAD(p) (*(p))
 #endif
 #ifndef GS_APPLY_UNROLL
-#define GS_APPLY_UNROLL 12         // patches in flight per wave (4 -> 8 -> 12; 16 loses occupancy to registers)
+#define GS_APPLY_UNROLL 4          // patches in flight per texel and wave (x GS_APPLY_TPW texels)
 #endif
 #ifndef GS_APPLY_WAVES
 #define GS_APPLY_WAVES 4            // texels (waves) per workgroup
@@ -461,63 +461,93 @@ extern "C" int gs_specular_weights_build(int R, const float* bounds, const float
 #ifndef GS_APPLY_LDS
 #define GS_APPLY_LDS 0              // dynamic LDS request (occupancy cap experiment)
 #endif
+#ifndef GS_APPLY_TPW
+#define GS_APPLY_TPW 2              // texels per wave, processed INTERLEAVED (their latency chains overlap)
+#endif
+// TPW texels per wave, interleaved: the offset loads, the weight batches and the tap batches of all TPW texels are
+// issued together, so one wave carries TPW independent latency chains (offsets -> weights (HBM) -> taps -> sum); the taps
+// are branch-free (zero-weight taps read texel 0 and are masked: a branch around a load makes the compiler wait for each
+// tap before it issues the next -- the first version ran its 12 taps strictly one after the other).
+// Measured (scripts/apply_experiment.py, ms per direction over the 6 levels): 12 serial taps 2.04; branch-free U=6 1.88;
+// TPW=2 x U=4 1.76 (default); TPW=2 x 6 1.88; TPW=4 x 3 1.82.  What bounds it (scripts/run_pmc_apply.sh): the weight
+// stream ALONE runs at 5.9-6.6 TB/s in this structure (a plain dword-per-lane stream: 7 TB/s, scripts/micro), the taps
+// hit L1 (1.1 L2 requests per patch) but every tap instruction is 8+ cache-line accesses in the CU's in-order
+// vector-memory pipeline behind the HBM-latency weight loads (latency-FIFO / pending stalls 30 % of the time, waves
+// cannot issue 1/3 of their cycles): the two costs add instead of overlapping.  Dead ends: 16-byte loads throughout (one
+// lane = 4 adjacent taps, 1 instead of 2 memory instructions per patch: 2.09-2.20), source regions staged through LDS
+// per 16-texel workgroup so that only the weight stream uses the memory pipeline (2.63: the three-barrier prologue and
+// the 58 staged texels per output texel cost more than the 211 taps they replace), workgroups of 8 / 16 waves (no L1
+// gain), taps addressed independently of the weights (more lanes fetch: slower at 256^2).
 template <bool SRC4>
 __global__ void __launch_bounds__(64 * GS_APPLY_WAVES)
 specular_apply_kernel(int R, const float* __restrict__ src, const int64_t* __restrict__ patch_offsets, int64_t total_patches,
                       const int32_t* __restrict__ patch_desc, const float* __restrict__ weights,
                       float* __restrict__ dst, int dst_stride, int accumulate)
 {
+    constexpr int TPW = GS_APPLY_TPW, U = GS_APPLY_UNROLL;
     const int lane = threadIdx.x & 63;
-    // XCD-aware order: workgroups go round-robin over the 8 XCDs, so XCD x takes the x-th contiguous eighth of the
-    // texels -- its private L2 then holds "its" part of the source cubemap (neighbouring texels tap the same patches);
-    // the weights are a pure stream and bypass the cache (together +5 %).
-    // Measured dead ends (scripts/apply_experiment.py): 16 texels per wave as one flat prefetched patch list (-30 %),
-    // next-batch prefetch in this kernel (-10 %), 16 patches in flight (-15 %): all lose occupancy to registers; the
-    // kernel streams 2.2-2.9 TB/s and is latency x occupancy bound (2.9-3.5 TB/s even without the texel taps).
 #if GS_APPLY_XCD
     const int per = gridDim.x / 8;
     const int grp = (blockIdx.x % 8) * per + blockIdx.x / 8;
 #else
     const int grp = blockIdx.x;
 #endif
-    // t is wave-uniform: telling the compiler so (readfirstlane) turns the offset / descriptor loads into scalar loads
-    // and the patch address arithmetic into SALU work
-    const int t = __builtin_amdgcn_readfirstlane(grp * GS_APPLY_WAVES + (int)(threadIdx.x >> 6));
+    const int t0 = __builtin_amdgcn_readfirstlane((grp * GS_APPLY_WAVES + (int)(threadIdx.x >> 6)) * TPW);
     const int n = 6 * R * R;
-    if (t >= n) return;
+    if (t0 >= n) return;
     const int lx = lane & 7, ly = lane >> 3;
-    const int64_t p0 = patch_offsets[t];
-    const int64_t p1 = (t + 1 < n) ? patch_offsets[t + 1] : total_patches;
-    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
-    for (int64_t p = p0; p < p1; p += GS_APPLY_UNROLL) {
-        float w[GS_APPLY_UNROLL]; unsigned ti[GS_APPLY_UNROLL];     // 32-bit element offsets: the source is < 4 G floats
+    int64_t pb[TPW], pe[TPW];
 #pragma unroll
-        for (int k = 0; k < GS_APPLY_UNROLL; ++k) {
-            const bool on = p + k < p1;
-            const int d = on ? patch_desc[p + k] : 0;
-            w[k] = on ? GS_STREAM_LOAD(weights + (size_t)(p + k) * 64 + lane) : 0.0f;
-            const int s = d >> 24, by = (d >> 12) & 0xfff, bx = d & 0xfff;
-            ti[k] = (unsigned)(((s * R + (by + ly)) * R + (bx + lx)) * (SRC4 ? 4 : 3));
-        }
-        float v[GS_APPLY_UNROLL][3];
-#pragma unroll
-        for (int k = 0; k < GS_APPLY_UNROLL; ++k) {
-            const bool nz = w[k] != 0.0f;
-            if (SRC4) {
-                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (nz) q = *reinterpret_cast<const float4*>(src + ti[k]);
-                v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z;
-            } else {
-                v[k][0] = nz ? src[ti[k]] : 0.0f; v[k][1] = nz ? src[ti[k] + 1] : 0.0f; v[k][2] = nz ? src[ti[k] + 2] : 0.0f;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < GS_APPLY_UNROLL; ++k) { c0 += v[k][0] * w[k]; c1 += v[k][1] * w[k]; c2 += v[k][2] * w[k]; }
+    for (int j = 0; j < TPW; ++j) {
+        const int t = min(t0 + j, n - 1);
+        pb[j] = patch_offsets[t];
+        pe[j] = (t + 1 < n) ? patch_offsets[t + 1] : total_patches;
+        if (t0 + j >= n) pe[j] = pb[j];
     }
-    c0 = gs_wave_sum(c0); c1 = gs_wave_sum(c1); c2 = gs_wave_sum(c2);
-    if (lane == 0) {
-        float* q = dst + (size_t)t * dst_stride;
-        if (accumulate) { q[0] += c0; q[1] += c1; q[2] += c2; } else { q[0] = c0; q[1] = c1; q[2] = c2; }
+    int64_t longest = 0;
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) longest = max(longest, pe[j] - pb[j]);
+    float c[TPW][3];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) c[j][0] = c[j][1] = c[j][2] = 0.0f;
+    for (int64_t o = 0; o < longest; o += U) {
+        float w[TPW][U]; unsigned ti[TPW][U];
+#pragma unroll
+        for (int j = 0; j < TPW; ++j)
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int64_t p = pb[j] + o + k;
+                const bool on = p < pe[j];
+                const int d = on ? patch_desc[p] : 0;
+                w[j][k] = on ? GS_STREAM_LOAD(weights + (size_t)p * 64 + lane) : 0.0f;
+                const int sf = d >> 24, by = (d >> 12) & 0xfff, bx = d & 0xfff;
+                ti[j][k] = (unsigned)(((sf * R + (by + ly)) * R + (bx + lx)) * (SRC4 ? 4 : 3));
+            }
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            float v[U][3];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const bool nz = w[j][k] != 0.0f;                     // zero-weight taps (outside the lobe / the face) read
+                const unsigned a = nz ? ti[j][k] : 0u;               // texel 0 and are masked: no branch around the load
+                if (SRC4) {
+                    const float4 q = *reinterpret_cast<const float4*>(src + a);
+                    v[k][0] = nz ? q.x : 0.0f; v[k][1] = nz ? q.y : 0.0f; v[k][2] = nz ? q.z : 0.0f;
+                } else {
+                    v[k][0] = nz ? src[a] : 0.0f; v[k][1] = nz ? src[a + 1] : 0.0f; v[k][2] = nz ? src[a + 2] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) { c[j][0] += v[k][0] * w[j][k]; c[j][1] += v[k][1] * w[j][k]; c[j][2] += v[k][2] * w[j][k]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const float s0 = gs_wave_sum(c[j][0]), s1 = gs_wave_sum(c[j][1]), s2 = gs_wave_sum(c[j][2]);
+        if (lane == 0 && t0 + j < n) {
+            float* q = dst + (size_t)(t0 + j) * dst_stride;
+            if (accumulate) { q[0] += s0; q[1] += s1; q[2] += s2; } else { q[0] = s0; q[1] = s1; q[2] = s2; }
+        }
     }
 }
 
@@ -527,7 +557,7 @@ extern "C" int gs_specular_apply(int R, const float* src, int src_stride, const 
 {
     GS_CHECK_ARG(R >= 1 && src && patch_offsets && patch_desc && weights && dst && dst_stride >= 3, "bad arguments");
     GS_CHECK_ARG(src_stride == 3 || src_stride == 4, "src_stride must be 3 or 4");
-    const int groups = (gs_cdiv(6 * R * R, GS_APPLY_WAVES) + 7) / 8 * 8;   // multiple of 8: one contiguous share per XCD
+    const int groups = (gs_cdiv(6 * R * R, GS_APPLY_WAVES * GS_APPLY_TPW) + 7) / 8 * 8;   // multiple of 8: one contiguous share per XCD
     if (src_stride == 4)
         hipLaunchKernelGGL(specular_apply_kernel<true>, dim3(groups), dim3(64 * GS_APPLY_WAVES), GS_APPLY_LDS, (hipStream_t)stream, R, src,
                            patch_offsets, total_patches, patch_desc, weights, dst, dst_stride, accumulate);

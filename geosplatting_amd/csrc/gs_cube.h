@@ -7,10 +7,22 @@
 #include "gs_common.h"
 
 struct FaceMap { int a, b, c; float sx, sy; };
-static __device__ __constant__ FaceMap c_faces[6] = {
-    { 2, 1, 0, -1.0f, -1.0f }, { 2, 1, 0, 1.0f, -1.0f }, { 0, 2, 1, 1.0f, 1.0f },
-    { 0, 2, 1, 1.0f, -1.0f },  { 0, 1, 2, 1.0f, -1.0f }, { 0, 1, 2, -1.0f, -1.0f },
-};
+// The per-face axis map  { a, b, c, sx, sy }:
+//   +x {2,1,0,-1,-1}  -x {2,1,0,+1,-1}  +y {0,2,1,+1,+1}  -y {0,2,1,+1,-1}  +z {0,1,2,+1,-1}  -z {0,1,2,-1,-1}
+// computed, not looked up: the face index differs per lane, so a __constant__ table is a VECTOR memory load -- and its
+// s_waitcnt also waits for every texel tap issued before it (loads return in order), which chained the taps of
+// successive cube lookups one after the other.
+__device__ __forceinline__ FaceMap face_map(int s)
+{
+    const int axis = s >> 1;
+    FaceMap m;
+    m.a = axis == 0 ? 2 : 0;
+    m.b = axis == 1 ? 2 : 1;
+    m.c = axis;
+    m.sx = (s == 0 || s == 5) ? -1.0f : 1.0f;
+    m.sy = s == 2 ? 1.0f : -1.0f;
+    return m;
+}
 
 __device__ __forceinline__ int select_face(const float* d)
 {
@@ -46,7 +58,7 @@ __device__ int resolve_texel(int s, int ix, int iy, int R)
     float p[3];
     face_point(s, xn, yn, p);
     const int s2 = select_face(p);
-    const FaceMap m = c_faces[s2];
+    const FaceMap m = face_map(s2);
     const float inv = 1.0f / fabsf(comp3(p, m.c));
     const float x2 = m.sx * comp3(p, m.a) * inv, y2 = m.sy * comp3(p, m.b) * inv;
     const float tx = (x2 + 1.0f) * 0.5f * (float)R - 0.5f, ty = (y2 + 1.0f) * 0.5f * (float)R - 0.5f;
@@ -67,7 +79,7 @@ struct CubeFp {
 __device__ void cube_footprint(const float* d, int R, CubeFp& fp)
 {
     const int s = select_face(d);
-    const FaceMap m = c_faces[s];
+    const FaceMap m = face_map(s);
     const float ac = fabsf(comp3(d, m.c));
     fp.valid = (ac > 0.0f) && isfinite(ac);
     fp.face = s;
@@ -140,7 +152,7 @@ __device__ void cube_fetch(const float* __restrict__ tex, int R, const float* d,
         if (WITH_GRAD) { for (int i = 0; i < 9; ++i) dd[i] = 0.0f; }
         return;
     }
-    const FaceMap m = c_faces[fp.face];
+    const FaceMap m = face_map(fp.face);
     const float sgn_c = comp3(d, m.c) < 0.0f ? -1.0f : 1.0f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {

@@ -10,6 +10,8 @@ Public surface (mirrors the reference's two call boundaries, SURVEY.md section 8
   HashEncoding / hash_encode              == HashEncoding backend='torch', rfstudio/model/components/encoding.py:87-241 (rank 3)
   FlexiCubes / get_geometry               == FlexiCubes.dual_marching_cubes / compute_entropy, rfstudio/graphics/_mesh/_flexicubes.py:369-802,
                                              GeoSplatter.get_geometry rfstudio/model/geosplat.py:751-769 (rank 4)
+  stage1.Stage1Model / stage1.train_step  == GeoSplatter (stage 1) + GeoSplatTrainer.step, rfstudio/model/geosplat.py:676-927,
+                                             rfstudio/trainer/geosplat_trainer.py:150-186 (BASELINE config 5)
 Every op calls hand-written HIP kernels in libgeosplat_hip.so through the C-ABI of include/geosplat_hip.h and
 raises if that library is missing -- there is no CPU or PyTorch fallback path.
 """

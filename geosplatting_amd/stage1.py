@@ -1,0 +1,196 @@
+"""The reference's stage-1 model and trainer step (BASELINE config 5: "full geosplat.py MGAdaptor training loop,
+FlexiCubes -> splats -> PBR"), composed from this package's HIP-backed pieces and data-parallel over views.
+
+`Stage1Model` mirrors `GeoSplatter` (rfstudio/model/geosplat.py:676-927): parameters `sdf_params`, `deform_params`,
+`weight_params`, `cubemap`, `exposure_params`, the `GaussianField` encoders, the scalar weights of `__setup__`
+(:703-728) and `get_geometry / get_envmap / get_gsplat('face') / render_report` in the reference's order.  `train_step`
+is `GeoSplatTrainer.step` (rfstudio/trainer/geosplat_trainer.py:150-186): per-view random-background SSIM/L1 + mask loss,
+mean over the views, plus the regulariser.
+
+Data parallel (one process per GPU): every rank holds the same parameters, extracts the same mesh, renders ITS views
+(`views[rank::world_size]`), and the gradients of all parameters travel as ONE flat fp32 all-reduce (RCCL over xGMI).
+With the loss normalised by the global view count and the regulariser by the world size, the reduced gradient is the
+single-process gradient.  The 'grad' / 'tv' smoothing branches of render_report (:879-921, kornia spatial_gradient over
+extra renders) are not built; `smooth_type` 'jitter' (the default) is.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from .cameras import Camera
+from .field import GaussianField
+from .flexicubes import FlexiCubes, get_geometry
+from .loss import photo_loss
+from .splitsum import as_splitsum
+
+_INITIAL_GUESS = {"outdoor": (0.0, 0.0), "diffuse": (0.0, -3.0), "hybrid": (-3.0, -3.0), "specular": (-3.0, 0.0),
+                  "glossy": (-3.0, 0.0)}                                   # geosplat.py:729-740
+
+
+class Stage1Model:
+    def __init__(self, resolution: int = 32, *, scale: float = 1.05, light_resolution: int = 512, min_roughness: float = 0.1,
+                 max_metallic: float = 1.0, initial_guess: str = "hybrid", device="cuda", seed: int = 0,
+                 log2_hashmap_size: int = 18, sdf_init: Optional[Tensor] = None):
+        dev = torch.device(device)
+        g = torch.Generator(device=dev).manual_seed(seed)
+        self.resolution, self.scale = resolution, scale
+        self.min_roughness, self.max_metallic = min_roughness, max_metallic
+        self.grid = FlexiCubes.from_resolution(resolution, device=dev, random_sdf=False, scale=scale)
+        V, Cn = self.grid.vertices.shape[0], resolution ** 3
+        # from_resolution's sdf = U(0,1) - 0.1 (:447-451), replicated on every rank from the seed
+        sdf0 = (torch.rand(V, 1, device=dev, generator=g) - 0.1) if sdf_init is None else sdf_init.to(dev).reshape(V, 1).clone()
+        self.sdf_params = sdf0.requires_grad_(True)
+        self.deform_params = torch.zeros(V, 3, device=dev, requires_grad=True)
+        self.weight_params = torch.zeros(Cn, 21, device=dev, requires_grad=True)
+        self.cubemap = torch.full((6, light_resolution, light_resolution, 3), 0.5, device=dev, requires_grad=True)   # :741-748
+        self.exposure_params = torch.zeros(1, device=dev, requires_grad=True)
+        self.field = GaussianField(device=dev, log2_hashmap_size=log2_hashmap_size, seed=seed + 1)
+        self.initial_guess_bias = torch.tensor(_INITIAL_GUESS[initial_guess], device=dev)
+        # scalar weights of __setup__ (:715-727); the trainer's schedule sets them
+        self.sdf_weight = 0.0; self.light_weight = 0.0
+        self.kd_grad_weight = 0.0; self.kd_regualr_perturb_std = 0.0
+        self.ks_grad_weight = 0.0; self.ks_regualr_perturb_std = 0.0
+        self.last_num_gaussians = 0
+
+    # ------------------------------------------------------------------------------------------------- parameters
+    def named_parameters(self) -> Dict[str, Tensor]:
+        out = {"sdf_params": self.sdf_params, "deform_params": self.deform_params, "weight_params": self.weight_params,
+               "cubemap": self.cubemap, "exposure_params": self.exposure_params}
+        for name, enc in (("kd_enc", self.field.kd_enc), ("ks_enc", self.field.ks_enc), ("z_enc", self.field.z_enc)):
+            for i, p in enumerate(enc.parameters()):
+                out[f"field.{name}.{i}"] = p
+        return out
+
+    def parameters(self) -> List[Tensor]:
+        return list(self.named_parameters().values())
+
+    # ------------------------------------------------------------------------------------------------- forward pieces
+    def get_geometry(self) -> Tuple[Tuple[Tensor, Tensor], Tensor]:
+        """:751-769"""
+        return get_geometry(self.grid, self.deform_params, self.sdf_params, self.weight_params, scale=self.scale,
+                            resolution=self.resolution, sdf_weight=self.sdf_weight)
+
+    def get_envmap(self):
+        """:780-785 -> (TextureSplitSum, white-balance regulariser)"""
+        white = self.cubemap.mean(-1, keepdim=True)
+        return as_splitsum(self.cubemap), (self.cubemap - white).abs().mean()
+
+    def get_gsplat(self):
+        """:787-831 with sampling='face', smooth_type='jitter' -> (mesh, splats, attrs, regularisation)"""
+        (v, f), reg = self.get_geometry()
+        self.last_num_gaussians = f.shape[0] * 6
+        splats, attrs, _ = self.field.get_gaussians_from_face(v, f, self.kd_regualr_perturb_std, self.ks_regualr_perturb_std,
+                                                              scale=self.scale, initial_guess=self.initial_guess_bias)
+        if self.kd_regualr_perturb_std > 0 and self.kd_grad_weight > 0:
+            reg = reg + self.kd_grad_weight * (attrs.kd_jitter - attrs.kd).abs().mean()
+        if self.ks_regualr_perturb_std > 0 and self.ks_grad_weight > 0:
+            reg = reg + self.ks_grad_weight * (attrs.ks_jitter - attrs.ks).abs().mean()
+        return (v, f), splats, attrs, reg
+
+    def render_report(self, cameras: Sequence[Camera]) -> Tuple[List[Tensor], int, Tensor]:
+        """:856-927 -> (tone-mapped linear RGBA image per camera, #Gaussians, regularisation)"""
+        _, splats, attrs, reg = self.get_gsplat()
+        envmap, light_reg = self.get_envmap()
+        exposure = self.exposure_params.exp()[0]
+        images = [attrs.splat(splats, [cam], exposure=exposure, envmap=envmap, min_roughness=self.min_roughness,
+                              max_metallic=self.max_metallic).reshape(cam.height, cam.width, 4) for cam in cameras]
+        return images, splats.means.shape[0], reg + light_reg * self.light_weight
+
+
+def flat_all_reduce(grads: List[Tensor], group=None) -> None:
+    """One flat fp32 all-reduce (sum) over a list of gradient tensors, written back in place."""
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, group=group)
+    o = 0
+    for g in grads:
+        g.copy_(flat[o:o + g.numel()].view_as(g)); o += g.numel()
+
+
+def train_step(model: Stage1Model, cameras: Sequence[Camera], gt_rgba: Sequence[Tensor], *, gt_is_srgb: bool = True,
+               use_mask_loss: bool = True, rank: int = 0, world_size: int = 1, all_reduce: Optional[bool] = None,
+               bg_generator: Optional[torch.Generator] = None, train_bg: Optional[Sequence[Tensor]] = None) -> Dict[str, Tensor]:
+    """One `GeoSplatTrainer.step` + backward over ALL `cameras`, of which this rank renders `cameras[rank::world_size]`.
+    Leaves d(loss + regularisation)/d(parameter) of the GLOBAL batch in every parameter's .grad (after the flat
+    all-reduce when world_size > 1).  train_bg: fixed per-view backgrounds instead of the trainer's torch.rand_like
+    (tests).  Returns detached metrics of the local views."""
+    n_total = len(cameras)
+    mine = list(range(rank, n_total, world_size))
+    for p in model.parameters():
+        p.grad = None
+    images, num_gaussians, reg = model.render_report([cameras[i] for i in mine])
+    total = reg / world_size                                            # identical on every rank: counted once
+    local = []
+    for i, img in zip(mine, images):
+        gt = gt_rgba[i]
+        bg = train_bg[i] if train_bg is not None else \
+            torch.rand(img.shape[0], img.shape[1], 3, device=img.device, generator=bg_generator)    # :172
+        loss, _ = photo_loss(img[..., :3], img[..., 3:], gt, bg, gt_is_srgb=gt_is_srgb, use_mask_loss=use_mask_loss)
+        local.append(loss.detach())
+        total = total + loss / n_total
+    total.backward()
+    params = model.parameters()
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    if (world_size > 1) if all_reduce is None else all_reduce:
+        flat_all_reduce([p.grad for p in params])
+    return {"loss_local_views": torch.stack(local).mean() if local else torch.zeros(()), "regularization": reg.detach(),
+            "#gaussians": torch.tensor(num_gaussians), "exposure": model.exposure_params.detach().exp().mean()}
+
+
+def _main() -> None:
+    """Launched as `python -m torch.distributed.run --nproc-per-node N -m geosplatting_amd.stage1 [iters]`: a short
+    synthetic stage-1 run (ellipsoid target rendered through the same path), loss printed by rank 0."""
+    import sys
+
+    from . import synthetic as syn
+    from .mesh import mesh_to_splats, vertex_normals
+    from .shading import RenderableAttrs
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    R, HW, n_views = 64, 256, max(8, world)
+    cams = syn.blender_cameras(n_views, HW, HW)
+    grid = FlexiCubes.from_resolution(R, device=dev, random_sdf=False, scale=1.05)
+    with torch.no_grad():
+        sdf_gt = (grid.vertices * torch.tensor([1.0, 1.25, 0.85], device=dev)).norm(dim=-1, keepdim=True) - 0.6
+        (vg, fg), _ = grid.replace(sdf_values=sdf_gt).dual_marching_cubes()
+        sp, n = mesh_to_splats(vg, fg, vertex_normals(vg, fg))
+        N = sp.means.shape[0]
+        attrs = RenderableAttrs(kd=torch.tensor([0.8, 0.3, 0.2], device=dev).expand(N, 3).contiguous(),
+                                ks=torch.tensor([0.4, 0.1], device=dev).expand(N, 2).contiguous(), normals=n)
+        env = as_splitsum(syn.make_cubemap(128).to(dev))
+        gts = [attrs.splat(sp, [c], exposure=torch.tensor(1.0, device=dev), envmap=env, min_roughness=0.1,
+                           max_metallic=1.0).reshape(HW, HW, 4) for c in cams]
+    model = Stage1Model(R, light_resolution=128, device=dev, log2_hashmap_size=16,
+                        sdf_init=grid.vertices.norm(dim=-1, keepdim=True) - 0.5)
+    model.sdf_weight = 0.1
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3)
+    import time
+    t0 = None
+    for it in range(iters):
+        if it == 2:                                          # after the table builds / allocator warm-up
+            torch.cuda.synchronize(); t0 = time.time()
+        m = train_step(model, cams, gts, gt_is_srgb=False, rank=rank, world_size=world)
+        opt.step()
+        if rank == 0 and (it % 5 == 0 or it == iters - 1):
+            print(f"iter {it:3d}  loss(local views) {float(m['loss_local_views']):.4f}  reg {float(m['regularization']):.4f}  "
+                  f"#gaussians {int(m['#gaussians'])}", flush=True)
+    torch.cuda.synchronize()
+    if rank == 0 and t0 is not None and iters > 2:
+        print(f"{(time.time() - t0) / (iters - 2) * 1e3:.1f} ms per iteration ({n_views} views of {HW}x{HW}, grid {R}^3, {world} rank(s))")
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    _main()

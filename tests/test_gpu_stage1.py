@@ -1,63 +1,110 @@
-"""One stage-1 iteration of the reference's geosplat loop, end to end on the HIP kernels, in the order
-`GeoSplatter.render_report` runs it (rfstudio/model/geosplat.py:856-927): get_geometry (FlexiCubes) -> vertex normals ->
-MGAdapter -> hash-grid field -> split-sum prefilter -> shade + rasterize + tone-map -> trainer loss -> backward into the
-SDF / deformation / FlexiCubes weights / field / cubemap / exposure, stepped by Adam for a few iterations."""
+"""BASELINE config 5 -- the reference's whole stage-1 iteration on the HIP kernels, in `GeoSplatter.render_report` /
+`GeoSplatTrainer.step` order (rfstudio/model/geosplat.py:856-927, rfstudio/trainer/geosplat_trainer.py:150-186):
+get_geometry (FlexiCubes) -> vertex normals -> MGAdapter -> hash-grid field -> split-sum prefilter -> shade + rasterize +
+tone-map -> per-view loss -> backward into SDF / deformation / FlexiCubes weights / field / cubemap / exposure; Adam steps
+reduce the loss, and two data-parallel ranks produce the single-process gradient."""
+import os
+import socket
+import sys
+
 import pytest
 import torch
+import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R, HW, N_VIEWS = 32, 160, 4
 
 
-def test_stage1_iterations_reduce_the_loss():
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _scene(dev):
+    """target images: an ellipsoid with a fixed albedo, rendered through the same path"""
     import geosplatting_amd as gs
     from geosplatting_amd import synthetic as syn
-    from geosplatting_amd.field import GaussianField
-    from geosplatting_amd.loss import photo_loss
-    dev = torch.device("cuda")
-    torch.manual_seed(3)
-    R, scale, HW = 32, 1.0, 160
-    grid = gs.FlexiCubes.from_resolution(R, device=dev, random_sdf=False, scale=scale)
-    cams = syn.blender_cameras(4, HW, HW)
-    env_gt = gs.as_splitsum(syn.make_cubemap(64).to(dev))
-    # target: an ellipsoid with a fixed albedo, rendered through the same path
+    cams = syn.blender_cameras(N_VIEWS, HW, HW)
+    grid = gs.FlexiCubes.from_resolution(R, device=dev, random_sdf=False, scale=1.0)
     with torch.no_grad():
         sdf_gt = (grid.vertices * torch.tensor([1.0, 1.25, 0.85], device=dev)).norm(dim=-1, keepdim=True) - 0.55
         (vg, fg), _ = grid.replace(sdf_values=sdf_gt).dual_marching_cubes()
-        sp_gt, n_gt = gs.mesh_to_splats(vg, fg, gs.vertex_normals(vg, fg))
-        N = sp_gt.means.shape[0]
-        attrs_gt = gs.RenderableAttrs(kd=torch.tensor([0.8, 0.3, 0.2], device=dev).expand(N, 3).contiguous(),
-                                      ks=torch.tensor([0.4, 0.1], device=dev).expand(N, 2).contiguous(), normals=n_gt)
-        gts = [attrs_gt.splat(sp_gt, [c], exposure=torch.tensor(1.0, device=dev), envmap=env_gt, min_roughness=0.1,
-                              max_metallic=1.0).reshape(HW, HW, 4) for c in cams]
-    # model: a sphere SDF, zero deformation / weights, fresh field, grey cubemap
-    sdf = (grid.vertices.norm(dim=-1, keepdim=True) - 0.5).clone().requires_grad_(True)
-    deform = torch.zeros_like(grid.vertices).requires_grad_(True)
-    weights = torch.zeros(R ** 3, 21, device=dev).requires_grad_(True)
-    cubemap = torch.full((6, 64, 64, 3), 0.5, device=dev).requires_grad_(True)
-    log_exposure = torch.zeros(1, device=dev).requires_grad_(True)
-    field = GaussianField(device=dev, log2_hashmap_size=15, seed=1)
-    guess = torch.tensor([0.0, -1.0], device=dev)
-    opt = torch.optim.Adam([dict(params=[sdf], lr=3e-3), dict(params=[deform, weights], lr=1e-2),
-                            dict(params=field.parameters(), lr=1e-2), dict(params=[cubemap, log_exposure], lr=1e-2)])
+        sp, n = gs.mesh_to_splats(vg, fg, gs.vertex_normals(vg, fg))
+        N = sp.means.shape[0]
+        attrs = gs.RenderableAttrs(kd=torch.tensor([0.8, 0.3, 0.2], device=dev).expand(N, 3).contiguous(),
+                                   ks=torch.tensor([0.4, 0.1], device=dev).expand(N, 2).contiguous(), normals=n)
+        env = gs.as_splitsum(syn.make_cubemap(64).to(dev))
+        gts = [attrs.splat(sp, [c], exposure=torch.tensor(1.0, device=dev), envmap=env, min_roughness=0.1,
+                           max_metallic=1.0).reshape(HW, HW, 4) for c in cams]
+    return cams, gts, grid
+
+
+def _model(dev, grid):
+    from geosplatting_amd.stage1 import Stage1Model
+    m = Stage1Model(R, scale=1.0, light_resolution=64, device=dev, seed=1, log2_hashmap_size=15, initial_guess="outdoor",
+                    sdf_init=grid.vertices.norm(dim=-1, keepdim=True) - 0.5)
+    m.sdf_weight, m.light_weight = 0.1, 0.01
+    m.kd_regualr_perturb_std = m.ks_regualr_perturb_std = 0.02; m.kd_grad_weight = m.ks_grad_weight = 0.05
+    return m
+
+
+def test_stage1_iterations_reduce_the_loss():
+    from geosplatting_amd.stage1 import train_step
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    cams, gts, grid = _scene(dev)
+    model = _model(dev, grid)
+    p = model.named_parameters()
+    opt = torch.optim.Adam([dict(params=[p["sdf_params"]], lr=3e-3),
+                            dict(params=[v for k, v in p.items() if k != "sdf_params"], lr=1e-2)])
     losses, faces_seen = [], set()
     for it in range(12):
-        opt.zero_grad(set_to_none=True)
-        (v, f), reg = gs.get_geometry(grid, deform, sdf, weights, scale=scale, resolution=R, sdf_weight=0.1)
-        faces_seen.add(f.shape[0])
-        splats, attrs, _ = field.get_gaussians_from_face(v, f, 0.0, 0.0, scale=scale, initial_guess=guess)
-        envmap = gs.as_splitsum(cubemap)
-        total = reg
-        for cam, gt in zip(cams, gts):
-            img = attrs.splat(splats, [cam], exposure=log_exposure.exp()[0], envmap=envmap, min_roughness=0.1,
-                              max_metallic=1.0).reshape(HW, HW, 4)
-            loss, _ = photo_loss(img[..., :3], img[..., 3:], gt, torch.rand(HW, HW, 3, device=dev), gt_is_srgb=False)
-            total = total + loss / len(cams)
-        total.backward()
-        for t in [sdf, deform, weights, cubemap, log_exposure] + field.parameters():
-            assert t.grad is not None and torch.isfinite(t.grad).all()
-        assert sdf.grad.abs().max() > 0 and deform.grad.abs().max() > 0 and weights.grad.abs().max() > 0
+        m = train_step(model, cams, gts, gt_is_srgb=False)
+        for k, t in p.items():
+            assert t.grad is not None and torch.isfinite(t.grad).all(), k
+        for k in ("sdf_params", "deform_params", "weight_params", "cubemap", "exposure_params"):
+            assert p[k].grad.abs().max() > 0, k
         opt.step()
-        losses.append(float(total.detach()))
+        losses.append(float(m["loss_local_views"] + m["regularization"]))
+        faces_seen.add(int(m["#gaussians"]))
     assert losses[-1] < 0.8 * losses[0], losses
     assert len(faces_seen) > 1                              # the topology (face count) changed while optimising
     print("\nstage-1 losses:", " ".join(f"{l:.4f}" for l in losses))
+
+
+def _grads(dev, rank, world):
+    from geosplatting_amd.stage1 import train_step
+    torch.manual_seed(11)                                   # field jitter draws: the same on every rank
+    cams, gts, grid = _scene(dev)
+    model = _model(dev, grid)
+    model.kd_regualr_perturb_std = model.ks_regualr_perturb_std = 0.0    # jitter is a per-rank random draw: off for the comparison
+    bgs = [torch.rand(HW, HW, 3, generator=torch.Generator().manual_seed(70 + i)).to(dev) for i in range(N_VIEWS)]
+    train_step(model, cams, gts, gt_is_srgb=False, rank=rank, world_size=world, train_bg=bgs)
+    torch.cuda.synchronize()
+    return {k: v.grad.detach().cpu().clone() for k, v in model.named_parameters().items()}
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      GEOSPLAT_DEBUG_SHARE_GPU="1")
+    import torch.distributed as dist
+    from geosplatting_amd.parallel import init_distributed_from_env
+    r, w, dev = init_distributed_from_env("cuda")
+    torch.save(_grads(dev, r, w), os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stage1_two_ranks_equal_single_process(tmp_path):
+    """views sharded over two ranks (gloo on one GPU), one flat gradient all-reduce: every parameter's gradient -- SDF,
+    deformation, FlexiCubes weights, hash tables, MLPs, cubemap, exposure -- equals the single-process one"""
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(2)]
+    want = _grads(torch.device("cuda", 0), 0, 1)
+    for k, w in want.items():
+        scale = w.abs().max().item() + 1e-30
+        for r in range(2):
+            err = (got[r][k] - w).abs().max().item() / scale
+            assert err < 5e-4, (k, r, err)          # atomics / summation order across views
+        assert torch.equal(got[0][k], got[1][k]), k

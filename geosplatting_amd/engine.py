@@ -61,6 +61,13 @@ class RenderStep:
         self._tail_stream = None
         self._pre_stream = None
 
+    def rebind(self, params: PathParams) -> None:
+        """New parameter tensors for the next step (a stage-1 loop extracts a different number of Gaussians every
+        iteration): the gradient bucket is re-laid out when a shape changed; streams and camera tensors are kept."""
+        self.p = params
+        if {k: tuple(v) for k, v in params.shapes().items()} != self.bucket.shapes:
+            self.bucket = GradBucket(params.shapes(), params.means.device, comm_stream=self.bucket.comm_stream)
+
     # ------------------------------------------------------------------------------------------------- fused path
     def _camera_tensors(self, cam: Camera):
         key = id(cam)
@@ -317,7 +324,7 @@ class MeshStep:
         if self.step is None:
             self.step = RenderStep(params, **self.render_kwargs)
         else:
-            self.step.p = params
+            self.step.rebind(params)
         grads, images = self.step(cameras, upstream, all_reduce=all_reduce, keep_images=keep_images)
         # shading normals == splat colours of the adapter: their gradient rides on `nrm`
         torch.autograd.backward([sp.means, sp.scales, sp.quats, nrm],

@@ -28,7 +28,7 @@ def shard_views(num_views: int, rank: int, world_size: int) -> List[int]:
 class GradBucket:
     """One flat fp32 buffer holding every parameter gradient of the path."""
 
-    def __init__(self, shapes: Dict[str, Sequence[int]], device: torch.device):
+    def __init__(self, shapes: Dict[str, Sequence[int]], device: torch.device, comm_stream=None):
         self.names = list(shapes.keys())
         self.shapes = {k: tuple(v) for k, v in shapes.items()}
         self.offsets: Dict[str, int] = {}
@@ -41,7 +41,8 @@ class GradBucket:
             off += (n + 63) // 64 * 64              # 256-byte aligned segments
         self.numel = off
         self.flat = torch.zeros(off, dtype=torch.float32, device=device)
-        self.comm_stream = torch.cuda.Stream(device=device) if device.type == "cuda" else None
+        self.comm_stream = (comm_stream if comm_stream is not None else torch.cuda.Stream(device=device)) \
+            if device.type == "cuda" else None
 
     def view(self, name: str) -> Tensor:
         o = self.offsets[name]

@@ -102,6 +102,46 @@ class Stage1Model:
         return images, splats.means.shape[0], reg + light_reg * self.light_weight
 
 
+def train_step_fused(model: Stage1Model, cameras: Sequence[Camera], gt_rgba: Sequence[Tensor], *, gt_is_srgb: bool = True,
+                     use_mask_loss: bool = True, rank: int = 0, world_size: int = 1, seed: int = 0,
+                     train_bg: Optional[Sequence[Tensor]] = None) -> Dict[str, Tensor]:
+    """`train_step` with the render / loss half on the hand-scheduled engine (engine.RenderStep: C-ABI drivers on three
+    streams, loss gradient from gs_photo_loss, per-Gaussian gradient bucket) instead of one autograd graph per view.
+    The all-reduce happens at the per-Gaussian cut (every rank extracted the same Gaussians), after which each rank
+    runs the same field / MGAdapter / FlexiCubes backward: no second collective."""
+    from .engine import PathParams, RenderStep
+    from .loss import TrainerUpstream
+    n_total = len(cameras)
+    mine = list(range(rank, n_total, world_size))
+    params = model.parameters()
+    for p in params:
+        p.grad = None
+    _, splats, attrs, reg = model.get_gsplat()
+    white = model.cubemap.mean(-1, keepdim=True)
+    reg = reg + (model.cubemap - white).abs().mean() * model.light_weight
+    exposure = model.exposure_params.exp()
+    cut = [splats.means, splats.scales, splats.quats, splats.opacities, attrs.normals, attrs.kd, attrs.ks]
+    pp = PathParams(*[t.detach().contiguous() for t in cut], model.cubemap.detach(), exposure.detach().reshape(()))
+    step = getattr(model, "_render_step", None)
+    if step is None:
+        step = model._render_step = RenderStep(pp, min_roughness=model.min_roughness, max_metallic=model.max_metallic)
+    else:
+        step.rebind(pp)
+    up = TrainerUpstream([gt_rgba[i] for i in mine], n_total, gt_is_srgb=gt_is_srgb, use_mask_loss=use_mask_loss, seed=seed + rank,
+                         train_bg=None if train_bg is None else [train_bg[i] for i in mine])
+    g, _ = step([cameras[i] for i in mine], up, all_reduce=world_size > 1)
+    heads = cut + [exposure]
+    gh = [g["means"], g["scales"], g["quats"], g["opacities"], g["normals"], g["kd"], g["ks"], g["exposure"].reshape(1)]
+    keep = [(h, gg) for h, gg in zip(heads, gh) if h.requires_grad]
+    torch.autograd.backward([h for h, _ in keep] + [reg], [gg.reshape(h.shape) for h, gg in keep] + [torch.ones_like(reg)])
+    model.cubemap.grad = g["cubemap"].clone() if model.cubemap.grad is None else model.cubemap.grad + g["cubemap"]
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    return {"loss_local_views": up.mean_loss() * (n_total / max(1, len(mine))), "regularization": reg.detach(),
+            "#gaussians": torch.tensor(splats.means.shape[0]), "exposure": exposure.detach().mean()}
+
+
 def flat_all_reduce(grads: List[Tensor], group=None) -> None:
     """One flat fp32 all-reduce (sum) over a list of gradient tensors, written back in place."""
     flat = torch.cat([g.reshape(-1) for g in grads])
@@ -180,7 +220,8 @@ def _main() -> None:
     for it in range(iters):
         if it == 2:                                          # after the table builds / allocator warm-up
             torch.cuda.synchronize(); t0 = time.time()
-        m = train_step(model, cams, gts, gt_is_srgb=False, rank=rank, world_size=world)
+        m = (train_step if os.environ.get("GEOSPLAT_STAGE1_AUTOGRAD") == "1" else train_step_fused)(
+            model, cams, gts, gt_is_srgb=False, rank=rank, world_size=world)
         opt.step()
         if rank == 0 and (it % 5 == 0 or it == iters - 1):
             print(f"iter {it:3d}  loss(local views) {float(m['loss_local_views']):.4f}  reg {float(m['regularization']):.4f}  "

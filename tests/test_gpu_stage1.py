@@ -72,8 +72,9 @@ def test_stage1_iterations_reduce_the_loss():
     print("\nstage-1 losses:", " ".join(f"{l:.4f}" for l in losses))
 
 
-def _grads(dev, rank, world):
-    from geosplatting_amd.stage1 import train_step
+def _grads(dev, rank, world, fused=False):
+    from geosplatting_amd.stage1 import train_step, train_step_fused
+    train_step = train_step_fused if fused else train_step
     torch.manual_seed(11)                                   # field jitter draws: the same on every rank
     cams, gts, grid = _scene(dev)
     model = _model(dev, grid)
@@ -84,14 +85,14 @@ def _grads(dev, rank, world):
     return {k: v.grad.detach().cpu().clone() for k, v in model.named_parameters().items()}
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, fused=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       GEOSPLAT_DEBUG_SHARE_GPU="1")
     import torch.distributed as dist
     from geosplatting_amd.parallel import init_distributed_from_env
     r, w, dev = init_distributed_from_env("cuda")
-    torch.save(_grads(dev, r, w), os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.save(_grads(dev, r, w, fused), os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -108,3 +109,17 @@ def test_stage1_two_ranks_equal_single_process(tmp_path):
             err = (got[r][k] - w).abs().max().item() / scale
             assert err < 5e-4, (k, r, err)          # atomics / summation order across views
         assert torch.equal(got[0][k], got[1][k]), k
+
+
+def test_stage1_fused_engine_step_equals_autograd_step(tmp_path):
+    """the same trainer step with the render / loss half on engine.RenderStep (C-ABI drivers on three streams, HIP loss
+    gradient, all-reduce at the per-Gaussian cut): one process against the autograd step, two ranks against one"""
+    want = _grads(torch.device("cuda", 0), 0, 1)
+    one = _grads(torch.device("cuda", 0), 0, 1, fused=True)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), True), nprocs=2, join=True)
+    two = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(2)]
+    for k, w in want.items():
+        scale = w.abs().max().item() + 1e-30
+        for name, got in (("fused", one), ("rank0", two[0]), ("rank1", two[1])):
+            err = (got[k] - w).abs().max().item() / scale
+            assert err < 5e-4, (k, name, err)

@@ -71,6 +71,41 @@ def hash_encode(x: Tensor, table: Tensor, scalings: Tensor, log2_hashmap_size: i
                            1.0 if grad_scaling is None else float(grad_scaling))
 
 
+class _Linear(torch.autograd.Function):
+    """y = x W^T (bias-free layer of rfstudio/nn/mlp.py:126-145).  Forward and dX are library GEMMs (N x 32 x 32: fine);
+    dW = dY^T X is a 32 x 32 x N product that the library runs at 2-5 ms for N = 2 M -- it goes through gs_mlp_wgrad."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor) -> Tensor:
+        ctx.save_for_backward(x, w)
+        return torch.nn.functional.linear(x, w)
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        x, w = ctx.saved_tensors
+        gx = gy @ w if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            lib = _lib.lib()
+            gyc, xc = gy.contiguous().float(), x.detach().contiguous().float()
+            N, O, I = xc.shape[0], w.shape[0], w.shape[1]
+            gw = torch.empty(O, I, device=w.device)
+            nbytes = lib.gs_mlp_wgrad_ws_bytes(_lib.i64(N))
+            ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=w.device)
+            _lib.check(lib.gs_mlp_wgrad(_lib.i64(N), O, I, _lib.ptr(gyc), _lib.ptr(xc), _lib.f32(1.0), _lib.ptr(gw), 0,
+                                        _lib.ptr(ws), C.c_size_t(nbytes), _lib.stream()), "gs_mlp_wgrad")
+        return gx, gw
+
+
+def linear(x: Tensor, w: Tensor) -> Tensor:
+    """torch.nn.functional.linear(x, w); 2-D x with both widths <= 32 (every layer of the field) takes the HIP weight
+    gradient, wider layers are plain library GEMMs in both directions."""
+    if x.dim() == 2 and w.shape[0] <= 32 and w.shape[1] <= 32:
+        _lib.require_cuda(x, w)
+        return _Linear.apply(x.float(), w)
+    return torch.nn.functional.linear(x, w)
+
+
 class HashEncoding:
     """Mirror of the reference's HashEncoding + MLP pair (same field names): `enc(x)` = mlp(hash features)."""
 
@@ -99,7 +134,7 @@ class HashEncoding:
     def __call__(self, x: Tensor) -> Tensor:
         f = hash_encode(x, self.hash_table, self.scalings, self.log2_hashmap_size, self.grad_scaling)
         for i, w in enumerate(self.weights):
-            f = torch.nn.functional.linear(f, w)
+            f = linear(f, w)
             if i < len(self.weights) - 1:
                 f = torch.relu(f)
             elif self.activation == "sigmoid":

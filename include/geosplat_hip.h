@@ -279,6 +279,13 @@ int gs_hashgrid_bwd(int N, int L, int F, int log2_T, const float* scalings_host,
                     void* ws /* with it: atomic-free LDS-slab kernel; NULL: per-point kernel with fp32 atomics */,
                     size_t ws_bytes, void* stream);
 
+/* Weight gradient of one bias-free linear layer of the field's MLPs (rfstudio/nn/mlp.py:126-145; widths <= 32):
+ *   dW[O,I] (+)= scale * dY[N,O]^T X[N,I]   (row-major, contiguous; O, I in [1,32]).  fp32 matrix unit, exact f32;
+ *   deterministic (partials summed in a fixed order).  ws: gs_mlp_wgrad_ws_bytes(N). */
+size_t gs_mlp_wgrad_ws_bytes(int64_t N);
+int gs_mlp_wgrad(int64_t N, int O, int I, const float* dY, const float* X, float scale, float* dW, int accumulate,
+                 void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------ X1: FlexiCubes extraction ------ */
 /* FlexiCubes.dual_marching_cubes(grad_func=None) + compute_entropy on the regular grid of FlexiCubes.from_resolution
  * (rfstudio/graphics/_mesh/_flexicubes.py:397-457, 559-713, 715-802; caller rfstudio/model/geosplat.py:751-769).

@@ -143,3 +143,26 @@ def test_gaussian_field_from_mesh():
     assert torch.isfinite(v.grad).all() and v.grad.abs().max().item() > 0
     for p_ in fld.kd_enc.parameters() + fld.ks_enc.parameters() + fld.z_enc.parameters():
         assert p_.grad is not None and torch.isfinite(p_.grad).all() and p_.grad.abs().max().item() > 0
+
+
+@pytest.mark.parametrize("N,O,I", [(1, 32, 32), (63, 3, 32), (1000, 32, 32), (200001, 2, 32), (4097, 1, 32), (5000, 32, 7), (0, 3, 32)])
+def test_mlp_weight_gradient_kernel(N, O, I):
+    """gs_mlp_wgrad (fp32 matrix unit) vs float64, through the `linear` autograd op; deterministic; dX untouched"""
+    from geosplatting_amd.field import linear
+    g = torch.Generator().manual_seed(N + O)
+    x = torch.randn(N, I, generator=g); w = torch.randn(O, I, generator=g); gy = torch.randn(N, O, generator=g)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    (torch.nn.functional.linear(xd, wd) * gy.double()).sum().backward()
+    outs = []
+    for _ in range(2):
+        xc, wc = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+        y = linear(xc, wc)
+        (y * gy.cuda()).sum().backward()
+        outs.append((y.detach().cpu(), xc.grad.cpu(), wc.grad.cpu()))
+    y, gx, gw = outs[0]
+    assert torch.equal(gw, outs[1][2])                                   # fixed summation order
+    if N > 0:
+        assert (y.double() - torch.nn.functional.linear(xd, wd).detach()).abs().max() < 1e-4
+        assert (gx.double() - xd.grad).abs().max() < 1e-4
+    scale = wd.grad.abs().max().item() + 1e-30
+    assert (gw.double() - wd.grad).abs().max().item() / scale < 2e-6, (gw.double() - wd.grad).abs().max().item() / scale

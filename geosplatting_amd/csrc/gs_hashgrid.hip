@@ -209,6 +209,9 @@ extern "C" int gs_hashgrid_fwd(int N, int L, int F, int log2_T, const float* sca
 // 256 at the GaussianField configuration, one per CU.  v_out is first transposed to level-major so that a workgroup
 // streams 8 contiguous bytes per point.
 #define GS_HG_SLAB_ROWS 16384
+#ifndef GS_HG_EXP
+#define GS_HG_EXP 0          // timing experiments only (scripts/hashgrid_experiment.py): 1 no LDS atomics, 2 no loads, 4 racy adds
+#endif
 
 __global__ void __launch_bounds__(256)
 hashgrid_transpose_kernel(int N, int LF, const float* __restrict__ v_out, float* __restrict__ v_lm)
@@ -239,8 +242,12 @@ hashgrid_bwd_slab_kernel(int N, int L, unsigned log2_T, HgLevels lv, int slabs_p
     const int n_lo = (int)((long long)N * part / parts), n_hi = (int)((long long)N * (part + 1) / parts);
     // PU points per thread and trip, their loads issued together and branch-free (clamped index, gradient zeroed past the
     // end) instead of two dependent L2 round trips per point (gradient, then -- behind the zero-gradient test -- the
-    // position).  Measured 5.6 -> 5.4 ms at 2 M points: the kernel is not at that latency but at the 16-fold redundant
-    // hashing (quarter-rate integer multiplies) plus ~16 sparse ds_add_f32 per 64 points.
+    // position).  Measured 5.6 -> 5.4 ms at 2 M points.  Where the time goes (scripts/hashgrid_experiment.py, 2 M points,
+    // table gradient only): 4.08 ms as is; 1.87 ms without the LDS atomics; 1.60 ms without atomics and loads (hashing +
+    // loop); 2.36 ms with a racy ds_read / add / ds_write in place of ds_add_f32 -- the float LDS atomic itself is the
+    // expensive instruction (54 % of the kernel), four times a plain read-modify-write.  Hashing a quarter of the points
+    // (binned index queues) and a DPP segmented scan that commits one lane per run of equal rows were both built and
+    // both lost.
     constexpr int PU = 4;
     for (int n0 = n_lo + (int)threadIdx.x; n0 < n_hi; n0 += (int)blockDim.x * PU) {
         float2 gq[PU]; float px[PU][3];
@@ -248,8 +255,13 @@ hashgrid_bwd_slab_kernel(int N, int L, unsigned log2_T, HgLevels lv, int slabs_p
         for (int u = 0; u < PU; ++u) {
             const int n = n0 + u * (int)blockDim.x;
             const int nn = min(n, n_hi - 1);
+#if GS_HG_EXP & 2
+            gq[u] = make_float2(1.0f + (float)(nn & 7), 2.0f);           /* timing experiment: no loads */
+            px[u][0] = (float)(nn & 1023) * (1.0f / 1024.0f) - 0.3f; px[u][1] = (float)((nn >> 10) & 1023) * (1.0f / 1024.0f) - 0.4f; px[u][2] = 0.1f;
+#else
             gq[u] = *reinterpret_cast<const float2*>(g_l + 2 * (size_t)nn);
             px[u][0] = x[3 * (size_t)nn]; px[u][1] = x[3 * (size_t)nn + 1]; px[u][2] = x[3 * (size_t)nn + 2];
+#endif
             if (n >= n_hi) gq[u] = make_float2(0.0f, 0.0f);
         }
 #pragma unroll
@@ -273,8 +285,14 @@ hashgrid_bwd_slab_kernel(int N, int L, unsigned log2_T, HgLevels lv, int slabs_p
                         const unsigned r = h - row0;
                         if (r < (unsigned)rows) {
                             const float w = (bx ? o[0] : 1.0f - o[0]) * (by ? o[1] : 1.0f - o[1]) * (bz ? o[2] : 1.0f - o[2]) * table_grad_scale;
+#if GS_HG_EXP & 1
+                            if (w == 123.456f) slab[2 * r] = g.x;       /* timing experiment: no LDS atomics */
+#elif GS_HG_EXP & 4
+                            slab[2 * r] += g.x * w; slab[2 * r + 1] += g.y * w;   /* timing experiment: racy read-modify-write */
+#else
                             atomicAdd(&slab[2 * r], g.x * w);            // (wave pre-aggregation of equal rows was measured: 20 % slower)
                             atomicAdd(&slab[2 * r + 1], g.y * w);
+#endif
                         }
                     }
         }

@@ -167,15 +167,25 @@ class _SpecularCubemap(torch.autograd.Function):
         return g, None, None, None
 
 
+APPLY_PACKED_SRC = os.environ.get("GEOSPLAT_APPLY_SRC", "3") == "3"   # 3: taps read the packed [6,R,R,3] map (one 12-byte load), 4: float4-padded copy
+
+
+def _apply_src(t: Tensor):
+    """(tensor, stride) of the tap source for gs_specular_apply"""
+    if APPLY_PACKED_SRC:
+        return t.contiguous(), 3
+    return torch.nn.functional.pad(t, (0, 1)).contiguous(), 4
+
+
 class _SpecularCubemapCached(torch.autograd.Function):
     """Same operator through the cached pair-weight tables (bit-identical weights, streamed instead of recomputed)."""
 
     @staticmethod
     def forward(ctx, cubemap: Tensor, res: int, roughness: float, cutoff: float) -> Tensor:
         e = specular_weights(res, roughness, cutoff, cubemap.device)
-        src4 = torch.nn.functional.pad(cubemap, (0, 1)).contiguous()          # float4 texels: one 16-byte tap per lane
+        src4, stride = _apply_src(cubemap)
         rgb = torch.empty(6, res, res, 3, dtype=torch.float32, device=cubemap.device)
-        L.check(L.lib().gs_specular_apply(res, L.ptr(src4), 4, L.ptr(e["offsets"]), L.i64(e["total"]), L.ptr(e["desc"]),
+        L.check(L.lib().gs_specular_apply(res, L.ptr(src4), stride, L.ptr(e["offsets"]), L.i64(e["total"]), L.ptr(e["desc"]),
                                           L.ptr(e["fwd"]), L.ptr(rgb), 3, 0, L.stream()), "gs_specular_apply")
         ctx.cfg = (res, roughness, cutoff)
         return rgb / e["wsum"]
@@ -184,9 +194,9 @@ class _SpecularCubemapCached(torch.autograd.Function):
     def backward(ctx, dout: Tensor):
         res, roughness, cutoff = ctx.cfg
         e = specular_weights(res, roughness, cutoff, dout.device)
-        v4 = torch.nn.functional.pad(dout / e["wsum"], (0, 1)).contiguous()
+        v4, stride = _apply_src(dout / e["wsum"])
         g = torch.empty_like(dout, memory_format=torch.contiguous_format)
-        L.check(L.lib().gs_specular_apply(res, L.ptr(v4), 4, L.ptr(e["offsets"]), L.i64(e["total"]), L.ptr(e["desc"]),
+        L.check(L.lib().gs_specular_apply(res, L.ptr(v4), stride, L.ptr(e["offsets"]), L.i64(e["total"]), L.ptr(e["desc"]),
                                           L.ptr(e["bwd"]), L.ptr(g), 3, 0, L.stream()), "gs_specular_apply")
         return g, None, None, None
 
@@ -270,9 +280,9 @@ def as_splitsum_backward(g_base: Tensor, g_levels: List[Tensor], *, cutoff: floa
         res = gl.shape[1]
         if CACHE_PAIR_WEIGHTS:
             e = specular_weights(res, rough, cutoff, gl.device)
-            v4 = torch.nn.functional.pad(gl / e["wsum"], (0, 1)).contiguous()
+            v4, stride = _apply_src(gl / e["wsum"])
             g = torch.empty(6, res, res, 3, dtype=torch.float32, device=gl.device)
-            L.check(L.lib().gs_specular_apply(res, L.ptr(v4), 4, L.ptr(e["offsets"]), L.i64(e["total"]), L.ptr(e["desc"]),
+            L.check(L.lib().gs_specular_apply(res, L.ptr(v4), stride, L.ptr(e["offsets"]), L.i64(e["total"]), L.ptr(e["desc"]),
                                               L.ptr(e["bwd"]), L.ptr(g), 3, 0, L.stream()), "gs_specular_apply")
         else:
             raise L.GeoSplatHipError("as_splitsum_backward needs the cached pair weights (GEOSPLAT_PREFILTER_CACHE=1)")

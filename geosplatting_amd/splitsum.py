@@ -91,6 +91,19 @@ def specular_weights(res: int, roughness: float, cutoff: float, device: torch.de
             entry[name] = w
             if wsum is not None:
                 entry["wsum"] = wsum.view(6, res, res, 1)
+        if DROP_EMPTY_PATCHES and total > 0:
+            # 8x8 patches tile each face AABB of the lobe; the ones in the AABB corners hold no texel inside the lobe.
+            # Membership (dot >= cutoff) is the same in both orientations, so one mask compacts fwd, bwd and the descriptors.
+            keep = (entry["fwd"].view(total, 64) != 0).any(dim=1)
+            csum_k = torch.cumsum(keep.long(), 0)
+            new_total = int(csum_k[-1].item())
+            before = torch.cat((csum_k.new_zeros(1), csum_k))             # kept patches in front of old patch p
+            entry["offsets"] = before[offsets].contiguous()
+            for name in ("fwd", "bwd"):
+                entry[name] = entry[name].view(total, 64)[keep].reshape(-1).contiguous()
+            entry["desc"] = desc[:total][keep].contiguous()
+            entry["total"] = new_total
+            entry["dropped"] = total - new_total
         _weights_cache[key] = entry
     return _weights_cache[key]
 
@@ -167,6 +180,7 @@ class _SpecularCubemap(torch.autograd.Function):
         return g, None, None, None
 
 
+DROP_EMPTY_PATCHES = os.environ.get("GEOSPLAT_DROP_EMPTY_PATCHES", "1") != "0"
 APPLY_PACKED_SRC = os.environ.get("GEOSPLAT_APPLY_SRC", "3") == "3"   # 3: taps read the packed [6,R,R,3] map (one 12-byte load), 4: float4-padded copy
 
 

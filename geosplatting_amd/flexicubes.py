@@ -53,7 +53,8 @@ class _Extract(torch.autograd.Function):
         _lib.check(lib.gs_flexicubes_count(R0, R1, R2, _lib.ptr(s), _lib.ptr(ws), C.c_size_t(ws_bytes), _lib.ptr(counts),
                                            _lib.stream()), "gs_flexicubes_count")
         N, Q, K, E, nq, _, _, _ = counts.tolist()                    # the reference syncs here too (:605, :651)
-        assert N > 0, "no surface cube"                                   # :606
+        if N <= 0:                                                        # the reference asserts here (:606)
+            raise AssertionError("no surface cube: the sdf does not change sign anywhere on the grid")
         out_v = torch.empty(Q + nq, 3, device=dev); faces = torch.empty(4 * nq, 3, dtype=torch.int64, device=dev)
         L_dev = torch.empty(K, device=dev)
         eps = -1.0 if sdf_eps is None else float(sdf_eps)

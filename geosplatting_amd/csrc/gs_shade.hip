@@ -194,7 +194,11 @@ __device__ __forceinline__ void cube_scatter_lds(float* lds, const CubeFp& fp, c
         if (fp.idx[i] < 0) continue;
         const float w = scale * fp.w[i];
         float* p = lds + (size_t)fp.idx[i] * 3;
+#ifdef GS_EXPERIMENT_NO_LDS_TEXEL_ATOMICS
+        if (w == 123.456f) p[0] = g[0];                      /* timing experiment only */
+#else
         atomicAdd(p, g[0] * w); atomicAdd(p + 1, g[1] * w); atomicAdd(p + 2, g[2] * w);
+#endif
     }
 }
 

@@ -45,6 +45,19 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and b"tile_size" in lib.gs_last_error()
     rc = lib.gs_shade_fwd(1, None, None, None, None, None, ctypes.c_float(0.1), ctypes.c_float(1.0), 7, None, None, None)
     assert rc == -1
+    # FlexiCubes / field entry points
+    assert lib.gs_flexicubes_ws_bytes(0, 4, 4) == 0 and lib.gs_flexicubes_ws_bytes(4, 4, 4) > 4 * 64 + 2 * 4 * 64 + 4 * 3 * 125
+    assert lib.gs_flexicubes_ws_bytes(2000, 2000, 2000) == 0                       # 3 * vertices would overflow int32
+    rc = lib.gs_flexicubes_count(0, 4, 4, None, None, ctypes.c_size_t(0), None, None)
+    assert rc == -1 and b"resolution" in lib.gs_last_error()
+    rc = lib.gs_flexicubes_count(4, 4, 4, None, None, ctypes.c_size_t(8), None, None)
+    assert rc == -1 and b"workspace" in lib.gs_last_error()
+    rc = lib.gs_mlp_wgrad(ctypes.c_int64(10), 33, 32, None, None, ctypes.c_float(1.0), None, 0, None, ctypes.c_size_t(0), None)
+    assert rc == -1 and b"[1, 32]" in lib.gs_last_error()
+    lib.gs_mlp_wgrad_ws_bytes.restype = ctypes.c_size_t
+    assert lib.gs_mlp_wgrad_ws_bytes(ctypes.c_int64(1 << 21)) == 1024 * 1024 * 4
+    rc = lib.gs_hashgrid_fwd(10, 16, 3, 18, None, None, None, None, None)
+    assert rc == -1
 
 
 def test_ops_refuse_cpu_tensors():

@@ -80,3 +80,30 @@ def test_bucket_layout_single_process():
     assert u["a"].sum() == 15 and u["b"].item() == 2 and u["c"].abs().sum() == 0
     assert [shard_views(8, r, 8) for r in range(8)] == [[r] for r in range(8)]
     assert shard_views(3, 2, 4) == [2] and shard_views(3, 3, 4) == []
+
+
+def _stage1_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from geosplatting_amd.parallel import init_distributed_from_env
+    from geosplatting_amd.stage1 import flat_all_reduce
+    init_distributed_from_env("cpu")
+    g = torch.Generator().manual_seed(7 + rank)
+    grads = [torch.randn(5, 3, generator=g), torch.randn(1, generator=g), torch.randn(2, 2, 2, generator=g)[:, :, 0]]   # one non-contiguous
+    flat_all_reduce(grads)
+    torch.save([t.clone() for t in grads], os.path.join(out_dir, f"s1_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stage1_flat_gradient_allreduce(tmp_path):
+    """the stage-1 trainer step's one flat all-reduce over an arbitrary list of parameter gradients (stage1.flat_all_reduce)"""
+    mp.spawn(_stage1_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    outs = [torch.load(os.path.join(tmp_path, f"s1_rank{r}.pt")) for r in range(2)]
+    want = None
+    for rank in range(2):
+        g = torch.Generator().manual_seed(7 + rank)
+        gs_ = [torch.randn(5, 3, generator=g), torch.randn(1, generator=g), torch.randn(2, 2, 2, generator=g)[:, :, 0]]
+        want = gs_ if want is None else [a + b for a, b in zip(want, gs_)]
+    for a, b, w in zip(outs[0], outs[1], want):
+        assert torch.equal(a, b) and torch.allclose(a, w, atol=1e-6)

@@ -35,7 +35,7 @@ SYMBOLS = [
     "gs_cubemap_mip_bwd", "gs_diffuse_cubemap_fwd", "gs_diffuse_cubemap_bwd", "gs_specular_bounds", "gs_cube_dir_table",
     "gs_specular_cubemap_fwd", "gs_specular_cubemap_bwd", "gs_specular_patch_count", "gs_specular_weights_build",
     "gs_specular_apply", "gs_mgadapter_fwd", "gs_mgadapter_bwd", "gs_vertex_normals_fwd",
-    "gs_vertex_normals_bwd", "gs_photo_loss_ws_bytes", "gs_photo_loss", "gs_hashgrid_fwd", "gs_hashgrid_bwd_ws_bytes", "gs_hashgrid_bwd", "gs_mlp_wgrad_ws_bytes", "gs_mlp_wgrad",
+    "gs_vertex_normals_bwd", "gs_photo_loss_ws_bytes", "gs_photo_loss", "gs_hashgrid_fwd", "gs_hashgrid_bwd_ws_bytes", "gs_hashgrid_bwd", "gs_hashgrid_bwd_fixed_ws_bytes", "gs_hashgrid_bwd_fixed", "gs_mlp_wgrad_ws_bytes", "gs_mlp_wgrad",
     "gs_flexicubes_ws_bytes", "gs_flexicubes_count", "gs_flexicubes_fwd", "gs_flexicubes_bwd", "gs_flexicubes_entropy_fwd",
     "gs_flexicubes_entropy_bwd",
 ]
@@ -65,6 +65,8 @@ def lib() -> C.CDLL:
         l.gs_shade_bwd_ws_bytes.argtypes = [C.c_void_p, C.c_int]
         l.gs_hashgrid_bwd_ws_bytes.restype = C.c_size_t
         l.gs_hashgrid_bwd_ws_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+        l.gs_hashgrid_bwd_fixed_ws_bytes.restype = C.c_size_t
+        l.gs_hashgrid_bwd_fixed_ws_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
         l.gs_mlp_wgrad_ws_bytes.restype = C.c_size_t
         l.gs_mlp_wgrad_ws_bytes.argtypes = [C.c_int64]
         l.gs_flexicubes_ws_bytes.restype = C.c_size_t

@@ -399,6 +399,231 @@ extern "C" int gs_hashgrid_bwd(int N, int L, int F, int log2_T, const float* sca
 }
 
 
+// ---- table gradient, fixed-point variant ------------------------------------------------------------------------------------
+// scripts/micro/lds_atomic_microbench.hip: ds_add_f32 retires ~1 LANE per 3 cycles (a dense wave instruction: ~190
+// cycles), ds_add_u32 / ds_add_u64 run at 0.10 / 0.17 cycles per lane -- 18-30x faster; the float slab kernel above spends
+// 54 % of its time in that one instruction.  So the slab accumulates in 64-bit FIXED POINT: value * 2^e with one power of
+// two per LEVEL, chosen from that level's max|v_out| so that no row sum can overflow (|sum| <= 8 N max scale < 2^62);
+// an addend 2^-14 of the largest one still keeps 24 bits.  Integer sums do not depend on the order: the table gradient
+// becomes bit-reproducible.  The 8-byte accumulators halve the slab (8192 rows), i.e. double the slabs per level -- paid
+// for by binning the points first: one pass appends every point index to the queues of the (level, slab) pairs its 8
+// corner rows fall into (~4 of 32: x-neighbours share the upper hash bits), workgroup-aggregated (LDS counters, one
+// global atomic per workgroup and queue), and a slab workgroup walks only its queue, with dense lanes.
+constexpr int HG_FX_ROWS = 8192;
+constexpr int HG_BIN_BLOCK = 1024;
+
+__global__ void __launch_bounds__(HG_BIN_BLOCK)
+hashgrid_bin_kernel(int N, int L, unsigned log2_T, HgLevels lv, int slabs, int rows_shift, const float* __restrict__ x,
+                    int* __restrict__ q_counts, int* __restrict__ queues)
+{
+    extern __shared__ int bin_lds[];                 // [L*slabs] block counts -> block bases, then [waves][L*slabs] wave offsets
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int LS = L * slabs;
+    int* s_cnt = bin_lds;
+    int* s_woff = bin_lds + LS;
+    const int n = blockIdx.x * HG_BIN_BLOCK + tid;
+    const bool valid = n < N;
+    const unsigned mask = (1u << log2_T) - 1u;
+    for (int i = tid; i < LS; i += HG_BIN_BLOCK) s_cnt[i] = 0;
+    __syncthreads();
+    float p[3] = {0.f, 0.f, 0.f};
+    if (valid) { p[0] = x[3 * (size_t)n] * 0.5f + 0.5f; p[1] = x[3 * (size_t)n + 1] * 0.5f + 0.5f; p[2] = x[3 * (size_t)n + 2] * 0.5f + 0.5f; }
+    for (int l = 0; l < L; ++l) {                                     // phase 1: counts (the masks are recomputed in phase 2)
+        unsigned long long m = 0ull;
+        if (valid) {
+            const float sc_ = lv.scaling[l];
+            int c[3], f[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const float v = p[k] * sc_; c[k] = (int)ceilf(v); f[k] = (int)floorf(v); }
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                m |= 1ull << (hg_hash(b & 4 ? c[0] : f[0], b & 2 ? c[1] : f[1], b & 1 ? c[2] : f[2], mask, log2_T) >> rows_shift);
+        }
+        for (int sl = 0; sl < slabs; ++sl) {
+            const unsigned long long bal = __ballot((m >> sl) & 1ull);
+            if (bal == 0ull) continue;
+            if (lane == 0) s_woff[wave * LS + l * slabs + sl] = atomicAdd(&s_cnt[l * slabs + sl], __popcll(bal));
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < LS; i += HG_BIN_BLOCK) {                    // one global atomic per (level, slab) and workgroup
+        const int c = s_cnt[i];
+        s_cnt[i] = c > 0 ? atomicAdd(&q_counts[i], c) : 0;
+    }
+    __syncthreads();
+    for (int l = 0; l < L; ++l) {                                     // phase 2: write the indices
+        unsigned long long m = 0ull;
+        if (valid) {
+            const float sc_ = lv.scaling[l];
+            int c[3], f[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const float v = p[k] * sc_; c[k] = (int)ceilf(v); f[k] = (int)floorf(v); }
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                m |= 1ull << (hg_hash(b & 4 ? c[0] : f[0], b & 2 ? c[1] : f[1], b & 1 ? c[2] : f[2], mask, log2_T) >> rows_shift);
+        }
+        for (int sl = 0; sl < slabs; ++sl) {
+            const bool on = (m >> sl) & 1ull;
+            const unsigned long long bal = __ballot(on);
+            if (bal == 0ull) continue;
+            const int i = l * slabs + sl;
+            if (on) queues[(size_t)i * N + s_cnt[i] + s_woff[wave * LS + i] + __popcll(bal & ((1ull << lane) - 1ull))] = n;
+        }
+    }
+}
+
+// per-level max |v| over the level-major copy (bit patterns of non-negative floats order like unsigned integers)
+__global__ void __launch_bounds__(1024)
+hashgrid_level_max_kernel(int N, const float* __restrict__ v_lm, unsigned* __restrict__ gmax_bits)
+{
+    __shared__ unsigned red[16];
+    const int l = blockIdx.y;
+    const float* p = v_lm + (size_t)l * N * 2;
+    unsigned m = 0u;
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < (size_t)N * 2; i += (size_t)gridDim.x * 1024)
+        m = max(m, (unsigned)__float_as_int(fabsf(p[i])));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) m = max(m, red[w]);
+        atomicMax(&gmax_bits[l], m);
+    }
+}
+
+// e such that 8 N gmax |tgs| 2^e < 2^62 (gmax > 0)
+__device__ __forceinline__ int hg_fx_exponent(int N, float gmax, float tgs)
+{
+    int ex;
+    frexpf(8.0f * (float)N * gmax * fabsf(tgs), &ex);               // value < 2^ex
+    return 62 - ex;
+}
+
+__global__ void __launch_bounds__(1024)
+hashgrid_bwd_slabfx_kernel(int N, int L, unsigned log2_T, HgLevels lv, int slabs, const float* __restrict__ x,
+                           const float* __restrict__ v_lm, const unsigned* __restrict__ gmax_bits, float table_grad_scale,
+                           float* __restrict__ v_table, int accumulate, const int* __restrict__ q_counts,
+                           const int* __restrict__ queues)
+{
+    extern __shared__ unsigned long long fx[];                       // [rows][2] fixed point, two's complement
+    const unsigned T = 1u << log2_T, mask = T - 1u;
+    const int b = blockIdx.x, sl = b % slabs, l = b / slabs;
+    for (int i = threadIdx.x; i < HG_FX_ROWS * 2; i += blockDim.x) fx[i] = 0ull;
+    __syncthreads();
+    const float gmax = __int_as_float((int)gmax_bits[l]);            // per level: the levels' gradients may differ by decades
+    const unsigned row0 = (unsigned)sl * (unsigned)HG_FX_ROWS;
+    float* dst = v_table + ((size_t)l * T + row0) * 2;
+    if (!(gmax > 0.0f)) {                                            // nothing to add (or NaN upstream: leave zeros)
+        for (int i = threadIdx.x; i < HG_FX_ROWS * 2; i += blockDim.x) if (!accumulate) dst[i] = 0.0f;
+        return;
+    }
+    const int e = hg_fx_exponent(N, gmax, table_grad_scale);
+    const double up = ldexp(1.0, e), down = ldexp(1.0, -e);
+    const float s = lv.scaling[l];
+    const float* g_l = v_lm + (size_t)l * N * 2;
+    const int* q = queues + (size_t)(l * slabs + sl) * N;
+    const int total = q_counts[l * slabs + sl];
+    constexpr int PU = 4;
+    for (int n0 = (int)threadIdx.x; n0 < total; n0 += (int)blockDim.x * PU) {
+        float2 gq[PU]; float px[PU][3];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const int i = n0 + u * (int)blockDim.x;
+            const int nn = q[min(i, total - 1)];
+            gq[u] = *reinterpret_cast<const float2*>(g_l + 2 * (size_t)nn);
+            px[u][0] = x[3 * (size_t)nn]; px[u][1] = x[3 * (size_t)nn + 1]; px[u][2] = x[3 * (size_t)nn + 2];
+            if (i >= total) gq[u] = make_float2(0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const float2 g = gq[u];
+            if (g.x == 0.0f && g.y == 0.0f) continue;
+            int c[3], f[3]; float o[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float sc = (px[u][k] * 0.5f + 0.5f) * s;
+                c[k] = (int)ceilf(sc); f[k] = (int)floorf(sc);
+                o[k] = sc - (float)f[k];
+            }
+#pragma unroll
+            for (int bx = 0; bx < 2; ++bx)
+#pragma unroll
+                for (int by = 0; by < 2; ++by)
+#pragma unroll
+                    for (int bz = 0; bz < 2; ++bz) {
+                        const unsigned h = hg_hash(bx ? c[0] : f[0], by ? c[1] : f[1], bz ? c[2] : f[2], mask, log2_T);
+                        const unsigned r = h - row0;
+                        if (r < (unsigned)HG_FX_ROWS) {
+                            const float w = (bx ? o[0] : 1.0f - o[0]) * (by ? o[1] : 1.0f - o[1]) * (bz ? o[2] : 1.0f - o[2]) * table_grad_scale;
+                            atomicAdd(&fx[2 * r], (unsigned long long)(long long)((double)(g.x * w) * up));
+                            atomicAdd(&fx[2 * r + 1], (unsigned long long)(long long)((double)(g.y * w) * up));
+                        }
+                    }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HG_FX_ROWS * 2; i += blockDim.x) {
+        const float v = (float)((double)(long long)fx[i] * down);
+        dst[i] = accumulate ? dst[i] + v : v;
+    }
+}
+
+extern "C" size_t gs_hashgrid_bwd_fixed_ws_bytes(int N, int L, int F, int log2_T)
+{
+    const size_t T = (size_t)1 << log2_T;
+    if (T < (size_t)HG_FX_ROWS * 4 || T > (size_t)HG_FX_ROWS * 64) return 0;       // 4..64 slabs per level
+    const size_t slabs = T / HG_FX_ROWS, n = (size_t)(N > 0 ? N : 1);
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    return al(gs_hashgrid_bwd_ws_bytes(N, L, F)) + al(sizeof(int) * L * slabs) + 256 + sizeof(int) * L * slabs * n;
+}
+
+// Table gradient in 64-bit fixed point over binned points (deterministic); v_x as gs_hashgrid_bwd.  gmax: DEVICE pointer to
+// (the per-level maxima of |v_out| that scale the fixed point are reduced on the device, no host sync).  ws: gs_hashgrid_bwd_fixed_ws_bytes (0 = table size unsupported).
+extern "C" int gs_hashgrid_bwd_fixed(int N, int L, int F, int log2_T, const float* scalings_host, const float* x,
+                                     const float* table, const float* v_out, float table_grad_scale, float* v_table,
+                                     int accumulate, float* v_x, void* ws, size_t ws_bytes, void* stream)
+{
+    const int rc = hg_check(N, L, F, log2_T);
+    if (rc != GS_OK) return rc;
+    const size_t need = gs_hashgrid_bwd_fixed_ws_bytes(N, L, F, log2_T);
+    GS_CHECK_ARG(need > 0, "table size outside the fixed-point path (2^15 .. 2^19 rows per level)");
+    GS_CHECK_ARG(ws != nullptr && ws_bytes >= need, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)L * ((size_t)1 << log2_T) * F;
+    HgLevels lv;
+    for (int l = 0; l < GS_HG_MAX_LEVELS; ++l) lv.scaling[l] = l < L ? scalings_host[l] : 0.0f;
+    if (N == 0) {
+        if (!accumulate) GS_CHECK_HIP(hipMemsetAsync(v_table, 0, sizeof(float) * n, s));
+        return GS_OK;
+    }
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const int slabs = (int)(((size_t)1 << log2_T) / HG_FX_ROWS);
+    float* v_lm = (float*)ws;
+    int* q_counts = (int*)((char*)ws + al(gs_hashgrid_bwd_ws_bytes(N, L, F)));
+    unsigned* gmax = (unsigned*)((char*)q_counts + al(sizeof(int) * L * slabs));
+    int* queues = (int*)((char*)gmax + 256);
+    hipLaunchKernelGGL(hashgrid_transpose_kernel, dim3(gs_cdiv((int64_t)N * L, 256)), dim3(256), 0, s, N, L * F, v_out, v_lm);
+    GS_CHECK_HIP(hipMemsetAsync(q_counts, 0, al(sizeof(int) * L * slabs) + 256, s));            // counters and maxima
+    hipLaunchKernelGGL(hashgrid_level_max_kernel, dim3(min(64, gs_cdiv(2 * (int64_t)N, 4096)), L), dim3(1024), 0, s, N, v_lm, gmax);
+    int rows_shift = 0;
+    while ((1 << rows_shift) < HG_FX_ROWS) ++rows_shift;
+    const size_t bin_lds = sizeof(int) * (size_t)L * slabs * (1 + HG_BIN_BLOCK / 64);
+    GS_CHECK_ARG(bin_lds <= 160 * 1024, "too many (level, slab) pairs for the binning pass");
+    GS_CHECK_HIP(hipFuncSetAttribute((const void*)hashgrid_bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds));
+    hipLaunchKernelGGL(hashgrid_bin_kernel, dim3(gs_cdiv(N, HG_BIN_BLOCK)), dim3(HG_BIN_BLOCK), bin_lds, s, N, L, (unsigned)log2_T, lv,
+                       slabs, rows_shift, x, q_counts, queues);
+    const size_t lds = sizeof(unsigned long long) * 2 * (size_t)HG_FX_ROWS;
+    GS_CHECK_HIP(hipFuncSetAttribute((const void*)hashgrid_bwd_slabfx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(hashgrid_bwd_slabfx_kernel, dim3(L * slabs), dim3(1024), lds, s, N, L, (unsigned)log2_T, lv, slabs, x, v_lm, gmax,
+                       table_grad_scale, v_table, accumulate, q_counts, queues);
+    if (v_x) hipLaunchKernelGGL(hashgrid_bwd_x_kernel<2>, dim3(gs_cdiv(N, 256)), dim3(256), 0, s, N, L, (unsigned)log2_T, lv, x, table,
+                                v_out, v_x);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
+
 // ---- weight gradient of the field's small MLP layers -----------------------------------------------------------------------
 // dW[o][i] = sum_n dY[n][o] * X[n][i] with O, I <= 32 and N = millions of Gaussians: a 32 x 32 x N product.  The library GEMM
 // behind torch.nn.functional.linear's backward takes 2-5 ms for it at N = 2 M (one 9 ms MLP backward per encoder, against

@@ -54,12 +54,21 @@ class _HashGrid(torch.autograd.Function):
         v_table = torch.empty_like(td)
         v_x = torch.empty_like(xd) if ctx.needs_input_grad[0] else None
         sc = (C.c_float * L)(*scalings)
-        use_slabs = os.environ.get("GEOSPLAT_HASHGRID_SLABS", "1") != "0"       # 0: per-point kernel with fp32 atomics
-        nbytes = _lib.lib().gs_hashgrid_bwd_ws_bytes(N, L, F) if use_slabs else 0
+        mode = os.environ.get("GEOSPLAT_HASHGRID_SLABS", "2")   # 2: fixed-point slabs over binned points, 1: float slabs, 0: fp32 atomics
+        lib = _lib.lib()
+        vo = v_out.contiguous().float()
+        fixed_bytes = lib.gs_hashgrid_bwd_fixed_ws_bytes(N, L, F, log2_T) if mode == "2" else 0
+        if fixed_bytes:
+            ws = torch.empty(fixed_bytes, dtype=torch.uint8, device=xd.device)
+            _lib.check(lib.gs_hashgrid_bwd_fixed(N, L, F, log2_T, sc, _lib.ptr(xd), _lib.ptr(td), _lib.ptr(vo),
+                                                 _lib.f32(tgs), _lib.ptr(v_table), 0, _lib.ptr(v_x), _lib.ptr(ws),
+                                                 C.c_size_t(fixed_bytes), _lib.stream()), "gs_hashgrid_bwd_fixed")
+            return v_x, v_table, None, None, None
+        nbytes = lib.gs_hashgrid_bwd_ws_bytes(N, L, F) if mode != "0" else 0
         ws = torch.empty(nbytes, dtype=torch.uint8, device=xd.device) if nbytes else None
-        _lib.check(_lib.lib().gs_hashgrid_bwd(N, L, F, log2_T, sc, _lib.ptr(xd), _lib.ptr(td), _lib.ptr(v_out.contiguous().float()),
-                                              _lib.f32(tgs), _lib.ptr(v_table), 0, _lib.ptr(v_x), _lib.ptr(ws),
-                                              C.c_size_t(nbytes), _lib.stream()), "gs_hashgrid_bwd")
+        _lib.check(lib.gs_hashgrid_bwd(N, L, F, log2_T, sc, _lib.ptr(xd), _lib.ptr(td), _lib.ptr(vo),
+                                       _lib.f32(tgs), _lib.ptr(v_table), 0, _lib.ptr(v_x), _lib.ptr(ws),
+                                       C.c_size_t(nbytes), _lib.stream()), "gs_hashgrid_bwd")
         return v_x, v_table, None, None, None
 
 

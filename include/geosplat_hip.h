@@ -279,6 +279,15 @@ int gs_hashgrid_bwd(int N, int L, int F, int log2_T, const float* scalings_host,
                     void* ws /* with it: atomic-free LDS-slab kernel; NULL: per-point kernel with fp32 atomics */,
                     size_t ws_bytes, void* stream);
 
+/* gs_hashgrid_bwd with the table gradient accumulated in 64-bit FIXED POINT over binned points: deterministic (integer
+ * sums), and faster -- LDS float atomics retire one lane per ~3 cycles on gfx950, integer ones 18-30x as many.  One power
+ * of two per level, from that level's max |v_out| (reduced on the device), scales the fixed point.  Arguments as
+ * gs_hashgrid_bwd; ws: gs_hashgrid_bwd_fixed_ws_bytes(N, L, F, log2_T) bytes (0: table size outside 2^15..2^19 rows). */
+size_t gs_hashgrid_bwd_fixed_ws_bytes(int N, int L, int F, int log2_T);
+int gs_hashgrid_bwd_fixed(int N, int L, int F, int log2_T, const float* scalings_host, const float* x, const float* table,
+                          const float* v_out, float table_grad_scale, float* v_table, int accumulate, float* v_x, void* ws,
+                          size_t ws_bytes, void* stream);
+
 /* Weight gradient of one bias-free linear layer of the field's MLPs (rfstudio/nn/mlp.py:126-145; widths <= 32):
  *   dW[O,I] (+)= scale * dY[N,O]^T X[N,I]   (row-major, contiguous; O, I in [1,32]).  fp32 matrix unit, exact f32;
  *   deterministic (partials summed in a fixed order).  ws: gs_mlp_wgrad_ws_bytes(N). */

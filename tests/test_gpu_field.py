@@ -166,3 +166,36 @@ def test_mlp_weight_gradient_kernel(N, O, I):
         assert (gx.double() - xd.grad).abs().max() < 1e-4
     scale = wd.grad.abs().max().item() + 1e-30
     assert (gw.double() - wd.grad).abs().max().item() / scale < 2e-6, (gw.double() - wd.grad).abs().max().item() / scale
+
+
+def test_hashgrid_fixed_point_table_gradient(monkeypatch):
+    """the 64-bit fixed-point table gradient (default for tables of 2^15..2^19 rows): bit-identical between runs (integer
+    sums), equal to the float-slab path within fp32 accumulation noise, and still exact where nothing was touched"""
+    from geosplatting_amd.field import hash_encode, level_scalings
+    g = torch.Generator().manual_seed(5)
+    N, log2_T = 150001, 15
+    sc = level_scalings(16, 16, 2048)
+    x = (torch.rand(N, 3, generator=g) * 1.2 - 0.6).cuda()
+    table = ((torch.rand(16 * 2 ** log2_T, 2, generator=g) * 2 - 1) * 1e-2).cuda()
+    gy = (torch.randn(N, 32, generator=g) * torch.logspace(-6, 0, 32)).cuda()          # six decades of gradient magnitudes
+    def run(mode):
+        monkeypatch.setenv("GEOSPLAT_HASHGRID_SLABS", mode)
+        t = table.clone().requires_grad_(True); xx = x.clone().requires_grad_(True)
+        hash_encode(xx, t, sc, log2_T, grad_scaling=16.0).backward(gy)
+        return t.grad.clone(), xx.grad.clone()
+    a1, x1 = run("2"); a2, _ = run("2"); b1, x2 = run("1")
+    assert torch.equal(a1, a2)                                            # deterministic
+    assert torch.equal(x1, x2)                                            # position gradient: same kernel
+    # float64 accumulation of the same fp32 cell weights (oracle/field_ref.py) as the yardstick for both paths
+    t64 = table.cpu().double().requires_grad_(True)
+    field_ref.encode(x.cpu(), t64, sc, log2_T).backward(gy.cpu().double())
+    ref = t64.grad * 16.0
+    scale = ref.abs().max()
+    err_fixed = (a1.cpu().double() - ref).abs(); err_float = (b1.cpu().double() - ref).abs()
+    assert (err_fixed.max() / scale).item() < 1e-6
+    assert err_fixed.max().item() <= err_float.max().item() * 1.5 + 1e-12          # no worse than fp32 LDS accumulation
+    small = (ref.abs() > 0) & (ref.abs() < 1e-4 * scale)                            # rows four decades below the largest
+    assert small.any()
+    # (cancellation makes the relative error of a small row unbounded for ANY accumulation: compare with the float path)
+    assert (err_fixed[small] / ref.abs()[small]).max().item() <= 1.5 * (err_float[small] / ref.abs()[small]).max().item() + 1e-6
+    assert torch.equal(a1.cpu() == 0, ref == 0)                                     # untouched rows are exactly zero

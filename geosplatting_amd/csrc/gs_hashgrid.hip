@@ -514,8 +514,12 @@ hashgrid_bwd_slabfx_kernel(int N, int L, unsigned log2_T, HgLevels lv, int slabs
     const float gmax = __int_as_float((int)gmax_bits[l]);            // per level: the levels' gradients may differ by decades
     const unsigned row0 = (unsigned)sl * (unsigned)HG_FX_ROWS;
     float* dst = v_table + ((size_t)l * T + row0) * 2;
-    if (!(gmax > 0.0f)) {                                            // nothing to add (or NaN upstream: leave zeros)
-        for (int i = threadIdx.x; i < HG_FX_ROWS * 2; i += blockDim.x) if (!accumulate) dst[i] = 0.0f;
+    if (!(gmax > 0.0f) || !(gmax < 3.0e38f)) {                       // all-zero level: nothing to add; NaN / inf upstream: propagate it
+        const bool bad = !(gmax == 0.0f);
+        for (int i = threadIdx.x; i < HG_FX_ROWS * 2; i += blockDim.x) {
+            if (bad) dst[i] = __int_as_float(0x7fc00000);
+            else if (!accumulate) dst[i] = 0.0f;
+        }
         return;
     }
     const int e = hg_fx_exponent(N, gmax, table_grad_scale);

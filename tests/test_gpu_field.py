@@ -199,3 +199,15 @@ def test_hashgrid_fixed_point_table_gradient(monkeypatch):
     # (cancellation makes the relative error of a small row unbounded for ANY accumulation: compare with the float path)
     assert (err_fixed[small] / ref.abs()[small]).max().item() <= 1.5 * (err_float[small] / ref.abs()[small]).max().item() + 1e-6
     assert torch.equal(a1.cpu() == 0, ref == 0)                                     # untouched rows are exactly zero
+
+
+def test_hashgrid_fixed_point_propagates_nan():
+    """a non-finite upstream gradient must not be silently dropped by the fixed-point scaling"""
+    from geosplatting_amd.field import hash_encode, level_scalings
+    sc = level_scalings(16, 16, 2048)
+    x = (torch.rand(5000, 3) * 1.2 - 0.6).cuda()
+    t = (torch.rand(16 * 2 ** 15, 2) * 1e-2).cuda().requires_grad_(True)
+    gy = torch.randn(5000, 32).cuda(); gy[17, 4] = float("nan")              # level 2
+    hash_encode(x, t, sc, 15).backward(gy)
+    g = t.grad.view(16, 2 ** 15, 2)
+    assert torch.isnan(g[2]).all() and torch.isfinite(g[[0, 1] + list(range(3, 16))]).all()

@@ -27,7 +27,7 @@ from .parallel import GradBucket
 from .rasterization import _bin_stage, _composite_stage, _forward_stages, _prepare_stage, _project_stage
 from .shading import _MODE, _TONE, RenderableAttrs, _make_env, get_fg_lut, shade_private_copies
 from .splitsum import CACHE_PAIR_WEIGHTS, TextureSplitSum, as_splitsum, as_splitsum_backward
-from .synthetic import SplatSet
+from .splats import SplatSet
 
 PARAM_NAMES = ("means", "scales", "quats", "opacities", "normals", "kd", "ks", "cubemap", "exposure")
 

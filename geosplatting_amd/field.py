@@ -171,7 +171,7 @@ class GaussianField:
         """Returns (SplatSet with the shifted means, RenderableAttrs, offsets[6F,3])."""
         from .mesh import mesh_to_splats, vertex_normals
         from .shading import RenderableAttrs
-        from .synthetic import SplatSet
+        from .splats import SplatSet
         splats, shading_normals = mesh_to_splats(vertices, faces, vertex_normals(vertices, faces))
         with torch.no_grad():                                  # MGAdapter.make: offsets = n.detach() * sqrt(area.detach())
             p = vertices[faces]

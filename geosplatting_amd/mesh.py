@@ -4,7 +4,7 @@ path every iteration (rfstudio/model/geosplat.py:378-472, called from :843-868).
 `mesh_to_splats(vertices, faces, vnormals)` has the semantics of `MGAdapter.make` with its default ratios and
 returns `(SplatSet, shading_normals)`; gradients flow to `vertices` and `vnormals` through one HIP kernel each
 way (csrc/gs_mesh.hip: forward-mode dual numbers inside the backward kernel, fp32 atomics into the vertices).
-No CPU path: the torch restatement used for parity lives in `synthetic.mesh_to_splats`.
+No CPU path: the torch restatement used for parity is test infrastructure (oracle/mesh_ref.py).
 """
 from __future__ import annotations
 
@@ -15,7 +15,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from .synthetic import SplatSet
+from .splats import SplatSet
 
 
 class _MGAdapter(torch.autograd.Function):

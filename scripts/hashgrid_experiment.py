@@ -16,7 +16,9 @@ dev = torch.device("cuda:0")
 sc = level_scalings(16, 16, 4096)
 table = ((torch.rand(16 * 2 ** 18, 2) * 2 - 1) * 1e-3).to(dev).requires_grad_(True)
 v, f = syn.icosphere(7, radius=0.8)
-sp, _ = syn.mesh_to_splats(v, f, syn.vertex_normals(v, f))
+from geosplatting_amd.mesh import mesh_to_splats, vertex_normals
+v, f = v.to(dev), f.to(dev)
+sp, _ = mesh_to_splats(v, f, vertex_normals(v, f))
 x = sp.means.clamp(-1, 1).to(dev)
 gy = torch.randn(x.shape[0], 32, device=dev)
 for rep in range(3):

@@ -90,7 +90,8 @@ ref_lut = np.fromfile("/root/reference/rfstudio/assets/geometry/pbr/bsdf_256_256
 # the S1 pin uses THIS repo's LUT (the reference asset is not shipped); which table is sampled does not matter for the arithmetic
 lut = np.fromfile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "geosplatting_amd", "assets", "fg_lut_256.bin"), dtype=np.float32).reshape(256, 256, 2)
 N = 512
-sc = syn.sphere_scene(1, seed=3, cubemap_res=16)
+from oracle import mesh_ref                                              # noqa: E402
+sc = syn.sphere_scene(1, seed=3, cubemap_res=16, mesh_to_splats_fn=mesh_ref.scene_builder)
 idx = torch.randperm(sc.splats.num, generator=g)[:N]
 means, normals, kd, ks = sc.splats.means[idx], sc.normals[idx], sc.kd[idx], sc.ks[idx]
 N = means.shape[0]

@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from geosplatting_amd import synthetic as syn
+from oracle import mesh_ref
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -31,12 +32,12 @@ def test_mgadapter_fwd_golden():
 
 @pytest.mark.parametrize("level,jitter", [(2, 0.01), (3, 0.02), (4, 0.01)])
 def test_mgadapter_fwd_bwd_vs_float64(level, jitter):
-    """forward + forward-mode-dual backward == float64 autograd of the restatement (synthetic.mesh_to_splats)"""
+    """forward + forward-mode-dual backward == float64 autograd of the restatement (oracle/mesh_ref.py)"""
     from geosplatting_amd.mesh import mesh_to_splats
     gen = torch.Generator().manual_seed(level)
     v, f = syn.icosphere(level)
     v = v + jitter * torch.randn(v.shape, generator=gen)
-    vn = syn.vertex_normals(v, f)
+    vn = mesh_ref.vertex_normals(v, f)
     vn = vn + 0.1 * torch.randn(vn.shape, generator=gen)            # not unit: exercises safe_normalize's Jacobian
     N = 6 * f.shape[0]
     gm, gs, gq, gn = (torch.randn(N, w, generator=gen) for w in (3, 3, 4, 3))
@@ -47,7 +48,7 @@ def test_mgadapter_fwd_bwd_vs_float64(level, jitter):
      + (nrm * gn.cuda()).sum()).backward()
 
     vd = v.double().requires_grad_(True); nd = vn.double().requires_grad_(True)
-    sp_ref, nrm_ref = syn.mesh_to_splats(vd, f, nd)
+    sp_ref, nrm_ref = mesh_ref.mesh_to_splats_set(vd, f, nd)
     # rot2quat picks the best-conditioned of four candidates by value: at (near-)ties fp32 and fp64 may pick
     # different ones, which represent the same rotation with opposite sign -> compare modulo the sign
     sign = torch.sign((sp.quats.detach().cpu().double() * sp_ref.quats.detach()).sum(-1, keepdim=True))
@@ -69,7 +70,7 @@ def test_mgadapter_no_normal_gradient_and_errors():
     from geosplatting_amd import _lib
     from geosplatting_amd.mesh import mesh_to_splats
     v, f = syn.icosphere(1)
-    vn = syn.vertex_normals(v, f)
+    vn = mesh_ref.vertex_normals(v, f)
     vc = v.cuda().requires_grad_(True); nc = vn.cuda().requires_grad_(True)
     sp, _ = mesh_to_splats(vc, f.cuda(), nc)
     sp.means.sum().backward()                                       # only means: vnormals gradient must be exactly 0
@@ -93,7 +94,7 @@ def test_mgadapter_feeds_render_path():
     from geosplatting_amd import rasterization
     from geosplatting_amd.mesh import mesh_to_splats
     v, f = syn.icosphere(3)
-    vn = syn.vertex_normals(v, f)
+    vn = mesh_ref.vertex_normals(v, f)
     cam = syn.blender_cameras(1, 128, 128)[0]
     vc = v.cuda().requires_grad_(True)
     sp, nrm = mesh_to_splats(vc, f.cuda(), vn.cuda())
@@ -124,7 +125,7 @@ def test_vertex_normals_golden_and_gradient():
     ((sp.means * gm.cuda()).sum() + (sp.scales * gs.cuda()).sum() + (sp.quats * gq.cuda()).sum()
      + (nrm * gn.cuda()).sum()).backward()
     vd = v.double().requires_grad_(True)
-    sp_ref, nrm_ref = syn.mesh_to_splats(vd, f, syn.vertex_normals(vd, f))
+    sp_ref, nrm_ref = mesh_ref.mesh_to_splats_set(vd, f, mesh_ref.vertex_normals(vd, f))
     sign = torch.sign((sp.quats.detach().cpu().double() * sp_ref.quats.detach()).sum(-1, keepdim=True))
     ((sp_ref.means * gm).sum() + (sp_ref.scales * gs).sum() + (sp_ref.quats * sign * gq).sum()
      + (nrm_ref * gn).sum()).backward()
@@ -185,3 +186,19 @@ def test_mesh_step_matches_autograd_composition():
         err = (grads[name] - ref).abs().max().item() / ref.abs().max().item()
         assert err < 2e-4, (name, err)
     assert abs(grads["exposure"].item() - el.grad.item()) < 2e-4 * abs(el.grad.item())
+
+
+def test_sphere_scene_hip_equals_restatement():
+    """The bench / smoke scenes are built by the product's own HIP MGAdapter (geosplatting_amd.synthetic.sphere_scene).
+    At the headline size (icosphere level 7 -> 1 966 080 Gaussians) they agree with the CPU restatement of
+    MGAdapter.make (oracle/mesh_ref.py, pinned by tests/golden/ref_mgadapter.npz): a full-size run of section 8f-1."""
+    hip = syn.sphere_scene(7, seed=1, cubemap_res=16)
+    ref = syn.sphere_scene(7, seed=1, cubemap_res=16, mesh_to_splats_fn=mesh_ref.scene_builder)
+    assert hip.splats.num == ref.splats.num == 1966080
+    assert (hip.splats.means - ref.splats.means).abs().max().item() < 1e-6
+    assert (hip.splats.scales - ref.splats.scales).abs().max().item() < 2e-4      # log of sliver areas (fp32 both sides)
+    assert torch.equal(hip.splats.opacities, ref.splats.opacities)
+    sign = torch.sign((hip.splats.quats * ref.splats.quats).sum(-1, keepdim=True))
+    assert (hip.splats.quats * sign - ref.splats.quats).abs().max().item() < 2e-5
+    assert (hip.normals - ref.normals).abs().max().item() < 2e-6
+    assert (hip.kd - ref.kd).abs().max().item() < 1e-5 and torch.equal(hip.ks, ref.ks)

@@ -5,6 +5,7 @@ import numpy as np
 import torch
 
 import geosplatting_amd.synthetic as syn
+from oracle import mesh_ref
 from geosplatting_amd.cameras import orbit_cameras
 
 
@@ -23,7 +24,9 @@ def activated(splats):
 
 
 def sphere_case(level, res, view=1, seed=1, cubemap_res=64):
-    sc = syn.sphere_scene(level, seed=seed, cubemap_res=cubemap_res)
+    # Gaussians from the CPU restatement (oracle/mesh_ref.py): the same scene with and without a GPU; the product's own
+    # HIP-built scene is compared with it in tests/test_gpu_mesh.py::test_sphere_scene_hip_equals_restatement
+    sc = syn.sphere_scene(level, seed=seed, cubemap_res=cubemap_res, mesh_to_splats_fn=mesh_ref.scene_builder)
     focal = 0.5 * res / math.tan(0.5 * 0.6911112)
     cam = orbit_cameras(8, 4.0 * (2.0 / 3.0), 30.0, res, res, focal=focal)[view]
     return sc, cam

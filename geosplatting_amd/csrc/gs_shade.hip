@@ -519,7 +519,9 @@ tonemap_fwd_kernel(int64_t P, int mode, const float4* __restrict__ rgba, const f
     const float e = exposure[0];
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
         const float4 v = rgba[p];
-        out[p] = make_float4(tone_fwd(mode, v.x * e), tone_fwd(mode, v.y * e), tone_fwd(mode, v.z * e), v.w);
+        // 'none' is `render_rgba * exposure` (rfstudio/model/geosplat.py:123-124): all four channels, alpha included
+        out[p] = make_float4(tone_fwd(mode, v.x * e), tone_fwd(mode, v.y * e), tone_fwd(mode, v.z * e),
+                             mode == GS_TONE_NONE ? v.w * e : v.w);
     }
 }
 
@@ -532,8 +534,8 @@ tonemap_bwd_kernel(int64_t P, int mode, const float4* __restrict__ rgba, const f
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
         const float4 v = rgba[p], g = v_out[p];
         const float gx = g.x * tone_grad(mode, v.x * e), gy = g.y * tone_grad(mode, v.y * e), gz = g.z * tone_grad(mode, v.z * e);
-        v_rgba[p] = make_float4(gx * e, gy * e, gz * e, g.w);
-        ve += gx * v.x + gy * v.y + gz * v.z;
+        v_rgba[p] = make_float4(gx * e, gy * e, gz * e, mode == GS_TONE_NONE ? g.w * e : g.w);
+        ve += gx * v.x + gy * v.y + gz * v.z + (mode == GS_TONE_NONE ? g.w * v.w : 0.0f);
     }
     ve = gs_wave_sum(ve);
     __shared__ float s[4];

@@ -56,7 +56,7 @@ class RenderStep:
         self.fused = fused
         self.bucket = GradBucket(params.shapes(), params.means.device)
         self._static_env: Optional[TextureSplitSum] = None
-        self._cam_cache: Dict[int, tuple] = {}
+        self._cam_cache: Dict[tuple, tuple] = {}
         self._side_stream = None
         self._tail_stream = None
         self._pre_stream = None
@@ -70,12 +70,19 @@ class RenderStep:
 
     # ------------------------------------------------------------------------------------------------- fused path
     def _camera_tensors(self, cam: Camera):
-        key = id(cam)
-        if key not in self._cam_cache:
+        """Device copies of (view matrix, K, camera position), cached by the camera's CONTENT (pose bytes + intrinsics):
+        a training loop that builds new Camera objects every step, or mutates one in place, can never be served another
+        camera's matrices (an id()-keyed cache could, after CPython recycles the id).  Bounded, oldest entry evicted."""
+        c2w = cam.c2w.detach().to("cpu", torch.float32).contiguous()
+        key = (c2w.numpy().tobytes(), float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy), int(cam.width), int(cam.height))
+        hit = self._cam_cache.get(key)
+        if hit is None:
             dev = self.p.means.device
-            self._cam_cache[key] = (cam.view_matrix.to(dev).contiguous(), cam.intrinsic_matrix.to(dev).contiguous(),
-                                    cam.c2w[:, 3].to(dev).contiguous())
-        return self._cam_cache[key]
+            if len(self._cam_cache) >= 1024:
+                self._cam_cache.pop(next(iter(self._cam_cache)))
+            hit = self._cam_cache[key] = (cam.view_matrix.to(dev).contiguous(), cam.intrinsic_matrix.to(dev).contiguous(),
+                                          cam.c2w[:, 3].to(dev).contiguous())
+        return hit
 
     def _step_fused(self, cameras, upstream, all_reduce, keep_images):
         """Same arithmetic as the autograd path, driven directly through the C-ABI: every per-view backward ADDS into

@@ -59,6 +59,14 @@ class _HashGrid(torch.autograd.Function):
         vo = v_out.contiguous().float()
         fixed_bytes = lib.gs_hashgrid_bwd_fixed_ws_bytes(N, L, F, log2_T) if mode == "2" else 0
         if fixed_bytes:
+            # the binned path reserves a worst-case queue of N ints per (level, slab) pair (4.3 GB at N = 2 M, 2^18 rows):
+            # fine on a 288 GB MI355X, but never let it crowd out the model -- beyond the budget (default: a quarter of the
+            # free memory, GEOSPLAT_HASHGRID_WS_GB overrides) fall back to the float-slab kernel, whose workspace is 4*N*L*F bytes
+            budget = os.environ.get("GEOSPLAT_HASHGRID_WS_GB")
+            budget_bytes = int(float(budget) * 2 ** 30) if budget else torch.cuda.mem_get_info(xd.device)[0] // 4
+            if fixed_bytes > budget_bytes:
+                fixed_bytes = 0
+        if fixed_bytes:
             ws = torch.empty(fixed_bytes, dtype=torch.uint8, device=xd.device)
             _lib.check(lib.gs_hashgrid_bwd_fixed(N, L, F, log2_T, sc, _lib.ptr(xd), _lib.ptr(td), _lib.ptr(vo),
                                                  _lib.f32(tgs), _lib.ptr(v_table), 0, _lib.ptr(v_x), _lib.ptr(ws),
@@ -167,7 +175,8 @@ class GaussianField:
         return self.kd_enc.parameters() + self.ks_enc.parameters() + self.z_enc.parameters()
 
     def get_gaussians_from_face(self, vertices: Tensor, faces: Tensor, kd_perturb_std: float = 0.0,
-                                ks_perturb_std: float = 0.0, *, scale: float, initial_guess: Tensor):
+                                ks_perturb_std: float = 0.0, *, scale: float, initial_guess: Tensor,
+                                generator: Optional[torch.Generator] = None):
         """Returns (SplatSet with the shifted means, RenderableAttrs, offsets[6F,3])."""
         from .mesh import mesh_to_splats, vertex_normals
         from .shading import RenderableAttrs
@@ -185,9 +194,9 @@ class GaussianField:
         shifted = splats.means - offsets
         kd_jitter = ks_jitter = None
         if kd_perturb_std > 0:
-            kd_jitter = self.kd_enc((means + torch.randn_like(means) * kd_perturb_std).clamp(-1, 1))
+            kd_jitter = self.kd_enc((means + torch.randn(means.shape, device=means.device, generator=generator) * kd_perturb_std).clamp(-1, 1))
         if ks_perturb_std > 0:
-            ks_jitter = (self.ks_enc((means + torch.randn_like(means) * ks_perturb_std).clamp(-1, 1)) + initial_guess).sigmoid()
+            ks_jitter = (self.ks_enc((means + torch.randn(means.shape, device=means.device, generator=generator) * ks_perturb_std).clamp(-1, 1)) + initial_guess).sigmoid()
         attrs = RenderableAttrs(kd=self.kd_enc(means), ks=(self.ks_enc(means) + initial_guess).sigmoid(), normals=shading_normals,
                                 kd_jitter=kd_jitter, ks_jitter=ks_jitter)
         return SplatSet(shifted, splats.scales, splats.quats, splats.opacities, splats.colors), attrs, offsets

@@ -81,13 +81,16 @@ class TrainerUpstream:
     and keeps the per-view values in `.out` ([num_local_views, 6] device tensor, no host sync)."""
 
     def __init__(self, gt_rgba, num_views_total: int, metric_bg: Optional[Tensor] = None, gt_is_srgb: bool = True,
-                 ssim_lambda: float = 0.2, use_mask_loss: bool = True, seed: int = 0, train_bg=None):
+                 ssim_lambda: float = 0.2, use_mask_loss: bool = True, seed: int = 0, train_bg=None,
+                 generator: Optional[torch.Generator] = None, device=None):
         self.gt = gt_rgba                              # sequence of [H,W,4] device tensors, local views in order
         self.scale = 1.0 / float(num_views_total)
         self.metric_bg, self.gt_is_srgb, self.ssim_lambda, self.use_mask_loss = metric_bg, gt_is_srgb, ssim_lambda, use_mask_loss
-        self.gen = torch.Generator(device=gt_rgba[0].device).manual_seed(seed)
+        dev = gt_rgba[0].device if len(gt_rgba) else torch.device(device if device is not None else "cuda")
+        # `generator`: a persistent stream owned by the caller (fresh noise every iteration, as the trainer's rand_like)
+        self.gen = generator if generator is not None else torch.Generator(device=dev).manual_seed(seed)
         self.train_bg = train_bg                       # optional fixed backgrounds (tests); default: the trainer's rand_like
-        self.out = torch.zeros(len(gt_rgba), 6, device=gt_rgba[0].device)
+        self.out = torch.zeros(len(gt_rgba), 6, device=dev)
 
     def __call__(self, i: int, image: Tensor) -> Tensor:
         img = image.reshape(image.shape[-3], image.shape[-2], 4)

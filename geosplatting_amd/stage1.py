@@ -56,6 +56,17 @@ class Stage1Model:
         self.kd_grad_weight = 0.0; self.kd_regualr_perturb_std = 0.0
         self.ks_grad_weight = 0.0; self.ks_regualr_perturb_std = 0.0
         self.last_num_gaussians = 0
+        # random streams owned by the model: the kd / ks jitter must be IDENTICAL on every rank (replicas extract and perturb
+        # the same Gaussians), the training-background noise differs per rank and advances every iteration
+        self._jitter_gen = torch.Generator(device=dev).manual_seed(seed * 7919 + 17)
+        self._bg_gens: Dict[int, torch.Generator] = {}
+        self._dev, self._seed = dev, seed
+
+    def bg_generator(self, rank: int) -> torch.Generator:
+        """persistent per-rank stream of the trainer's random training background (geosplat_trainer.py:172)"""
+        if rank not in self._bg_gens:
+            self._bg_gens[rank] = torch.Generator(device=self._dev).manual_seed((self._seed * 1000003 + rank) * 2654435761 % (2 ** 63))
+        return self._bg_gens[rank]
 
     # ------------------------------------------------------------------------------------------------- parameters
     def named_parameters(self) -> Dict[str, Tensor]:
@@ -85,7 +96,8 @@ class Stage1Model:
         (v, f), reg = self.get_geometry()
         self.last_num_gaussians = f.shape[0] * 6
         splats, attrs, _ = self.field.get_gaussians_from_face(v, f, self.kd_regualr_perturb_std, self.ks_regualr_perturb_std,
-                                                              scale=self.scale, initial_guess=self.initial_guess_bias)
+                                                              scale=self.scale, initial_guess=self.initial_guess_bias,
+                                                              generator=self._jitter_gen)
         if self.kd_regualr_perturb_std > 0 and self.kd_grad_weight > 0:
             reg = reg + self.kd_grad_weight * (attrs.kd_jitter - attrs.kd).abs().mean()
         if self.ks_regualr_perturb_std > 0 and self.ks_grad_weight > 0:
@@ -108,7 +120,10 @@ def train_step_fused(model: Stage1Model, cameras: Sequence[Camera], gt_rgba: Seq
     """`train_step` with the render / loss half on the hand-scheduled engine (engine.RenderStep: C-ABI drivers on three
     streams, loss gradient from gs_photo_loss, per-Gaussian gradient bucket) instead of one autograd graph per view.
     The all-reduce happens at the per-Gaussian cut (every rank extracted the same Gaussians), after which each rank
-    runs the same field / MGAdapter / FlexiCubes backward: no second collective."""
+    runs the same field / MGAdapter / FlexiCubes backward: no second collective.  Replicas must start identical
+    (`broadcast_parameters`) and stay so: the backward kernels behind the cut use fp32 atomics, so callers re-broadcast
+    every few hundred steps (`_main`: GEOSPLAT_RESYNC_EVERY); the Gaussian count is checked across ranks before every
+    collective (a topology that differs on one rank would otherwise reduce buffers of different sizes)."""
     from .engine import PathParams, RenderStep
     from .loss import TrainerUpstream
     n_total = len(cameras)
@@ -121,14 +136,17 @@ def train_step_fused(model: Stage1Model, cameras: Sequence[Camera], gt_rgba: Seq
     reg = reg + (model.cubemap - white).abs().mean() * model.light_weight
     exposure = model.exposure_params.exp()
     cut = [splats.means, splats.scales, splats.quats, splats.opacities, attrs.normals, attrs.kd, attrs.ks]
+    if world_size > 1:
+        assert_same_count(splats.means.shape[0])
     pp = PathParams(*[t.detach().contiguous() for t in cut], model.cubemap.detach(), exposure.detach().reshape(()))
     step = getattr(model, "_render_step", None)
     if step is None:
         step = model._render_step = RenderStep(pp, min_roughness=model.min_roughness, max_metallic=model.max_metallic)
     else:
         step.rebind(pp)
-    up = TrainerUpstream([gt_rgba[i] for i in mine], n_total, gt_is_srgb=gt_is_srgb, use_mask_loss=use_mask_loss, seed=seed + rank,
-                         train_bg=None if train_bg is None else [train_bg[i] for i in mine])
+    up = TrainerUpstream([gt_rgba[i] for i in mine], n_total, gt_is_srgb=gt_is_srgb, use_mask_loss=use_mask_loss,
+                         train_bg=None if train_bg is None else [train_bg[i] for i in mine],
+                         generator=model.bg_generator(rank), device=splats.means.device)   # `mine` may be empty (world > views)
     g, _ = step([cameras[i] for i in mine], up, all_reduce=world_size > 1)
     heads = cut + [exposure]
     gh = [g["means"], g["scales"], g["quats"], g["opacities"], g["normals"], g["kd"], g["ks"], g["exposure"].reshape(1)]
@@ -140,6 +158,29 @@ def train_step_fused(model: Stage1Model, cameras: Sequence[Camera], gt_rgba: Seq
             p.grad = torch.zeros_like(p)
     return {"loss_local_views": up.mean_loss() * (n_total / max(1, len(mine))), "regularization": reg.detach(),
             "#gaussians": torch.tensor(splats.means.shape[0]), "exposure": exposure.detach().mean()}
+
+
+def broadcast_parameters(model: "Stage1Model", src: int = 0, group=None) -> None:
+    """Make every replica bit-identical to rank `src` (start-up, and periodically against low-bit drift of the
+    atomics-based backward kernels): one flat broadcast."""
+    params = model.parameters()
+    with torch.no_grad():
+        flat = torch.cat([p.detach().reshape(-1) for p in params])
+        dist.broadcast(flat, src=src, group=group)
+        o = 0
+        for p in params:
+            p.copy_(flat[o:o + p.numel()].view_as(p)); o += p.numel()
+
+
+def assert_same_count(n: int, group=None) -> None:
+    """Every rank must have extracted the same number of Gaussians before a flat collective over per-Gaussian buffers."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    t = torch.tensor([n, -n], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    lo, hi = -int(t[1]), int(t[0])
+    if lo != hi:
+        raise RuntimeError(f"replicas diverged: this rank extracted {n} Gaussians, the group has between {lo} and {hi}; "
+                           "call broadcast_parameters() (and keep the jitter generator in step on every rank)")
 
 
 def flat_all_reduce(grads: List[Tensor], group=None) -> None:
@@ -215,6 +256,9 @@ def _main() -> None:
                         sdf_init=grid.vertices.norm(dim=-1, keepdim=True) - 0.5)
     model.sdf_weight = 0.1
     opt = torch.optim.Adam(model.parameters(), lr=5e-3)
+    resync = int(os.environ.get("GEOSPLAT_RESYNC_EVERY", "200"))
+    if world > 1:
+        broadcast_parameters(model)
     import time
     t0 = None
     for it in range(iters):
@@ -223,6 +267,8 @@ def _main() -> None:
         m = (train_step if os.environ.get("GEOSPLAT_STAGE1_AUTOGRAD") == "1" else train_step_fused)(
             model, cams, gts, gt_is_srgb=False, rank=rank, world_size=world)
         opt.step()
+        if world > 1 and resync > 0 and (it + 1) % resync == 0:
+            broadcast_parameters(model)
         if rank == 0 and (it % 5 == 0 or it == iters - 1):
             print(f"iter {it:3d}  loss(local views) {float(m['loss_local_views']):.4f}  reg {float(m['regularization']):.4f}  "
                   f"#gaussians {int(m['#gaussians'])}", flush=True)

@@ -350,6 +350,34 @@ def specular_cubemap_bwd(bounds, v_out_rgb, roughness, costheta_cutoff):
     return g
 
 
+def specular_subset(cubemap, sel, roughness, costheta_cutoff):
+    """Forward prefilter of the output texels `sel` (flat indices (s*R+y)*R+x) only: returns (out[n,4] = (sum rgb*w, sum w),
+    bounds[n,24]).  Same statements as the full loops (parity tests at R = 512 / 256 / 128)."""
+    cubemap = _f32(cubemap); R = cubemap.shape[1]
+    sel = np.ascontiguousarray(sel, dtype=np.int32); n = int(sel.shape[0])
+    b = np.empty((n, 24), np.float32); out = np.empty((n, 4), np.float32)
+    lib().gso_specular_bounds_subset(int(R), _fl(costheta_cutoff), n, sel.ctypes.data_as(C.c_void_p), _p(b))
+    lib().gso_specular_cubemap_fwd_subset(int(R), _p(cubemap), n, sel.ctypes.data_as(C.c_void_p), _p(b), _fl(roughness),
+                                          _fl(costheta_cutoff), _p(out))
+    return out, b
+
+
+def specular_subset_bwd(R, sel, bounds, v_out_rgb, roughness, costheta_cutoff):
+    """Cubemap gradient [6,R,R,3] of a cotangent that is non-zero on the texels `sel` only (v_out_rgb[n,3] w.r.t. the
+    un-normalised rgb sums)."""
+    sel = np.ascontiguousarray(sel, dtype=np.int32); n = int(sel.shape[0])
+    bounds, v = _f32(bounds), _f32(v_out_rgb)
+    g = np.empty((6, R, R, 3), np.float32)
+    lib().gso_specular_cubemap_bwd_subset(int(R), n, sel.ctypes.data_as(C.c_void_p), _p(bounds), _p(v), _fl(roughness),
+                                          _fl(costheta_cutoff), _p(g))
+    return g
+
+
+def splitsum_roughness(L, min_roughness=0.08, max_roughness=0.5):
+    """per-level prefilter roughness (rfstudio/graphics/_mesh/_texture.py:545-548)"""
+    return [(i / (L - 2)) * (max_roughness - min_roughness) + min_roughness for i in range(L - 1)] + [1.0]
+
+
 def as_splitsum(cubemap, cutoff=0.99, min_resolution=16, min_roughness=0.08, max_roughness=0.5):
     """TextureCubeMap.as_splitsum (rfstudio/graphics/_mesh/_texture.py:530-557).
     Returns (base[6,16,16,3], levels list of [6,R_l,R_l,3], saved-state for the backward)."""

@@ -605,7 +605,8 @@ GSO_API void gso_project_bwd(int N, int V, int D,
 /* ------------------------------------------------------------------------- */
 /* S4: tone mapping (rfstudio/model/geosplat.py:474-480).
  * naive: rgb' = 1 - softplus_{beta=100, threshold=20}(1 - rgb*exposure); alpha passthrough.
- * mode 0 = none (rgb*exposure), 1 = naive, 2 = aces.                         */
+ * mode 0 = none, 1 = naive, 2 = aces.  'none' is `render_rgba * exposure` (geosplat.py:123-124): the product covers
+ * all FOUR channels, alpha included.                                          */
 static inline float softplus100(float x)
 {
     /* torch.nn.Softplus(beta=100, threshold=20): x if beta*x > 20 else log1p(exp(beta*x))/beta */
@@ -623,7 +624,7 @@ GSO_API void gso_tonemap_fwd(int64_t P, int mode, const float* rgba, float expos
             else o = rgb;
             out[4 * p + k] = o;
         }
-        out[4 * p + 3] = rgba[4 * p + 3];
+        out[4 * p + 3] = mode == 0 ? rgba[4 * p + 3] * exposure : rgba[4 * p + 3];
     }
 }
 /* returns d/d(exposure) in *v_exposure (double-accumulated), writes v_rgba */
@@ -648,7 +649,11 @@ GSO_API void gso_tonemap_bwd(int64_t P, int mode, const float* rgba, float expos
             v_rgba[4 * p + k] = g * exposure;
             ve += (double)(g * c);
         }
-        v_rgba[4 * p + 3] = v_out[4 * p + 3];
+        if (mode == 0) {
+            v_rgba[4 * p + 3] = v_out[4 * p + 3] * exposure;
+            ve += (double)(v_out[4 * p + 3] * rgba[4 * p + 3]);
+        } else
+            v_rgba[4 * p + 3] = v_out[4 * p + 3];
     }
     *v_exposure = (float)ve;
 }

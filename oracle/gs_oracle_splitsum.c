@@ -248,3 +248,126 @@ GSO_API void gso_specular_cubemap_bwd(int R, const float* bounds, const float* v
     for (size_t i = 0; i < n * 3; ++i) v_cubemap[i] = (float)acc[i];
     free(acc);
 }
+
+/* ---------------- subsets of output texels (full-size parity tests: R = 512 / 256 / 128) ----------------
+ * The prefilter is independent per output texel, so a test can evaluate it on a random subset `sel[n_sel]` of the
+ * 6*R*R texels (flat index (s*R + y)*R + x) in seconds.  Same statements as the full loops above; bounds / out /
+ * v_out are COMPACT (row i belongs to texel sel[i]), v_cubemap is the full [6,R,R,3] gradient. */
+static void bounds_of_texel(int R, float costheta_cutoff, int o, float* b24)
+{
+    const int TILE = 16;
+    int pz = o / (R * R), py = (o / R) % R, px = o % R;
+    float VNR[3]; cube_to_dir(px, py, pz, R, VNR);
+    for (int s = 0; s < 6; ++s) {
+        int min_x = R - 1, max_x = 0, min_y = R - 1, max_y = 0;
+        for (int tx = 0; tx < (R + TILE - 1) / TILE; ++tx)
+            for (int ty = 0; ty < (R + TILE - 1) / TILE; ++ty) {
+                int tsx = tx * TILE, tsy = ty * TILE;
+                int tex = (tx + 1) * TILE < R ? (tx + 1) * TILE : R;
+                int tey = (ty + 1) * TILE < R ? (ty + 1) * TILE : R;
+                float L0[3], L1[3], L2[3], L3[3];
+                cube_to_dir(tsx, tsy, s, R, L0); cube_to_dir(tex, tsy, s, R, L1);
+                cube_to_dir(tsx, tey, s, R, L2); cube_to_dir(tex, tey, s, R, L3);
+                float mn[3], mx[3];
+                for (int k = 0; k < 3; ++k) {
+                    mn[k] = fminf(fminf(L0[k], L1[k]), fminf(L2[k], L3[k]));
+                    mx[k] = fmaxf(fmaxf(L0[k], L1[k]), fmaxf(L2[k], L3[k]));
+                }
+                float maxdp = fmaxf(mn[0] * VNR[0], mx[0] * VNR[0]) + fmaxf(mn[1] * VNR[1], mx[1] * VNR[1])
+                            + fmaxf(mn[2] * VNR[2], mx[2] * VNR[2]);
+                if (maxdp >= costheta_cutoff) {
+                    for (int y = tsy; y < tey; ++y)
+                        for (int x = tsx; x < tex; ++x) {
+                            float L[3]; cube_to_dir(x, y, s, R, L);
+                            if (dot3(L, VNR) >= costheta_cutoff) {
+                                if (x < min_x) min_x = x; if (x > max_x) max_x = x;
+                                if (y < min_y) min_y = y; if (y > max_y) max_y = y;
+                            }
+                        }
+                }
+            }
+        float* b = b24 + s * 4;
+        b[0] = (float)min_x; b[1] = (float)max_x; b[2] = (float)min_y; b[3] = (float)max_y;
+    }
+}
+
+GSO_API void gso_specular_bounds_subset(int R, float costheta_cutoff, int n_sel, const int* sel, float* bounds /*[n_sel,24]*/)
+{
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int i = 0; i < n_sel; ++i) bounds_of_texel(R, costheta_cutoff, sel[i], bounds + (size_t)i * 24);
+}
+
+GSO_API void gso_specular_cubemap_fwd_subset(int R, const float* cubemap, int n_sel, const int* sel, const float* bounds,
+                                             float roughness, float costheta_cutoff, float* out /*[n_sel,4]*/)
+{
+    float alpha = roughness * roughness;
+    float alphaSqr = alpha * alpha;
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int i = 0; i < n_sel; ++i) {
+        int o = sel[i];
+        int pz = o / (R * R), py = (o / R) % R, px = o % R;
+        float VNR[3]; cube_to_dir(px, py, pz, R, VNR);
+        float wsum = 0.0f, col[3] = { 0, 0, 0 };
+        for (int s = 0; s < 6; ++s) {
+            const float* b = bounds + (size_t)i * 24 + s * 4;
+            int xmin = (int)b[0], xmax = (int)b[1], ymin = (int)b[2], ymax = (int)b[3];
+            if (xmin <= xmax)
+                for (int y = ymin; y <= ymax; ++y)
+                    for (int x = xmin; x <= xmax; ++x) {
+                        float L[3]; cube_to_dir(x, y, s, R, L);
+                        if (dot3(L, VNR) >= costheta_cutoff) {
+                            float Hv[3] = { L[0] + VNR[0], L[1] + VNR[1], L[2] + VNR[2] };
+                            safe_normalize3(Hv);
+                            float wiDotN = fmaxf(dot3(L, VNR), 0.0f);
+                            float VNRDotH = fmaxf(dot3(VNR, Hv), 0.0f);
+                            float w = wiDotN * ndfGGX(alphaSqr, VNRDotH) * pixel_area(x, y, R) / 4.0f;
+                            const float* t = cubemap + (((size_t)s * R + y) * R + x) * 3;
+                            col[0] += t[0] * w; col[1] += t[1] * w; col[2] += t[2] * w;
+                            wsum += w;
+                        }
+                    }
+        }
+        out[(size_t)i * 4] = col[0]; out[(size_t)i * 4 + 1] = col[1]; out[(size_t)i * 4 + 2] = col[2];
+        out[(size_t)i * 4 + 3] = wsum;
+    }
+}
+
+GSO_API void gso_specular_cubemap_bwd_subset(int R, int n_sel, const int* sel, const float* bounds, const float* v_out /*[n_sel,3]*/,
+                                             float roughness, float costheta_cutoff, float* v_cubemap /*[6,R,R,3]*/)
+{
+    float alpha = roughness * roughness;
+    float alphaSqr = alpha * alpha;
+    size_t n = (size_t)6 * R * R;
+    double* acc = (double*)calloc(n * 3, sizeof(double));
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int i = 0; i < n_sel; ++i) {
+        int o = sel[i];
+        int pz = o / (R * R), py = (o / R) % R, px = o % R;
+        float VNR[3]; cube_to_dir(px, py, pz, R, VNR);
+        const float* g = v_out + (size_t)i * 3;
+        for (int s = 0; s < 6; ++s) {
+            const float* b = bounds + (size_t)i * 24 + s * 4;
+            int xmin = (int)b[0], xmax = (int)b[1], ymin = (int)b[2], ymax = (int)b[3];
+            if (xmin <= xmax)
+                for (int y = ymin; y <= ymax; ++y)
+                    for (int x = xmin; x <= xmax; ++x) {
+                        float L[3]; cube_to_dir(x, y, s, R, L);
+                        if (dot3(L, VNR) >= costheta_cutoff) {
+                            float Hv[3] = { L[0] + VNR[0], L[1] + VNR[1], L[2] + VNR[2] };
+                            safe_normalize3(Hv);
+                            float wiDotN = fmaxf(dot3(L, VNR), 0.0f);
+                            float VNRDotH = fmaxf(dot3(VNR, Hv), 0.0f);
+                            float w = wiDotN * ndfGGX(alphaSqr, VNRDotH) * pixel_area(x, y, R) / 4.0f;
+                            double* a = acc + (((size_t)s * R + y) * R + x) * 3;
+                            for (int c = 0; c < 3; ++c) {
+                                double v = (double)(g[c] * w);
+#pragma omp atomic
+                                a[c] += v;
+                            }
+                        }
+                    }
+        }
+    }
+    for (size_t i = 0; i < n * 3; ++i) v_cubemap[i] = (float)acc[i];
+    free(acc);
+}

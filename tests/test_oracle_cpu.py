@@ -61,6 +61,18 @@ def test_golden_tonemap():
         assert rel_err(t(torch.tensor(g["rgba"]), torch.tensor(float(g["exposure"]))).numpy(), g[mode]) < 2e-6
 
 
+def test_tonemap_none_scales_alpha_too():
+    """tone_type='none' is `render_rgba * exposure` (rfstudio/model/geosplat.py:123-124): alpha is scaled with the colours and
+    the exposure gradient carries the alpha term"""
+    g = gold("ref_tonemap.npz")
+    e = float(g["exposure"])
+    out = oracle.tonemap_fwd(g["rgba"], e, "none")
+    assert np.array_equal(out, (g["rgba"] * np.float32(e)).astype(np.float32))
+    v = np.random.default_rng(0).standard_normal(g["rgba"].shape).astype(np.float32)
+    v_rgba, v_e = oracle.tonemap_bwd(g["rgba"], e, v, "none")
+    assert np.allclose(v_rgba, v * np.float32(e)) and abs(v_e - float((v.astype(np.float64) * g["rgba"]).sum())) < 1e-4 * abs(v_e) + 1e-5
+
+
 def test_golden_atlas_and_mip():
     g = gold("ref_atlas.npz")
     levels = [torch.tensor(g[k]) for k in ("l0", "l1", "l2")]

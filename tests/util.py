@@ -17,6 +17,14 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
+def elem_frac(a, b, rtol=1e-4, atol_rel=1e-6):
+    """element-wise figure: fraction of elements with |a-b| > rtol*|b| + atol_rel*max|b|"""
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    if a.size == 0:
+        return 0.0
+    return float((np.abs(a - b) > rtol * np.abs(b) + atol_rel * np.abs(b).max()).mean())
+
+
 def activated(splats):
     """numpy (means, quats, scales_exp, opacities_sigmoid) like GSplatter.render_rgba does (rfstudio/model/gsplat.py:336-339)"""
     return (splats.means.numpy(), splats.quats.numpy(), splats.scales.exp().numpy(),

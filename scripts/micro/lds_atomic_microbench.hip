@@ -8,7 +8,7 @@ template <int MODE, int SPARSE>
 __global__ void __launch_bounds__(1024) k(int iters, float* out)
 {
     extern __shared__ unsigned char raw[];
-    float* f = (float*)raw; unsigned* u = (unsigned*)raw; unsigned long long* q = (unsigned long long*)raw;
+    float* f = (float*)raw; unsigned* u = (unsigned*)raw; unsigned long long* q = (unsigned long long*)raw; double* d = (double*)raw;
     for (int i = threadIdx.x; i < 32768; i += 1024) f[i] = 0.0f;
     __syncthreads();
     unsigned s = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
@@ -16,13 +16,18 @@ __global__ void __launch_bounds__(1024) k(int iters, float* out)
         s = s * 1664525u + 1013904223u;
         const unsigned r = (s >> 8);
         const bool act = SPARSE ? ((r & 15u) == 0u) : true;
-        const unsigned a = (r >> 4) & 16383u;                    // 16384 slots (x 8 bytes = 128 KB for the 64-bit case)
+        unsigned a = (r >> 4) & 16383u;                          // 16384 slots (x 8 bytes = 128 KB for the 64-bit case)
+        if (MODE >= 6) a = __shfl(a, threadIdx.x & ~7u, 64);     // clustered: groups of 8 adjacent lanes hit ONE address (compositor case)
         if (act) {
             if (MODE == 0) atomicAdd(&f[a], 1.0f);
             else if (MODE == 1) atomicAdd(&u[a], 1u);
             else if (MODE == 2) atomicAdd(&q[a], 1ull);
             else if (MODE == 3) f[a] += 1.0f;                    // racy read-modify-write
             else if (MODE == 4) { if (r == 0x7fffffffu) f[a] = 1.0f; }   // no LDS traffic: loop + rng only
+            else if (MODE == 5) atomicAdd(&d[a], 1.0);          // ds_add_f64
+            else if (MODE == 6) atomicAdd(&q[a], 1ull);
+            else if (MODE == 7) atomicAdd(&f[a], 1.0f);
+            else if (MODE == 8) atomicAdd(&d[a], 1.0);
         }
     }
     __syncthreads();
@@ -54,5 +59,7 @@ int main()
     run<1, 1>("ds_add_u32");      run<1, 0>("ds_add_u32");
     run<2, 1>("ds_add_u64");      run<2, 0>("ds_add_u64");
     run<3, 1>("racy f32 rmw");    run<3, 0>("racy f32 rmw");
+    run<5, 1>("ds_add_f64");      run<5, 0>("ds_add_f64");
+    run<6, 0>("ds_add_u64 8-lane same addr"); run<7, 0>("ds_add_f32 8-lane same addr"); run<8, 0>("ds_add_f64 8-lane same addr");
     return 0;
 }

@@ -24,11 +24,11 @@ TOL = 1e-4
 ELEM_FRAC_MAX = 2e-3      # fraction of elements allowed outside |a-b| <= 1e-4 |b| + 1e-6 max|b|  (atomics / summation order)
 
 
-def _report(name, got, want, scale=None):
+def _report(name, got, want, scale=None, atol_rel=1e-6):
     got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
     s = np.abs(want).max() if scale is None else scale
     mx = float(np.abs(got - want).max() / (s + 1e-30))
-    fr = elem_frac(got, want)
+    fr = elem_frac(got, want, atol_rel=atol_rel)
     print(f"  {name:12s} max-norm rel {mx:.3e}   element-wise outliers {fr:.3e}   (n={want.size})")
     return mx, fr
 
@@ -173,7 +173,9 @@ def test_view_fullsize_vs_oracle(cuda, level):
             scale = max(scale, np.abs(v_logscale).max())
         worst[name] = _report(name, got.cpu().numpy(), want, scale)
     for i, (a, b) in enumerate(zip(tl, gsh["v_levels"])):
-        worst[f"level{i}"] = _report(f"v_level{i}", a.grad.cpu().numpy(), b)
+        # a texel of the 16^2 .. 64^2 levels sums 1e4 .. 1e5 SIGNED contributions (random cotangent) in fp32 on both sides: the
+        # absolute floor of its element-wise figure is the rounding of that cancelling sum, 1e-5 of the largest texel gradient
+        worst[f"level{i}"] = _report(f"v_level{i}", a.grad.cpu().numpy(), b, atol_rel=1e-5)
     assert tb.grad is None or float(tb.grad.abs().max()) == 0.0     # 'pbr' never uses the diffuse lookup
     for name, (mx, fr) in worst.items():
         # quats / scales of FLAT disks (3rd scale e^-10) are ill-conditioned: the fp32 oracle itself is ~2e-4 from float64

@@ -29,7 +29,9 @@ def _report(name, got, want, scale=None, atol_rel=1e-6):
     s = np.abs(want).max() if scale is None else scale
     mx = float(np.abs(got - want).max() / (s + 1e-30))
     fr = elem_frac(got, want, atol_rel=atol_rel)
-    print(f"  {name:12s} max-norm rel {mx:.3e}   element-wise outliers {fr:.3e}   (n={want.size})")
+    w = int(np.abs(got - want).argmax())
+    print(f"  {name:12s} max-norm rel {mx:.3e}   element-wise outliers {fr:.3e}   (n={want.size}; worst element {w}: "
+          f"{got.reshape(-1)[w]:.6e} vs {want.reshape(-1)[w]:.6e}, scale {s:.3e})")
     return mx, fr
 
 

@@ -113,6 +113,29 @@ struct GsBfly {
     }
 };
 
+// exp(-sigma) of the compositor in the canonical operation order shared with the oracle (oracle/gs_oracle.c gso_exp_neg):
+// y = -sigma*log2(e), n = rint(y), degree-6 polynomial for 2^(y-n) in explicit FMAs, ldexp.  10 VALU operations instead of
+// v_exp_f32's 1 quarter-rate one -- and alpha, T, every skip / stop decision, the image and last_ids come out bit-identical
+// to the CPU oracle (v_exp_f32 differs from any libm in the last bits, which moved thresholds and made the stored-state
+// backward's T_final = 1 - alpha differ by an ulp of 1.0, i.e. by 1e-3 of a saturated pixel's transmittance).
+__device__ __forceinline__ float gs_exp_neg(float sigma)
+{
+#pragma clang fp contract(off)
+    const float y = sigma * -1.44269504f;
+    const float yc = fminf(fmaxf(y, -126.0f), 126.0f);
+    const float n = __builtin_rintf(yc);
+    const float f = yc - n;
+    float p = 0x1.41a6fep-13f;
+    p = __builtin_fmaf(p, f, 0x1.5f44f0p-10f);
+    p = __builtin_fmaf(p, f, 0x1.3b2dfep-7f);
+    p = __builtin_fmaf(p, f, 0x1.c6aed6p-5f);
+    p = __builtin_fmaf(p, f, 0x1.ebfbdap-3f);
+    p = __builtin_fmaf(p, f, 0x1.62e430p-1f);
+    p = __builtin_fmaf(p, f, 1.0f);
+    const float r = __builtin_ldexpf(p, (int)n);
+    return (y >= -125.0f) ? r : 0.0f;
+}
+
 __device__ __forceinline__ int gs_lane_id() { return (int)(threadIdx.x & 63); }
 
 // fp32 atomic add that lowers to the hardware global_atomic_add_f32 (no CAS loop), agent (device) scope:

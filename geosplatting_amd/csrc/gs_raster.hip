@@ -19,6 +19,7 @@
 //     across the wave with DPP row operations and ONE lane issues the fp32 atomics.
 // Both kernels are FP32-VALU / transcendental bound (one v_exp_f32 per evaluated pair), not HBM bound.
 #include "gs_common.h"
+#include <stdlib.h>
 
 #pragma clang fp contract(off)   // sigma / compositing are spelled with explicit fmaf (bit-exact vs oracle)
 
@@ -40,8 +41,10 @@ extern "C" int gs_raster_stats_read(unsigned long long* host8, int reset)
     return 0;
 }
 #define GS_STAT(i, v) do { const unsigned long long _sv = (unsigned long long)(v); if ((threadIdx.x & 63) == 0) atomicAdd(&g_raster_stats[i], _sv); } while (0)
+#define GS_STAT_ALL(i, v) atomicAdd(&g_raster_stats[i], (unsigned long long)(v))      /* every active lane adds */
 #else
 #define GS_STAT(i, v) do { } while (0)
+#define GS_STAT_ALL(i, v) do { } while (0)
 #endif
 
 // extent of {alpha >= 1/255} for a Gaussian, conservatively inflated; returns false if it can never reach
@@ -266,7 +269,7 @@ raster_fwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
             const float dx = gx - px, dy = gy - py;
             const float t0 = ga * dx, t1 = gc * dy, t2 = gb * dx;
             const float sigma = fmaf(t0, dx, fmaf(t1, dy, t2 * dy));
-            alpha = fminf(0.999f, go * __expf(-sigma));
+            alpha = fminf(0.999f, go * gs_exp_neg(sigma));
             pre = sigma >= 0.0f && alpha >= GS_ALPHA_MIN;
         };
         auto phase_b = [&](int j, float alpha, bool pre) {
@@ -408,7 +411,7 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
             const float dx = gx - px, dy = gy - py;
             const float t0 = ga * dx, t1 = gc * dy, t2 = gb * dx;
             const float sigma = fmaf(t0, dx, fmaf(t1, dy, t2 * dy));
-            const float vis = __expf(-sigma);
+            const float vis = gs_exp_neg(sigma);
             const float alpha = fminf(0.999f, go * vis);
             const bool valid = (idxj <= bin_final) && sigma >= 0.0f && alpha >= GS_ALPHA_MIN;
             const unsigned long long vmask = __ballot(valid);
@@ -465,6 +468,353 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
     }
 }
 
+// ===================================================================================================
+// PER-LANE LISTS ("lanes" kernels).  The quadrant kernels above spend all 64 lanes on every survivor of the
+// ballot cull although a surface splat at 2 M / 800^2 covers ~8 of the 64 pixels (7.8 valid lanes per survivor,
+// 128 wave instructions each in the backward).  Here every PIXEL walks only its own candidates:
+//   * lane j of a batch turns record j's {alpha >= 1/255} rectangle into a 64-bit pixel mask of the quadrant;
+//   * a 64x64 bit-matrix transpose across the wave (6 exchange stages: ds_swizzle / ds_bpermute, no LDS storage)
+//     hands lane p the 64-bit LIST of the records that can touch pixel p;
+//   * the 64 records of the batch sit in LDS (wave-private, no barrier); lane p pops its list front to back
+//     (back to front in the backward), fetching "its" record with two 16-byte LDS reads -- a trip of the loop
+//     evaluates up to 64 DIFFERENT (pixel, Gaussian) pairs, and the loop runs max-over-lanes(list length)
+//     ~ 6-9 times per batch instead of once per survivor (~18.5);
+//   * backward: the 6+D per-Gaussian sums can no longer be reduced across the wave (every lane works on another
+//     Gaussian), so they accumulate in LDS with ds_add_f64 -- measured 0.32 cycles per lane on MI355X, TEN times
+//     the rate of ds_add_f32 (3.0), scripts/micro/lds_atomic_microbench.hip -- one accumulator row per record of
+//     the batch, and are committed once per (quadrant, Gaussian): 7 records x 9 values per atomic instruction,
+//     the 9 lanes of a record falling into one 64-byte gradient record = one memory-side request, as before.
+// Per-pixel evaluation order and arithmetic are those of the quadrant kernels, so the forward is bit-identical.
+
+template <int K>
+__device__ __forceinline__ unsigned gs_lane_xor(unsigned v)
+{
+    if (K == 32) return (unsigned)__shfl_xor((int)v, 32, 64);
+    return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (K << 10) | 0x1f);      // bit mode: lane ^ K inside 32 lanes
+}
+
+// out[lane p] bit j = in[lane j] bit p   (64 x 64 bits held as one 64-bit value per lane)
+__device__ __forceinline__ unsigned long long gs_bit_transpose64(unsigned long long x, int lane)
+{
+    unsigned lo = (unsigned)x, hi = (unsigned)(x >> 32);
+    {
+        const bool up = (lane & 32) != 0;
+        const unsigned recv = gs_lane_xor<32>(up ? lo : hi);
+        if (up) lo = recv; else hi = recv;
+    }
+#define GS_TR_STAGE(K, LOM)                                                                                        \
+    {                                                                                                              \
+        const bool up = (lane & K) != 0;                                                                           \
+        const unsigned rl = gs_lane_xor<K>(lo), rh = gs_lane_xor<K>(hi);                                           \
+        lo = up ? ((lo & ~LOM) | ((rl & ~LOM) >> K)) : ((lo & LOM) | ((rl & LOM) << K));                           \
+        hi = up ? ((hi & ~LOM) | ((rh & ~LOM) >> K)) : ((hi & LOM) | ((rh & LOM) << K));                           \
+    }
+    GS_TR_STAGE(16, 0x0000ffffu)
+    GS_TR_STAGE(8, 0x00ff00ffu)
+    GS_TR_STAGE(4, 0x0f0f0f0fu)
+    GS_TR_STAGE(2, 0x33333333u)
+    GS_TR_STAGE(1, 0x55555555u)
+#undef GS_TR_STAGE
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// active rectangle of a quadrant wave in QUADRANT pixel indices (0..7)
+__device__ __forceinline__ void active_rect_i(unsigned long long act, int& xmin, int& xmax, int& ymin, int& ymax)
+{
+    unsigned cols = (unsigned)(act | (act >> 32));
+    cols |= cols >> 16; cols |= cols >> 8; cols &= 0xffu;
+    xmin = __builtin_ctz(cols); xmax = 31 - __builtin_clz(cols);
+    ymin = __builtin_ctzll(act) >> 3; ymax = (63 - __builtin_clzll(act)) >> 3;
+}
+
+// 64-bit mask (bit y*8+x) of the quadrant pixels whose centre lies inside record's alpha extent, clipped to the active
+// rectangle; 0 if the record cannot reach any of them
+__device__ __forceinline__ unsigned long long record_pixel_mask(bool ok, float mx, float my, float hx, float hy, int qx0, int qy0,
+                                                                int xmin, int xmax, int ymin, int ymax)
+{
+    const float ox = (float)qx0 + 0.5f, oy = (float)qy0 + 0.5f;
+    const float x0f = fmaxf(ceilf(mx - hx - ox), (float)xmin), x1f = fminf(floorf(mx + hx - ox), (float)xmax);
+    const float y0f = fmaxf(ceilf(my - hy - oy), (float)ymin), y1f = fminf(floorf(my + hy - oy), (float)ymax);
+    if (!(ok && hx >= 0.0f && x0f <= x1f && y0f <= y1f)) return 0ull;
+    const int x0 = (int)x0f, x1 = (int)x1f, y0 = (int)y0f, y1 = (int)y1f;
+    const unsigned colmask = ((2u << x1) - 1u) & ~((1u << x0) - 1u);
+    const unsigned rep = colmask * 0x01010101u;
+    const unsigned long long rows = (~0ull >> (8 * (7 - y1))) & (~0ull << (8 * y0));
+    return ((((unsigned long long)rep) << 32) | rep) & rows;
+}
+
+struct LaneLds {
+    float4* a;      // {mx, my, 0.5a, b}
+    float4* b;      // {0.5c, opacity, c0, c1}
+    int2* c;        // {bits(c2), g}
+};
+static constexpr int GS_LANES_REC_BYTES = 64 * (16 + 16 + 8);       // per wave
+
+__device__ __forceinline__ void lanes_store_batch(const LaneLds& l, int lane, const Batch& cur)
+{
+    l.a[lane] = cur.r0;
+    l.b[lane] = make_float4(cur.r1.x, cur.r1.y, cur.r2.x, cur.r2.y);
+    l.c[lane] = make_int2(__float_as_int(cur.r2.z), __float_as_int(cur.r2.w));
+}
+
+template <int CD>
+__global__ void __launch_bounds__(256)
+raster_fwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* __restrict__ tile_order,
+                        const float4* __restrict__ rec0, const float4* __restrict__ rec1, const float4* __restrict__ rec2,
+                        const float* __restrict__ colors, const float* __restrict__ background, int n_isects,
+                        const int32_t* __restrict__ offsets,
+                        float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids)
+{
+    extern __shared__ __align__(16) unsigned char gs_lds_raw[];
+    const int tile = tile_order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tx = tile % tile_w, ty = tile / tile_w;
+    const int qx0 = tx * GS_TILE + (wave & 1) * 8, qy0 = ty * GS_TILE + (wave >> 1) * 8;
+    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
+    const bool inside = pxi < W && pyi < H;
+    const float px = (float)pxi + 0.5f, py = (float)pyi + 0.5f;
+    LaneLds lds;
+    lds.a = (float4*)(gs_lds_raw + (size_t)wave * GS_LANES_REC_BYTES);
+    lds.b = lds.a + 64;
+    lds.c = (int2*)(lds.b + 64);
+
+    const int start = offsets[tile];
+    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+
+    float T = 1.0f;
+    int cur_idx = 0;
+    bool done = !inside;
+    float pix[CD];
+#pragma unroll
+    for (int k = 0; k < CD; ++k) pix[k] = 0.0f;
+
+    Batch nxt = load_batch(rec0, rec1, rec2, start + lane, start + lane < end);
+    for (int base = start; base < end; base += 64) {
+        const unsigned long long act = __ballot(!done);
+        if (act == 0ull) break;
+        int xmin, xmax, ymin, ymax;
+        active_rect_i(act, xmin, xmax, ymin, ymax);
+        const Batch cur = nxt;
+        {
+            const int nidx = base + 64 + lane;
+            nxt = load_batch(rec0, rec1, rec2, nidx, nidx < end);
+        }
+        const unsigned long long pm = record_pixel_mask(cur.ok, cur.r0.x, cur.r0.y, cur.r1.z, cur.r1.w, qx0, qy0, xmin, xmax, ymin, ymax);
+        const unsigned long long hmask = __ballot(pm != 0ull);
+        GS_STAT(0, 1); GS_STAT(1, __popcll(hmask));
+        if (hmask == 0ull) continue;
+        lanes_store_batch(lds, lane, cur);
+        unsigned long long list = gs_bit_transpose64(pm, lane);
+        if (done) list = 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        while (__ballot(list != 0ull) != 0ull) {
+            GS_STAT(3, 1);
+            if (list != 0ull) {
+                const int j = __builtin_ctzll(list);
+                list &= list - 1ull;
+                const float4 a = lds.a[j], b = lds.b[j];
+                const int2 c = lds.c[j];
+                const float dx = a.x - px, dy = a.y - py;
+                const float t0 = a.z * dx, t1 = b.x * dy, t2 = a.w * dx;
+                const float sigma = fmaf(t0, dx, fmaf(t1, dy, t2 * dy));
+                const float alpha = fminf(0.999f, b.y * gs_exp_neg(sigma));
+                if (sigma >= 0.0f && alpha >= GS_ALPHA_MIN) {
+                    GS_STAT_ALL(2, 1);
+                    const float next_T = T * (1.0f - alpha);
+                    if (next_T <= 1e-4f) {
+                        done = true; list = 0ull;
+                    } else {
+                        const float vis = alpha * T;
+                        if (CD <= 3) {
+                            pix[0] = fmaf(b.z, vis, pix[0]);
+                            if (CD > 1) pix[1] = fmaf(b.w, vis, pix[1]);
+                            if (CD > 2) pix[2] = fmaf(__int_as_float(c.x), vis, pix[2]);
+                        } else {
+                            const float* cg = colors + (size_t)c.y * D;
+#pragma unroll
+                            for (int k = 0; k < CD; ++k) if (k < D) pix[k] = fmaf(cg[k], vis, pix[k]);
+                        }
+                        T = next_T;
+                        cur_idx = base + j;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();       // every lane is done reading this batch before the next one overwrites it
+    }
+
+    if (inside) {
+        const size_t pid = (size_t)pyi * W + pxi;
+        alphas[pid] = 1.0f - T;
+        last_ids[pid] = cur_idx;
+#pragma unroll
+        for (int k = 0; k < CD; ++k)
+            if (k < D) render[pid * D + k] = background ? fmaf(T, background[k], pix[k]) : pix[k];
+    }
+}
+
+template <int CD>
+__global__ void __launch_bounds__(256)
+raster_bwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* __restrict__ tile_order,
+                        const float4* __restrict__ rec0, const float4* __restrict__ rec1, const float4* __restrict__ rec2,
+                        const float* __restrict__ colors, const float* __restrict__ background, int n_isects,
+                        const int32_t* __restrict__ offsets,
+                        const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
+                        const float* __restrict__ v_render, const float* __restrict__ v_alphas,
+                        float* __restrict__ v_packed, int rec_stride)
+{
+    constexpr int NV = 6 + CD;
+    constexpr int RPI = 64 / NV;                                   // records committed per atomic instruction
+    constexpr int WAVE_BYTES = GS_LANES_REC_BYTES + NV * 64 * 8 + 64 * 4;
+    extern __shared__ __align__(16) unsigned char gs_lds_raw[];
+    const int tile = tile_order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tx = tile % tile_w, ty = tile / tile_w;
+    const int qx0 = tx * GS_TILE + (wave & 1) * 8, qy0 = ty * GS_TILE + (wave >> 1) * 8;
+    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
+    const bool inside = pxi < W && pyi < H;
+    const float px = (float)pxi + 0.5f, py = (float)pyi + 0.5f;
+
+    const int start = offsets[tile];
+    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    if (end <= start) return;
+
+    LaneLds lds;
+    lds.a = (float4*)(gs_lds_raw + (size_t)wave * WAVE_BYTES);
+    lds.b = lds.a + 64;
+    lds.c = (int2*)(lds.b + 64);
+    double* acc = (double*)(lds.c + 64);                           // [NV][64]: row k, record j
+    int* hitlist = (int*)(acc + NV * 64);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k * 64 + lane] = 0.0;
+
+    float T_final = 1.0f, v_a = 0.0f;
+    int bin_final = -1;
+    float v_rc[CD], buffer[CD];
+#pragma unroll
+    for (int k = 0; k < CD; ++k) { v_rc[k] = 0.0f; buffer[k] = 0.0f; }
+    if (inside) {
+        const size_t pid = (size_t)pyi * W + pxi;
+        T_final = 1.0f - alphas[pid];
+        bin_final = last_ids[pid];
+        v_a = v_alphas[pid];
+#pragma unroll
+        for (int k = 0; k < CD; ++k) if (k < D) v_rc[k] = v_render[pid * D + k];
+    }
+    float bg_dot = 0.0f;
+    if (background) {
+#pragma unroll
+        for (int k = 0; k < CD; ++k) if (k < D) bg_dot += background[k] * v_rc[k];
+    }
+    float T = T_final;
+
+    int top = bin_final;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) top = max(top, __shfl_xor(top, off, 64));
+    if (top >= end) top = end - 1;
+
+    Batch nxt = load_batch_pred(rec0, rec1, rec2, top - lane, top - lane >= start);
+    for (; top >= start; top -= 64) {
+        const Batch cur = nxt;
+        {
+            const int nidx = top - 64 - lane;
+            nxt = load_batch_pred(rec0, rec1, rec2, nidx, nidx >= start);
+        }
+        // pixels whose last composited entry lies at or after this batch's lowest index can be valid in it
+        const bool live = bin_final >= top - 63;
+        const unsigned long long act = __ballot(live);
+        if (act == 0ull) continue;
+        int xmin, xmax, ymin, ymax;
+        active_rect_i(act, xmin, xmax, ymin, ymax);
+        const unsigned long long pm = record_pixel_mask(cur.ok, cur.r0.x, cur.r0.y, cur.r1.z, cur.r1.w, qx0, qy0, xmin, xmax, ymin, ymax);
+        const bool hit = pm != 0ull;
+        const unsigned long long hmask = __ballot(hit);
+        GS_STAT(4, 1); GS_STAT(5, __popcll(hmask));
+        if (hmask == 0ull) continue;
+        lanes_store_batch(lds, lane, cur);                          // record of stream index top - lane
+        if (hit) hitlist[__popcll(hmask & ((1ull << lane) - 1ull))] = lane;
+        unsigned long long list = gs_bit_transpose64(pm, lane);
+        // record j of the batch has stream index top - j: only j >= top - bin_final were composited by this pixel
+        const int jmin = top - bin_final;
+        if (!live) list = 0ull;
+        else if (jmin > 0) list &= ~0ull << jmin;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        while (__ballot(list != 0ull) != 0ull) {
+            GS_STAT(6, 1);
+            if (list != 0ull) {
+                const int j = __builtin_ctzll(list);
+                list &= list - 1ull;
+                const float4 a = lds.a[j], b = lds.b[j];
+                const int2 c = lds.c[j];
+                const float ga = a.z, gb = a.w, gc = b.x, go = b.y;
+                const float dx = a.x - px, dy = a.y - py;
+                const float t0 = ga * dx, t1 = gc * dy, t2 = gb * dx;
+                const float sigma = fmaf(t0, dx, fmaf(t1, dy, t2 * dy));
+                const float vis = gs_exp_neg(sigma);
+                const float alpha = fminf(0.999f, go * vis);
+                if (sigma >= 0.0f && alpha >= GS_ALPHA_MIN) {
+                    GS_STAT_ALL(7, 1);
+                    float gcol[CD];
+                    if (CD <= 3) {
+                        gcol[0] = b.z;
+                        if (CD > 1) gcol[1] = b.w;
+                        if (CD > 2) gcol[2] = __int_as_float(c.x);
+                    } else {
+                        const float* cg = colors + (size_t)c.y * D;
+#pragma unroll
+                        for (int k = 0; k < CD; ++k) gcol[k] = (k < D) ? cg[k] : 0.0f;
+                    }
+                    const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);
+                    T *= ra;
+                    const float fac = alpha * T;
+                    float v_alpha = 0.0f;
+                    double* arow = acc + j;
+#pragma unroll
+                    for (int k = 0; k < CD; ++k) {
+                        if (k < D) atomicAdd(arow + (6 + k) * 64, (double)(fac * v_rc[k]));
+                        v_alpha += (gcol[k] * T - buffer[k] * ra) * v_rc[k];
+                    }
+                    v_alpha += T_final * ra * v_a;
+                    if (background) v_alpha += -T_final * ra * bg_dot;
+                    if (go * vis <= 0.999f) {
+                        const float v_sigma = -go * vis * v_alpha;
+                        atomicAdd(arow + 0 * 64, (double)(v_sigma * ((2.0f * ga) * dx + gb * dy)));
+                        atomicAdd(arow + 1 * 64, (double)(v_sigma * (gb * dx + (2.0f * gc) * dy)));
+                        atomicAdd(arow + 2 * 64, (double)(0.5f * v_sigma * dx * dx));
+                        atomicAdd(arow + 3 * 64, (double)(v_sigma * dx * dy));
+                        atomicAdd(arow + 4 * 64, (double)(0.5f * v_sigma * dy * dy));
+                        atomicAdd(arow + 5 * 64, (double)(vis * v_alpha));
+                    }
+#pragma unroll
+                    for (int k = 0; k < CD; ++k) buffer[k] += gcol[k] * fac;
+                }
+            }
+        }
+        // commit: RPI records x NV values per atomic instruction; the NV lanes of a record hit one packed gradient record
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int nh = __popcll(hmask);
+        const int r = lane / NV, k = lane - r * NV;
+        for (int it = 0; it * RPI < nh; ++it) {
+            const int idx = it * RPI + r;
+            if (r < RPI && idx < nh) {
+                const int j = hitlist[idx];
+                const double v = acc[k * 64 + j];
+                if (v != 0.0) {
+                    acc[k * 64 + j] = 0.0;
+                    gs_atomic_add(v_packed + (size_t)lds.c[j].y * rec_stride + k, (float)v);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Occupancy cap of the two compositor kernels: they use no LDS, so a dynamic LDS request of 160 KB / 4 limits a CU to
 // FOUR resident 256-thread blocks (4 waves per SIMD instead of 8).  Measured on the bench workload: backward
@@ -473,7 +823,15 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
 // saturate it, the other four only stretch every chain, delay the long tiles and thrash the scalar/vector L1s -- and
 // the freed wave slots let the memory-bound kernels of the engine's other two streams co-reside.
 #define GS_RASTER_BLOCKS_PER_CU 4
-static size_t gs_raster_lds_pad() { return (size_t)(160 * 1024 / GS_RASTER_BLOCKS_PER_CU) - 1024; }
+static int gs_env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+static int gs_raster_blocks_per_cu() { static const int b = gs_env_int("GEOSPLAT_RASTER_BLOCKS", GS_RASTER_BLOCKS_PER_CU); return b < 1 ? 1 : (b > 8 ? 8 : b); }
+static size_t gs_raster_lds_pad() { return (size_t)(160 * 1024 / gs_raster_blocks_per_cu()) - 1024; }
+// compositor variant: 1 = per-lane lists (default), 0 = one wave per survivor (the round-1 kernels, kept for A/B runs)
+static int gs_raster_lanes() { static const int m = gs_env_int("GEOSPLAT_RASTER_LANES", 1); return m; }
 
 // workspace layout: [rec0 | rec1 | rec2 | tile_order], every segment 256-byte aligned
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -512,6 +870,15 @@ static int launch_fwd(int W, int H, int D, const RasterWs& ws, const float* colo
                       hipStream_t s)
 {
     const int tile_w = (W + GS_TILE - 1) / GS_TILE, tile_h = (H + GS_TILE - 1) / GS_TILE;
+    if (gs_raster_lanes()) {
+        size_t lds = 4 * (size_t)GS_LANES_REC_BYTES;
+        if (lds < gs_raster_lds_pad()) lds = gs_raster_lds_pad();
+        hipLaunchKernelGGL(raster_fwd_lanes_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
+                           ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, (int)n_isects, offsets, render, alphas,
+                           last_ids);
+        GS_CHECK_LAUNCH();
+        return GS_OK;
+    }
     hipLaunchKernelGGL(raster_fwd_kernel<CD>, dim3(tile_w * tile_h), dim3(256), gs_raster_lds_pad(), s, W, H, tile_w, tile_w * tile_h, D,
                        ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, (int)n_isects, offsets, render, alphas,
                        last_ids);
@@ -593,6 +960,20 @@ static int launch_bwd(int W, int H, int D, const RasterWs& ws, const float* colo
                       const float* v_render, const float* v_alphas, float* v_packed, int rec_stride, hipStream_t s)
 {
     const int tile_w = (W + GS_TILE - 1) / GS_TILE, tile_h = (H + GS_TILE - 1) / GS_TILE;
+    if (gs_raster_lanes()) {
+        size_t lds = 4 * ((size_t)GS_LANES_REC_BYTES + (size_t)(6 + CD) * 64 * 8 + 64 * 4);
+        if (lds < gs_raster_lds_pad()) lds = gs_raster_lds_pad();
+        static bool attr_set = false;                  // > 64 KB of dynamic LDS (D > 16) needs the opt-in once per kernel
+        if (!attr_set && lds > 64 * 1024) {
+            GS_CHECK_HIP(hipFuncSetAttribute((const void*)raster_bwd_lanes_kernel<CD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(raster_bwd_lanes_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
+                           ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, (int)n_isects, offsets, alphas, last_ids,
+                           v_render, v_alphas, v_packed, rec_stride);
+        GS_CHECK_LAUNCH();
+        return GS_OK;
+    }
     hipLaunchKernelGGL(raster_bwd_kernel<CD>, dim3(tile_w * tile_h), dim3(256), gs_raster_lds_pad(), s, W, H, tile_w, tile_w * tile_h, D,
                        ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, (int)n_isects, offsets, alphas, last_ids,
                        v_render, v_alphas, v_packed, rec_stride);

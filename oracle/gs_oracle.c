@@ -309,6 +309,28 @@ static inline float gso_sigma(float a, float b, float c, float dx, float dy)
     return fmaf(t0, dx, fmaf(t1, dy, t2 * dy));
 }
 
+/* exp(-sigma) in ONE canonical operation order shared with the HIP compositor (gs_common.h gs_exp_neg): the upstream
+ * kernel calls the hardware's approximate exponential (__expf), whose bits no CPU reproduces; spelling the function
+ * out -- 2^(y) with y = -sigma*log2(e), n = rint(y), a degree-6 polynomial for 2^(y-n) in explicit FMAs, ldexp -- makes
+ * alpha, the transmittance chain, every skip / stop decision and therefore the image and last_ids BIT-IDENTICAL
+ * between this oracle and the GPU (max relative error of the function 8e-8, the size of __expf's own error). */
+static inline float gso_exp_neg(float sigma)
+{
+    float y = sigma * -1.44269504f;
+    float yc = fminf(fmaxf(y, -126.0f), 126.0f);   /* keeps rint / ldexp in range; NaN -> -126 */
+    float n = rintf(yc);                        /* round to nearest even */
+    float f = yc - n;                           /* exact */
+    float p = 0x1.41a6fep-13f;
+    p = fmaf(p, f, 0x1.5f44f0p-10f);
+    p = fmaf(p, f, 0x1.3b2dfep-7f);
+    p = fmaf(p, f, 0x1.c6aed6p-5f);
+    p = fmaf(p, f, 0x1.ebfbdap-3f);
+    p = fmaf(p, f, 0x1.62e430p-1f);
+    p = fmaf(p, f, 1.0f);
+    float r = ldexpf(p, (int)n);
+    return (y >= -125.0f) ? r : 0.0f;           /* underflow (and NaN): such a pair is far below 1/255 anyway */
+}
+
 GSO_API void gso_raster_fwd(int W, int H, int tile_size, int D,
                             const float* means2d, const float* conics, const float* opacities,
                             const float* colors, const float* background /* nullable [D] */,
@@ -337,7 +359,7 @@ GSO_API void gso_raster_fwd(int W, int H, int tile_size, int D,
                     int g = flatten_ids[idx];
                     float dx = means2d[2 * g] - px, dy = means2d[2 * g + 1] - py;
                     float sigma = gso_sigma(conics[3 * g], conics[3 * g + 1], conics[3 * g + 2], dx, dy);
-                    float alpha = fminf(0.999f, opacities[g] * expf(-sigma));
+                    float alpha = fminf(0.999f, opacities[g] * gso_exp_neg(sigma));
                     ++pairs;
                     if (fabsf(alpha - 1.0f / 255.0f) < 1e-5f * (1.0f / 255.0f)) amb = 1;
                     if (sigma < 0.0f || alpha < 1.0f / 255.0f) continue;
@@ -401,7 +423,7 @@ GSO_API void gso_raster_bwd(int W, int H, int tile_size, int D,
                     float opac = opacities[g];
                     float dx = means2d[2 * g] - px, dy = means2d[2 * g + 1] - py;
                     float sigma = gso_sigma(ca, cb, cc, dx, dy);
-                    float vis = expf(-sigma);
+                    float vis = gso_exp_neg(sigma);
                     float alpha = fminf(0.999f, opac * vis);
                     if (sigma < 0.0f || alpha < 1.0f / 255.0f) continue;
                     float ra = 1.0f / (1.0f - alpha);

@@ -469,21 +469,24 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
 }
 
 // ===================================================================================================
-// PER-LANE LISTS ("lanes" kernels).  The quadrant kernels above spend all 64 lanes on every survivor of the
-// ballot cull although a surface splat at 2 M / 800^2 covers ~8 of the 64 pixels (7.8 valid lanes per survivor,
-// 128 wave instructions each in the backward).  Here every PIXEL walks only its own candidates:
-//   * lane j of a batch turns record j's {alpha >= 1/255} rectangle into a 64-bit pixel mask of the quadrant;
+// PER-LANE LISTS over DENSE batches ("lanes" kernels).  The quadrant kernels above spend all 64 lanes on every
+// survivor of the ballot cull although a surface splat at 2 M / 800^2 covers ~8 of the 64 pixels (7.8 valid lanes
+// per survivor, 128 wave instructions each in the backward).  Here every PIXEL walks only its own candidates:
+//   * CULL + COMPACT: a raw batch of 64 stream records is tested against the rectangle of the still-active pixels
+//     (as before) and the ~20 survivors are appended, in stream order, to a wave-private LDS queue; a DENSE batch
+//     of 64 surviving records is processed whenever the queue holds one (the per-batch work below is SIMD over the
+//     records of a batch, so it is paid per 64 useful records instead of per 64 stream records);
+//   * lane j of a dense batch turns record j's EXACT {alpha >= 1/255} ellipse (one interval per pixel row, with
+//     slack) into a 64-bit pixel mask of the quadrant;
 //   * a 64x64 bit-matrix transpose across the wave (6 exchange stages: ds_swizzle / ds_bpermute, no LDS storage)
 //     hands lane p the 64-bit LIST of the records that can touch pixel p;
-//   * the 64 records of the batch sit in LDS (wave-private, no barrier); lane p pops its list front to back
-//     (back to front in the backward), fetching "its" record with two 16-byte LDS reads -- a trip of the loop
-//     evaluates up to 64 DIFFERENT (pixel, Gaussian) pairs, and the loop runs max-over-lanes(list length)
-//     ~ 6-9 times per batch instead of once per survivor (~18.5);
+//   * lane p pops its list front to back (back to front in the backward), fetching "its" record from the LDS queue
+//     -- one trip of the loop evaluates up to 64 DIFFERENT (pixel, Gaussian) pairs;
 //   * backward: the 6+D per-Gaussian sums can no longer be reduced across the wave (every lane works on another
 //     Gaussian), so they accumulate in LDS with ds_add_f64 -- measured 0.32 cycles per lane on MI355X, TEN times
 //     the rate of ds_add_f32 (3.0), scripts/micro/lds_atomic_microbench.hip -- one accumulator row per record of
-//     the batch, and are committed once per (quadrant, Gaussian): 7 records x 9 values per atomic instruction,
-//     the 9 lanes of a record falling into one 64-byte gradient record = one memory-side request, as before.
+//     the dense batch, and are committed once per (quadrant, Gaussian): 7 records x 9 values per atomic
+//     instruction, the 9 lanes of a record falling into one 64-byte gradient record = one memory-side request.
 // Per-pixel evaluation order and arithmetic are those of the quadrant kernels, so the forward is bit-identical.
 
 template <int K>
@@ -527,34 +530,86 @@ __device__ __forceinline__ void active_rect_i(unsigned long long act, int& xmin,
     ymin = __builtin_ctzll(act) >> 3; ymax = (63 - __builtin_clzll(act)) >> 3;
 }
 
-// 64-bit mask (bit y*8+x) of the quadrant pixels whose centre lies inside record's alpha extent, clipped to the active
-// rectangle; 0 if the record cannot reach any of them
-__device__ __forceinline__ unsigned long long record_pixel_mask(bool ok, float mx, float my, float hx, float hy, int qx0, int qy0,
-                                                                int xmin, int xmax, int ymin, int ymax)
+#ifndef GS_LANES_EXACT_MASK
+#define GS_LANES_EXACT_MASK 1
+#endif
+
+// 64-bit mask (bit y*8+x) of the quadrant pixels whose centre can lie inside the record's {alpha >= 1/255} set, clipped to
+// the active rectangle.  A SUPERSET is all that is needed (every popped pair is tested exactly); the tighter it is, the
+// shorter the per-pixel lists: the bounding rectangle of a thin diagonal ellipse holds twice the pixels of the ellipse.
+//   sigma(dx, dy) = ha dx^2 + cb dx dy + hc dy^2 <= tau := log(255 op)     (ha = a/2, hc = c/2, dx = mx - px)
+// per pixel row (fixed dy):  dx in [xc - w, xc + w],  xc = -cb dy / (2 ha),  w = sqrt(dy^2 (cb^2 - 4 ha hc) + 4 ha tau) / (2 ha).
+__device__ __forceinline__ unsigned long long record_pixel_mask(bool ok, float mx, float my, float ha, float cb, float hc, float op,
+                                                                float hx, float hy, int qx0, int qy0, int xmin, int xmax, int ymin,
+                                                                int ymax)
 {
     const float ox = (float)qx0 + 0.5f, oy = (float)qy0 + 0.5f;
     const float x0f = fmaxf(ceilf(mx - hx - ox), (float)xmin), x1f = fminf(floorf(mx + hx - ox), (float)xmax);
     const float y0f = fmaxf(ceilf(my - hy - oy), (float)ymin), y1f = fminf(floorf(my + hy - oy), (float)ymax);
     if (!(ok && hx >= 0.0f && x0f <= x1f && y0f <= y1f)) return 0ull;
-    const int x0 = (int)x0f, x1 = (int)x1f, y0 = (int)y0f, y1 = (int)y1f;
-    const unsigned colmask = ((2u << x1) - 1u) & ~((1u << x0) - 1u);
-    const unsigned rep = colmask * 0x01010101u;
-    const unsigned long long rows = (~0ull >> (8 * (7 - y1))) & (~0ull << (8 * y0));
-    return ((((unsigned long long)rep) << 32) | rep) & rows;
+    const int y0 = (int)y0f, y1 = (int)y1f;
+    if (!GS_LANES_EXACT_MASK || !(ha > 1e-12f) || !(hx < 1e20f)) {          // bounding rectangle (degenerate conics)
+        const int x0 = (int)x0f, x1 = (int)x1f;
+        const unsigned colmask = ((2u << x1) - 1u) & ~((1u << x0) - 1u);
+        const unsigned rep = colmask * 0x01010101u;
+        const unsigned long long rows = (~0ull >> (8 * (7 - y1))) & (~0ull << (8 * y0));
+        return ((((unsigned long long)rep) << 32) | rep) & rows;
+    }
+    const float tau = __logf(255.0f * op) + 0.004f;                         // slack >> rounding of sigma at a pixel
+    const float inv2a = 0.5f / ha;
+    const float k1 = cb * cb - 4.0f * ha * hc, k2 = 4.0f * ha * tau, k3 = cb * inv2a;
+    const float mxo = mx - ox, dy0 = my - oy;
+    unsigned lo = 0u, hi = 0u;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+        const float dy = dy0 - (float)y;
+        const float disc = fmaf(dy * dy, k1, k2);
+        const float w = sqrtf(fmaxf(disc, 0.0f)) * inv2a + 0.01f;
+        const float xc = fmaf(dy, k3, mxo);                                  // px - ox = mxo - dx,  dx centre = -k3 dy
+        const float xl = fmaxf(ceilf(xc - w), x0f), xh = fminf(floorf(xc + w), x1f);
+        const bool on = (y >= y0) && (y <= y1) && (disc >= 0.0f) && (xl <= xh);
+        const unsigned bits = on ? (((2u << (int)xh) - 1u) & ~((1u << (int)xl) - 1u)) : 0u;
+        if (y < 4) lo |= bits << (8 * y); else hi |= bits << (8 * (y - 4));
+    }
+    return ((unsigned long long)hi << 32) | lo;
 }
 
-struct LaneLds {
+// wave-private LDS queue of culled records (ring of 128): appended in stream order, consumed 64 at a time
+struct LaneQueue {
     float4* a;      // {mx, my, 0.5a, b}
-    float4* b;      // {0.5c, opacity, c0, c1}
-    int2* c;        // {bits(c2), g}
+    float4* b;      // {0.5c, opacity, hx, hy}
+    float4* c;      // {c0, c1, c2, bits(g)}
+    int* idx;       // stream index
 };
-static constexpr int GS_LANES_REC_BYTES = 64 * (16 + 16 + 8);       // per wave
+static constexpr int GS_LANES_Q = 128;
+static constexpr int GS_LANES_Q_BYTES = GS_LANES_Q * (16 + 16 + 16 + 4);   // per wave
 
-__device__ __forceinline__ void lanes_store_batch(const LaneLds& l, int lane, const Batch& cur)
+__device__ __forceinline__ LaneQueue lane_queue(unsigned char* base)
 {
-    l.a[lane] = cur.r0;
-    l.b[lane] = make_float4(cur.r1.x, cur.r1.y, cur.r2.x, cur.r2.y);
-    l.c[lane] = make_int2(__float_as_int(cur.r2.z), __float_as_int(cur.r2.w));
+    LaneQueue q;
+    q.a = (float4*)base; q.b = q.a + GS_LANES_Q; q.c = q.b + GS_LANES_Q; q.idx = (int*)(q.c + GS_LANES_Q);
+    return q;
+}
+
+// cull one raw batch against the active rectangle (pixel-centre coordinates) and append the survivors; returns their number
+__device__ __forceinline__ int lanes_cull_append(const LaneQueue& q, const Batch& cur, int idx, int lane, float rx0, float rx1,
+                                                 float ry0, float ry1, int qtail)
+{
+    const float mx = cur.r0.x, my = cur.r0.y, hx = cur.r1.z, hy = cur.r1.w;
+    const bool hit = cur.ok && (hx >= 0.0f) && (mx + hx >= rx0) && (mx - hx <= rx1) && (my + hy >= ry0) && (my - hy <= ry1);
+    const unsigned long long hmask = __ballot(hit);
+    if (hit) {
+        const int slot = (qtail + __popcll(hmask & ((1ull << lane) - 1ull))) & (GS_LANES_Q - 1);
+        q.a[slot] = cur.r0; q.b[slot] = cur.r1; q.c[slot] = cur.r2; q.idx[slot] = idx;
+    }
+    return __popcll(hmask);
+}
+
+__device__ __forceinline__ void lanes_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 template <int CD>
@@ -573,10 +628,7 @@ raster_fwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
     const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
     const bool inside = pxi < W && pyi < H;
     const float px = (float)pxi + 0.5f, py = (float)pyi + 0.5f;
-    LaneLds lds;
-    lds.a = (float4*)(gs_lds_raw + (size_t)wave * GS_LANES_REC_BYTES);
-    lds.b = lds.a + 64;
-    lds.c = (int2*)(lds.b + 64);
+    const LaneQueue q = lane_queue(gs_lds_raw + (size_t)wave * GS_LANES_Q_BYTES);
 
     const int start = offsets[tile];
     const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
@@ -588,34 +640,48 @@ raster_fwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
 #pragma unroll
     for (int k = 0; k < CD; ++k) pix[k] = 0.0f;
 
+    int qhead = 0, qcount = 0;                                    // wave-uniform
+    int base = start;
     Batch nxt = load_batch(rec0, rec1, rec2, start + lane, start + lane < end);
-    for (int base = start; base < end; base += 64) {
-        const unsigned long long act = __ballot(!done);
+    for (;;) {
+        unsigned long long act = __ballot(!done);
         if (act == 0ull) break;
+        // ---- fill: cull raw batches into the queue until a dense batch is available
+        while (qcount < 64 && base < end) {
+            float rx0, rx1, ry0, ry1;
+            active_rect(act, qx0, qy0, rx0, rx1, ry0, ry1);
+            const Batch cur = nxt;
+            {
+                const int nidx = base + 64 + lane;
+                nxt = load_batch(rec0, rec1, rec2, nidx, nidx < end);
+            }
+            GS_STAT(0, 1);
+            qcount += lanes_cull_append(q, cur, base + lane, lane, rx0, rx1, ry0, ry1, qhead + qcount);
+            base += 64;
+        }
+        if (qcount == 0) break;
+        const int nb = qcount < 64 ? qcount : 64;
+        lanes_lds_sync();
+        // ---- dense batch: lane j owns queue slot qhead + j
         int xmin, xmax, ymin, ymax;
         active_rect_i(act, xmin, xmax, ymin, ymax);
-        const Batch cur = nxt;
+        unsigned long long pm;
         {
-            const int nidx = base + 64 + lane;
-            nxt = load_batch(rec0, rec1, rec2, nidx, nidx < end);
+            const int slot = (qhead + lane) & (GS_LANES_Q - 1);
+            const float4 a = q.a[slot], b = q.b[slot];
+            pm = record_pixel_mask(lane < nb, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, qx0, qy0, xmin, xmax, ymin, ymax);
         }
-        const unsigned long long pm = record_pixel_mask(cur.ok, cur.r0.x, cur.r0.y, cur.r1.z, cur.r1.w, qx0, qy0, xmin, xmax, ymin, ymax);
-        const unsigned long long hmask = __ballot(pm != 0ull);
-        GS_STAT(0, 1); GS_STAT(1, __popcll(hmask));
-        if (hmask == 0ull) continue;
-        lanes_store_batch(lds, lane, cur);
+        GS_STAT(1, nb);
         unsigned long long list = gs_bit_transpose64(pm, lane);
         if (done) list = 0ull;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         while (__ballot(list != 0ull) != 0ull) {
             GS_STAT(3, 1);
             if (list != 0ull) {
                 const int j = __builtin_ctzll(list);
                 list &= list - 1ull;
-                const float4 a = lds.a[j], b = lds.b[j];
-                const int2 c = lds.c[j];
+                const int slot = (qhead + j) & (GS_LANES_Q - 1);
+                const float4 a = q.a[slot];
+                const float2 b = *reinterpret_cast<const float2*>(q.b + slot);
                 const float dx = a.x - px, dy = a.y - py;
                 const float t0 = a.z * dx, t1 = b.x * dy, t2 = a.w * dx;
                 const float sigma = fmaf(t0, dx, fmaf(t1, dy, t2 * dy));
@@ -627,22 +693,25 @@ raster_fwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
                         done = true; list = 0ull;
                     } else {
                         const float vis = alpha * T;
+                        const float4 c = q.c[slot];
                         if (CD <= 3) {
-                            pix[0] = fmaf(b.z, vis, pix[0]);
-                            if (CD > 1) pix[1] = fmaf(b.w, vis, pix[1]);
-                            if (CD > 2) pix[2] = fmaf(__int_as_float(c.x), vis, pix[2]);
+                            pix[0] = fmaf(c.x, vis, pix[0]);
+                            if (CD > 1) pix[1] = fmaf(c.y, vis, pix[1]);
+                            if (CD > 2) pix[2] = fmaf(c.z, vis, pix[2]);
                         } else {
-                            const float* cg = colors + (size_t)c.y * D;
+                            const float* cg = colors + (size_t)__float_as_int(c.w) * D;
 #pragma unroll
                             for (int k = 0; k < CD; ++k) if (k < D) pix[k] = fmaf(cg[k], vis, pix[k]);
                         }
                         T = next_T;
-                        cur_idx = base + j;
+                        cur_idx = q.idx[slot];
                     }
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();       // every lane is done reading this batch before the next one overwrites it
+        lanes_lds_sync();                     // every lane is done reading these slots before the fill overwrites them
+        qhead = (qhead + nb) & (GS_LANES_Q - 1);
+        qcount -= nb;
     }
 
     if (inside) {
@@ -667,7 +736,7 @@ raster_bwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
 {
     constexpr int NV = 6 + CD;
     constexpr int RPI = 64 / NV;                                   // records committed per atomic instruction
-    constexpr int WAVE_BYTES = GS_LANES_REC_BYTES + NV * 64 * 8 + 64 * 4;
+    constexpr int WAVE_BYTES = GS_LANES_Q_BYTES + NV * 64 * 8;
     extern __shared__ __align__(16) unsigned char gs_lds_raw[];
     const int tile = tile_order[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -681,12 +750,8 @@ raster_bwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
     const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
     if (end <= start) return;
 
-    LaneLds lds;
-    lds.a = (float4*)(gs_lds_raw + (size_t)wave * WAVE_BYTES);
-    lds.b = lds.a + 64;
-    lds.c = (int2*)(lds.b + 64);
-    double* acc = (double*)(lds.c + 64);                           // [NV][64]: row k, record j
-    int* hitlist = (int*)(acc + NV * 64);
+    const LaneQueue q = lane_queue(gs_lds_raw + (size_t)wave * WAVE_BYTES);
+    double* acc = (double*)(gs_lds_raw + (size_t)wave * WAVE_BYTES + GS_LANES_Q_BYTES);      // [NV][64]: row k, dense record j
 #pragma unroll
     for (int k = 0; k < NV; ++k) acc[k * 64 + lane] = 0.0;
 
@@ -715,56 +780,70 @@ raster_bwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
     for (int off = 32; off >= 1; off >>= 1) top = max(top, __shfl_xor(top, off, 64));
     if (top >= end) top = end - 1;
 
+    int qhead = 0, qcount = 0;                                    // wave-uniform
     Batch nxt = load_batch_pred(rec0, rec1, rec2, top - lane, top - lane >= start);
-    for (; top >= start; top -= 64) {
-        const Batch cur = nxt;
-        {
-            const int nidx = top - 64 - lane;
-            nxt = load_batch_pred(rec0, rec1, rec2, nidx, nidx >= start);
+    for (;;) {
+        // ---- fill: cull raw batches (walking DOWN the list) into the queue
+        while (qcount < 64 && top >= start) {
+            const Batch cur = nxt;
+            {
+                const int nidx = top - 64 - lane;
+                nxt = load_batch_pred(rec0, rec1, rec2, nidx, nidx >= start);
+            }
+            // pixels whose last composited entry lies at or after this batch's lowest index can be valid in it
+            const unsigned long long act = __ballot(bin_final >= top - 63);
+            if (act != 0ull) {
+                float rx0, rx1, ry0, ry1;
+                active_rect(act, qx0, qy0, rx0, rx1, ry0, ry1);
+                GS_STAT(4, 1);
+                qcount += lanes_cull_append(q, cur, top - lane, lane, rx0, rx1, ry0, ry1, qhead + qcount);
+            }
+            top -= 64;
         }
-        // pixels whose last composited entry lies at or after this batch's lowest index can be valid in it
-        const bool live = bin_final >= top - 63;
+        if (qcount == 0) break;
+        const int nb = qcount < 64 ? qcount : 64;
+        lanes_lds_sync();
+        // ---- dense batch: lane j owns queue slot qhead + j (stream indices DEcrease with j)
+        const int idx_low = q.idx[(qhead + nb - 1) & (GS_LANES_Q - 1)];          // lowest stream index of the batch (uniform)
+        const bool live = bin_final >= idx_low;
         const unsigned long long act = __ballot(live);
-        if (act == 0ull) continue;
-        int xmin, xmax, ymin, ymax;
-        active_rect_i(act, xmin, xmax, ymin, ymax);
-        const unsigned long long pm = record_pixel_mask(cur.ok, cur.r0.x, cur.r0.y, cur.r1.z, cur.r1.w, qx0, qy0, xmin, xmax, ymin, ymax);
-        const bool hit = pm != 0ull;
-        const unsigned long long hmask = __ballot(hit);
-        GS_STAT(4, 1); GS_STAT(5, __popcll(hmask));
-        if (hmask == 0ull) continue;
-        lanes_store_batch(lds, lane, cur);                          // record of stream index top - lane
-        if (hit) hitlist[__popcll(hmask & ((1ull << lane) - 1ull))] = lane;
-        unsigned long long list = gs_bit_transpose64(pm, lane);
-        // record j of the batch has stream index top - j: only j >= top - bin_final were composited by this pixel
-        const int jmin = top - bin_final;
-        if (!live) list = 0ull;
-        else if (jmin > 0) list &= ~0ull << jmin;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        unsigned long long list = 0ull;
+        if (act != 0ull) {
+            int xmin, xmax, ymin, ymax;
+            active_rect_i(act, xmin, xmax, ymin, ymax);
+            const int slot = (qhead + lane) & (GS_LANES_Q - 1);
+            const float4 a = q.a[slot], b = q.b[slot];
+            const unsigned long long pm = record_pixel_mask(lane < nb, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, qx0, qy0, xmin, xmax,
+                                                            ymin, ymax);
+            list = gs_bit_transpose64(pm, lane);
+            if (!live) list = 0ull;
+        }
+        GS_STAT(5, nb);
         while (__ballot(list != 0ull) != 0ull) {
             GS_STAT(6, 1);
             if (list != 0ull) {
                 const int j = __builtin_ctzll(list);
                 list &= list - 1ull;
-                const float4 a = lds.a[j], b = lds.b[j];
-                const int2 c = lds.c[j];
+                const int slot = (qhead + j) & (GS_LANES_Q - 1);
+                const float4 a = q.a[slot];
+                const float2 b = *reinterpret_cast<const float2*>(q.b + slot);
+                const int idxj = q.idx[slot];
                 const float ga = a.z, gb = a.w, gc = b.x, go = b.y;
                 const float dx = a.x - px, dy = a.y - py;
                 const float t0 = ga * dx, t1 = gc * dy, t2 = gb * dx;
                 const float sigma = fmaf(t0, dx, fmaf(t1, dy, t2 * dy));
                 const float vis = gs_exp_neg(sigma);
                 const float alpha = fminf(0.999f, go * vis);
-                if (sigma >= 0.0f && alpha >= GS_ALPHA_MIN) {
+                if (idxj <= bin_final && sigma >= 0.0f && alpha >= GS_ALPHA_MIN) {
                     GS_STAT_ALL(7, 1);
+                    const float4 c = q.c[slot];
                     float gcol[CD];
                     if (CD <= 3) {
-                        gcol[0] = b.z;
-                        if (CD > 1) gcol[1] = b.w;
-                        if (CD > 2) gcol[2] = __int_as_float(c.x);
+                        gcol[0] = c.x;
+                        if (CD > 1) gcol[1] = c.y;
+                        if (CD > 2) gcol[2] = c.z;
                     } else {
-                        const float* cg = colors + (size_t)c.y * D;
+                        const float* cg = colors + (size_t)__float_as_int(c.w) * D;
 #pragma unroll
                         for (int k = 0; k < CD; ++k) gcol[k] = (k < D) ? cg[k] : 0.0f;
                     }
@@ -775,43 +854,285 @@ raster_bwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
                     double* arow = acc + j;
 #pragma unroll
                     for (int k = 0; k < CD; ++k) {
+#ifndef GS_EXP_NOATOMIC
                         if (k < D) atomicAdd(arow + (6 + k) * 64, (double)(fac * v_rc[k]));
+#endif
                         v_alpha += (gcol[k] * T - buffer[k] * ra) * v_rc[k];
                     }
                     v_alpha += T_final * ra * v_a;
                     if (background) v_alpha += -T_final * ra * bg_dot;
                     if (go * vis <= 0.999f) {
                         const float v_sigma = -go * vis * v_alpha;
+#ifndef GS_EXP_NOATOMIC
                         atomicAdd(arow + 0 * 64, (double)(v_sigma * ((2.0f * ga) * dx + gb * dy)));
                         atomicAdd(arow + 1 * 64, (double)(v_sigma * (gb * dx + (2.0f * gc) * dy)));
                         atomicAdd(arow + 2 * 64, (double)(0.5f * v_sigma * dx * dx));
                         atomicAdd(arow + 3 * 64, (double)(v_sigma * dx * dy));
                         atomicAdd(arow + 4 * 64, (double)(0.5f * v_sigma * dy * dy));
                         atomicAdd(arow + 5 * 64, (double)(vis * v_alpha));
+#else
+                        if (v_sigma == 123.456f) arow[0] = 1.0;
+#endif
                     }
 #pragma unroll
                     for (int k = 0; k < CD; ++k) buffer[k] += gcol[k] * fac;
                 }
             }
         }
-        // commit: RPI records x NV values per atomic instruction; the NV lanes of a record hit one packed gradient record
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int nh = __popcll(hmask);
-        const int r = lane / NV, k = lane - r * NV;
-        for (int it = 0; it * RPI < nh; ++it) {
-            const int idx = it * RPI + r;
-            if (r < RPI && idx < nh) {
-                const int j = hitlist[idx];
-                const double v = acc[k * 64 + j];
-                if (v != 0.0) {
-                    acc[k * 64 + j] = 0.0;
-                    gs_atomic_add(v_packed + (size_t)lds.c[j].y * rec_stride + k, (float)v);
+        // ---- commit: RPI records x NV values per atomic instruction; the NV lanes of a record hit one packed gradient record
+        lanes_lds_sync();
+        {
+            const int r = lane / NV, k = lane - r * NV;
+            for (int it = 0; it * RPI < nb; ++it) {
+                const int j = it * RPI + r;
+                if (r < RPI && j < nb) {
+                    const double v = acc[k * 64 + j];
+                    if (v != 0.0) {
+                        acc[k * 64 + j] = 0.0;
+                        const int g = __float_as_int(q.c[(qhead + j) & (GS_LANES_Q - 1)].w);
+                        gs_atomic_add(v_packed + (size_t)g * rec_stride + k, (float)v);
+                    }
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        lanes_lds_sync();
+        qhead = (qhead + nb) & (GS_LANES_Q - 1);
+        qcount -= nb;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Backward for D <= 3 WITHOUT atomics in the walk.  Removal experiment on the kernel above (bench workload): 975 us as
+// built, 545 us with the nine ds_add_f64 per pair compiled out -- the accumulation, not the arithmetic, was 44 % of it
+// (308 M lane-adds per view at ~0.9 LDS cycles each: three to four pixels of a trip add to the same record).  Here the
+// walk only produces TWO scalars per popped pair,  s = v_sigma  (0 when the 0.999 cap was active)  and  f = alpha*T,
+// and stores them with a plain ds_write_b64 at  pairbuf[base_j + rank of the pixel inside record j's mask]  -- distinct
+// addresses, no conflicts.  Then the lanes switch roles: lane j owns record j of the dense batch, walks the set bits
+// of ITS pixel mask, and accumulates the moments  sum s {1, dx, dy, dx^2, dx dy, dy^2}  and  sum f v_render  in
+// registers (dx = mx - px is a function of the pixel index), from which the nine gradients follow:
+//     v_xy = (2 ha Mx + b My, b Mx + 2 hc My),  v_conic = (Mxx/2, Mxy, Myy/2),  v_opacity = -M0 / opacity.
+// The sums are exact per-lane fp32 FMAs in pixel order: the per-(quadrant, Gaussian) result is deterministic.
+static constexpr int GS_PAIR_CAP = 512;                       // pair slots per dense batch (records beyond wait for the next one)
+template <int CD>
+struct Lanes2Lds {
+    static constexpr int NV = 6 + CD;
+    static constexpr int OFF_MSK = GS_LANES_Q_BYTES;
+    static constexpr int OFF_BASE = OFF_MSK + 64 * 8;
+    static constexpr int OFF_PIX = OFF_BASE + 64 * 4;
+    static constexpr int OFF_PAIR = OFF_PIX + 64 * 16;
+    static constexpr int PAIR_BYTES = GS_PAIR_CAP * 8 > 64 * NV * 4 ? GS_PAIR_CAP * 8 : 64 * NV * 4;
+    static constexpr int WAVE_BYTES = OFF_PAIR + PAIR_BYTES;
+};
+
+template <int CD>
+__global__ void __launch_bounds__(256)
+raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* __restrict__ tile_order,
+                         const float4* __restrict__ rec0, const float4* __restrict__ rec1, const float4* __restrict__ rec2,
+                         const float* __restrict__ background, int n_isects, const int32_t* __restrict__ offsets,
+                         const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
+                         const float* __restrict__ v_render, const float* __restrict__ v_alphas,
+                         float* __restrict__ v_packed, int rec_stride)
+{
+    static_assert(CD <= 3, "colours come from the record stream (D <= 3)");
+    using LD = Lanes2Lds<CD>;
+    constexpr int NV = 6 + CD;
+    constexpr int RPI = 64 / NV;
+    extern __shared__ __align__(16) unsigned char gs_lds_raw[];
+    const int tile = tile_order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tx = tile % tile_w, ty = tile / tile_w;
+    const int qx0 = tx * GS_TILE + (wave & 1) * 8, qy0 = ty * GS_TILE + (wave >> 1) * 8;
+    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
+    const bool inside = pxi < W && pyi < H;
+    const float px = (float)pxi + 0.5f, py = (float)pyi + 0.5f;
+
+    const int start = offsets[tile];
+    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    if (end <= start) return;
+
+    unsigned char* wbase = gs_lds_raw + (size_t)wave * LD::WAVE_BYTES;
+    const LaneQueue q = lane_queue(wbase);
+    unsigned long long* msk = (unsigned long long*)(wbase + LD::OFF_MSK);
+    int* pbase = (int*)(wbase + LD::OFF_BASE);
+    float4* pix = (float4*)(wbase + LD::OFF_PIX);
+    float2* pairbuf = (float2*)(wbase + LD::OFF_PAIR);
+    float* stage = (float*)(wbase + LD::OFF_PAIR);              // aliases pairbuf (separated by wave syncs)
+
+    float T_final = 1.0f, v_a = 0.0f;
+    int bin_final = -1;
+    float v_rc[CD], buffer[CD];
+#pragma unroll
+    for (int k = 0; k < CD; ++k) { v_rc[k] = 0.0f; buffer[k] = 0.0f; }
+    if (inside) {
+        const size_t pid = (size_t)pyi * W + pxi;
+        T_final = 1.0f - alphas[pid];
+        bin_final = last_ids[pid];
+        v_a = v_alphas[pid];
+#pragma unroll
+        for (int k = 0; k < CD; ++k) if (k < D) v_rc[k] = v_render[pid * D + k];
+    }
+    pix[lane] = make_float4(v_rc[0], CD > 1 ? v_rc[1] : 0.0f, CD > 2 ? v_rc[2] : 0.0f, CD > 3 ? v_rc[3] : 0.0f);
+    float bg_dot = 0.0f;
+    if (background) {
+#pragma unroll
+        for (int k = 0; k < CD; ++k) if (k < D) bg_dot += background[k] * v_rc[k];
+    }
+    float T = T_final;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+
+    int top = bin_final;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) top = max(top, __shfl_xor(top, off, 64));
+    if (top >= end) top = end - 1;
+
+    int qhead = 0, qcount = 0;                                    // wave-uniform
+    Batch nxt = load_batch_pred(rec0, rec1, rec2, top - lane, top - lane >= start);
+    for (;;) {
+        // ---- fill: cull raw batches (walking DOWN the list) into the queue
+        while (qcount < 64 && top >= start) {
+            const Batch cur = nxt;
+            {
+                const int nidx = top - 64 - lane;
+                nxt = load_batch_pred(rec0, rec1, rec2, nidx, nidx >= start);
+            }
+            const unsigned long long act = __ballot(bin_final >= top - 63);
+            if (act != 0ull) {
+                float rx0, rx1, ry0, ry1;
+                active_rect(act, qx0, qy0, rx0, rx1, ry0, ry1);
+                GS_STAT(4, 1);
+                qcount += lanes_cull_append(q, cur, top - lane, lane, rx0, rx1, ry0, ry1, qhead + qcount);
+            }
+            top -= 64;
+        }
+        if (qcount == 0) break;
+        int nb = qcount < 64 ? qcount : 64;
+        lanes_lds_sync();
+        // ---- dense batch: lane j owns queue slot qhead + j (stream indices DEcrease with j)
+        const int idx_low = q.idx[(qhead + nb - 1) & (GS_LANES_Q - 1)];
+        const bool live = bin_final >= idx_low;
+        const unsigned long long act = __ballot(live);
+        const int myslot = (qhead + lane) & (GS_LANES_Q - 1);
+        const float4 ra4 = q.a[myslot], rb4 = q.b[myslot];       // the record this lane OWNS in the reduction
+        unsigned long long pm = 0ull;
+        if (act != 0ull) {
+            int xmin, xmax, ymin, ymax;
+            active_rect_i(act, xmin, xmax, ymin, ymax);
+            pm = record_pixel_mask(lane < nb, ra4.x, ra4.y, ra4.z, ra4.w, rb4.x, rb4.y, rb4.z, rb4.w, qx0, qy0, xmin, xmax, ymin, ymax) & act;
+        }
+        // pair slots: exclusive scan of the mask sizes; records whose pairs do not fit wait for the next dense batch
+        const int cnt = __popcll(pm);
+        int cum = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(cum, off, 64);
+            if (lane >= off) cum += up;
+        }
+        if (__ballot(cum > GS_PAIR_CAP) != 0ull) {
+            nb = min(nb, __popcll(__ballot(cum <= GS_PAIR_CAP)));   // cum is monotone: a prefix of the records fits (>= 8 of them)
+            if (lane >= nb) pm = 0ull;
+        }
+        msk[lane] = pm;
+        pbase[lane] = cum - cnt;
+        unsigned long long list = gs_bit_transpose64(pm, lane);
+        GS_STAT(5, nb);
+        lanes_lds_sync();
+        while (__ballot(list != 0ull) != 0ull) {
+            GS_STAT(6, 1);
+            if (list != 0ull) {
+                const int j = __builtin_ctzll(list);
+                list &= list - 1ull;
+                const int slot = (qhead + j) & (GS_LANES_Q - 1);
+                const float4 a = q.a[slot];
+                const float2 b = *reinterpret_cast<const float2*>(q.b + slot);
+                const int idxj = q.idx[slot];
+                const int e = pbase[j] + __popcll(msk[j] & lane_lt);
+                const float ga = a.z, gb = a.w, gc = b.x, go = b.y;
+                const float dx = a.x - px, dy = a.y - py;
+                const float t0 = ga * dx, t1 = gc * dy, t2 = gb * dx;
+                const float sigma = fmaf(t0, dx, fmaf(t1, dy, t2 * dy));
+                const float vis = gs_exp_neg(sigma);
+                const float alpha = fminf(0.999f, go * vis);
+                float s_out = 0.0f, f_out = 0.0f;
+                if (idxj <= bin_final && sigma >= 0.0f && alpha >= GS_ALPHA_MIN) {
+                    GS_STAT_ALL(7, 1);
+                    const float4 c = q.c[slot];
+                    const float gcol[4] = { c.x, c.y, c.z, 0.0f };
+                    const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);
+                    T *= ra;
+                    const float fac = alpha * T;
+                    float v_alpha = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < CD; ++k) v_alpha += (gcol[k] * T - buffer[k] * ra) * v_rc[k];
+                    v_alpha += T_final * ra * v_a;
+                    if (background) v_alpha += -T_final * ra * bg_dot;
+                    if (go * vis <= 0.999f) s_out = -go * vis * v_alpha;
+                    f_out = fac;
+#pragma unroll
+                    for (int k = 0; k < CD; ++k) buffer[k] += gcol[k] * fac;
+                }
+                pairbuf[e] = make_float2(s_out, f_out);
+            }
+        }
+        lanes_lds_sync();
+        // ---- reduction: lane j sums the pairs of record j over the set bits of its pixel mask (pixel order)
+        float sum[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) sum[k] = 0.0f;
+        {
+            const float X = ra4.x - ((float)qx0 + 0.5f), Y = ra4.y - ((float)qy0 + 0.5f);    // dx = X - x,  dy = Y - y
+            unsigned long long m = pm;
+            int e = cum - cnt;
+            while (__ballot(m != 0ull) != 0ull) {
+                if (m != 0ull) {
+                    const int p = __builtin_ctzll(m);
+                    m &= m - 1ull;
+                    const float2 sf = pairbuf[e++];
+                    const float4 vr = pix[p];
+                    const float dx = X - (float)(p & 7), dy = Y - (float)(p >> 3);
+                    const float sx = sf.x * dx, sy = sf.x * dy;
+                    sum[0] += sf.x; sum[1] += sx; sum[2] += sy;
+                    sum[3] = fmaf(sx, dx, sum[3]); sum[4] = fmaf(sx, dy, sum[4]); sum[5] = fmaf(sy, dy, sum[5]);
+                    sum[6] = fmaf(sf.y, vr.x, sum[6]);
+                    if (CD > 1) sum[7] = fmaf(sf.y, vr.y, sum[7]);
+                    if (CD > 2) sum[8] = fmaf(sf.y, vr.z, sum[8]);
+                    if (CD > 3) sum[9] = fmaf(sf.y, vr.w, sum[9]);
+                }
+            }
+        }
+        lanes_lds_sync();                                          // pairbuf is dead: its space becomes the commit staging
+        {
+            const float ga = ra4.z, gb = ra4.w, gc = rb4.x, go = rb4.y;
+            const float M0 = sum[0], Mx = sum[1], My = sum[2];
+            float out[NV];
+            out[0] = (2.0f * ga) * Mx + gb * My;
+            out[1] = gb * Mx + (2.0f * gc) * My;
+            out[2] = 0.5f * sum[3]; out[3] = sum[4]; out[4] = 0.5f * sum[5];
+            out[5] = (M0 != 0.0f) ? -M0 / go : 0.0f;             // sum of vis * v_alpha over the uncapped pairs
+#pragma unroll
+            for (int k = 0; k < CD; ++k) out[6 + k] = sum[6 + k];
+            if (lane < nb) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) stage[lane * NV + k] = out[k];
+            }
+        }
+        lanes_lds_sync();
+        // ---- commit: RPI records x NV values per atomic instruction; the NV lanes of a record hit one packed gradient record
+        {
+            const int r = lane / NV, k = lane - r * NV;
+            for (int it = 0; it * RPI < nb; ++it) {
+                const int j = it * RPI + r;
+                if (r < RPI && j < nb && k < 6 + D) {
+                    const float v = stage[j * NV + k];
+                    if (v != 0.0f) {
+                        const int g = __float_as_int(q.c[(qhead + j) & (GS_LANES_Q - 1)].w);
+                        gs_atomic_add(v_packed + (size_t)g * rec_stride + k, v);
+                    }
+                }
+            }
+        }
+        lanes_lds_sync();
+        qhead = (qhead + nb) & (GS_LANES_Q - 1);
+        qcount -= nb;
     }
 }
 
@@ -830,7 +1151,8 @@ static int gs_env_int(const char* name, int dflt)
 }
 static int gs_raster_blocks_per_cu() { static const int b = gs_env_int("GEOSPLAT_RASTER_BLOCKS", GS_RASTER_BLOCKS_PER_CU); return b < 1 ? 1 : (b > 8 ? 8 : b); }
 static size_t gs_raster_lds_pad() { return (size_t)(160 * 1024 / gs_raster_blocks_per_cu()) - 1024; }
-// compositor variant: 1 = per-lane lists (default), 0 = one wave per survivor (the round-1 kernels, kept for A/B runs)
+// compositor variant: 1 = per-lane lists (default; backward: pair buffer + record-lane reduction for D <= 3), 2 = per-lane lists
+// with ds_add_f64 accumulators for every D, 0 = one wave per survivor (the round-1 kernels, kept for A/B runs)
 static int gs_raster_lanes() { static const int m = gs_env_int("GEOSPLAT_RASTER_LANES", 1); return m; }
 
 // workspace layout: [rec0 | rec1 | rec2 | tile_order], every segment 256-byte aligned
@@ -871,7 +1193,7 @@ static int launch_fwd(int W, int H, int D, const RasterWs& ws, const float* colo
 {
     const int tile_w = (W + GS_TILE - 1) / GS_TILE, tile_h = (H + GS_TILE - 1) / GS_TILE;
     if (gs_raster_lanes()) {
-        size_t lds = 4 * (size_t)GS_LANES_REC_BYTES;
+        size_t lds = 4 * (size_t)GS_LANES_Q_BYTES;
         if (lds < gs_raster_lds_pad()) lds = gs_raster_lds_pad();
         hipLaunchKernelGGL(raster_fwd_lanes_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
                            ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, (int)n_isects, offsets, render, alphas,
@@ -960,8 +1282,19 @@ static int launch_bwd(int W, int H, int D, const RasterWs& ws, const float* colo
                       const float* v_render, const float* v_alphas, float* v_packed, int rec_stride, hipStream_t s)
 {
     const int tile_w = (W + GS_TILE - 1) / GS_TILE, tile_h = (H + GS_TILE - 1) / GS_TILE;
-    if (gs_raster_lanes()) {
-        size_t lds = 4 * ((size_t)GS_LANES_REC_BYTES + (size_t)(6 + CD) * 64 * 8 + 64 * 4);
+    if constexpr (CD <= 3) {                                  // colours travel in the record stream only for D <= 3
+        if (gs_raster_lanes() == 1) {
+            size_t lds = 4 * (size_t)Lanes2Lds<CD>::WAVE_BYTES;
+            if (lds < gs_raster_lds_pad()) lds = gs_raster_lds_pad();
+            hipLaunchKernelGGL(raster_bwd_lanes2_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
+                               ws.order, ws.rec0, ws.rec1, ws.rec2, background, (int)n_isects, offsets, alphas, last_ids,
+                               v_render, v_alphas, v_packed, rec_stride);
+            GS_CHECK_LAUNCH();
+            return GS_OK;
+        }
+    }
+    if (gs_raster_lanes()) {                                  // D > 3, or GEOSPLAT_RASTER_LANES=2: LDS ds_add_f64 accumulators
+        size_t lds = 4 * ((size_t)GS_LANES_Q_BYTES + (size_t)(6 + CD) * 64 * 8);
         if (lds < gs_raster_lds_pad()) lds = gs_raster_lds_pad();
         static bool attr_set = false;                  // > 64 KB of dynamic LDS (D > 16) needs the opt-in once per kernel
         if (!attr_set && lds > 64 * 1024) {

@@ -28,10 +28,10 @@ lib.gs_raster_stats_read(buf, 0)
 v = list(buf)
 I = meta["flatten_ids"].numel()
 if os.environ.get("GEOSPLAT_RASTER_LANES", "1") != "0":
-    print(f"I={I}  per-lane lists  fwd: wave-batches {v[0]}  hit records {v[1]} ({v[1]/max(v[0],1):.1f}/batch)  trips {v[3]} "
-          f"({v[3]/max(v[0],1):.2f}/batch)  valid pairs {v[2]} ({v[2]/max(v[3],1):.1f}/trip)")
-    print(f"       bwd: wave-batches {v[4]}  hit records {v[5]} ({v[5]/max(v[4],1):.1f}/batch)  trips {v[6]} ({v[6]/max(v[4],1):.2f}/batch)  "
-          f"valid pairs {v[7]} ({v[7]/max(v[6],1):.1f}/trip)")
+    print(f"I={I}  per-lane lists  fwd: raw wave-batches {v[0]}  culled records {v[1]} ({v[1]/max(v[0],1):.1f}/raw batch)  trips {v[3]} "
+          f"({64*v[3]/max(v[1],1):.2f} per 64 culled records)  valid pairs {v[2]} ({v[2]/max(v[3],1):.1f}/trip)")
+    print(f"       bwd: raw wave-batches {v[4]}  culled records {v[5]} ({v[5]/max(v[4],1):.1f}/raw batch)  trips {v[6]} "
+          f"({64*v[6]/max(v[5],1):.2f} per 64 culled records)  valid pairs {v[7]} ({v[7]/max(v[6],1):.1f}/trip)")
     sys.exit(0)
 print(f"I={I}  fwd: wave-batches {v[0]}  survivors {v[1]} ({v[1]/max(v[0],1):.1f}/batch)  ok lane-pairs {v[2]} ({v[2]/max(v[1],1):.1f}/survivor)")
 print(f"       bwd: wave-batches {v[4]}  survivors {v[5]} ({v[5]/max(v[4],1):.1f}/batch)  reduced hits {v[6]}  valid lane-pairs {v[7]} ({v[7]/max(v[6],1):.1f}/hit)")

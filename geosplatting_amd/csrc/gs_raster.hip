@@ -426,7 +426,7 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
 #pragma unroll
             for (int k = 0; k < NV; ++k) part[k] = 0.0f;
             if (valid) {
-                const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);
+                const float ra = 1.0f / (1.0f - alpha);        // correctly rounded (v_rcp_f32 alone drifts 1e-4 over a 1000-pair transmittance chain)
                 T *= ra;
                 const float fac = alpha * T;
                 float v_alpha = 0.0f;
@@ -847,7 +847,7 @@ raster_bwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
 #pragma unroll
                         for (int k = 0; k < CD; ++k) gcol[k] = (k < D) ? cg[k] : 0.0f;
                     }
-                    const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);
+                    const float ra = 1.0f / (1.0f - alpha);        // correctly rounded (v_rcp_f32 alone drifts 1e-4 over a 1000-pair transmittance chain)
                     T *= ra;
                     const float fac = alpha * T;
                     float v_alpha = 0.0f;
@@ -1057,7 +1057,7 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
                     GS_STAT_ALL(7, 1);
                     const float4 c = q.c[slot];
                     const float gcol[4] = { c.x, c.y, c.z, 0.0f };
-                    const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);
+                    const float ra = 1.0f / (1.0f - alpha);        // correctly rounded (v_rcp_f32 alone drifts 1e-4 over a 1000-pair transmittance chain)
                     T *= ra;
                     const float fac = alpha * T;
                     float v_alpha = 0.0f;

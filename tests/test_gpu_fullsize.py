@@ -2,9 +2,10 @@
 512^2 environment -> `as_splitsum` (6 levels, cached pair-weight tables) -> shade -> rasterize -> tone-map, and the full
 backward, HIP (through the C-ABI) vs the CPU oracle on the GPU box's host threads.
 
-  * tile / sort indices bit-exact, image and EVERY gradient (means / quats / scales / opacities / kd / ks / normals /
-    pyramid levels / exposure) <= 1e-4 max-norm relative; the element-wise figure
-    frac(|a-b| > 1e-4 |b| + 1e-6 max|b|) is printed and bounded too;
+  * tile / sort indices bit-exact; the composited image is BIT-IDENTICAL to the oracle's (canonical exp, same operation
+    order), the tone-mapped one within 1e-6; EVERY gradient (means / opacities / kd / ks / normals / pyramid levels /
+    exposure) <= 1e-5 max-norm relative (measured 1e-7 .. 1e-6), quats / scales of the flat disks <= 1e-4; the element-wise
+    figure frac(|a-b| > 1e-4 |b| + 1e-6 max|b|) is printed and bounded too (0 for everything but quats / scales);
   * S5 itself at R = 512 / 256 / 128 / 64 / 32 / 16: the oracle evaluates a random subset of output texels (the prefilter is
     independent per output texel, oracle/gs_oracle_splitsum.c `*_subset`) forward, and the cubemap gradient of a cotangent
     that is non-zero on that subset backward, through the whole mip chain down to the 512^2 parameter.
@@ -105,7 +106,14 @@ def test_view_fullsize_vs_oracle(cuda, level):
     base = env0.base.cpu(); levels = [l.cpu() for l in env0.levels]
     assert [l.shape[1] for l in levels] == [512, 256, 128, 64, 32, 16]
     lut = gs.get_fg_lut(torch.device("cpu"))[0].numpy()
-    means, quats, scales, opac = activated(sc.splats)
+    means, quats, _, _ = activated(sc.splats)
+    # The activations of GSplatter.render_rgba (exp / sigmoid, rfstudio/model/gsplat.py:336-339) are evaluated ONCE, by the same
+    # torch-on-GPU ops the product runs, and handed to the oracle: a libm exp on the host differs from the device's in the last
+    # bit of a few scales, which moves alpha of a nearly saturated pixel by one ulp of 1.0 -- and the stored-state backward
+    # restarts from T_final = 1 - alpha, so that ulp is 6e-4 of a transmittance of 1e-4 and of every gradient term behind it
+    # (measured: 1.2e-4 max-norm on kd with host-side activations, <1e-6 with shared ones; scripts/debug_fullsize.py).
+    scales = sc.splats.scales.to(cuda).exp().cpu().numpy()
+    opac = torch.sigmoid(sc.splats.opacities.to(cuda)).squeeze(-1).cpu().numpy()
     cam_pos = cam.c2w[:, 3].numpy()
     lv = [l.numpy() for l in levels]
     vm, K = cam.view_matrix.numpy(), cam.intrinsic_matrix.numpy()
@@ -148,7 +156,7 @@ def test_view_fullsize_vs_oracle(cuda, level):
     assert img.shape == (H, W, 4)
     ok = ~(amb | mism)
     mx, fr = _report("image", img.detach().cpu().numpy()[ok], img_ref[ok])
-    assert mx < TOL and fr < ELEM_FRAC_MAX
+    assert mx < 1e-6 and fr == 0.0            # the compositor is bit-identical to the oracle; the tone map differs in libm's last bit
     mse = float(((img.detach().cpu().numpy()[..., :3][ok] - img_ref[..., :3][ok]).astype(np.float64) ** 2).mean())
     print(f"  PSNR vs oracle image {10 * np.log10(1.0 / max(mse, 1e-30)):.1f} dB")
 
@@ -163,7 +171,7 @@ def test_view_fullsize_vs_oracle(cuda, level):
     v_means = gr["v_means"] + gsh["v_means"]
     v_logscale = gr["v_scales"] * scales
     v_logit = (gr["v_opacities"] * opac * (1 - opac))[:, None]
-    assert abs(et.grad.item() - v_e) < TOL * max(1.0, abs(v_e)), (et.grad.item(), v_e)
+    assert abs(et.grad.item() - v_e) < 1e-5 * max(1.0, abs(v_e)), (et.grad.item(), v_e)
     print(f"  exposure     {et.grad.item():.6e} vs {v_e:.6e}")
     worst = {}
     for name, got, want in (("means", gsn.means.grad, v_means), ("scales", gsn.scales.grad, v_logscale),
@@ -180,9 +188,8 @@ def test_view_fullsize_vs_oracle(cuda, level):
         worst[f"level{i}"] = _report(f"v_level{i}", a.grad.cpu().numpy(), b, atol_rel=1e-5)
     assert tb.grad is None or float(tb.grad.abs().max()) == 0.0     # 'pbr' never uses the diffuse lookup
     for name, (mx, fr) in worst.items():
-        # quats / scales of FLAT disks (3rd scale e^-10) are ill-conditioned: the fp32 oracle itself is ~2e-4 from float64
-        # autograd there (tests/test_oracle_cpu.py::test_oracle_backward_vs_float64_autograd)
-        tol = 1e-3 if name in ("quats", "scales") else TOL
+        # measured <= 1.3e-6 (5e-6 / 2e-5 for the scales / quats of FLAT disks, 3rd scale e^-10, whose projection backward cancels:
+        # the fp32 oracle itself is ~2e-4 from float64 autograd there, tests/test_oracle_cpu.py); bars with a 10x margin
+        tol = 1e-4 if name in ("quats", "scales") else 1e-5
         assert mx < tol, f"{name}: max-norm {mx:.3e}"
-        if name not in ("quats", "scales"):
-            assert fr < ELEM_FRAC_MAX, f"{name}: element-wise outliers {fr:.3e}"
+        assert fr < (ELEM_FRAC_MAX if name in ("quats", "scales") else 1e-5), f"{name}: element-wise outliers {fr:.3e}"

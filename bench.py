@@ -11,7 +11,10 @@ Workload (BASELINE.json `metric`: "fwd+bwd views/sec at 2M Gaussians, 800x800"):
   tests/model/test_geosplat.py:28):
       split-sum prefilter forward (S5) -> 8 x [shade -> project/bin/sort/composite -> tone-map, then the backward of
       all of it] -> prefilter backward -> (N>1) one flat RCCL all-reduce of all parameter gradients.
-  value = views/sec = 8 * N / (max-over-ranks step time).  Weak scaling: every GPU renders its own 8 views.
+  value = views/sec = 8 * N / (max-over-ranks step time).  Weak scaling (default): every GPU renders its own 8 views.
+  --views-total V: STRONG scaling -- the reference batch of V views (8) is spread over the N GPUs, view i -> rank i mod N
+  (one view per GPU at N = 8, BASELINE.json config 4); value = V / step time.  With N > 1 the split-sum prefilter is sharded
+  over the ranks (geosplatting_amd/splitsum.py) in both modes.
 """
 import argparse
 import ctypes as C
@@ -38,6 +41,8 @@ def parse():
     ap.add_argument("--level", type=int, default=7, help="icosphere level: 7 -> 1 966 080 Gaussians, 6 -> 491 520")
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--views", type=int, default=8, help="views per step per GPU (reference batch_size = 8)")
+    ap.add_argument("--views-total", type=int, default=0,
+                    help="strong scaling: this many views per step over ALL GPUs (view i -> rank i mod N); 0 = weak scaling")
     ap.add_argument("--cubemap-res", type=int, default=512)
     ap.add_argument("--no-prefilter", action="store_true", help="diagnostic only: keep the pyramid fixed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -50,9 +55,15 @@ def algorithmic_bytes_per_view(N, V, I, P, E):
     return 228 * N + 184 * V + 120 * I + 44 * P + 2 * E
 
 
+FLOPS_FWD_PER_PAIR = 37      # dx,dy 2 | sigma 8 | canonical exp 16 | alpha 2 | T 3 | colour FMAs 6
+FLOPS_BWD_PER_PAIR = 76      # sigma/exp/alpha 28 | 1/(1-alpha), T, fac 3 | v_alpha 18 | v_sigma 2 | buffer 6 | moment reduction 19
+VALU_PEAK_TFLOPS = 157.3     # FP32 vector peak, MI355X_MICROARCH.md
+
+
 def time_dominant_kernels(scene_state, iters):
-    """Per-kernel durations with HIP events on the stream the kernels are launched on (torch's current stream):
-    raster forward and raster backward (the two VALU-bound kernels) and the projection kernel (HBM-bound)."""
+    """Durations of the compositor kernels ALONE, with HIP events on the stream they are launched on (torch's current stream):
+    `gs_raster_composite` on a prepared workspace (no record-stream build) and `gs_raster_bwd_acc` (no memset); the
+    workspace preparation (per-visible records, sorted record stream, tile order) is timed as its own entry."""
     import geosplatting_amd._lib as L
     lib = L.lib()
     st = scene_state
@@ -63,22 +74,27 @@ def time_dominant_kernels(scene_state, iters):
     render = torch.empty(H, W, D, dtype=f32, device=dev); alphas = torch.empty(H, W, dtype=f32, device=dev)
     last = torch.empty(H, W, dtype=torch.int32, device=dev)
     v_render = torch.rand(H, W, D, device=dev) * 2 - 1; v_alpha = torch.rand(H, W, device=dev) * 2 - 1
-    v_packed = torch.empty(V, lib.gs_raster_grad_stride(D), dtype=f32, device=dev)
+    v_packed = torch.zeros(V, lib.gs_raster_grad_stride(D), dtype=f32, device=dev)
     s = L.stream()
     rws_bytes = lib.gs_raster_ws_bytes(L.i64(I), V, W, H, 16)
     rws = torch.empty(rws_bytes, dtype=torch.uint8, device=dev)
 
+    def prep():
+        L.check(lib.gs_raster_prepare(W, H, 16, D, V, L.ptr(st["means2d"]), L.ptr(st["conics"]), L.ptr(st["opacities"]),
+                                      L.ptr(st["colors"]), L.i64(I), L.ptr(st["offsets"]), L.ptr(st["flatten_ids"]),
+                                      L.ptr(rws), C.c_size_t(rws_bytes), s), "raster_prepare")
+
     def fwd():
-        L.check(lib.gs_raster_fwd(W, H, 16, D, V, L.ptr(st["means2d"]), L.ptr(st["conics"]), L.ptr(st["opacities"]),
-                                  L.ptr(st["colors"]), None, L.i64(I), L.ptr(st["offsets"]), L.ptr(st["flatten_ids"]),
-                                  L.ptr(render), L.ptr(alphas), L.ptr(last), L.ptr(rws), C.c_size_t(rws_bytes), s), "raster_fwd")
+        L.check(lib.gs_raster_composite(W, H, 16, D, V, L.ptr(st["colors"]), None, L.i64(I), L.ptr(st["offsets"]),
+                                        L.ptr(render), L.ptr(alphas), L.ptr(last), L.ptr(rws), C.c_size_t(rws_bytes), s),
+                "raster_composite")
 
     def bwd():
-        L.check(lib.gs_raster_bwd(W, H, 16, D, V, L.ptr(st["colors"]), None, L.i64(I), L.ptr(st["offsets"]),
-                                  L.ptr(alphas), L.ptr(last), L.ptr(v_render), L.ptr(v_alpha), L.ptr(v_packed),
-                                  L.ptr(rws), C.c_size_t(rws_bytes), s), "raster_bwd")
+        L.check(lib.gs_raster_bwd_acc(W, H, 16, D, V, L.ptr(st["colors"]), None, L.i64(I), L.ptr(st["offsets"]),
+                                      L.ptr(alphas), L.ptr(last), L.ptr(v_render), L.ptr(v_alpha), L.ptr(v_packed),
+                                      L.ptr(rws), C.c_size_t(rws_bytes), s), "raster_bwd_acc")
     out = {}
-    for name, fn in (("raster_fwd_kernel", fwd), ("raster_bwd_kernel", bwd)):
+    for name, fn in (("raster_prepare (stream build)", prep), ("raster_fwd_kernel", fwd), ("raster_bwd_kernel", bwd)):
         fn(); torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -89,6 +105,68 @@ def time_dominant_kernels(scene_state, iters):
     return out
 
 
+def time_view_without_prefilter(params, cam, up, iters):
+    """GPU time of ONE view fwd+bwd with the pyramid held fixed (shade + project + bin + sort + composite + tone map and the
+    whole backward): the same work the cpu_baseline sample times, so the two are comparable."""
+    from geosplatting_amd.engine import RenderStep
+    step = RenderStep(params, prefilter=False)
+    for _ in range(2):
+        step([cam], lambda i, img: up, all_reduce=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step([cam], lambda i, img: up, all_reduce=False)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def file_sha16(path):
+    import hashlib
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+
+
+def committed_profile(name, kernel_source):
+    """A committed profile summary (profiles/<name>) is only quoted while the kernel source it was measured on is unchanged:
+    the file records the sha256[:16] of that source."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    try:
+        j = json.load(open(path))
+        if j.get("source_sha16") != file_sha16(os.path.join(ROOT, "geosplatting_amd", "csrc", kernel_source)):
+            return None
+        return j
+    except Exception:
+        return None
+
+
+def cpu_baseline_cfg1():
+    """BASELINE.json configs[0]: 10k random Gaussians, 256x256, 4 orbit views, fwd+bwd on the CPU oracle (rasterizer only, as
+    that config has no shading); median of 5 runs after one warm-up."""
+    import numpy as np
+    import oracle
+    import geosplatting_amd.synthetic as syn
+    from geosplatting_amd.cameras import orbit_cameras
+    sp = syn.random_splats(10000, seed=1)
+    means, quats = sp.means.numpy(), sp.quats.numpy()
+    scales, opac = sp.scales.exp().numpy(), torch.sigmoid(sp.opacities).squeeze(-1).numpy()
+    col = sp.colors.numpy()
+    cams = orbit_cameras(4, 3.0, 30.0, 256, 256, hfov_degree=40.0)
+    g = torch.Generator().manual_seed(0)
+    v = (torch.rand(256, 256, 4, generator=g) * 2 - 1).numpy()
+    times = []
+    for rep in range(6):
+        t0 = time.perf_counter()
+        for cam in cams:
+            vm, K = cam.view_matrix.numpy(), cam.intrinsic_matrix.numpy()
+            m = oracle.rasterization(means, quats, scales, opac, col, vm, K, 256, 256)
+            oracle.rasterization_bwd(means, quats, scales, opac, col, vm, K, 256, 256, m, v[..., :3], v[..., 3])
+        times.append(time.perf_counter() - t0)
+    med = sorted(times[1:])[2]
+    return {"value": 4.0 / med, "unit": "views/s", "views": 4, "N": 10000, "res": 256, "median_s_per_4_views": med,
+            "sample": "BASELINE.json configs[0] in full: 4 views fwd+bwd, median of 5 after 1 warm-up"}
+
+
 def cpu_baseline(scene, cam, res, budget_note):
     """The CPU oracle (plain-C restatement, OpenMP over host cores) timed on ONE view fwd+bwd of the same workload."""
     import numpy as np
@@ -97,7 +175,11 @@ def cpu_baseline(scene, cam, res, budget_note):
     cores = os.cpu_count() or 1
     sp = scene.splats
     means, quats = sp.means.numpy(), sp.quats.numpy()
-    scales, opac = sp.scales.exp().numpy(), torch.sigmoid(sp.opacities).squeeze(-1).numpy()
+    # activations evaluated by the same torch-on-GPU ops the product runs (a host libm exp differs in the last bit of a few
+    # scales, and the parity figure below is about the path, not about two exp implementations)
+    adev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    scales = sp.scales.to(adev).exp().cpu().numpy()
+    opac = torch.sigmoid(sp.opacities.to(adev)).squeeze(-1).cpu().numpy()
     lut = gs.get_fg_lut(torch.device("cpu"))[0].numpy()
     # pyramid: the prefilter is excluded from the CPU sample (it is once per 8 views and its oracle is O(minutes) at 512^2);
     # a seeded random pyramid of the right shape stands in -- texture values do not change the work done.
@@ -136,7 +218,8 @@ def cpu_baseline(scene, cam, res, budget_note):
     return {"parity": parity, "value": 1.0 / dt, "unit": "views/s", "cores": cores, "kind": "port",
             "sample": f"1 view fwd+bwd (shade+project+bin+sort+composite+tonemap and backward; prefilter excluded), "
                       f"N={means.shape[0]}, {res}x{res}, oracle/libgs_oracle.so with OpenMP on {cores} host threads; {budget_note}",
-            "pairs_fwd": m["pairs"], "V": int(len(m["gaussian_ids"])), "I": int(len(m["flatten_ids"]))}
+            "pairs_evaluated_by_oracle": m["pairs"], "pairs_valid": m["pairs_valid"],
+            "V": int(len(m["gaussian_ids"])), "I": int(len(m["flatten_ids"]))}
 
 
 def main():
@@ -151,14 +234,16 @@ def main():
     if world != args.gpus and rank == 0:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     torch.manual_seed(1)
-    scene = syn.sphere_scene(args.level, seed=1, cubemap_res=args.cubemap_res)
+    scene = syn.sphere_scene(args.level, seed=1, cubemap_res=args.cubemap_res, device=dev)
     N = scene.splats.num
-    all_cams = syn.blender_cameras(num=args.views * world, width=args.res, height=args.res)
-    cams = [all_cams[i] for i in range(rank, args.views * world, world)]      # view i -> rank i mod world
+    strong = args.views_total > 0
+    views_total = args.views_total if strong else args.views * world
+    all_cams = syn.blender_cameras(num=views_total, width=args.res, height=args.res)
+    cams = [all_cams[i] for i in range(rank, views_total, world)]                # view i -> rank i mod world
     params = params_from_scene(scene, dev)
     step = RenderStep(params, prefilter=not args.no_prefilter)
     g = torch.Generator().manual_seed(100 + rank)
-    ups = [(torch.rand(args.res, args.res, 4, generator=g) * 2 - 1).to(dev) for _ in range(len(cams))]
+    ups = [(torch.rand(args.res, args.res, 4, generator=g) * 2 - 1).to(dev) for _ in range(max(1, len(cams)))]
 
     def one_step():
         step(cams, lambda i, img: ups[i], all_reduce=(world > 1))
@@ -180,12 +265,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    views_per_s = args.views * world * args.steps / dt
+    views_per_s = views_total * args.steps / dt
 
     # ---------------- measurements for the roofline objects (rank 0, one representative view)
     result = None
     if rank == 0:
-        cam = cams[0]
+        cam = all_cams[0]
         with torch.no_grad():
             env = step._static_env if args.no_prefilter else gs.as_splitsum(params.cubemap)
             colors = gs.shade(params.means, params.normals, params.kd, params.ks, cam.c2w[:, 3].to(dev).contiguous(), env,
@@ -200,57 +285,77 @@ def main():
                   colors=colors[meta["gaussian_ids"]].contiguous(), offsets=meta["isect_offsets"].reshape(-1).contiguous(),
                   flatten_ids=meta["flatten_ids"], V=V, I=I, res=args.res)
         kt = time_dominant_kernels(st, args.kernel_iters)
-        dom = max(kt, key=kt.get)
-        # algorithmic bytes of the compositor launches (DESIGN.md section 5):
-        #   fwd: ids 4 I + gathered geometry+colour 36 I + image write 20 P
-        #   bwd: ids 4 I + gathered geometry+colour 36 I + image read 24 P + per-visible grad write 36 V
-        kbytes = {"raster_fwd_kernel": 40 * I + 20 * P, "raster_bwd_kernel": 40 * I + 24 * P + 36 * V}
-        achieved = kbytes[dom] / (kt[dom] * 1e-3) / 1e9
+        view_ms = time_view_without_prefilter(params, cam, ups[0], max(3, args.kernel_iters // 2))
+        comp = {k: v for k, v in kt.items() if k.startswith("raster_") and "prepare" not in k}
+        dom = max(comp, key=comp.get)
+        # algorithmic bytes of the compositor launches (DESIGN.md section 4):
+        #   fwd: sorted record stream 48 I + image write 20 P        bwd: record stream 48 I + image read 24 P + per-visible grad write 36 V
+        kbytes = {"raster_fwd_kernel": 48 * I + 20 * P, "raster_bwd_kernel": 48 * I + 24 * P + 36 * V}
+        hbm_achieved = kbytes[dom] / (kt[dom] * 1e-3) / 1e9
         view_bytes = algorithmic_bytes_per_view(N, V, I, P, E)
-        # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes (scripts/run_pmc.sh ->
-        # scripts/pmc_summary.py: FETCH_SIZE x 2 (gfx950 under-count of wide reads) + WRITE_SIZE, KiB -> bytes) on this
-        # same workload and committed under profiles/; counters cannot be read inside this process
-        traffic, traffic_src, valu_insts = None, None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath) and args.level == 7 and args.res == 800:
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj[dom + "<3>"]["hbm_bytes"]
-                valu_insts = tj[dom + "<3>"].get("valu_wave_instructions")
-                traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, per launch)"
-            except Exception:
-                traffic = None
-        result = {
-            "metric": "fwd+bwd views/sec at 2M Gaussians, 800x800",
-            "value": views_per_s, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"surface splats (MGAdapter on icosphere level {args.level}) N={N}, {args.res}x{args.res}, "
-                                   f"split-sum GGX envmap {args.cubemap_res}^2, {args.views} views/step/GPU, "
-                                   f"prefilter fwd+bwd {'in' if not args.no_prefilter else 'EXCLUDED from'} every step",
-                       "N": N, "V": V, "I": I, "P": P, "views_per_step_per_gpu": args.views,
-                       "parallelism": f"dp{world} (views sharded, flat RCCL all-reduce of grads)"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel_ms": kt, "algorithmic_bytes": kbytes[dom],
-                         # the binding resource of this kernel is FP32 VALU issue, not HBM: wave64 instructions (PMC
-                         # SQ_INSTS_VALU, same passes) x 4 cycles on a SIMD16 / (time x 1024 SIMDs x 2.4 GHz)
-                         "valu": None if valu_insts is None else {
-                             "wave_instructions": valu_insts,
-                             "issue_frac": valu_insts * 4.0 / (kt[dom] * 1e-3 * 1024 * 2.4e9)},
-                         "note": "compositor kernels are FP32-VALU/exp bound (SURVEY 8d); HBM fraction reported as the contract asks"},
-            "view_roofline": {"algorithmic_bytes_per_view": view_bytes,
-                              "achieved_GBs": view_bytes * views_per_s / world / 1e9,
-                              "frac_of_8TBs": view_bytes * views_per_s / world / 1e9 / HBM_PEAK_GBS},
-        }
+        cb = None
         if not args.no_cpu_baseline:
             try:
                 cb = cpu_baseline(scene, cam, args.res, "bounded to one view")
-                result["parity"] = cb.pop("parity")
-                result["cpu_baseline"] = cb
             except Exception as e:       # the baseline must never take the bench line down
-                result["cpu_baseline"] = {"value": None, "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
-                                          "sample": f"failed: {e}"}
+                cb = {"value": None, "unit": "views/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}", "parity": None}
+        pairs_valid = cb.get("pairs_valid") if cb else None
+        # the compositor is FP32-VALU bound: useful flops = composited (pixel, Gaussian) pairs x flops per pair
+        t_pair = (kt["raster_fwd_kernel"] + kt["raster_bwd_kernel"]) * 1e-3
+        valu_tf = None if not pairs_valid else pairs_valid * (FLOPS_FWD_PER_PAIR + FLOPS_BWD_PER_PAIR) / t_pair / 1e12
+        dom_flops = FLOPS_FWD_PER_PAIR if dom == "raster_fwd_kernel" else FLOPS_BWD_PER_PAIR
+        dom_tf = None if not pairs_valid else pairs_valid * dom_flops / (kt[dom] * 1e-3) / 1e12
+        # committed counter summaries, quoted only while gs_raster.hip is the source they were measured on
+        stats = committed_profile("r02_raster_stats.json", "gs_raster.hip")
+        pmc = committed_profile("r02_pmc_traffic.json", "gs_raster.hip")
+        lane_util = None
+        if stats and args.level == 7 and args.res == 800:
+            key = "fwd" if dom == "raster_fwd_kernel" else "bwd"
+            lane_util = {"valid_pairs": stats[key]["valid_pairs"], "trips": stats[key]["trips"],
+                         "valid_lanes_per_trip_of_64": stats[key]["valid_pairs"] / max(1, stats[key]["trips"]),
+                         "source": "profiles/r02_raster_stats.json (scripts/raster_stats.py, -DGS_RASTER_STATS build of the same source)"}
+        traffic = traffic_src = None
+        if pmc and args.level == 7 and args.res == 800 and dom in pmc.get("kernels", {}):
+            traffic = pmc["kernels"][dom]["hbm_bytes"]
+            traffic_src = ("profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes per launch, "
+                           f"measured at commit {pmc.get('commit', '?')} on this kernel source)")
+        result = {
+            "metric": "fwd+bwd views/sec at 2M Gaussians, 800x800",
+            "value": views_per_s, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"surface splats (HIP MGAdapter on icosphere level {args.level}) N={N}, {args.res}x{args.res}, "
+                                   f"split-sum GGX envmap {args.cubemap_res}^2, "
+                                   + (f"{views_total} views/step over all GPUs (strong scaling)" if strong else f"{args.views} views/step/GPU")
+                                   + f", prefilter fwd+bwd {'in' if not args.no_prefilter else 'EXCLUDED from'} every step",
+                       "N": N, "V": V, "I": I, "P": P, "views_per_step_total": views_total,
+                       "parallelism": f"dp{world} (views sharded, prefilter sharded, flat RCCL all-reduce of per-Gaussian grads)"},
+            "roofline": {"bound": "valu", "kernel": dom, "achieved": dom_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": None if dom_tf is None else dom_tf / VALU_PEAK_TFLOPS,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "pairs_valid": pairs_valid, "flops_per_pair": {"fwd": FLOPS_FWD_PER_PAIR, "bwd": FLOPS_BWD_PER_PAIR},
+                         "compositor_fwd_plus_bwd": {"achieved_TFLOPs": valu_tf,
+                                                     "frac_of_157.3": None if valu_tf is None else valu_tf / VALU_PEAK_TFLOPS},
+                         "lane_utilisation": lane_util,
+                         "kernel_ms": kt,
+                         "hbm": {"algorithmic_bytes": kbytes[dom], "achieved_GBs": hbm_achieved, "peak_GBs": HBM_PEAK_GBS,
+                                 "frac": hbm_achieved / HBM_PEAK_GBS},
+                         "note": "kernels timed alone with HIP events on the launch stream (gs_raster_composite / gs_raster_bwd_acc: no "
+                                 "stream build, no memset); useful flops = composited (pixel, Gaussian) pairs x flops per pair"},
+            "view_roofline": {"algorithmic_bytes_per_view": view_bytes,
+                              "achieved_GBs": view_bytes * views_per_s / world / 1e9,
+                              "frac_of_8TBs": view_bytes * views_per_s / world / 1e9 / HBM_PEAK_GBS},
+            "gpu_view_ms_without_prefilter": view_ms,
+        }
+        if cb is not None:
+            result["parity"] = cb.pop("parity", None)
+            if cb.get("value"):
+                cb["gpu_over_cpu_same_work"] = (1e3 / view_ms) / cb["value"]
+            try:
+                cb["cfg1"] = cpu_baseline_cfg1()
+            except Exception as e:
+                cb["cfg1"] = {"value": None, "sample": f"failed: {e}"}
+            result["cpu_baseline"] = cb
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

@@ -1316,10 +1316,33 @@ static int launch_bwd(int W, int H, int D, const RasterWs& ws, const float* colo
 
 extern "C" int gs_raster_grad_stride(int D) { return ((6 + D) + 15) / 16 * 16; }
 
+static int raster_bwd_impl(int W, int H, int tile_size, int D, int V, const float* colors, const float* background,
+                           int64_t n_isects, const int32_t* offsets, const float* alphas, const int32_t* last_ids,
+                           const float* v_render, const float* v_alphas, float* v_packed, const void* ws,
+                           size_t ws_bytes, void* stream, bool zero);
+
 extern "C" int gs_raster_bwd(int W, int H, int tile_size, int D, int V, const float* colors, const float* background,
                              int64_t n_isects, const int32_t* offsets, const float* alphas, const int32_t* last_ids,
                              const float* v_render, const float* v_alphas, float* v_packed, const void* ws,
                              size_t ws_bytes, void* stream)
+{
+    return raster_bwd_impl(W, H, tile_size, D, V, colors, background, n_isects, offsets, alphas, last_ids, v_render, v_alphas,
+                           v_packed, ws, ws_bytes, stream, true);
+}
+
+extern "C" int gs_raster_bwd_acc(int W, int H, int tile_size, int D, int V, const float* colors, const float* background,
+                                 int64_t n_isects, const int32_t* offsets, const float* alphas, const int32_t* last_ids,
+                                 const float* v_render, const float* v_alphas, float* v_packed, const void* ws,
+                                 size_t ws_bytes, void* stream)
+{
+    return raster_bwd_impl(W, H, tile_size, D, V, colors, background, n_isects, offsets, alphas, last_ids, v_render, v_alphas,
+                           v_packed, ws, ws_bytes, stream, false);
+}
+
+static int raster_bwd_impl(int W, int H, int tile_size, int D, int V, const float* colors, const float* background,
+                           int64_t n_isects, const int32_t* offsets, const float* alphas, const int32_t* last_ids,
+                           const float* v_render, const float* v_alphas, float* v_packed, const void* ws,
+                           size_t ws_bytes, void* stream, bool zero)
 {
     GS_CHECK_ARG(W > 0 && H > 0 && V >= 0, "bad sizes");
     GS_CHECK_ARG(tile_size == GS_TILE, "only tile_size=16 is built (rfstudio/model/gsplat.py:30)");
@@ -1329,7 +1352,7 @@ extern "C" int gs_raster_bwd(int W, int H, int tile_size, int D, int V, const fl
     if (ws_bytes < gs_raster_ws_bytes(n_isects, V, W, H, tile_size)) { gs_set_error("gs_raster_bwd: workspace too small"); return GS_ENOSPC; }
     hipStream_t s = (hipStream_t)stream;
     const int rec_stride = gs_raster_grad_stride(D);
-    if (V > 0) GS_CHECK_HIP(hipMemsetAsync(v_packed, 0, sizeof(float) * (size_t)rec_stride * (size_t)V, s));
+    if (V > 0 && zero) GS_CHECK_HIP(hipMemsetAsync(v_packed, 0, sizeof(float) * (size_t)rec_stride * (size_t)V, s));
     if (n_isects == 0 || V == 0) return GS_OK;
     const int tiles = ((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
     const RasterWs r = carve((void*)ws, n_isects, V, tiles);

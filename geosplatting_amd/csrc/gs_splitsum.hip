@@ -484,7 +484,7 @@ template <bool SRC4>
 __global__ void __launch_bounds__(64 * GS_APPLY_WAVES)
 specular_apply_kernel(int R, const float* __restrict__ src, const int64_t* __restrict__ patch_offsets, int64_t total_patches,
                       const int32_t* __restrict__ patch_desc, const float* __restrict__ weights,
-                      float* __restrict__ dst, int dst_stride, int accumulate)
+                      float* __restrict__ dst, int dst_stride, int accumulate, int t_begin, int t_end)
 {
     constexpr int TPW = GS_APPLY_TPW, U = GS_APPLY_UNROLL;
     const int lane = threadIdx.x & 63;
@@ -494,8 +494,10 @@ specular_apply_kernel(int R, const float* __restrict__ src, const int64_t* __res
 #else
     const int grp = blockIdx.x;
 #endif
-    const int t0 = __builtin_amdgcn_readfirstlane((grp * GS_APPLY_WAVES + (int)(threadIdx.x >> 6)) * TPW);
-    const int n = 6 * R * R;
+    // texels [t_begin, t_end) of the level: the whole level on one GPU, this rank's share when the prefilter is sharded
+    const int t0 = t_begin + __builtin_amdgcn_readfirstlane((grp * GS_APPLY_WAVES + (int)(threadIdx.x >> 6)) * TPW);
+    const int n = t_end;
+    const int n_all = 6 * R * R;
     if (t0 >= n) return;
     const int lx = lane & 7, ly = lane >> 3;
     int64_t pb[TPW], pe[TPW];
@@ -503,7 +505,7 @@ specular_apply_kernel(int R, const float* __restrict__ src, const int64_t* __res
     for (int j = 0; j < TPW; ++j) {
         const int t = min(t0 + j, n - 1);
         pb[j] = patch_offsets[t];
-        pe[j] = (t + 1 < n) ? patch_offsets[t + 1] : total_patches;
+        pe[j] = (t + 1 < n_all) ? patch_offsets[t + 1] : total_patches;
         if (t0 + j >= n) pe[j] = pb[j];
     }
     int64_t longest = 0;
@@ -555,21 +557,31 @@ specular_apply_kernel(int R, const float* __restrict__ src, const int64_t* __res
     }
 }
 
+extern "C" int gs_specular_apply_range(int R, const float* src, int src_stride, const int64_t* patch_offsets,
+                                       int64_t total_patches, const int32_t* patch_desc, const float* weights, float* dst,
+                                       int dst_stride, int accumulate, int t_begin, int t_end, void* stream)
+{
+    GS_CHECK_ARG(R >= 1 && src && patch_offsets && patch_desc && weights && dst && dst_stride >= 3, "bad arguments");
+    GS_CHECK_ARG(src_stride == 3 || src_stride == 4, "src_stride must be 3 or 4");
+    GS_CHECK_ARG(t_begin >= 0 && t_begin <= t_end && t_end <= 6 * R * R, "texel range outside [0, 6 R^2]");
+    if (t_begin == t_end) return GS_OK;
+    const int groups = (gs_cdiv(t_end - t_begin, GS_APPLY_WAVES * GS_APPLY_TPW) + 7) / 8 * 8;   // multiple of 8: one contiguous share per XCD
+    if (src_stride == 4)
+        hipLaunchKernelGGL(specular_apply_kernel<true>, dim3(groups), dim3(64 * GS_APPLY_WAVES), GS_APPLY_LDS, (hipStream_t)stream, R, src,
+                           patch_offsets, total_patches, patch_desc, weights, dst, dst_stride, accumulate, t_begin, t_end);
+    else
+        hipLaunchKernelGGL(specular_apply_kernel<false>, dim3(groups), dim3(64 * GS_APPLY_WAVES), GS_APPLY_LDS, (hipStream_t)stream, R, src,
+                           patch_offsets, total_patches, patch_desc, weights, dst, dst_stride, accumulate, t_begin, t_end);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
 extern "C" int gs_specular_apply(int R, const float* src, int src_stride, const int64_t* patch_offsets,
                                  int64_t total_patches, const int32_t* patch_desc, const float* weights, float* dst,
                                  int dst_stride, int accumulate, void* stream)
 {
-    GS_CHECK_ARG(R >= 1 && src && patch_offsets && patch_desc && weights && dst && dst_stride >= 3, "bad arguments");
-    GS_CHECK_ARG(src_stride == 3 || src_stride == 4, "src_stride must be 3 or 4");
-    const int groups = (gs_cdiv(6 * R * R, GS_APPLY_WAVES * GS_APPLY_TPW) + 7) / 8 * 8;   // multiple of 8: one contiguous share per XCD
-    if (src_stride == 4)
-        hipLaunchKernelGGL(specular_apply_kernel<true>, dim3(groups), dim3(64 * GS_APPLY_WAVES), GS_APPLY_LDS, (hipStream_t)stream, R, src,
-                           patch_offsets, total_patches, patch_desc, weights, dst, dst_stride, accumulate);
-    else
-        hipLaunchKernelGGL(specular_apply_kernel<false>, dim3(groups), dim3(64 * GS_APPLY_WAVES), GS_APPLY_LDS, (hipStream_t)stream, R, src,
-                           patch_offsets, total_patches, patch_desc, weights, dst, dst_stride, accumulate);
-    GS_CHECK_LAUNCH();
-    return GS_OK;
+    return gs_specular_apply_range(R, src, src_stride, patch_offsets, total_patches, patch_desc, weights, dst, dst_stride,
+                                   accumulate, 0, 6 * R * R, stream);
 }
 
 extern "C" int gs_specular_cubemap_fwd(int R, const float* cubemap, const float* bounds, const float* dir_table,

@@ -26,7 +26,8 @@ from .cameras import Camera
 from .parallel import GradBucket
 from .rasterization import _bin_stage, _composite_stage, _forward_stages, _prepare_stage, _project_stage
 from .shading import _MODE, _TONE, RenderableAttrs, _make_env, get_fg_lut, shade_private_copies
-from .splitsum import CACHE_PAIR_WEIGHTS, TextureSplitSum, as_splitsum, as_splitsum_backward
+from .splitsum import (CACHE_PAIR_WEIGHTS, TextureSplitSum, as_splitsum, as_splitsum_backward, as_splitsum_backward_sharded,
+                       as_splitsum_sharded, can_shard_prefilter)
 from .splats import SplatSet
 
 PARAM_NAMES = ("means", "scales", "quats", "opacities", "normals", "kd", "ks", "cubemap", "exposure")
@@ -60,6 +61,15 @@ class RenderStep:
         self._side_stream = None
         self._tail_stream = None
         self._pre_stream = None
+        self._pre_group = None
+
+    def _prefilter_group(self):
+        """A second communicator for the prefilter exchange (25 MB all-reduce + two rounds of small all-gathers), so that it
+        never queues behind the 149 MB per-Gaussian all-reduce on the default one.  Created collectively on first use."""
+        import torch.distributed as dist
+        if self._pre_group is None:
+            self._pre_group = dist.new_group()
+        return self._pre_group
 
     def rebind(self, params: PathParams) -> None:
         """New parameter tensors for the next step (a stage-1 loop extracts a different number of Gaussians every
@@ -101,8 +111,15 @@ class RenderStep:
         # the first half placed on its own stream, under the compositor of the remaining views
         explicit_pre = self.prefilter and CACHE_PAIR_WEIGHTS
         cubemap = p.cubemap.detach().requires_grad_(self.prefilter and not explicit_pre)
+        import torch.distributed as dist
+        world = dist.get_world_size() if (all_reduce and dist.is_available() and dist.is_initialized()) else 1
+        # S5 sharded over the ranks (each applies 1/world of every level's texels, all-gather): splitsum.py
+        sharded = (explicit_pre and world > 1 and os.environ.get("GEOSPLAT_SHARD_PREFILTER", "1") != "0"
+                   and can_shard_prefilter(int(cubemap.shape[1]), world))
         if self.prefilter:
-            if explicit_pre:
+            if sharded:
+                env = as_splitsum_sharded(cubemap, dist.get_rank(), world, self._prefilter_group())
+            elif explicit_pre:
                 with torch.no_grad():
                     env = as_splitsum(cubemap)
             else:
@@ -119,15 +136,19 @@ class RenderStep:
         # texel-gradient accumulators.  Two sets (views [0, n/2) and [n/2, n)) with the first half's prefilter backward
         # on its own stream under the remaining compositor work was measured: 30.4 vs 28.7 ms per step -- the backward is
         # linear, so splitting it doubles its 2.4 ms and the overlap does not pay that back.  One set.
-        n_sets = 2 if (explicit_pre and len(cameras) >= 4 and os.environ.get("GEOSPLAT_SPLIT_PREFILTER_BWD") == "1") else 1
+        n_sets = 2 if (explicit_pre and not sharded and len(cameras) >= 4 and os.environ.get("GEOSPLAT_SPLIT_PREFILTER_BWD") == "1") else 1
         g_sets = []
         for _ in range(n_sets):
-            gb = torch.zeros_like(env_d.base); gl = [torch.zeros_like(l) for l in env_d.levels]
+            # one flat buffer behind the base + level gradients: the sharded prefilter sums them over the ranks in ONE all-reduce
+            sizes = [env_d.base.numel()] + [l.numel() for l in env_d.levels]
+            g_flat = torch.zeros(sum(sizes), dtype=f32, device=dev)
+            parts = torch.split(g_flat, sizes)
+            gb = parts[0].view_as(env_d.base); gl = [q.view_as(l) for q, l in zip(parts[1:], env_d.levels)]
             egs = L.GsEnvGrad(); egs.base = gb.data_ptr()
             for i, g in enumerate(gl):
                 egs.levels[i] = g.data_ptr()
-            g_sets.append((gb, gl, egs))
-        g_base, g_levels, eg = g_sets[0]
+            g_sets.append((gb, gl, egs, g_flat))
+        g_base, g_levels, eg, _ = g_sets[0]
         half = (len(cameras) + 1) // 2 if n_sets == 2 else len(cameras)
         g_cube_first = None
         ws_bytes = lib.gs_shade_bwd_ws_bytes(C.byref(e), mode) if shade_private_copies() else 0
@@ -243,10 +264,21 @@ class RenderStep:
         # the communication stream) overlaps the prefilter backward, whose cubemap gradient is reduced afterwards
         torch.mul(g_scales_act, scales_act, out=b["scales"])
         b["opacities"].copy_((g_opac_act * opac_act * (1.0 - opac_act)).unsqueeze(-1))
+        if sharded:
+            grp = self._prefilter_group()
+            gb, gl, _, g_flat = g_sets[0]                       # (the split-backward experiment is single-GPU only: n_sets == 1 here)
+            dist.all_reduce(g_flat, op=dist.ReduceOp.SUM, group=grp)             # texel gradients of ALL views: needed by every share
+            start_head, _ = self.bucket.all_reduce_split("cubemap")
+            start_head()                                        # per-Gaussian segments: communication stream, default communicator
+            g_cube = as_splitsum_backward_sharded(gb, gl, dist.get_rank(), world, grp, min_roughness=env.min_roughness,
+                                                  max_roughness=env.max_roughness)
+            b["cubemap"].copy_(g_cube)                          # identical on every rank: not reduced again
+            self.bucket.all_reduce_names(["exposure"])          # queues behind the head on the communication stream, then joins it
+            return b, (images if keep_images else None)
         start_head, finish = self.bucket.all_reduce_split("cubemap") if all_reduce else ((lambda: None), (lambda: None))
         start_head()
         if self.prefilter and explicit_pre:
-            gb, gl, _ = g_sets[n_sets - 1]
+            gb, gl, _, _ = g_sets[n_sets - 1]
             g_cube = as_splitsum_backward(gb, gl, min_roughness=env.min_roughness, max_roughness=env.max_roughness)
             if g_cube_first is not None:
                 main.wait_stream(self._pre_stream)

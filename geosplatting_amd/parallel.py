@@ -113,6 +113,21 @@ class GradBucket:
                 dist.all_reduce(tail, op=dist.ReduceOp.SUM)
         return start_head, finish
 
+    def all_reduce_names(self, names: Sequence[str], group=None) -> None:
+        """Sum only the listed segments (on the communication stream, joined before returning)."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        cs = self.comm_stream
+        if cs is not None:
+            cs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cs):
+                for k in names:
+                    dist.all_reduce(self.view(k), op=dist.ReduceOp.SUM, group=group)
+            torch.cuda.current_stream().wait_stream(cs)
+        else:
+            for k in names:
+                dist.all_reduce(self.view(k), op=dist.ReduceOp.SUM, group=group)
+
     def unpack(self) -> Dict[str, Tensor]:
         return {k: self.view(k) for k in self.names}
 

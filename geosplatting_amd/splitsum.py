@@ -330,3 +330,101 @@ def as_splitsum(cubemap: Tensor, *, cutoff: float = 0.99, min_resolution: int = 
         levels.append(specular_cubemap(mips[idx], roughness, cutoff))
     levels.append(specular_cubemap(mips[-1], 1.0, cutoff))
     return TextureSplitSum(base, levels, min_roughness, max_roughness)
+
+
+# ----------------------------------------------------------------------------- sharded prefilter (multi-GPU)
+# The reference prefilters the environment once per step on its one device (rfstudio/model/geosplat.py:780-785); with one
+# view per GPU that replicated 3.9 ms would sit beside a ~2.5 ms view on every rank (Amdahl).  The operator is independent
+# per OUTPUT texel in both directions (forward: a level texel gathers cubemap texels; backward: a cubemap texel gathers
+# level-gradient texels through the transposed tables), so rank r applies texels [r n/G, (r+1) n/G) of every level and the
+# ranks all-gather in place:
+#   forward : G x (1/G of the 12 GB weight stream)  + all-gather of the 25 MB pyramid
+#   backward: all-reduce of the 25 MB texel gradients (they are sums over the views of ALL ranks), 1/G of the transposed
+#             stream per rank, all-gather of the per-level cubemap-gradient pieces; the mip chain / diffuse backward are
+#             cheap and replicated, so every rank ends with the same cubemap gradient and NO all-reduce of it is needed.
+def _level_roughness(n: int, min_roughness: float, max_roughness: float) -> List[float]:
+    return [(idx / (n - 2)) * (max_roughness - min_roughness) + min_roughness for idx in range(n - 1)] + [1.0]
+
+
+def shard_texels(n_texels: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous share of a level's 6 R^2 texels; equal sizes (6 * 16^2 = 1536 divides by 2, 3, 4, 6, 8, ...)."""
+    if n_texels % world != 0:
+        raise L.GeoSplatHipError(f"{n_texels} texels do not split evenly over {world} ranks")
+    per = n_texels // world
+    return rank * per, (rank + 1) * per
+
+
+def can_shard_prefilter(cubemap_res: int, world: int, min_resolution: int = 16) -> bool:
+    return world > 1 and CACHE_PAIR_WEIGHTS and (6 * min_resolution * min_resolution) % world == 0 and cubemap_res >= 4 * min_resolution
+
+
+def _all_gather_inplace(full: Tensor, t0: int, t1: int, group) -> None:
+    """full: [n, 3] contiguous; rows [t0, t1) hold this rank's share -> every rank's share lands in place."""
+    import torch.distributed as dist
+    flat = full.view(-1)
+    mine = flat[t0 * 3:t1 * 3]
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(flat, mine, group=group)             # in place: input is the rank-th slice of the output
+    else:
+        world = dist.get_world_size(group)
+        per = (t1 - t0) * 3
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine.clone(), group=group)
+        for r, part in enumerate(parts):
+            flat[r * per:(r + 1) * per].copy_(part)
+
+
+def _apply_range(e, table: str, src: Tensor, dst: Tensor, t0: int, t1: int, res: int) -> None:
+    src_t, stride = _apply_src(src)
+    L.check(L.lib().gs_specular_apply_range(res, L.ptr(src_t), stride, L.ptr(e["offsets"]), L.i64(e["total"]), L.ptr(e["desc"]),
+                                            L.ptr(e[table]), L.ptr(dst), 3, 0, t0, t1, L.stream()), "gs_specular_apply_range")
+
+
+def as_splitsum_sharded(cubemap: Tensor, rank: int, world: int, group=None, *, cutoff: float = 0.99, min_resolution: int = 16,
+                        min_roughness: float = 0.08, max_roughness: float = 0.5) -> TextureSplitSum:
+    """`as_splitsum` (no autograd graph) with the specular levels computed 1/world per rank and all-gathered."""
+    L.require_cuda(cubemap)
+    with torch.no_grad():
+        mips = [cubemap.detach().float().contiguous()]
+        while mips[-1].shape[1] > min_resolution:
+            mips.append(_CubeMapMip.apply(mips[-1]))
+        assert len(mips) > 2, "Min resolution is too large."
+        base = diffuse_cubemap(mips[-1])
+        levels = []
+        for mip, rough in zip(mips, _level_roughness(len(mips), min_roughness, max_roughness)):
+            res = mip.shape[1]
+            e = specular_weights(res, rough, cutoff, mip.device)
+            t0, t1 = shard_texels(6 * res * res, rank, world)
+            out = torch.empty(6, res, res, 3, dtype=torch.float32, device=mip.device)
+            _apply_range(e, "fwd", mip, out, t0, t1, res)
+            o2 = out.view(-1, 3)
+            o2[t0:t1].div_(e["wsum"].view(-1, 1)[t0:t1])
+            _all_gather_inplace(o2, t0, t1, group)
+            levels.append(out)
+    return TextureSplitSum(base, levels, min_roughness, max_roughness)
+
+
+def as_splitsum_backward_sharded(g_base: Tensor, g_levels: List[Tensor], rank: int, world: int, group=None, *, cutoff: float = 0.99,
+                                 min_roughness: float = 0.08, max_roughness: float = 0.5) -> Tensor:
+    """Cubemap gradient from texel gradients that are ALREADY summed over the ranks; identical result on every rank."""
+    n = len(g_levels)
+    g_mips = []
+    for gl, rough in zip(g_levels, _level_roughness(n, min_roughness, max_roughness)):
+        res = gl.shape[1]
+        e = specular_weights(res, rough, cutoff, gl.device)
+        t0, t1 = shard_texels(6 * res * res, rank, world)
+        g = torch.empty(6, res, res, 3, dtype=torch.float32, device=gl.device)
+        _apply_range(e, "bwd", gl / e["wsum"], g, t0, t1, res)
+        _all_gather_inplace(g.view(-1, 3), t0, t1, group)
+        g_mips.append(g)
+    gd = g_base.contiguous()
+    gdb = torch.empty_like(gd)
+    L.check(L.lib().gs_diffuse_cubemap_bwd(gd.shape[1], L.ptr(gd), L.ptr(gdb), 0, L.stream()), "gs_diffuse_cubemap_bwd")
+    g_mips[-1] = g_mips[-1] + gdb
+    for idx in range(n - 1, 0, -1):
+        dout = g_mips[idx].contiguous()
+        R = dout.shape[1]
+        up = torch.empty(6, 2 * R, 2 * R, 3, dtype=torch.float32, device=dout.device)
+        L.check(L.lib().gs_cubemap_mip_bwd(R, L.ptr(dout), L.ptr(up), 0, L.stream()), "gs_cubemap_mip_bwd")
+        g_mips[idx - 1] = g_mips[idx - 1] + up
+    return g_mips[0]

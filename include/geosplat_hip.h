@@ -132,6 +132,13 @@ int gs_raster_bwd(int W, int H, int tile_size, int D, int V, const float* colors
                   const float* v_render, const float* v_alphas, float* v_packed, const void* ws, size_t ws_bytes,
                   void* stream);
 
+/* The compositor backward alone: ADDS into a v_packed the caller has zeroed (or that already holds another view's
+ * packed gradients of the same visible set); same arguments. */
+int gs_raster_bwd_acc(int W, int H, int tile_size, int D, int V, const float* colors, const float* background,
+                      int64_t n_isects, const int32_t* offsets, const float* alphas, const int32_t* last_ids,
+                      const float* v_render, const float* v_alphas, float* v_packed, const void* ws, size_t ws_bytes,
+                      void* stream);
+
 /* ------------------------------------------------------------------ A7 ----------------------------- */
 /* Projection backward + gather backward from the packed records of gs_raster_bwd; dense outputs [N,*] are fully
  * written (zeros for culled Gaussians) -- no caller-side zeroing needed -- or, with accumulate != 0, ADDED to
@@ -225,6 +232,11 @@ int gs_specular_weights_build(int R, const float* bounds, const float* dir_table
 int gs_specular_apply(int R, const float* src, int src_stride /* 3, or 4 = float4-padded texels (faster) */,
                       const int64_t* patch_offsets, int64_t total_patches, const int32_t* patch_desc,
                       const float* weights, float* dst, int dst_stride, int accumulate, void* stream);
+/* The same operator on the output texels [t_begin, t_end) only (flat index (s*R + y)*R + x): the prefilter is independent per
+ * output texel, so G ranks each apply 1/G of every level and all-gather (geosplatting_amd/splitsum.py, sharded S5). */
+int gs_specular_apply_range(int R, const float* src, int src_stride, const int64_t* patch_offsets, int64_t total_patches,
+                            const int32_t* patch_desc, const float* weights, float* dst, int dst_stride, int accumulate,
+                            int t_begin, int t_end, void* stream);
 
 /* ------------------------------------------------------------------ M1: MGAdapter (mesh -> Gaussians) */
 /* rfstudio/model/geosplat.py:378-472 (MGAdapter.make, default ratios): every face -> 6 flat Gaussians (two rings

@@ -110,12 +110,12 @@ def raster_fwd(W, H, tile_size, means2d, conics, opacities, colors, offsets, fla
     offsets = np.ascontiguousarray(offsets, np.int32); flatten_ids = np.ascontiguousarray(flatten_ids, np.int32)
     render = np.empty((H, W, D), np.float32); alphas = np.empty((H, W), np.float32)
     last_ids = np.empty((H, W), np.int32); amb = np.empty((H, W), np.uint8)
-    pairs = C.c_int64(0)
+    pairs = (C.c_int64 * 2)(0, 0)          # evaluated pairs, composited (valid) pairs
     bg = None if background is None else _f32(background)
     lib().gso_raster_fwd(int(W), int(H), int(tile_size), int(D), _p(means2d), _p(conics), _p(opacities), _p(colors),
                          _p(bg), C.c_int64(flatten_ids.shape[0]), _p(offsets), _p(flatten_ids),
-                         _p(render), _p(alphas), _p(last_ids), _p(amb), C.byref(pairs))
-    return render, alphas, last_ids, amb.astype(bool), int(pairs.value)
+                         _p(render), _p(alphas), _p(last_ids), _p(amb), pairs)
+    return render, alphas, last_ids, amb.astype(bool), (int(pairs[0]), int(pairs[1]))
 
 
 def raster_bwd(W, H, tile_size, means2d, conics, opacities, colors, offsets, flatten_ids, alphas, last_ids,
@@ -170,7 +170,7 @@ def rasterization(means, quats, scales, opacities, colors, viewmat, K, W, H, til
     render, alphas, last_ids, amb, pairs = raster_fwd(W, H, tile_size, m["means2d"], m["conics"], m["opacities"],
                                                        m["colors"], off, flat, background)
     m.update(tiles_per_gauss=tpg, isect_ids=ids, flatten_ids=flat, isect_offsets=off.reshape(th, tw),
-             render=render, alphas=alphas, last_ids=last_ids, ambiguous=amb, pairs=pairs,
+             render=render, alphas=alphas, last_ids=last_ids, ambiguous=amb, pairs=pairs[0], pairs_valid=pairs[1],
              tile_width=tw, tile_height=th)
     return m
 

@@ -337,12 +337,12 @@ GSO_API void gso_raster_fwd(int W, int H, int tile_size, int D,
                             int64_t n_isects, const int32_t* offsets, const int32_t* flatten_ids,
                             float* render /*[H,W,D]*/, float* alphas /*[H,W]*/, int32_t* last_ids /*[H,W]*/,
                             uint8_t* ambiguous /* nullable [H,W]: 1 if a threshold test was within 1e-5 rel */,
-                            int64_t* pair_count /* nullable: evaluated (pixel,gaussian) pairs */)
+                            int64_t* pair_count /* nullable [2]: evaluated (pixel,gaussian) pairs, composited pairs */)
 {
     int tw = (W + tile_size - 1) / tile_size, th = (H + tile_size - 1) / tile_size;
     int n_tiles = tw * th;
-    int64_t pairs = 0;
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : pairs)
+    int64_t pairs = 0, composited = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : pairs, composited)
     for (int tile = 0; tile < n_tiles; ++tile) {
         int ty = tile / tw, tx = tile % tw;
         int64_t start = offsets[tile];
@@ -367,6 +367,7 @@ GSO_API void gso_raster_fwd(int W, int H, int tile_size, int D,
                     if (fabsf(next_T - 1e-4f) < 1e-5f * 1e-4f) amb = 1;
                     if (next_T <= 1e-4f) break;
                     float vis = alpha * T;
+                    ++composited;
                     for (int k = 0; k < D; ++k) pix_out[k] = fmaf(colors[(size_t)g * D + k], vis, pix_out[k]);
                     cur_idx = (int32_t)idx;
                     T = next_T;
@@ -379,7 +380,7 @@ GSO_API void gso_raster_fwd(int W, int H, int tile_size, int D,
                 if (ambiguous) ambiguous[pid] = (uint8_t)amb;
             }
     }
-    if (pair_count) *pair_count = pairs;
+    if (pair_count) { pair_count[0] = pairs; pair_count[1] = composited; }
 }
 
 /* ------------------------------------------------------------------------- */

@@ -28,6 +28,13 @@ lib.gs_raster_stats_read(buf, 0)
 v = list(buf)
 I = meta["flatten_ids"].numel()
 if os.environ.get("GEOSPLAT_RASTER_LANES", "1") != "0":
+    if len(sys.argv) > 2:                                  # python scripts/raster_stats.py 7 profiles/r02_raster_stats.json
+        import hashlib, json
+        src = os.path.join(B.CSRC, "gs_raster.hip")
+        json.dump({"source_sha16": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16], "workload": f"icosphere level {level}, 800x800, view 0",
+                   "I": I, "fwd": {"raw_wave_batches": v[0], "culled_records": v[1], "trips": v[3], "valid_pairs": v[2]},
+                   "bwd": {"raw_wave_batches": v[4], "culled_records": v[5], "trips": v[6], "valid_pairs": v[7]}},
+                  open(sys.argv[2], "w"), indent=1)
     print(f"I={I}  per-lane lists  fwd: raw wave-batches {v[0]}  culled records {v[1]} ({v[1]/max(v[0],1):.1f}/raw batch)  trips {v[3]} "
           f"({64*v[3]/max(v[1],1):.2f} per 64 culled records)  valid pairs {v[2]} ({v[2]/max(v[3],1):.1f}/trip)")
     print(f"       bwd: raw wave-batches {v[4]}  culled records {v[5]} ({v[5]/max(v[4],1):.1f}/raw batch)  trips {v[6]} "

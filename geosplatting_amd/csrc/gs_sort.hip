@@ -1,37 +1,213 @@
-// gs_sort.hip -- A3: stable ascending sort of the (tile|depth) keys with their packed-index payload.
-// Semantics: cub::DeviceRadixSort::SortPairs over the low 32 + tile_bits key bits (gsplat 1.4
-// `isect_tiles(sort=True)`, reached from rfstudio/model/gsplat.py:334).  Stability makes equal keys keep
-// their emission order (= ascending packed index), which is what fixes the composited order bit-exactly.
+// gs_sort.hip -- A2 + A3: tile binning and the stable (tile | depth) order of the intersections, hand-written for gfx950.
+// Semantics: gsplat 1.4 `isect_tiles(sort=True)` as reached from rfstudio/model/gsplat.py:334 -- keys
+// (tile_id << 32) | float_bits(depth), payload = packed Gaussian index, stable ascending radix sort, so that equal keys
+// keep their emission order (= ascending packed index); that order fixes the composited order bit-exactly.
 //
-// Round-1 implementation: rocPRIM's device-wide LSD radix sort (header-only, compiled for gfx950 into this
-// library) restricted to the significant bits.  It is HBM-bound: ~(12 B read + 12 B write) per
-// intersection per 8-bit digit pass.  DESIGN.md lists the planned replacement (tile-binned scatter +
-// per-tile LDS bitonic with index tie-break) that touches each key once.
+// Two entry points, both on the radix machinery below (no vendor sort library on the path):
+//   gs_isect_sort : the upstream call shape -- sorts already emitted (isect_ids, flatten_ids) pairs, six 8-bit passes
+//                   over the 32 + tile_bits significant key bits (kept for callers that hold emitted keys);
+//   gs_isect_bin  : what rasterization() and the engine use.  The 44-bit key of an intersection is (tile, depth of
+//                   its Gaussian): the depth half is a property of the V Gaussians, not of the I = 2.1 V intersections,
+//                   so it is sorted ONCE on the Gaussians (4 passes over 8-byte (depth, index) items, V-sized), the
+//                   intersections are then EMITTED in depth order as 8-byte (tile, index) items, and two stable passes
+//                   over the tile bits (6 + 6 for 2 500 tiles) finish the order: 2 I-sized passes of 8-byte items instead
+//                   of 6 passes of 12-byte pairs, and the unsorted key array is never materialised.  Stability of every
+//                   pass makes the result identical to the upstream order: by tile, then depth bits, then packed index.
+//
+// One radix pass = three kernels: per-block digit histogram -> exclusive scan of the [digit][block] table -> scatter.
+// A block owns 4 096 consecutive items, a wave 1 024 of them (striped over its lanes: coalesced, and wave-major order =
+// index order), and ranks them with ballots: for every item the lanes holding the same digit are found with one ballot
+// per digit bit, the rank inside the wave is a popcount, and one lane per digit group advances the wave's running
+// counter in LDS -- no sorting network, no atomics.
 #include "gs_common.h"
 
-#include <cstring>
 #include <cstdlib>
-#include <rocprim/device/device_radix_sort.hpp>
+#include <cstring>
+
+#define RS_THREADS 256
+#define RS_WAVES 4
+#define RS_ITEMS 16                       // per thread
+#define RS_TILE (RS_THREADS * RS_ITEMS)   // 4096 items per block
+#define RS_WCHUNK (64 * RS_ITEMS)         // 1024 items per wave
+
+typedef unsigned long long u64;
 
 static int tile_bits(int tile_w, int tile_h)
 {
-    // floor(log2(n_tiles)) + 1
-    unsigned n = (unsigned)(tile_w * tile_h);
+    unsigned n = (unsigned)(tile_w * tile_h);       // floor(log2(n_tiles)) + 1, as upstream
     int b = 0;
     while (n > 1) { n >>= 1; ++b; }
     return b + 1;
 }
 
+// ---- item kinds ----------------------------------------------------------------------------------------------------
+struct PairItem { u64 key; int32_t val; };                      // emitted (isect_id, flatten_id)
+struct PairIn {
+    const u64* keys; const int32_t* vals;
+    __device__ __forceinline__ PairItem load(int64_t i) const { return PairItem{ keys[i], vals[i] }; }
+};
+struct PairOut {
+    u64* keys; int32_t* vals;
+    __device__ __forceinline__ void store(int64_t i, const PairItem& it) const { keys[i] = it.key; vals[i] = it.val; }
+};
+struct PairDigit {
+    int shift; unsigned mask;
+    __device__ __forceinline__ unsigned operator()(const PairItem& it) const { return (unsigned)(it.key >> shift) & mask; }
+};
+
+struct U2In {
+    const uint2* p;
+    __device__ __forceinline__ uint2 load(int64_t i) const { return p[i]; }
+};
+struct U2Out {
+    uint2* p;
+    __device__ __forceinline__ void store(int64_t i, const uint2& it) const { p[i] = it; }
+};
+struct DepthIn {                                                   // (depth bits, packed index) straight from the depth array
+    const float* depths;
+    __device__ __forceinline__ uint2 load(int64_t i) const { return make_uint2(__float_as_uint(depths[i]), (unsigned)i); }
+};
+struct XDigit {                                                    // digit of .x
+    int shift; unsigned mask;
+    __device__ __forceinline__ unsigned operator()(const uint2& it) const { return (it.x >> shift) & mask; }
+};
+struct FinalOut {                                                  // last tile pass: the two sorted meta arrays
+    u64* isect_ids; int32_t* flatten_ids; const float* depths;
+    __device__ __forceinline__ void store(int64_t i, const uint2& it) const
+    {
+        flatten_ids[i] = (int32_t)it.y;
+        isect_ids[i] = ((u64)it.x << 32) | (u64)__float_as_uint(depths[it.y]);
+    }
+};
+
+// ---- pass kernels --------------------------------------------------------------------------------------------------
+template <typename Item, typename In, typename Digit>
+__global__ void __launch_bounds__(RS_THREADS)
+radix_hist_kernel(int64_t n, In in, Digit digit, int nbins, int nblocks, unsigned* __restrict__ table)
+{
+    __shared__ unsigned hist[256];
+    hist[threadIdx.x] = 0u;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll 4
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const int64_t i = base + (int64_t)k * RS_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&hist[digit(in.load(i))], 1u);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nbins) table[(size_t)threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
+}
+
+// exclusive scan of the digit-major table (nbins * nblocks entries) by ONE workgroup: every wave owns a contiguous
+// sixteenth and walks it 64 entries at a time (coalesced), first summing, then scanning with a running carry
+__global__ void __launch_bounds__(1024)
+radix_scan_kernel(int total, unsigned* __restrict__ table)
+{
+    __shared__ unsigned wsum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = ((total + 15) / 16 + 63) / 64 * 64;              // entries per wave, a multiple of 64
+    const int lo = wave * per, hi = min(lo + per, total);
+    unsigned s = 0u;
+    for (int i = lo + lane; i < hi; i += 64) s += table[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) wsum[wave] = s;
+    __syncthreads();
+    unsigned carry = 0u;
+    for (int w = 0; w < wave; ++w) carry += wsum[w];
+    for (int i0 = lo; i0 < hi; i0 += 64) {
+        const int i = i0 + lane;
+        const unsigned v = i < hi ? table[i] : 0u;
+        unsigned incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (i < hi) table[i] = carry + incl - v;
+        carry += __shfl(incl, 63, 64);
+    }
+}
+
+template <typename Item, typename In, typename Digit, typename Out, int NBITS>
+__global__ void __launch_bounds__(RS_THREADS)
+radix_scatter_kernel(int64_t n, In in, Digit digit, int nblocks, const unsigned* __restrict__ table, Out out)
+{
+    constexpr int NB = 1 << NBITS;
+    __shared__ unsigned cnt[RS_WAVES][NB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < RS_WAVES * NB; i += RS_THREADS) (&cnt[0][0])[i] = 0u;
+    __syncthreads();
+    const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)wave * RS_WCHUNK;
+    const u64 lane_lt = (1ull << lane) - 1ull;
+    Item item[RS_ITEMS];
+    unsigned dig[RS_ITEMS];
+    unsigned rank[RS_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const int64_t i = wbase + (int64_t)k * 64 + lane;
+        const bool valid = i < n;
+        if (valid) item[k] = in.load(i);
+        const unsigned d = valid ? digit(item[k]) : 0u;
+        u64 m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < NBITS; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const u64 bal = __ballot(bit);
+            m &= bit ? bal : ~bal;
+        }
+        const unsigned old = cnt[wave][d];                       // running count of this wave for digit d (same for the group)
+        __builtin_amdgcn_wave_barrier();
+        const unsigned r = __popcll(m & lane_lt);
+        if (valid && r == 0u) cnt[wave][d] = old + (unsigned)__popcll(m);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        dig[k] = d;
+        rank[k] = old + r;
+    }
+    __syncthreads();
+    // destination = global start of (digit, block) + items of the same digit in earlier waves of the block + rank in wave
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const int64_t i = wbase + (int64_t)k * 64 + lane;
+        if (i < n) {
+            const unsigned d = dig[k];
+            unsigned off = table[(size_t)d * nblocks + blockIdx.x];
+            for (int w = 0; w < wave; ++w) off += cnt[w][d];
+            out.store((int64_t)off + rank[k], item[k]);
+        }
+    }
+}
+
+template <typename Item, typename In, typename Digit, typename Out>
+static int radix_pass(int64_t n, In in, Digit digit, Out out, int nbits, unsigned* table, hipStream_t s)
+{
+    const int nblocks = (int)((n + RS_TILE - 1) / RS_TILE);
+    const int nbins = 1 << nbits;
+    hipLaunchKernelGGL((radix_hist_kernel<Item, In, Digit>), dim3(nblocks), dim3(RS_THREADS), 0, s, n, in, digit, nbins, nblocks, table);
+    GS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, s, nbins * nblocks, table);
+    GS_CHECK_LAUNCH();
+    switch (nbits) {
+#define RS_CASE(B) case B: hipLaunchKernelGGL((radix_scatter_kernel<Item, In, Digit, Out, B>), dim3(nblocks), dim3(RS_THREADS), 0, s, n, in, digit, nblocks, table, out); break;
+        RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
+#undef RS_CASE
+        default: gs_set_error("radix_pass: bad digit width %d", nbits); return GS_EINVAL;
+    }
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static size_t table_bytes(int64_t n) { return align256((size_t)256 * (size_t)((n + RS_TILE - 1) / RS_TILE + 1) * sizeof(unsigned)); }
+
+// ---- gs_isect_sort: the upstream call shape ---------------------------------------------------------------------
 extern "C" size_t gs_sort_ws_bytes(int64_t n_isects, int tile_w, int tile_h)
 {
     if (n_isects <= 0) return 0;
-    size_t bytes = 0;
-    const int end_bit = 32 + tile_bits(tile_w, tile_h);
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
-                                             (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)n_isects, 0,
-                                             (unsigned)end_bit, (hipStream_t)0);
-    if (e != hipSuccess) return 0;
-    return bytes + 256;
+    (void)tile_w; (void)tile_h;
+    return table_bytes(n_isects) + align256((size_t)n_isects * 8) + align256((size_t)n_isects * 4) + 256;
 }
 
 extern "C" int gs_isect_sort(int64_t n_isects, const int64_t* isect_ids, const int32_t* flatten_ids,
@@ -40,14 +216,175 @@ extern "C" int gs_isect_sort(int64_t n_isects, const int64_t* isect_ids, const i
 {
     GS_CHECK_ARG(n_isects >= 0 && tile_w > 0 && tile_h > 0, "bad sizes");
     if (n_isects == 0) return GS_OK;
-    size_t need = 0;
+    GS_CHECK_ARG(ws != nullptr, "workspace must not be NULL");
+    if (ws_bytes < gs_sort_ws_bytes(n_isects, tile_w, tile_h)) { gs_set_error("gs_isect_sort: workspace too small"); return GS_ENOSPC; }
+    hipStream_t s = (hipStream_t)stream;
+    char* p = (char*)ws;
+    unsigned* table = (unsigned*)p; p += table_bytes(n_isects);
+    u64* tk = (u64*)p; p += align256((size_t)n_isects * 8);
+    int32_t* tv = (int32_t*)p;
     const int end_bit = 32 + tile_bits(tile_w, tile_h);
-    GS_CHECK_HIP(rocprim::radix_sort_pairs(nullptr, need, (const uint64_t*)isect_ids, (uint64_t*)isect_ids_sorted,
-                                           flatten_ids, flatten_ids_sorted, (size_t)n_isects, 0, (unsigned)end_bit,
-                                           (hipStream_t)stream));
-    if (ws_bytes < need) { gs_set_error("gs_isect_sort: workspace too small (%zu < %zu)", ws_bytes, need); return GS_ENOSPC; }
-    GS_CHECK_HIP(rocprim::radix_sort_pairs(ws, need, (const uint64_t*)isect_ids, (uint64_t*)isect_ids_sorted,
-                                           flatten_ids, flatten_ids_sorted, (size_t)n_isects, 0, (unsigned)end_bit,
-                                           (hipStream_t)stream));
+    const int npass = (end_bit + 7) / 8;
+    // ping-pong so that the LAST pass lands in the caller's output: pass parity decides where the first one goes
+    const u64* src_k = (const u64*)isect_ids; const int32_t* src_v = flatten_ids;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int shift = pass * 8;
+        const int nbits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
+        const bool to_out = ((npass - 1 - pass) % 2) == 0;
+        u64* dk = to_out ? (u64*)isect_ids_sorted : tk;
+        int32_t* dv = to_out ? flatten_ids_sorted : tv;
+        const int rc = radix_pass<PairItem>(n_isects, PairIn{ src_k, src_v }, PairDigit{ shift, (1u << nbits) - 1u }, PairOut{ dk, dv }, nbits, table, s);
+        if (rc != GS_OK) return rc;
+        src_k = dk; src_v = dv;
+    }
+    return GS_OK;
+}
+
+// ---- gs_isect_bin: depth-major binning --------------------------------------------------------------------------
+// emission in depth order.  tile_range_exact == gs_project.hip (same operation order: the counts come from there)
+__device__ __forceinline__ void tile_range_sorted(float mx, float my, int radius, int tile_size, int tw, int th,
+                                                  int& x0, int& y0, int& x1, int& y1)
+{
+#pragma clang fp contract(off)
+    const float ts = (float)tile_size;
+    const float tr = (float)radius / ts;
+    const float tx = mx / ts, ty = my / ts;
+    const float fx0 = floorf(tx - tr), fy0 = floorf(ty - tr);
+    const float fx1 = ceilf(tx + tr), fy1 = ceilf(ty + tr);
+    x0 = fx0 < 0.0f ? 0 : (fx0 > (float)tw ? tw : (int)fx0);
+    y0 = fy0 < 0.0f ? 0 : (fy0 > (float)th ? th : (int)fy0);
+    x1 = fx1 < 0.0f ? 0 : (fx1 > (float)tw ? tw : (int)fx1);
+    y1 = fy1 < 0.0f ? 0 : (fy1 > (float)th ? th : (int)fy1);
+}
+
+#define EM_THREADS 256
+#define EM_PER 4
+#define EM_TILE (EM_THREADS * EM_PER)        // ranks per block
+
+// per-block totals of tiles_per_gauss in DEPTH order
+__global__ void __launch_bounds__(EM_THREADS)
+emit_blocksum_kernel(int V, const uint2* __restrict__ order, const int32_t* __restrict__ tpg, unsigned* __restrict__ blocksum)
+{
+    __shared__ unsigned ws[EM_THREADS / 64];
+    unsigned s = 0u;
+#pragma unroll
+    for (int k = 0; k < EM_PER; ++k) {
+        const int r = blockIdx.x * EM_TILE + k * EM_THREADS + threadIdx.x;
+        if (r < V) s += (unsigned)tpg[order[r].y];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = 0u;
+        for (int w = 0; w < EM_THREADS / 64; ++w) t += ws[w];
+        blocksum[blockIdx.x] = t;
+    }
+}
+
+// thread r (depth rank) writes the (tile, index) items of its Gaussian, tiles row-major, at the exclusive prefix of the
+// tile counts in depth order
+__global__ void __launch_bounds__(EM_THREADS)
+emit_sorted_kernel(int V, const uint2* __restrict__ order, const int32_t* __restrict__ tpg, const unsigned* __restrict__ blockbase,
+                   const float* __restrict__ means2d, const int32_t* __restrict__ radii, int tile_size, int tile_w, int tile_h,
+                   uint2* __restrict__ items)
+{
+    __shared__ unsigned ws[EM_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // blocked arrangement: thread t owns ranks base + t*EM_PER .. +EM_PER-1 (consecutive: the scan stays in index order)
+    const int r0 = blockIdx.x * EM_TILE + (int)threadIdx.x * EM_PER;
+    int v[EM_PER]; unsigned c[EM_PER];
+    unsigned mine = 0u;
+#pragma unroll
+    for (int k = 0; k < EM_PER; ++k) {
+        const int r = r0 + k;
+        v[k] = r < V ? (int)order[r].y : -1;
+        c[k] = v[k] >= 0 ? (unsigned)tpg[v[k]] : 0u;
+        mine += c[k];
+    }
+    unsigned incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    unsigned cur = blockbase[blockIdx.x] + incl - mine;
+    for (int w = 0; w < wave; ++w) cur += ws[w];
+#pragma unroll
+    for (int k = 0; k < EM_PER; ++k) {
+        if (v[k] < 0 || c[k] == 0u) continue;
+        const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)v[k]);
+        int x0, y0, x1, y1;
+        tile_range_sorted(m.x, m.y, radii[v[k]], tile_size, tile_w, tile_h, x0, y0, x1, y1);
+        for (int i = y0; i < y1; ++i)
+            for (int j = x0; j < x1; ++j) items[cur++] = make_uint2((unsigned)(i * tile_w + j), (unsigned)v[k]);
+    }
+}
+
+extern "C" size_t gs_isect_bin_ws_bytes(int V, int64_t n_isects, int tile_w, int tile_h)
+{
+    (void)tile_w; (void)tile_h;
+    const size_t v = V > 0 ? (size_t)V : 1, n = n_isects > 0 ? (size_t)n_isects : 1;
+    const size_t tb = table_bytes((int64_t)(v > n ? v : n));
+    return tb + 2 * align256(v * 8) + align256(((v + EM_TILE - 1) / EM_TILE + 1) * 4) + 2 * align256(n * 8) + 256;
+}
+
+extern "C" int gs_isect_bin(int V, const float* means2d, const int32_t* radii, const float* depths,
+                            const int32_t* tiles_per_gauss, int64_t n_isects, int tile_size, int tile_w, int tile_h,
+                            int64_t* isect_ids_sorted, int32_t* flatten_ids_sorted, void* ws, size_t ws_bytes, void* stream)
+{
+    GS_CHECK_ARG(V >= 0 && n_isects >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0, "bad sizes");
+    GS_CHECK_ARG(n_isects < (1ll << 31), "n_isects must fit int32");
+    GS_CHECK_ARG((int64_t)tile_w * tile_h < (1ll << 24), "more than 2^24 tiles");
+    if (V == 0 || n_isects == 0) return GS_OK;
+    GS_CHECK_ARG(ws != nullptr, "workspace must not be NULL");
+    if (ws_bytes < gs_isect_bin_ws_bytes(V, n_isects, tile_w, tile_h)) { gs_set_error("gs_isect_bin: workspace too small"); return GS_ENOSPC; }
+    hipStream_t s = (hipStream_t)stream;
+    char* p = (char*)ws;
+    unsigned* table = (unsigned*)p; p += table_bytes((int64_t)V > n_isects ? (int64_t)V : n_isects);
+    uint2* da = (uint2*)p; p += align256((size_t)V * 8);
+    uint2* db = (uint2*)p; p += align256((size_t)V * 8);
+    const int eblocks = (V + EM_TILE - 1) / EM_TILE;
+    unsigned* blocksum = (unsigned*)p; p += align256(((size_t)eblocks + 1) * 4);
+    uint2* ia = (uint2*)p; p += align256((size_t)n_isects * 8);
+    uint2* ib = (uint2*)p;
+
+    // 1. depth order of the Gaussians: four stable 8-bit passes over (depth bits, index); the first reads the depth array
+    int rc = radix_pass<uint2>((int64_t)V, DepthIn{ depths }, XDigit{ 0, 255u }, U2Out{ da }, 8, table, s);
+    if (rc != GS_OK) return rc;
+    rc = radix_pass<uint2>((int64_t)V, U2In{ da }, XDigit{ 8, 255u }, U2Out{ db }, 8, table, s);
+    if (rc != GS_OK) return rc;
+    rc = radix_pass<uint2>((int64_t)V, U2In{ db }, XDigit{ 16, 255u }, U2Out{ da }, 8, table, s);
+    if (rc != GS_OK) return rc;
+    rc = radix_pass<uint2>((int64_t)V, U2In{ da }, XDigit{ 24, 255u }, U2Out{ db }, 8, table, s);
+    if (rc != GS_OK) return rc;
+    // 2. emission in depth order
+    hipLaunchKernelGGL(emit_blocksum_kernel, dim3(eblocks), dim3(EM_THREADS), 0, s, V, db, tiles_per_gauss, blocksum);
+    GS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, s, eblocks, blocksum);
+    GS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(emit_sorted_kernel, dim3(eblocks), dim3(EM_THREADS), 0, s, V, db, tiles_per_gauss, blocksum, means2d, radii,
+                       tile_size, tile_w, tile_h, ia);
+    GS_CHECK_LAUNCH();
+    // 3. stable split by tile id: npass digits of `width` bits, the last one writes the sorted meta arrays
+    int tb = 0;
+    while ((1 << tb) < tile_w * tile_h) ++tb;
+    if (tb < 1) tb = 1;
+    const int npass = (tb + 7) / 8, width = (tb + npass - 1) / npass;
+    uint2* src = ia; uint2* dst = ib;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int shift = pass * width;
+        const int nbits = (tb - shift) < width ? (tb - shift) : width;
+        if (pass == npass - 1)
+            rc = radix_pass<uint2>(n_isects, U2In{ src }, XDigit{ shift, (1u << nbits) - 1u },
+                                   FinalOut{ (u64*)isect_ids_sorted, flatten_ids_sorted, depths }, nbits, table, s);
+        else
+            rc = radix_pass<uint2>(n_isects, U2In{ src }, XDigit{ shift, (1u << nbits) - 1u }, U2Out{ dst }, nbits, table, s);
+        if (rc != GS_OK) return rc;
+        uint2* t = src; src = dst; dst = t;
+    }
     return GS_OK;
 }

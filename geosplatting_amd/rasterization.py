@@ -8,6 +8,7 @@ for gfx950) through the C-ABI in include/geosplat_hip.h -- there is no PyTorch o
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -86,14 +87,20 @@ def _bin_stage(pr: _Projected, depth_channel: bool = False):
         D = D + 1
     colors_p = colors_p.contiguous()
 
-    ids = torch.empty(I, dtype=torch.int64, device=dev); flat = torch.empty(I, dtype=i32, device=dev)
     ids_s = torch.empty(I, dtype=torch.int64, device=dev); flat_s = torch.empty(I, dtype=i32, device=dev)
-    L.check(lib.gs_isect_emit(V, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(cum), tile_size, tw, th,
-                              L.ptr(ids), L.ptr(flat), st), "gs_isect_emit")
-    sort_bytes = lib.gs_sort_ws_bytes(L.i64(I), tw, th)
-    sort_ws = torch.empty(max(sort_bytes, 1), dtype=torch.uint8, device=dev)
-    L.check(lib.gs_isect_sort(L.i64(I), L.ptr(ids), L.ptr(flat), L.ptr(ids_s), L.ptr(flat_s), tw, th, L.ptr(sort_ws),
-                              C.c_size_t(sort_bytes), st), "gs_isect_sort")
+    if os.environ.get("GEOSPLAT_BINNING", "depth_major") == "emit_sort":        # the upstream call shape: emit, then sort the pairs
+        ids = torch.empty(I, dtype=torch.int64, device=dev); flat = torch.empty(I, dtype=i32, device=dev)
+        L.check(lib.gs_isect_emit(V, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(cum), tile_size, tw, th,
+                                  L.ptr(ids), L.ptr(flat), st), "gs_isect_emit")
+        sort_bytes = lib.gs_sort_ws_bytes(L.i64(I), tw, th)
+        sort_ws = torch.empty(max(sort_bytes, 1), dtype=torch.uint8, device=dev)
+        L.check(lib.gs_isect_sort(L.i64(I), L.ptr(ids), L.ptr(flat), L.ptr(ids_s), L.ptr(flat_s), tw, th, L.ptr(sort_ws),
+                                  C.c_size_t(sort_bytes), st), "gs_isect_sort")
+    else:                                                                        # depth-major binning (csrc/gs_sort.hip)
+        bin_bytes = lib.gs_isect_bin_ws_bytes(V, L.i64(I), tw, th)
+        bin_ws = torch.empty(max(bin_bytes, 1), dtype=torch.uint8, device=dev)
+        L.check(lib.gs_isect_bin(V, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(tpg), L.i64(I), tile_size, tw, th,
+                                 L.ptr(ids_s), L.ptr(flat_s), L.ptr(bin_ws), C.c_size_t(bin_bytes), st), "gs_isect_bin")
     offsets = torch.empty(th * tw, dtype=i32, device=dev)
     L.check(lib.gs_isect_offsets(L.i64(I), L.ptr(ids_s), tw * th, L.ptr(offsets), st), "gs_isect_offsets")
     state = dict(gaussian_ids_i32=gids, radii=radii, means2d=means2d, depths=depths, conics=conics,

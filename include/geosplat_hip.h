@@ -83,6 +83,16 @@ int gs_isect_emit(int V, const float* means2d, const int32_t* radii, const float
                   const int64_t* cum_tiles, int tile_size, int tile_w, int tile_h,
                   int64_t* isect_ids, int32_t* flatten_ids, void* stream);
 
+/* ------------------------------------------------------------------ A2 + A3 (depth-major binning) -- */
+/* The sorted intersection list straight from the projection outputs, WITHOUT emitting the unsorted keys: the Gaussians are
+ * ordered by depth once (V-sized), their intersections are emitted in that order as (tile, index) items and two stable
+ * passes over the tile bits finish the (tile | depth | packed index) order -- bit-identical to gs_isect_emit + gs_isect_sort
+ * (csrc/gs_sort.hip).  tiles_per_gauss [V] and n_isects (= their sum) come from gs_project_fwd. */
+size_t gs_isect_bin_ws_bytes(int V, int64_t n_isects, int tile_w, int tile_h);
+int gs_isect_bin(int V, const float* means2d, const int32_t* radii, const float* depths, const int32_t* tiles_per_gauss,
+                 int64_t n_isects, int tile_size, int tile_w, int tile_h, int64_t* isect_ids_sorted,
+                 int32_t* flatten_ids_sorted, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------ A3 ----------------------------- */
 size_t gs_sort_ws_bytes(int64_t n_isects, int tile_w, int tile_h);
 /* Stable ascending sort of (isect_ids, flatten_ids) over the 32 + tile_bits significant key bits. */

@@ -98,47 +98,100 @@ radix_hist_kernel(int64_t n, In in, Digit digit, int nbins, int nblocks, unsigne
     if ((int)threadIdx.x < nbins) table[(size_t)threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
 }
 
-// exclusive scan of the digit-major table (nbins * nblocks entries) by ONE workgroup: every wave owns a contiguous
-// sixteenth and walks it 64 entries at a time (coalesced), first summing, then scanning with a running carry
-__global__ void __launch_bounds__(1024)
-radix_scan_kernel(int total, unsigned* __restrict__ table)
+// Offsets of a pass: table[d][b] (items of digit d in block b) -> exclusive prefix along b inside every digit row (one workgroup
+// per digit, coalesced row), row totals -> digit_base[d] = exclusive prefix over the digits (one small workgroup).  The scatter adds
+// the two.  (A single workgroup scanning the whole 260 k-entry table was a 50 us latency chain per pass.)
+__global__ void __launch_bounds__(256)
+radix_rowscan_kernel(int nblocks, unsigned* __restrict__ table, unsigned* __restrict__ row_total)
 {
-    __shared__ unsigned wsum[16];
+    __shared__ unsigned wsum[4];
+    unsigned* row = table + (size_t)blockIdx.x * nblocks;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int per = ((total + 15) / 16 + 63) / 64 * 64;              // entries per wave, a multiple of 64
-    const int lo = wave * per, hi = min(lo + per, total);
-    unsigned s = 0u;
-    for (int i = lo + lane; i < hi; i += 64) s += table[i];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (lane == 0) wsum[wave] = s;
-    __syncthreads();
     unsigned carry = 0u;
-    for (int w = 0; w < wave; ++w) carry += wsum[w];
-    for (int i0 = lo; i0 < hi; i0 += 64) {
-        const int i = i0 + lane;
-        const unsigned v = i < hi ? table[i] : 0u;
+    for (int i0 = 0; i0 < nblocks; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        const unsigned v = i < nblocks ? row[i] : 0u;
         unsigned incl = v;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const unsigned t = __shfl_up(incl, off, 64);
             if (lane >= off) incl += t;
         }
-        if (i < hi) table[i] = carry + incl - v;
-        carry += __shfl(incl, 63, 64);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        unsigned before = 0u, all = 0u;
+        for (int w = 0; w < 4; ++w) { if (w < wave) before += wsum[w]; all += wsum[w]; }
+        if (i < nblocks) row[i] = carry + before + incl - v;
+        carry += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) row_total[blockIdx.x] = carry;
+}
+
+__global__ void __launch_bounds__(256)
+radix_digitscan_kernel(int nbins, const unsigned* __restrict__ row_total, unsigned* __restrict__ digit_base)
+{
+    __shared__ unsigned wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned v = (int)threadIdx.x < nbins ? row_total[threadIdx.x] : 0u;
+    unsigned incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned before = 0u;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if ((int)threadIdx.x < nbins) digit_base[threadIdx.x] = before + incl - v;
+}
+
+// exclusive scan of a short array (<= a few thousand entries) by one workgroup: per-block bases of the emission
+__global__ void __launch_bounds__(1024)
+small_scan_kernel(int total, unsigned* __restrict__ a)
+{
+    __shared__ unsigned wsum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned carry = 0u;
+    for (int i0 = 0; i0 < total; i0 += 1024) {
+        const int i = i0 + threadIdx.x;
+        const unsigned v = i < total ? a[i] : 0u;
+        unsigned incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        unsigned before = 0u, all = 0u;
+        for (int w = 0; w < 16; ++w) { if (w < wave) before += wsum[w]; all += wsum[w]; }
+        if (i < total) a[i] = carry + before + incl - v;
+        carry += all;
+        __syncthreads();
     }
 }
 
+// Scatter of one pass.  Ranks come from ballots (see the file header); the items are then staged through LDS in their
+// block-local sorted order, so that the global stores of a digit run are contiguous (a wave writing 64 items of 64 different
+// digits straight from registers is 64 partial-sector stores).
 template <typename Item, typename In, typename Digit, typename Out, int NBITS>
 __global__ void __launch_bounds__(RS_THREADS)
-radix_scatter_kernel(int64_t n, In in, Digit digit, int nblocks, const unsigned* __restrict__ table, Out out)
+radix_scatter_kernel(int64_t n, In in, Digit digit, int nblocks, const unsigned* __restrict__ table,
+                     const unsigned* __restrict__ digit_base, Out out)
 {
     constexpr int NB = 1 << NBITS;
     __shared__ unsigned cnt[RS_WAVES][NB];
+    __shared__ unsigned dstart[NB];                              // start of digit d inside the block's sorted order
+    __shared__ unsigned gbase[NB];                               // global position of that start
+    __shared__ Item stage[RS_TILE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < RS_WAVES * NB; i += RS_THREADS) (&cnt[0][0])[i] = 0u;
     __syncthreads();
-    const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)wave * RS_WCHUNK;
+    const int64_t bbase = (int64_t)blockIdx.x * RS_TILE;
+    const int64_t wbase = bbase + (int64_t)wave * RS_WCHUNK;
+    const int n_here = (int)((n - bbase) < RS_TILE ? (n - bbase) : RS_TILE);
     const u64 lane_lt = (1ull << lane) - 1ull;
     Item item[RS_ITEMS];
     unsigned dig[RS_ITEMS];
@@ -167,15 +220,46 @@ radix_scatter_kernel(int64_t n, In in, Digit digit, int nblocks, const unsigned*
         rank[k] = old + r;
     }
     __syncthreads();
-    // destination = global start of (digit, block) + items of the same digit in earlier waves of the block + rank in wave
+    // block-local start of every digit (exclusive scan of the digit totals by the first NB threads) and its global position
+    {
+        const int d = threadIdx.x;
+        unsigned tot = 0u;
+        if (d < NB) for (int w = 0; w < RS_WAVES; ++w) tot += cnt[w][d];
+        unsigned incl = tot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        __shared__ unsigned wtot[RS_WAVES];
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        unsigned before = 0u;
+        for (int w = 0; w < wave; ++w) before += wtot[w];
+        if (d < NB) {
+            dstart[d] = before + incl - tot;
+            gbase[d] = digit_base[d] + table[(size_t)d * nblocks + blockIdx.x];
+        }
+    }
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < RS_ITEMS; ++k) {
         const int64_t i = wbase + (int64_t)k * 64 + lane;
         if (i < n) {
             const unsigned d = dig[k];
-            unsigned off = table[(size_t)d * nblocks + blockIdx.x];
+            unsigned off = dstart[d] + rank[k];
             for (int w = 0; w < wave; ++w) off += cnt[w][d];
-            out.store((int64_t)off + rank[k], item[k]);
+            stage[off] = item[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const int p = k * RS_THREADS + (int)threadIdx.x;
+        if (p < n_here) {
+            const Item it = stage[p];
+            const unsigned d = digit(it);
+            out.store((int64_t)gbase[d] + (int64_t)(p - (int)dstart[d]), it);
         }
     }
 }
@@ -185,12 +269,16 @@ static int radix_pass(int64_t n, In in, Digit digit, Out out, int nbits, unsigne
 {
     const int nblocks = (int)((n + RS_TILE - 1) / RS_TILE);
     const int nbins = 1 << nbits;
+    unsigned* row_total = table + (size_t)256 * nblocks;        // [256] + [256] behind the table
+    unsigned* digit_base = row_total + 256;
     hipLaunchKernelGGL((radix_hist_kernel<Item, In, Digit>), dim3(nblocks), dim3(RS_THREADS), 0, s, n, in, digit, nbins, nblocks, table);
     GS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, s, nbins * nblocks, table);
+    hipLaunchKernelGGL(radix_rowscan_kernel, dim3(nbins), dim3(256), 0, s, nblocks, table, row_total);
+    GS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(radix_digitscan_kernel, dim3(1), dim3(256), 0, s, nbins, row_total, digit_base);
     GS_CHECK_LAUNCH();
     switch (nbits) {
-#define RS_CASE(B) case B: hipLaunchKernelGGL((radix_scatter_kernel<Item, In, Digit, Out, B>), dim3(nblocks), dim3(RS_THREADS), 0, s, n, in, digit, nblocks, table, out); break;
+#define RS_CASE(B) case B: hipLaunchKernelGGL((radix_scatter_kernel<Item, In, Digit, Out, B>), dim3(nblocks), dim3(RS_THREADS), 0, s, n, in, digit, nblocks, table, digit_base, out); break;
         RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
 #undef RS_CASE
         default: gs_set_error("radix_pass: bad digit width %d", nbits); return GS_EINVAL;
@@ -200,7 +288,7 @@ static int radix_pass(int64_t n, In in, Digit digit, Out out, int nbits, unsigne
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-static size_t table_bytes(int64_t n) { return align256((size_t)256 * (size_t)((n + RS_TILE - 1) / RS_TILE + 1) * sizeof(unsigned)); }
+static size_t table_bytes(int64_t n) { return align256(((size_t)256 * (size_t)((n + RS_TILE - 1) / RS_TILE + 1) + 512) * sizeof(unsigned)); }
 
 // ---- gs_isect_sort: the upstream call shape ---------------------------------------------------------------------
 extern "C" size_t gs_sort_ws_bytes(int64_t n_isects, int tile_w, int tile_h)
@@ -364,7 +452,7 @@ extern "C" int gs_isect_bin(int V, const float* means2d, const int32_t* radii, c
     // 2. emission in depth order
     hipLaunchKernelGGL(emit_blocksum_kernel, dim3(eblocks), dim3(EM_THREADS), 0, s, V, db, tiles_per_gauss, blocksum);
     GS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, s, eblocks, blocksum);
+    hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(1024), 0, s, eblocks, blocksum);
     GS_CHECK_LAUNCH();
     hipLaunchKernelGGL(emit_sorted_kernel, dim3(eblocks), dim3(EM_THREADS), 0, s, V, db, tiles_per_gauss, blocksum, means2d, radii,
                        tile_size, tile_w, tile_h, ia);

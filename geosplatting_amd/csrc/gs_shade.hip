@@ -11,6 +11,8 @@
 // ~25 MB).  The backward recomputes the forward (no saved state) and scatters texel gradients with fp32
 // atomics.  HBM-bound by design; cube-map texel semantics are documented in oracle/gs_oracle_shade.c.
 #include "gs_common.h"
+#include <stdlib.h>
+#include <math.h>
 
 // Contraction OFF for the whole file: texel / LUT-cell / lobe-membership selection are discontinuous in the
 // coordinates, so the coordinates are computed in the same one-rounding-per-operation order as the CPU oracle
@@ -206,9 +208,15 @@ __device__ __forceinline__ void cube_scatter_lds(float* lds, const CubeFp& fp, c
 // 160 KB LDS).  2 M Gaussians send ~13 M atomics at the 4 608 floats of the 16^2 level alone: in HBM/L2 that
 // serialises per address (5.5 ms per view measured); in LDS it is a ds_add_f32 and the block flushes its
 // copy once at the end.
-#define GS_SHADE_BWD_BLOCK 1024
-template <bool PRIV>
-__global__ void __launch_bounds__(GS_SHADE_BWD_BLOCK)
+// Block size and the largest LDS-privatised level are run-time choices (GEOSPLAT_SHADE_BWD_BLOCK / GEOSPLAT_SHADE_LDS_MAXRES):
+// the round-1 shape -- 1024-thread blocks, one per CU, levels <= 32^2 in 92 KB of LDS -- caps the kernel at 128 VGPRs and it
+// SPILLS (264 bytes of scratch per lane, -Rpass-analysis): the recomputed forward then runs at a fifth of the forward
+// kernel's rate.  Smaller blocks lift the cap (256 registers at 2 waves per SIMD).  Measured at the bench workload (scripts/shade_ab.py):
+// 1024 threads / <= 32^2 in LDS 470 us (round 1); 512 / 32^2 389 us (default); 256 / 32^2 527 (4 waves per CU); 512 or 256 with only
+// the 16^2 level in LDS 930-960 (the 32^2 level through memory-side atomics: 2 800 requests per cache line); no LDS copies 1 570.
+// Removal experiment at 512 / 32^2: 349 us without the LDS atomics, 333 without the global ones, 254 without either.
+template <bool PRIV, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
 shade_bwd_kernel(int N, const float* __restrict__ means, const float* __restrict__ normals,
                  const float* __restrict__ kd, const float* __restrict__ ks, const float* __restrict__ cam_pos,
                  float min_roughness, float max_metallic, int mode, EnvDev env, const float* __restrict__ v_colors,
@@ -370,6 +378,7 @@ priv_reduce_kernel(long long n, int copies, const float* __restrict__ priv, long
 }
 
 #define GS_XCD_COPIES 8
+static size_t lds_bytes_of(int floats) { return (size_t)floats * sizeof(float); }
 static size_t shade_bwd_priv_floats(const EnvDev& e, int mode, long long* level_off, long long* base_off)
 {
     long long off = 0;
@@ -434,18 +443,20 @@ extern "C" int gs_shade_bwd(int N, const float* means, const float* normals, con
     for (int l = 0; l < GS_MAX_LEVELS; ++l) eg.levels[l] = l < e.L ? env_grad->levels[l] : nullptr;
     if (mode == GS_MODE_DIFFUSE) GS_CHECK_ARG(eg.base != nullptr, "env_grad->base required in diffuse mode");
     else for (int l = 0; l < e.L; ++l) GS_CHECK_ARG(eg.levels[l] != nullptr, "env_grad->levels[l] required");
-    // LDS layout: privatise every level of at most 32^2 texels per face (and the diffuse base) within 128 KB
+    // LDS layout: privatise every level of at most maxres^2 texels per face (and the diffuse base) within 128 KB
+    static const int s_block = [] { const char* v = getenv("GEOSPLAT_SHADE_BWD_BLOCK"); const int b = v ? atoi(v) : 256; return (b == 256 || b == 768 || b == 1024) ? b : 512; }();
+    static const int s_maxres = [] { const char* v = getenv("GEOSPLAT_SHADE_LDS_MAXRES"); const int r = v ? atoi(v) : 32; return r; }();
     const int lds_budget_floats = 128 * 1024 / 4;
     int used = 0;
     eg.lds_base = -1;
     for (int l = 0; l < GS_MAX_LEVELS; ++l) eg.lds_level[l] = -1;
     if (mode == GS_MODE_DIFFUSE) {
         const int cnt = 18 * e.base_res * e.base_res;
-        if (e.base_res <= 32 && used + cnt <= lds_budget_floats) { eg.lds_base = used; used += cnt; }
+        if (e.base_res <= s_maxres && used + cnt <= lds_budget_floats) { eg.lds_base = used; used += cnt; }
     } else {
         for (int l = e.L - 1; l >= 0; --l) {
             const int cnt = 18 * e.res[l] * e.res[l];
-            if (e.res[l] <= 32 && used + cnt <= lds_budget_floats) { eg.lds_level[l] = used; used += cnt; }
+            if (e.res[l] <= s_maxres && used + cnt <= lds_budget_floats) { eg.lds_level[l] = used; used += cnt; }
         }
     }
     eg.lds_floats = used;
@@ -458,15 +469,21 @@ extern "C" int gs_shade_bwd(int N, const float* means, const float* normals, con
     if (N == 0) return GS_OK;
     hipStream_t s = (hipStream_t)stream;
     const size_t lds_bytes = (size_t)used * sizeof(float);
-    int blocks = gs_cdiv(N, GS_SHADE_BWD_BLOCK);
-    const int max_blocks = used > 0 ? 256 : 2048;
+    int blocks = gs_cdiv(N, s_block);
+    // persistent blocks when LDS copies have to be flushed at the end (one flush per block): as many as are resident at once
+    const int per_cu = used > 0 ? (int)fmin(8.0, fmax(1.0, floor(160.0 * 1024.0 / (double)(lds_bytes_of(used) + 1024)))) : 8;
+    const int max_blocks = used > 0 ? 256 * per_cu : 2048;
     if (blocks > max_blocks) blocks = max_blocks;
     if (use_priv) {
         GS_CHECK_HIP(hipMemsetAsync(ws, 0, priv_floats * sizeof(float) * GS_XCD_COPIES, s));
-        GS_CHECK_HIP(hipFuncSetAttribute((const void*)shade_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(shade_bwd_kernel<true>, dim3(blocks), dim3(GS_SHADE_BWD_BLOCK), lds_bytes, s, N, means, normals, kd, ks,
-                           cam_pos, min_roughness, max_metallic, mode, e, v_colors, v_means, v_normals, v_kd, v_ks, eg, accumulate);
-        GS_CHECK_LAUNCH();
+#define GS_SHADE_LAUNCH(P, B)                                                                                                   \
+        do {                                                                                                                    \
+            GS_CHECK_HIP(hipFuncSetAttribute((const void*)shade_bwd_kernel<P, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+            hipLaunchKernelGGL((shade_bwd_kernel<P, B>), dim3(blocks), dim3(B), lds_bytes, s, N, means, normals, kd, ks, cam_pos,     \
+                               min_roughness, max_metallic, mode, e, v_colors, v_means, v_normals, v_kd, v_ks, eg, accumulate);   \
+            GS_CHECK_LAUNCH();                                                                                                  \
+        } while (0)
+        if (s_block == 1024) GS_SHADE_LAUNCH(true, 1024); else if (s_block == 768) GS_SHADE_LAUNCH(true, 768); else if (s_block == 512) GS_SHADE_LAUNCH(true, 512); else GS_SHADE_LAUNCH(true, 256);
         // fold the 8 copies into the caller's gradient buffers, level by level
         for (int l = -1; l < e.L; ++l) {
             const long long off = l < 0 ? eg.priv_base : eg.priv_level[l];
@@ -479,10 +496,8 @@ extern "C" int gs_shade_bwd(int N, const float* means, const float* normals, con
             GS_CHECK_LAUNCH();
         }
     } else {
-        GS_CHECK_HIP(hipFuncSetAttribute((const void*)shade_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(shade_bwd_kernel<false>, dim3(blocks), dim3(GS_SHADE_BWD_BLOCK), lds_bytes, s, N, means, normals, kd, ks,
-                           cam_pos, min_roughness, max_metallic, mode, e, v_colors, v_means, v_normals, v_kd, v_ks, eg, accumulate);
-        GS_CHECK_LAUNCH();
+        if (s_block == 1024) GS_SHADE_LAUNCH(false, 1024); else if (s_block == 768) GS_SHADE_LAUNCH(false, 768); else if (s_block == 512) GS_SHADE_LAUNCH(false, 512); else GS_SHADE_LAUNCH(false, 256);
+#undef GS_SHADE_LAUNCH
     }
     return GS_OK;
 }

@@ -444,7 +444,7 @@ extern "C" int gs_shade_bwd(int N, const float* means, const float* normals, con
     if (mode == GS_MODE_DIFFUSE) GS_CHECK_ARG(eg.base != nullptr, "env_grad->base required in diffuse mode");
     else for (int l = 0; l < e.L; ++l) GS_CHECK_ARG(eg.levels[l] != nullptr, "env_grad->levels[l] required");
     // LDS layout: privatise every level of at most maxres^2 texels per face (and the diffuse base) within 128 KB
-    static const int s_block = [] { const char* v = getenv("GEOSPLAT_SHADE_BWD_BLOCK"); const int b = v ? atoi(v) : 256; return (b == 256 || b == 768 || b == 1024) ? b : 512; }();
+    static const int s_block = [] { const char* v = getenv("GEOSPLAT_SHADE_BWD_BLOCK"); const int b = v ? atoi(v) : 512; return (b == 256 || b == 768 || b == 1024) ? b : 512; }();
     static const int s_maxres = [] { const char* v = getenv("GEOSPLAT_SHADE_LDS_MAXRES"); const int r = v ? atoi(v) : 32; return r; }();
     const int lds_budget_floats = 128 * 1024 / 4;
     int used = 0;

@@ -349,16 +349,36 @@ __device__ __forceinline__ void tile_range_sorted(float mx, float my, int radius
 #define EM_PER 4
 #define EM_TILE (EM_THREADS * EM_PER)        // ranks per block
 
-// per-block totals of tiles_per_gauss in DEPTH order
+// tile rectangle of every visible Gaussian, packed (x0 | y0 << 16, x1 | y1 << 16): computed once in packed order (coalesced) so
+// that the two depth-order kernels below gather ONE 8-byte word per Gaussian instead of means2d + radii + tiles_per_gauss
+__global__ void __launch_bounds__(256)
+tile_rect_kernel(int V, const float* __restrict__ means2d, const int32_t* __restrict__ radii, int tile_size, int tile_w, int tile_h,
+                 uint2* __restrict__ rect)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)v);
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    const int r = radii[v];
+    if (r > 0) tile_range_sorted(m.x, m.y, r, tile_size, tile_w, tile_h, x0, y0, x1, y1);
+    rect[v] = make_uint2((unsigned)x0 | ((unsigned)y0 << 16), (unsigned)x1 | ((unsigned)y1 << 16));
+}
+__device__ __forceinline__ unsigned rect_count(uint2 q)
+{
+    const int w = (int)(q.y & 0xffffu) - (int)(q.x & 0xffffu), h = (int)(q.y >> 16) - (int)(q.x >> 16);
+    return (w > 0 && h > 0) ? (unsigned)(w * h) : 0u;
+}
+
+// per-block totals of the tile counts in DEPTH order
 __global__ void __launch_bounds__(EM_THREADS)
-emit_blocksum_kernel(int V, const uint2* __restrict__ order, const int32_t* __restrict__ tpg, unsigned* __restrict__ blocksum)
+emit_blocksum_kernel(int V, const uint2* __restrict__ order, const uint2* __restrict__ rect, unsigned* __restrict__ blocksum)
 {
     __shared__ unsigned ws[EM_THREADS / 64];
     unsigned s = 0u;
 #pragma unroll
     for (int k = 0; k < EM_PER; ++k) {
         const int r = blockIdx.x * EM_TILE + k * EM_THREADS + threadIdx.x;
-        if (r < V) s += (unsigned)tpg[order[r].y];
+        if (r < V) s += rect_count(rect[order[r].y]);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
@@ -374,21 +394,21 @@ emit_blocksum_kernel(int V, const uint2* __restrict__ order, const int32_t* __re
 // thread r (depth rank) writes the (tile, index) items of its Gaussian, tiles row-major, at the exclusive prefix of the
 // tile counts in depth order
 __global__ void __launch_bounds__(EM_THREADS)
-emit_sorted_kernel(int V, const uint2* __restrict__ order, const int32_t* __restrict__ tpg, const unsigned* __restrict__ blockbase,
-                   const float* __restrict__ means2d, const int32_t* __restrict__ radii, int tile_size, int tile_w, int tile_h,
-                   uint2* __restrict__ items)
+emit_sorted_kernel(int V, const uint2* __restrict__ order, const uint2* __restrict__ rect, const unsigned* __restrict__ blockbase,
+                   int tile_w, uint2* __restrict__ items)
 {
     __shared__ unsigned ws[EM_THREADS / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // blocked arrangement: thread t owns ranks base + t*EM_PER .. +EM_PER-1 (consecutive: the scan stays in index order)
     const int r0 = blockIdx.x * EM_TILE + (int)threadIdx.x * EM_PER;
-    int v[EM_PER]; unsigned c[EM_PER];
+    int v[EM_PER]; unsigned c[EM_PER]; uint2 q[EM_PER];
     unsigned mine = 0u;
 #pragma unroll
     for (int k = 0; k < EM_PER; ++k) {
         const int r = r0 + k;
         v[k] = r < V ? (int)order[r].y : -1;
-        c[k] = v[k] >= 0 ? (unsigned)tpg[v[k]] : 0u;
+        q[k] = v[k] >= 0 ? rect[v[k]] : make_uint2(0u, 0u);
+        c[k] = rect_count(q[k]);
         mine += c[k];
     }
     unsigned incl = mine;
@@ -404,9 +424,7 @@ emit_sorted_kernel(int V, const uint2* __restrict__ order, const int32_t* __rest
 #pragma unroll
     for (int k = 0; k < EM_PER; ++k) {
         if (v[k] < 0 || c[k] == 0u) continue;
-        const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)v[k]);
-        int x0, y0, x1, y1;
-        tile_range_sorted(m.x, m.y, radii[v[k]], tile_size, tile_w, tile_h, x0, y0, x1, y1);
+        const int x0 = (int)(q[k].x & 0xffffu), y0 = (int)(q[k].x >> 16), x1 = (int)(q[k].y & 0xffffu), y1 = (int)(q[k].y >> 16);
         for (int i = y0; i < y1; ++i)
             for (int j = x0; j < x1; ++j) items[cur++] = make_uint2((unsigned)(i * tile_w + j), (unsigned)v[k]);
     }
@@ -417,7 +435,7 @@ extern "C" size_t gs_isect_bin_ws_bytes(int V, int64_t n_isects, int tile_w, int
     (void)tile_w; (void)tile_h;
     const size_t v = V > 0 ? (size_t)V : 1, n = n_isects > 0 ? (size_t)n_isects : 1;
     const size_t tb = table_bytes((int64_t)(v > n ? v : n));
-    return tb + 2 * align256(v * 8) + align256(((v + EM_TILE - 1) / EM_TILE + 1) * 4) + 2 * align256(n * 8) + 256;
+    return tb + 3 * align256(v * 8) + align256(((v + EM_TILE - 1) / EM_TILE + 1) * 4) + 2 * align256(n * 8) + 256;
 }
 
 extern "C" int gs_isect_bin(int V, const float* means2d, const int32_t* radii, const float* depths,
@@ -435,6 +453,7 @@ extern "C" int gs_isect_bin(int V, const float* means2d, const int32_t* radii, c
     unsigned* table = (unsigned*)p; p += table_bytes((int64_t)V > n_isects ? (int64_t)V : n_isects);
     uint2* da = (uint2*)p; p += align256((size_t)V * 8);
     uint2* db = (uint2*)p; p += align256((size_t)V * 8);
+    uint2* rect = (uint2*)p; p += align256((size_t)V * 8);
     const int eblocks = (V + EM_TILE - 1) / EM_TILE;
     unsigned* blocksum = (unsigned*)p; p += align256(((size_t)eblocks + 1) * 4);
     uint2* ia = (uint2*)p; p += align256((size_t)n_isects * 8);
@@ -450,12 +469,15 @@ extern "C" int gs_isect_bin(int V, const float* means2d, const int32_t* radii, c
     rc = radix_pass<uint2>((int64_t)V, U2In{ da }, XDigit{ 24, 255u }, U2Out{ db }, 8, table, s);
     if (rc != GS_OK) return rc;
     // 2. emission in depth order
-    hipLaunchKernelGGL(emit_blocksum_kernel, dim3(eblocks), dim3(EM_THREADS), 0, s, V, db, tiles_per_gauss, blocksum);
+    GS_CHECK_ARG(tile_w < 65536 && tile_h < 65536, "tile grid too large");
+    (void)tiles_per_gauss;                                  // the counts are re-derived from the rectangles (same arithmetic as gs_project_fwd)
+    hipLaunchKernelGGL(tile_rect_kernel, dim3(gs_cdiv(V, 256)), dim3(256), 0, s, V, means2d, radii, tile_size, tile_w, tile_h, rect);
+    GS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(emit_blocksum_kernel, dim3(eblocks), dim3(EM_THREADS), 0, s, V, db, rect, blocksum);
     GS_CHECK_LAUNCH();
     hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(1024), 0, s, eblocks, blocksum);
     GS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(emit_sorted_kernel, dim3(eblocks), dim3(EM_THREADS), 0, s, V, db, tiles_per_gauss, blocksum, means2d, radii,
-                       tile_size, tile_w, tile_h, ia);
+    hipLaunchKernelGGL(emit_sorted_kernel, dim3(eblocks), dim3(EM_THREADS), 0, s, V, db, rect, blocksum, tile_w, ia);
     GS_CHECK_LAUNCH();
     // 3. stable split by tile id: npass digits of `width` bits, the last one writes the sorted meta arrays
     int tb = 0;

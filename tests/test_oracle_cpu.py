@@ -114,6 +114,63 @@ def test_golden_splat_arithmetic_and_mip_map():
     assert mine.min() >= 0.0 and mine.max() <= 5.0
 
 
+# ----------------------------------------------------------------------------- S5 known answers (cubemap.cu by formula)
+def _np_cube_dirs(R):
+    """cube_to_dir (rfstudio/graphics/_mesh/_splitsum/c_src/cubemap.cu:32-46) for every texel, float64: [6,R,R,3]"""
+    f = 2.0 * ((np.arange(R) + 0.5) / R) - 1.0
+    fy, fx = np.meshgrid(f, f, indexing="ij")
+    one = np.ones_like(fx)
+    faces = [(one, -fy, -fx), (-one, -fy, fx), (fx, one, fy), (fx, -one, -fy), (fx, -fy, one), (-fx, -fy, -one)]
+    d = np.stack([np.stack(t, -1) for t in faces], 0)
+    return d / np.linalg.norm(d, axis=-1, keepdims=True)
+
+
+def _np_pixel_area(R):
+    """pixel_area (cubemap.cu:17-30) incl. its |x - H| convention, float64: [R,R] indexed [y,x]"""
+    H = R // 2
+    a = np.abs(np.arange(R) - H)
+    d = np.arctan((a + 1) / H) - np.arctan(a / H)
+    return d[:, None] * d[None, :]
+
+
+def test_s5_known_answers_from_the_published_formulae():
+    """The prefilter oracle against closed-form cases written straight from cubemap.cu:110-139,174-179,246-298 in float64 numpy:
+    a constant environment (normalised specular == the constant at every roughness; diffuse == c * sum_L clamp(N.L) dA / 3.141592)
+    and a single hot texel at roughness 1.0, where D_GGX(alpha^2 = 1) = 1/pi so that every weight is (N.L) dA / (4 pi) inside
+    the lobe -- evaluated WITHOUT the per-face bounding boxes, which also shows that the boxes drop no lobe texel."""
+    R = 16
+    dirs = _np_cube_dirs(R).reshape(-1, 3); area = np.tile(_np_pixel_area(R)[None], (6, 1, 1)).reshape(-1)
+    c = np.array([0.3, 1.7, 0.9], np.float32)
+    const = np.broadcast_to(c, (6, R, R, 3)).copy()
+    for rough in (0.08, 0.29, 1.0):
+        ct = oracle.ndf_cutoff(rough)
+        raw = oracle.specular_cubemap_fwd(const, oracle.specular_bounds(R, ct), rough, ct)
+        hit = raw[..., 3] > 0
+        # SpecularBoundsKernel culls 16x16 tiles with the bounding box of their NORMALISED corner directions (cubemap.cu:209-217),
+        # which under-estimates the interior of a tile: with one tile per face (R = 16) a narrow lobe is culled altogether and
+        # the texel gets weight 0 -- reference behaviour, restated as is (it cannot happen for the wide lobe of roughness 1)
+        assert hit.all() if rough == 1.0 else hit.any()
+        assert np.abs(raw[hit][:, :3] / raw[hit][:, 3:] - c).max() < 3e-6 * c.max()
+    cosm = np.clip(dirs @ dirs.T, 0.0, 0.999)                                   # [out texel, in texel]
+    irr = (cosm * area[None, :]).sum(1) / 3.141592
+    got = oracle.diffuse_cubemap_fwd(const).reshape(-1, 3)
+    assert np.abs(got - irr[:, None] * c[None, :]).max() < 2e-5 * c.max()
+    assert abs(irr.mean() - 1.0) < 0.15          # ~ pi / pi (the atan-product texel area of cubemap.cu:17-30 over-counts by 8 % at R = 16)
+    # single hot texel, roughness 1.0
+    hot = (4 * R + 5) * R + 11
+    cube = np.zeros((6 * R * R, 3), np.float32); cube[hot, 0] = 1.0
+    rough = 1.0; ct = oracle.ndf_cutoff(rough)
+    raw = oracle.specular_cubemap_fwd(cube.reshape(6, R, R, 3), oracle.specular_bounds(R, ct), rough, ct).reshape(-1, 4)
+    dots = dirs @ dirs.T                                                        # [out o, in L]
+    inside = dots.astype(np.float32) >= np.float32(ct)
+    w = np.maximum(dots, 0.0) * (1.0 / np.pi) * area[None, :] / 4.0 * inside
+    # membership is decided in fp32 by the oracle: leave texels within 1e-6 of the cutoff out of the comparison
+    edge = (np.abs(dots - ct) < 1e-6).any(1)
+    assert np.abs(raw[~edge, 3] - w.sum(1)[~edge]).max() < 2e-5 * w.sum(1).max()
+    assert np.abs(raw[~edge, 0] - w[~edge, hot]).max() < 2e-5 * w[:, hot].max()
+    assert np.abs(raw[:, 1:3]).max() == 0.0
+
+
 def test_fg_lut_against_reference_subsample():
     g = gold("ref_fg_lut_sub16.npz")
     lut = np.fromfile(os.path.join(os.path.dirname(GOLD), "..", "geosplatting_amd", "assets", "fg_lut_256.bin"),

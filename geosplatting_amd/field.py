@@ -148,6 +148,29 @@ class HashEncoding:
     def parameters(self) -> List[Tensor]:
         return [self.hash_table] + self.weights
 
+    def state_dict(self) -> dict:
+        """Keys of the reference module's state_dict: the table is `encoder.params` (a ParameterModule,
+        rfstudio/model/components/encoding.py:144-148), layer i of the bias-free MLP `mlp.nn_layers.{i}.weight` ([out, in],
+        rfstudio/nn/mlp.py:52-62) -- what `export_model` stores under 'ks_enc' and stage 2 loads with `load_state_dict`."""
+        sd = {"encoder.params": self.hash_table.detach().cpu().clone()}
+        for i, w in enumerate(self.weights):
+            sd[f"mlp.nn_layers.{i}.weight"] = w.detach().cpu().clone()
+        return sd
+
+    def load_state_dict(self, sd: dict) -> None:
+        want = set(self.state_dict().keys())
+        if set(sd.keys()) != want:
+            raise KeyError(f"HashEncoding.load_state_dict: expected keys {sorted(want)}, got {sorted(sd.keys())}")
+        with torch.no_grad():
+            if tuple(sd["encoder.params"].shape) != tuple(self.hash_table.shape):
+                raise ValueError("hash table shape mismatch")
+            self.hash_table.copy_(sd["encoder.params"].to(self.hash_table.device))
+            for i, w in enumerate(self.weights):
+                src = sd[f"mlp.nn_layers.{i}.weight"]
+                if tuple(src.shape) != tuple(w.shape):
+                    raise ValueError(f"layer {i} shape mismatch")
+                w.copy_(src.to(w.device))
+
     def __call__(self, x: Tensor) -> Tensor:
         f = hash_encode(x, self.hash_table, self.scalings, self.log2_hashmap_size, self.grad_scaling)
         for i, w in enumerate(self.weights):

@@ -10,8 +10,11 @@ mean over the views, plus the regulariser.
 Data parallel (one process per GPU): every rank holds the same parameters, extracts the same mesh, renders ITS views
 (`views[rank::world_size]`), and the gradients of all parameters travel as ONE flat fp32 all-reduce (RCCL over xGMI).
 With the loss normalised by the global view count and the regulariser by the world size, the reduced gradient is the
-single-process gradient.  The 'grad' / 'tv' smoothing branches of render_report (:879-921, kornia spatial_gradient over
-extra renders) are not built; `smooth_type` 'jitter' (the default) is.
+single-process gradient.  `smooth_type` 'jitter' (the reference's default) runs on the fused engine too; the 'grad' / 'tv'
+branches and `normal_grad_weight` of render_report (:881-922: extra un-shaded renders of kd / ks / normals, kornia's
+`spatial_gradient` restated below -- kornia is absent, so that one function is unpinned) run on the autograd step.  The stage hand-off files are: `export_model`
+(:839-854, the dict stage 2 loads), `state_dict` with the reference's names and `<step:010d>.ckpt` checkpoints
+(rfstudio/engine/train.py:172-190).
 """
 from __future__ import annotations
 
@@ -27,6 +30,27 @@ from .field import GaussianField
 from .flexicubes import FlexiCubes, get_geometry
 from .loss import photo_loss
 from .splitsum import as_splitsum
+
+def spatial_gradient(img: Tensor) -> Tensor:
+    """kornia.filters.spatial_gradient(x[None].permute(0,3,1,2), order=1)[0] for an [H,W,C] image -> [C,2,H,W]: normalised Sobel
+    pair (kernel / 8), replicate padding, cross-correlation; channel 0 = d/dx, 1 = d/dy (kornia ~= 0.7 defaults: mode='sobel',
+    normalized=True).  Restated from the published definition."""
+    x = img.permute(2, 0, 1)[:, None]                                     # [C,1,H,W]
+    kx = torch.tensor([[-1.0, 0.0, 1.0], [-2.0, 0.0, 2.0], [-1.0, 0.0, 1.0]], device=img.device, dtype=img.dtype) / 8.0
+    k = torch.stack((kx, kx.t()))[:, None]                                # [2,1,3,3]
+    xp = torch.nn.functional.pad(x, (1, 1, 1, 1), mode="replicate")
+    return torch.nn.functional.conv2d(xp, k)                              # [C,2,H,W]
+
+
+def _edge_aware(rendered: Tensor, gt_rgb: Tensor) -> Tensor:
+    """first_order_edge_aware_loss of rfstudio/model/geosplat.py:885-889"""
+    return (spatial_gradient(rendered).abs() * (-spatial_gradient(gt_rgb).abs()).exp()).sum(1).mean()
+
+
+def _tv(rendered: Tensor) -> Tensor:
+    """tv_loss of rfstudio/model/geosplat.py:907-910"""
+    return (rendered[1:, :] - rendered[:-1, :]).square().mean() + (rendered[:, 1:] - rendered[:, :-1]).square().mean()
+
 
 _INITIAL_GUESS = {"outdoor": (0.0, 0.0), "diffuse": (0.0, -3.0), "hybrid": (-3.0, -3.0), "specular": (-3.0, 0.0),
                   "glossy": (-3.0, 0.0)}                                   # geosplat.py:729-740
@@ -55,6 +79,9 @@ class Stage1Model:
         self.sdf_weight = 0.0; self.light_weight = 0.0
         self.kd_grad_weight = 0.0; self.kd_regualr_perturb_std = 0.0
         self.ks_grad_weight = 0.0; self.ks_regualr_perturb_std = 0.0
+        self.normal_grad_weight = 0.0
+        self.smooth_type = "jitter"                              # 'jitter' | 'grad' | 'tv'  (geosplat.py:697)
+        self.background_color = torch.ones(3, device=dev)        # get_background_color() of a 'white' model
         self.last_num_gaussians = 0
         # random streams owned by the model: the kd / ks jitter must be IDENTICAL on every rank (replicas extract and perturb
         # the same Gaussians), the training-background noise differs per rank and advances every iteration
@@ -80,6 +107,88 @@ class Stage1Model:
     def parameters(self) -> List[Tensor]:
         return list(self.named_parameters().values())
 
+    # ------------------------------------------------------------------------------------------------- stage hand-off
+    def export_model(self, path) -> None:
+        """`GeoSplatter.export_model` (rfstudio/model/geosplat.py:839-854): the file stage 2 starts from
+        (`GeoSplatterMC.__setup__` reads exactly these keys, rfstudio/model/geosplat_mc.py:56-70)."""
+        with torch.no_grad():
+            attributes = {
+                "geom_scale": self.scale,
+                "resolution": self.resolution,
+                "min_roughness": self.min_roughness,
+                "max_metallic": self.max_metallic,
+                "exposure": self.exposure_params.detach().cpu().clone(),
+                "cubemap": self.cubemap.detach().cpu().clone(),
+                "deforms": self.deform_params.detach().cpu().clone(),
+                "weights": self.weight_params.detach().cpu().clone(),
+                "sdfs": self.sdf_params.detach().cpu().clone(),
+                "ks_enc": self.field.ks_enc.state_dict(),
+                "initial_guess": self.initial_guess_bias.detach().cpu().clone(),
+            }
+        torch.save(attributes, path)
+
+    @classmethod
+    def from_export(cls, path, device="cuda", **kwargs) -> "Stage1Model":
+        """Rebuild the geometry / lighting / ks side of a model from an `export_model` file, as the stage-2 loader does
+        (geosplat_mc.py:56-70); the kd / z encoders are not part of the hand-off and start fresh."""
+        a = torch.load(path, map_location="cpu")
+        log2 = int(round(float(torch.log2(torch.tensor(a["ks_enc"]["encoder.params"].shape[0] / 16.0)))))
+        m = cls(int(a["resolution"]), scale=float(a["geom_scale"]), light_resolution=int(a["cubemap"].shape[1]),
+                min_roughness=float(a["min_roughness"]), max_metallic=float(a["max_metallic"]), device=device,
+                log2_hashmap_size=log2, **kwargs)
+        with torch.no_grad():
+            m.exposure_params.copy_(a["exposure"].to(m.exposure_params.device))
+            m.cubemap.copy_(a["cubemap"].to(m.cubemap.device))
+            m.deform_params.copy_(a["deforms"].to(m.deform_params.device))
+            m.weight_params.copy_(a["weights"].to(m.weight_params.device))
+            m.sdf_params.copy_(a["sdfs"].to(m.sdf_params.device))
+            m.initial_guess_bias = a["initial_guess"].to(m.initial_guess_bias.device).float()
+        m.field.ks_enc.load_state_dict(a["ks_enc"])
+        return m
+
+    def state_dict(self) -> Dict[str, Tensor]:
+        """Names of the reference's `GeoSplatter.state_dict()` (probed in the build container): the five parameters,
+        `initial_guess_bias`, the unused `latlng` placeholder, and the three encoders under `field.<name>.`."""
+        sd = {"exposure_params": self.exposure_params, "deform_params": self.deform_params, "sdf_params": self.sdf_params,
+              "weight_params": self.weight_params, "initial_guess_bias": self.initial_guess_bias, "cubemap": self.cubemap,
+              "latlng": torch.zeros(256, 512, 3)}
+        out = {k: v.detach().cpu().clone() for k, v in sd.items()}
+        for name in ("kd_enc", "ks_enc", "z_enc"):
+            for k, v in getattr(self.field, name).state_dict().items():
+                out[f"field.{name}.{k}"] = v
+        return out
+
+    def load_state_dict(self, sd: Dict[str, Tensor]) -> None:
+        with torch.no_grad():
+            for k in ("exposure_params", "deform_params", "sdf_params", "weight_params", "cubemap"):
+                getattr(self, k).copy_(sd[k].to(getattr(self, k).device))
+            self.initial_guess_bias = sd["initial_guess_bias"].to(self.initial_guess_bias.device).float()
+        for name in ("kd_enc", "ks_enc", "z_enc"):
+            pre = f"field.{name}."
+            getattr(self.field, name).load_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)})
+
+    def save_checkpoint(self, ckpt_dir, step: int) -> str:
+        """`TrainTask.save_checkpoint` (rfstudio/engine/train.py:172-175): `<ckpt_dir>/<step:010d>.ckpt` = state_dict."""
+        os.makedirs(ckpt_dir, exist_ok=True)
+        path = os.path.join(ckpt_dir, f"{step:010d}.ckpt")
+        torch.save(self.state_dict(), path)
+        return path
+
+    def load_checkpoint(self, ckpt_dir, step: Optional[int] = None) -> Optional[int]:
+        """`TrainTask.load_checkpoint` (train.py:177-190): the given step, else the newest `*.ckpt`; None if there is none."""
+        if not os.path.isdir(ckpt_dir):
+            return None
+        if step is None:
+            steps = [int(f.rsplit(".", 1)[0]) for f in os.listdir(ckpt_dir) if f.endswith(".ckpt")]
+            if not steps:
+                return None
+            step = max(steps)
+        path = os.path.join(ckpt_dir, f"{step:010d}.ckpt")
+        if not os.path.exists(path):
+            return None
+        self.load_state_dict(torch.load(path, map_location="cpu"))
+        return step
+
     # ------------------------------------------------------------------------------------------------- forward pieces
     def get_geometry(self) -> Tuple[Tuple[Tensor, Tensor], Tensor]:
         """:751-769"""
@@ -104,13 +213,47 @@ class Stage1Model:
             reg = reg + self.ks_grad_weight * (attrs.ks_jitter - attrs.ks).abs().mean()
         return (v, f), splats, attrs, reg
 
-    def render_report(self, cameras: Sequence[Camera]) -> Tuple[List[Tensor], int, Tensor]:
-        """:856-927 -> (tone-mapped linear RGBA image per camera, #Gaussians, regularisation)"""
+    def smoothing_regularization(self, splats, attrs, cameras: Sequence[Camera], gt_rgba: Optional[Sequence[Tensor]],
+                                 batch_size: int) -> Tensor:
+        """The 'grad' / 'tv' branches and `normal_grad_weight` of render_report (:881-922): edge-aware first-order / total-variation
+        penalties on UN-shaded renders of kd, (0, ks) and normals * 0.5 + 0.5 over the model's background colour."""
+        from .shading import render_rgb
+        reg = splats.means.new_zeros(())
+        need_gt = (self.smooth_type == "grad" and (self.kd_grad_weight > 0 or self.ks_grad_weight > 0)) or self.normal_grad_weight > 0
+        if need_gt and gt_rgba is None:
+            raise ValueError("smooth_type='grad' / normal_grad_weight need the ground-truth images (gt_outputs.blend(background))")
+        bg = self.background_color
+        rr = lambda colors, cam: render_rgb(splats.means, splats.scales, splats.quats, splats.opacities, colors, cam, bg)
+        gts = None if not need_gt else [g[..., :3] * g[..., 3:] + bg * (1 - g[..., 3:]) for g in gt_rgba]   # RGBAImages.blend
+        ks3 = torch.cat((torch.zeros_like(attrs.ks[..., :1]), attrs.ks), dim=-1)
+        for i, cam in enumerate(cameras):
+            if self.smooth_type == "grad":
+                if self.kd_grad_weight > 0:
+                    reg = reg + _edge_aware(rr(attrs.kd, cam), gts[i]) * self.kd_grad_weight / batch_size
+                if self.ks_grad_weight > 0:
+                    reg = reg + _edge_aware(rr(ks3, cam), gts[i]) * self.ks_grad_weight / batch_size
+            if self.normal_grad_weight > 0:
+                reg = reg + _edge_aware(rr(attrs.normals * 0.5 + 0.5, cam), gts[i]) * self.normal_grad_weight / batch_size
+            if self.smooth_type == "tv":
+                if self.kd_grad_weight > 0:
+                    reg = reg + _tv(rr(attrs.kd, cam)) * self.kd_grad_weight / batch_size
+                if self.ks_grad_weight > 0:
+                    reg = reg + _tv(rr(ks3, cam)) * self.ks_grad_weight / batch_size
+        return reg
+
+    def render_report(self, cameras: Sequence[Camera], gt_rgba: Optional[Sequence[Tensor]] = None,
+                      batch_size: Optional[int] = None) -> Tuple[List[Tensor], int, Tensor]:
+        """:856-927 -> (tone-mapped linear RGBA image per camera, #Gaussians, regularisation); gt_rgba (linear RGBA per camera) is
+        only read by the 'grad' / normal smoothing branches; batch_size = number of views of the whole step (all ranks)."""
         _, splats, attrs, reg = self.get_gsplat()
         envmap, light_reg = self.get_envmap()
         exposure = self.exposure_params.exp()[0]
         images = [attrs.splat(splats, [cam], exposure=exposure, envmap=envmap, min_roughness=self.min_roughness,
                               max_metallic=self.max_metallic).reshape(cam.height, cam.width, 4) for cam in cameras]
+        self._last_smoothing = reg.new_zeros(())
+        if self.smooth_type != "jitter" or self.normal_grad_weight > 0:
+            self._last_smoothing = self.smoothing_regularization(splats, attrs, cameras, gt_rgba, batch_size or len(cameras))
+            reg = reg + self._last_smoothing                 # per-view terms (already / batch_size): NOT replicated across ranks
         return images, splats.means.shape[0], reg + light_reg * self.light_weight
 
 
@@ -128,6 +271,8 @@ def train_step_fused(model: Stage1Model, cameras: Sequence[Camera], gt_rgba: Seq
     from .loss import TrainerUpstream
     n_total = len(cameras)
     mine = list(range(rank, n_total, world_size))
+    if model.smooth_type != "jitter" or model.normal_grad_weight > 0:
+        raise NotImplementedError("the 'grad' / 'tv' / normal smoothing renders run on the autograd step (train_step)")
     params = model.parameters()
     for p in params:
         p.grad = None
@@ -203,8 +348,9 @@ def train_step(model: Stage1Model, cameras: Sequence[Camera], gt_rgba: Sequence[
     mine = list(range(rank, n_total, world_size))
     for p in model.parameters():
         p.grad = None
-    images, num_gaussians, reg = model.render_report([cameras[i] for i in mine])
-    total = reg / world_size                                            # identical on every rank: counted once
+    images, num_gaussians, reg = model.render_report([cameras[i] for i in mine], [gt_rgba[i] for i in mine], batch_size=n_total)
+    smooth = model._last_smoothing                                      # per-view smoothing terms of THIS rank's views
+    total = (reg - smooth) / world_size + smooth                        # the rest is identical on every rank: counted once
     local = []
     for i, img in zip(mine, images):
         gt = gt_rgba[i]

@@ -124,3 +124,36 @@ def test_prefilter_texel_shards_partition_every_level():
     assert can_shard_prefilter(512, 8) and not can_shard_prefilter(512, 1) and not can_shard_prefilter(512, 5)
     with pytest.raises(_lib.GeoSplatHipError):
         shard_texels(6 * 16 * 16, 0, 5)
+
+
+def test_stage_handoff_files(tmp_path):
+    """export_model / checkpoints (rfstudio/model/geosplat.py:839-854, rfstudio/engine/train.py:172-190): key names and shapes as the
+    reference writes them (state_dict names probed from the real GeoSplatter in the build container), values round-trip."""
+    from geosplatting_amd.stage1 import Stage1Model
+    m = Stage1Model(8, light_resolution=16, device="cpu", log2_hashmap_size=12, seed=3)
+    with torch.no_grad():
+        m.sdf_params.add_(0.25); m.cubemap.mul_(1.5); m.exposure_params.fill_(0.3)
+    path = tmp_path / "stage1.pkl"
+    m.export_model(path)
+    a = torch.load(path, map_location="cpu")
+    assert set(a) == {"geom_scale", "resolution", "min_roughness", "max_metallic", "exposure", "cubemap", "deforms", "weights",
+                      "sdfs", "ks_enc", "initial_guess"}
+    assert a["resolution"] == 8 and a["deforms"].shape == (729, 3) and a["sdfs"].shape == (729, 1) and a["weights"].shape == (512, 21)
+    assert a["cubemap"].shape == (6, 16, 16, 3) and a["exposure"].shape == (1,) and a["initial_guess"].shape == (2,)
+    assert set(a["ks_enc"]) == {"encoder.params", "mlp.nn_layers.0.weight", "mlp.nn_layers.1.weight"}
+    assert a["ks_enc"]["encoder.params"].shape == (16 * 2 ** 12, 2) and a["ks_enc"]["mlp.nn_layers.1.weight"].shape == (2, 32)
+    m2 = Stage1Model.from_export(path, device="cpu")
+    for k in ("sdf_params", "deform_params", "weight_params", "cubemap", "exposure_params"):
+        assert torch.equal(getattr(m2, k), getattr(m, k)), k
+    assert torch.equal(m2.field.ks_enc.hash_table, m.field.ks_enc.hash_table)
+    # checkpoints
+    sd = m.state_dict()
+    assert {"exposure_params", "deform_params", "sdf_params", "weight_params", "initial_guess_bias", "cubemap", "latlng"} <= set(sd)
+    assert "field.kd_enc.mlp.nn_layers.2.weight" in sd and sd["field.kd_enc.mlp.nn_layers.2.weight"].shape == (3, 32)
+    m.save_checkpoint(tmp_path / "ckpts", 7); m.save_checkpoint(tmp_path / "ckpts", 120)
+    assert sorted(os.listdir(tmp_path / "ckpts")) == ["0000000007.ckpt", "0000000120.ckpt"]
+    m3 = Stage1Model(8, light_resolution=16, device="cpu", log2_hashmap_size=12, seed=9)
+    assert m3.load_checkpoint(tmp_path / "ckpts") == 120
+    for (k, a_), (_, b_) in zip(m.named_parameters().items(), m3.named_parameters().items()):
+        assert torch.equal(a_, b_), k
+    assert m3.load_checkpoint(tmp_path / "nowhere") is None

@@ -153,18 +153,17 @@ def test_smoothing_branches(cuda):
         _, splats, attrs, _ = m.get_gsplat()
         bg = m.background_color
         want = 0.0
+        ks3 = torch.cat((torch.zeros_like(attrs.ks[..., :1]), attrs.ks), -1)
+        rr = lambda colors, cam: render_rgb(splats.means, splats.scales, splats.quats, splats.opacities, colors, cam, bg)
+        tv = lambda img: (img[1:] - img[:-1]).square().mean() + (img[:, 1:] - img[:, :-1]).square().mean()
         for cam, gt in zip(cams, gts):
             gt_rgb = gt[..., :3] * gt[..., 3:] + bg * (1 - gt[..., 3:])
-            for colors, w in ((attrs.kd, m.kd_grad_weight), (torch.cat((torch.zeros_like(attrs.ks[..., :1]), attrs.ks), -1), m.ks_grad_weight),
-                              (attrs.normals * 0.5 + 0.5, m.normal_grad_weight)):
-                if w == 0 or (colors is not attrs.kd and mode == "tv" and w == m.normal_grad_weight and kn == 0):
-                    continue
-                img = render_rgb(splats.means, splats.scales, splats.quats, splats.opacities, colors, cam, bg)
-                if mode == "tv" and w != m.normal_grad_weight:
-                    term = (img[1:] - img[:-1]).square().mean() + (img[:, 1:] - img[:, :-1]).square().mean()
-                else:
-                    term = (spatial_gradient(img).abs() * (-spatial_gradient(gt_rgb).abs()).exp()).sum(1).mean()
-                want = want + term * w / len(cams)
+            edge = lambda img: (spatial_gradient(img).abs() * (-spatial_gradient(gt_rgb).abs()).exp()).sum(1).mean()
+            if mode == "tv":
+                want = want + (tv(rr(attrs.kd, cam)) * m.kd_grad_weight + tv(rr(ks3, cam)) * m.ks_grad_weight) / len(cams)
+            else:
+                want = want + (edge(rr(attrs.kd, cam)) * m.kd_grad_weight + edge(rr(ks3, cam)) * m.ks_grad_weight
+                               + edge(rr(attrs.normals * 0.5 + 0.5, cam)) * m.normal_grad_weight) / len(cams)
         assert abs(float(smooth) - float(want)) < 1e-5 * max(1.0, abs(float(want))), (mode, float(smooth), float(want))
         smooth.backward()
         assert float(m.field.kd_enc.hash_table.grad.abs().sum()) > 0 and float(m.field.ks_enc.hash_table.grad.abs().sum()) > 0

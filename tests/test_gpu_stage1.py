@@ -133,7 +133,7 @@ def test_smoothing_branches(cuda):
     from geosplatting_amd.shading import render_rgb
     from geosplatting_amd.stage1 import Stage1Model, spatial_gradient
     cams = syn.blender_cameras(2, 96, 96)
-    m = Stage1Model(16, light_resolution=32, device=cuda, log2_hashmap_size=12, sdf_init=None, seed=1)
+    m = Stage1Model(16, light_resolution=64, device=cuda, log2_hashmap_size=12, sdf_init=None, seed=1)
     with torch.no_grad():
         m.sdf_params.copy_(m.grid.vertices.norm(dim=-1, keepdim=True) - 0.6)
     g = torch.Generator().manual_seed(4)

@@ -136,6 +136,32 @@ __device__ __forceinline__ float gs_exp_neg(float sigma)
     return (y >= -125.0f) ? r : 0.0f;
 }
 
+// extent of {alpha >= 1/255} for a Gaussian, conservatively inflated; returns false if it can never reach
+__device__ __forceinline__ bool alpha_extent(float ca, float cb, float cc, float o, float& hx, float& hy)
+{
+    const float tau = __logf(255.0f * o);
+    const float det = ca * cc - cb * cb;
+    if (!(tau > -0.002f)) return false;              // o*255 < ~1: never visible (also rejects NaN)
+    if (!(det > 0.0f)) { hx = hy = 1e30f; return true; }
+    const float k = 2.0f * (tau + 0.002f) / det;
+    hx = sqrtf(k * cc) * 1.0005f + 0.02f;
+    hy = sqrtf(k * ca) * 1.0005f + 0.02f;
+    return true;
+}
+
+// the 64-byte per-visible record the compositor's stream build gathers (one cache line per intersection):
+//   {mx, my, 0.5a, b | 0.5c, opacity, hx, hy | c0, c1, c2, - | pad}      (colours only for D <= 3)
+__device__ __forceinline__ void gs_write_vis_record(float4* __restrict__ rec, float mx, float my, float ca, float cb, float cc, float op,
+                                                    float c0, float c1, float c2)
+{
+    float hx = -1.0f, hy = -1.0f;
+    if (!alpha_extent(ca, cb, cc, op, hx, hy)) { hx = -1.0f; hy = -1.0f; }
+    rec[0] = make_float4(mx, my, 0.5f * ca, cb);
+    rec[1] = make_float4(0.5f * cc, op, hx, hy);
+    rec[2] = make_float4(c0, c1, c2, 0.0f);
+    rec[3] = make_float4(0.f, 0.f, 0.f, 0.f);             // full-line write (a partial line costs a read-modify-write)
+}
+
 __device__ __forceinline__ int gs_lane_id() { return (int)(threadIdx.x & 63); }
 
 // fp32 atomic add that lowers to the hardware global_atomic_add_f32 (no CAS loop), agent (device) scope:

@@ -47,19 +47,6 @@ extern "C" int gs_raster_stats_read(unsigned long long* host8, int reset)
 #define GS_STAT_ALL(i, v) do { } while (0)
 #endif
 
-// extent of {alpha >= 1/255} for a Gaussian, conservatively inflated; returns false if it can never reach
-__device__ __forceinline__ bool alpha_extent(float ca, float cb, float cc, float o, float& hx, float& hy)
-{
-    const float tau = __logf(255.0f * o);
-    const float det = ca * cc - cb * cb;
-    if (!(tau > -0.002f)) return false;              // o*255 < ~1: never visible (also rejects NaN)
-    if (!(det > 0.0f)) { hx = hy = 1e30f; return true; }
-    const float k = 2.0f * (tau + 0.002f) / det;
-    hx = sqrtf(k * cc) * 1.0005f + 0.02f;
-    hy = sqrtf(k * ca) * 1.0005f + 0.02f;
-    return true;
-}
-
 // ---------------------------------------------------------------------------------------------------
 // stream build: rec0 = {mx, my, 0.5a, b}, rec1 = {0.5c, opacity, hx, hy}, rec2 = {c0, c1, c2, bits(g)}
 // (hx < 0 marks "can never reach alpha_min").  One thread per sorted intersection.
@@ -116,18 +103,13 @@ pack_visible_kernel(int V, int D, const float* __restrict__ means2d, const float
     const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)g);
     const float ca = conics[3 * (size_t)g], cb = conics[3 * (size_t)g + 1], cc = conics[3 * (size_t)g + 2];
     const float op = opacities[g];
-    float hx = -1.0f, hy = -1.0f;
-    if (!alpha_extent(ca, cb, cc, op, hx, hy)) { hx = -1.0f; hy = -1.0f; }
-    vis[4 * (size_t)g] = make_float4(m.x, m.y, 0.5f * ca, cb);
-    vis[4 * (size_t)g + 1] = make_float4(0.5f * cc, op, hx, hy);
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
     if (D <= 3) {
         c0 = colors[(size_t)g * D];
         if (D > 1) c1 = colors[(size_t)g * D + 1];
         if (D > 2) c2 = colors[(size_t)g * D + 2];
     }
-    vis[4 * (size_t)g + 2] = make_float4(c0, c1, c2, 0.0f);
-    vis[4 * (size_t)g + 3] = make_float4(0.f, 0.f, 0.f, 0.f);     // full-line write (a partial line costs a read-modify-write)
+    gs_write_vis_record(vis + 4 * (size_t)g, m.x, m.y, ca, cb, cc, op, c0, c1, c2);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1223,9 +1205,29 @@ static int raster_check(const char* who, int W, int H, int tile_size, int D, int
 
 // A5 preparation: per-visible records, the sorted record stream and the longest-first tile order (HBM-bound; a caller
 // that overlaps streams runs it next to the sort, away from the VALU-bound compositor).
+static int raster_prepare_impl(int W, int H, int tile_size, int D, int V, const float* means2d, const float* conics,
+                               const float* opacities, const float* colors, const float* vis_records, int64_t n_isects,
+                               const int32_t* offsets, const int32_t* flatten_ids, void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int gs_raster_prepare(int W, int H, int tile_size, int D, int V, const float* means2d, const float* conics,
                                  const float* opacities, const float* colors, int64_t n_isects, const int32_t* offsets,
                                  const int32_t* flatten_ids, void* ws, size_t ws_bytes, void* stream)
+{
+    return raster_prepare_impl(W, H, tile_size, D, V, means2d, conics, opacities, colors, nullptr, n_isects, offsets, flatten_ids,
+                               ws, ws_bytes, stream);
+}
+
+extern "C" int gs_raster_prepare_vis(int W, int H, int tile_size, int D, int V, const float* vis_records, int64_t n_isects,
+                                     const int32_t* offsets, const int32_t* flatten_ids, void* ws, size_t ws_bytes, void* stream)
+{
+    GS_CHECK_ARG(vis_records != nullptr, "vis_records (written by gs_project_fwd_vis) must not be NULL");
+    return raster_prepare_impl(W, H, tile_size, D, V, nullptr, nullptr, nullptr, nullptr, vis_records, n_isects, offsets,
+                               flatten_ids, ws, ws_bytes, stream);
+}
+
+static int raster_prepare_impl(int W, int H, int tile_size, int D, int V, const float* means2d, const float* conics,
+                               const float* opacities, const float* colors, const float* vis_records, int64_t n_isects,
+                               const int32_t* offsets, const int32_t* flatten_ids, void* ws, size_t ws_bytes, void* stream)
 {
     const int rc = raster_check("gs_raster_prepare", W, H, tile_size, D, V, n_isects, ws, ws_bytes);
     if (rc != GS_OK) return rc;
@@ -1233,11 +1235,15 @@ extern "C" int gs_raster_prepare(int W, int H, int tile_size, int D, int V, cons
     const int tiles = ((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
     const RasterWs r = carve(ws, n_isects, V, tiles);
     if (n_isects > 0 && V > 0) {
-        hipLaunchKernelGGL(pack_visible_kernel, dim3(gs_cdiv(V, 256)), dim3(256), 0, s, V, D, means2d, conics, opacities, colors,
-                           r.vis);
-        GS_CHECK_LAUNCH();
+        const float4* vis = (const float4*)vis_records;
+        if (!vis) {                                          // per-visible records not supplied by the projection: build them here
+            hipLaunchKernelGGL(pack_visible_kernel, dim3(gs_cdiv(V, 256)), dim3(256), 0, s, V, D, means2d, conics, opacities, colors,
+                               r.vis);
+            GS_CHECK_LAUNCH();
+            vis = r.vis;
+        }
         hipLaunchKernelGGL(build_stream_packed_kernel, dim3(gs_cdiv(n_isects, 256)), dim3(256), 0, s, (int)n_isects, flatten_ids,
-                           r.vis, r.rec0, r.rec1, r.rec2);
+                           vis, r.rec0, r.rec1, r.rec2);
         GS_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, tiles, (int)n_isects, offsets, r.order);

@@ -24,7 +24,7 @@ class _Projected:
     """Outputs of the projection stage (A1 + A1' + A2 count) of one view, with the (V, I) counts on their way to a
     pinned host buffer.  Nothing here blocks: `counts()` waits for the copy only when the sizes are needed, so a
     caller can launch the projection of view i+1 before it finishes view i (engine.RenderStep does)."""
-    __slots__ = ("args", "bufs", "host_counts", "event", "D")
+    __slots__ = ("args", "bufs", "host_counts", "event", "D", "vis")
 
 
 _pinned_pool = []
@@ -46,18 +46,21 @@ def _project_stage(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tens
     ws_bytes = lib.gs_project_ws_bytes(N)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     counts = torch.empty(2, dtype=torch.int64, device=dev)
+    # the compositor's 64-byte per-visible records come straight out of the projection (colours ride along for D <= 3)
+    vis = torch.empty(N, 16, dtype=f32, device=dev) if 0 < D <= 3 else None
     st = L.stream()
-    L.check(lib.gs_project_fwd(N, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opacities), L.ptr(colors), D,
-                               L.ptr(viewmat), L.ptr(K), W, H, tile_size, L.f32(eps2d), L.f32(near), L.f32(far),
-                               L.f32(radius_clip), L.ptr(gids), L.ptr(radii), L.ptr(means2d), L.ptr(depths),
-                               L.ptr(conics), L.ptr(comps), L.ptr(opac_p), L.ptr(colors_p), L.ptr(tpg), L.ptr(cum),
-                               None, L.ptr(ws), C.c_size_t(ws_bytes), L.ptr(counts), st), "gs_project_fwd")
+    L.check(lib.gs_project_fwd_vis(N, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opacities), L.ptr(colors), D,
+                                   L.ptr(viewmat), L.ptr(K), W, H, tile_size, L.f32(eps2d), L.f32(near), L.f32(far),
+                                   L.f32(radius_clip), L.ptr(gids), L.ptr(radii), L.ptr(means2d), L.ptr(depths),
+                                   L.ptr(conics), L.ptr(comps), L.ptr(opac_p), L.ptr(colors_p), L.ptr(tpg), L.ptr(cum),
+                                   None, L.ptr(vis), L.ptr(ws), C.c_size_t(ws_bytes), L.ptr(counts), st), "gs_project_fwd_vis")
     pr = _Projected()
     pr.host_counts = _pinned_pool.pop() if _pinned_pool else torch.empty(2, dtype=torch.int64).pin_memory()
     pr.host_counts.copy_(counts, non_blocking=True)          # 16 bytes, asynchronous
     pr.event = torch.cuda.Event()
     pr.event.record()
     pr.bufs = (gids, radii, means2d, depths, conics, comps, opac_p, colors_p, tpg, cum, counts)
+    pr.vis = vis
     pr.args = (W, H, tile_size)
     pr.D = D
     return pr
@@ -106,6 +109,8 @@ def _bin_stage(pr: _Projected, depth_channel: bool = False):
     state = dict(gaussian_ids_i32=gids, radii=radii, means2d=means2d, depths=depths, conics=conics,
                  compensations=comps, opacities=opac_p, colors=colors_p, tiles_per_gauss=tpg, isect_ids=ids_s,
                  flatten_ids=flat_s, isect_offsets=offsets)
+    if pr.vis is not None and not depth_channel:             # (a depth channel changes the composited colours after the projection)
+        state["vis_records"] = pr.vis
     return state, V, I, D, (W, H, tile_size)
 
 
@@ -115,11 +120,17 @@ def _prepare_stage(state, V: int, I: int, D: int, whs):
     W, H, tile_size = whs
     rws_bytes = lib.gs_raster_ws_bytes(L.i64(I), V, W, H, tile_size)
     rws = torch.empty(rws_bytes, dtype=torch.uint8, device=state["means2d"].device)   # written here, read by fwd AND bwd
-    L.check(lib.gs_raster_prepare(W, H, tile_size, D, V, L.ptr(state["means2d"]), L.ptr(state["conics"]),
-                                  L.ptr(state["opacities"]), L.ptr(state["colors"]), L.i64(I),
-                                  L.ptr(state["isect_offsets"]), L.ptr(state["flatten_ids"]), L.ptr(rws),
-                                  C.c_size_t(rws_bytes), L.stream()), "gs_raster_prepare")
-    return dict(state, raster_ws=rws)
+    vis = state.get("vis_records")
+    if vis is not None:
+        L.check(lib.gs_raster_prepare_vis(W, H, tile_size, D, V, L.ptr(vis), L.i64(I), L.ptr(state["isect_offsets"]),
+                                          L.ptr(state["flatten_ids"]), L.ptr(rws), C.c_size_t(rws_bytes), L.stream()),
+                "gs_raster_prepare_vis")
+    else:
+        L.check(lib.gs_raster_prepare(W, H, tile_size, D, V, L.ptr(state["means2d"]), L.ptr(state["conics"]),
+                                      L.ptr(state["opacities"]), L.ptr(state["colors"]), L.i64(I),
+                                      L.ptr(state["isect_offsets"]), L.ptr(state["flatten_ids"]), L.ptr(rws),
+                                      C.c_size_t(rws_bytes), L.stream()), "gs_raster_prepare")
+    return dict({k: v for k, v in state.items() if k != "vis_records"}, raster_ws=rws)
 
 
 def _composite_stage(state, V: int, I: int, D: int, whs, background: Optional[Tensor]):

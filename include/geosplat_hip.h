@@ -76,6 +76,17 @@ int gs_project_fwd(int N, const float* means, const float* quats, const float* s
                    int32_t* tiles_per_gauss, int64_t* cum_tiles, int32_t* packed_index,
                    void* ws, size_t ws_bytes, int64_t* counts, void* stream);
 
+/* The same, additionally writing the compositor's 64-byte per-visible records {mx,my,a/2,b | c/2,opacity,hx,hy | c0,c1,c2,- | pad}
+ * (vis_records [N,16] floats, nullable) straight from the projection's registers; gs_raster_prepare_vis then skips its own packing
+ * pass.  Colours travel in the record for D <= 3. */
+int gs_project_fwd_vis(int N, const float* means, const float* quats, const float* scales, const float* opacities,
+                       const float* colors, int D, const float* viewmat, const float* K, int W, int H, int tile_size,
+                       float eps2d, float near_plane, float far_plane, float radius_clip,
+                       int32_t* gaussian_ids, int32_t* radii, float* means2d, float* depths, float* conics,
+                       float* compensations, float* opacities_packed, float* colors_packed,
+                       int32_t* tiles_per_gauss, int64_t* cum_tiles, int32_t* packed_index, float* vis_records,
+                       void* ws, size_t ws_bytes, int64_t* counts, void* stream);
+
 /* ------------------------------------------------------------------ A2 (emit) ---------------------- */
 /* isect_ids[i] = (tile_id << 32) | float_bits(depth), flatten_ids[i] = packed index; emission order =
  * ascending packed index, tiles row-major. */
@@ -124,6 +135,9 @@ int gs_raster_fwd(int W, int H, int tile_size, int D, int V, const float* means2
 int gs_raster_prepare(int W, int H, int tile_size, int D, int V, const float* means2d, const float* conics,
                       const float* opacities, const float* colors, int64_t n_isects, const int32_t* offsets,
                       const int32_t* flatten_ids, void* ws, size_t ws_bytes, void* stream);
+int gs_raster_prepare_vis(int W, int H, int tile_size, int D, int V, const float* vis_records /* gs_project_fwd_vis */,
+                          int64_t n_isects, const int32_t* offsets, const int32_t* flatten_ids, void* ws, size_t ws_bytes,
+                          void* stream);
 int gs_raster_composite(int W, int H, int tile_size, int D, int V, const float* colors, const float* background,
                         int64_t n_isects, const int32_t* offsets, float* render, float* alphas, int32_t* last_ids,
                         const void* ws, size_t ws_bytes, void* stream);

@@ -1220,7 +1220,7 @@ extern "C" int gs_raster_prepare(int W, int H, int tile_size, int D, int V, cons
 extern "C" int gs_raster_prepare_vis(int W, int H, int tile_size, int D, int V, const float* vis_records, int64_t n_isects,
                                      const int32_t* offsets, const int32_t* flatten_ids, void* ws, size_t ws_bytes, void* stream)
 {
-    GS_CHECK_ARG(vis_records != nullptr, "vis_records (written by gs_project_fwd_vis) must not be NULL");
+    GS_CHECK_ARG(vis_records != nullptr || V == 0, "vis_records (written by gs_project_fwd_vis) must not be NULL");
     return raster_prepare_impl(W, H, tile_size, D, V, nullptr, nullptr, nullptr, nullptr, vis_records, n_isects, offsets,
                                flatten_ids, ws, ws_bytes, stream);
 }

@@ -47,7 +47,7 @@ def _project_stage(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tens
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     counts = torch.empty(2, dtype=torch.int64, device=dev)
     # the compositor's 64-byte per-visible records come straight out of the projection (colours ride along for D <= 3)
-    vis = torch.empty(N, 16, dtype=f32, device=dev) if 0 < D <= 3 else None
+    vis = torch.empty(N, 16, dtype=f32, device=dev) if (0 < D <= 3 and N > 0) else None
     st = L.stream()
     L.check(lib.gs_project_fwd_vis(N, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opacities), L.ptr(colors), D,
                                    L.ptr(viewmat), L.ptr(K), W, H, tile_size, L.f32(eps2d), L.f32(near), L.f32(far),

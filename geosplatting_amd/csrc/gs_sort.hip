@@ -277,8 +277,8 @@ static int radix_pass(int64_t n, In in, Digit digit, Out out, int nbits, unsigne
 }
 
 // ---- one-kernel pass (decoupled look-back) ----------------------------------------------------------------------------
-// The three-kernel pass above costs two extra launches and a second read of the items; under the engine's three-stream overlap
-// its small kernels also wait for CU slots one after the other.  `radix_onesweep_kernel` does a pass in ONE launch: the
+// EXPERIMENT (off by default, GEOSPLAT_RADIX=onesweep): the three-kernel pass above costs two extra launches and a second read of
+// the items.  `radix_onesweep_kernel` does a pass in ONE launch: the
 // global digit histogram is known beforehand (all four depth digits from one read of the depth array; the tile digits are
 // counted while the intersections are emitted), blocks take a TICKET (arrival order, so a block only ever waits for blocks that
 // are already running), publish their per-digit counts as {flag, value} words and thread d looks back over the predecessors of
@@ -634,7 +634,9 @@ extern "C" int gs_isect_bin(int V, const float* means2d, const int32_t* radii, c
     unsigned* blocksum = (unsigned*)p; p += align256(((size_t)eblocks + 1) * 4);
     uint2* ia = (uint2*)p; p += align256((size_t)n_isects * 8);
     uint2* ib = (uint2*)p; p += align256((size_t)n_isects * 8);
-    static const bool three_kernel = [] { const char* e = getenv("GEOSPLAT_RADIX"); return e && !strcmp(e, "3k"); }();
+    // default: three kernels per pass.  GEOSPLAT_RADIX=onesweep selects the one-kernel look-back passes (bit-identical, measured
+    // SLOWER on this workload: 265 vs 238 us of pass kernels per view)
+    static const bool three_kernel = [] { const char* e = getenv("GEOSPLAT_RADIX"); return !(e && !strcmp(e, "onesweep")); }();
     int tb = 0;
     while ((1 << tb) < tile_w * tile_h) ++tb;
     if (tb < 1) tb = 1;

@@ -271,3 +271,26 @@ def test_binning_variants_bit_identical(cuda, monkeypatch):
     ref = oracle.rasterization(means, quats, scales, opac, sp.colors.numpy(), cam.view_matrix.numpy(), cam.intrinsic_matrix.numpy(), 320, 320)
     assert np.array_equal(out["depth_major"][2]["isect_ids"].cpu().numpy(), ref["isect_ids"])
     assert np.array_equal(out["depth_major"][2]["flatten_ids"].cpu().numpy(), ref["flatten_ids"])
+
+
+def test_onesweep_passes_bit_identical(cuda):
+    """the one-kernel look-back radix passes (GEOSPLAT_RADIX=onesweep, off by default: slower here) give the same order; the switch is
+    read once per process, so the comparison runs in a child process"""
+    import subprocess, sys, os
+    code = ("import os,sys,torch,numpy as np\n"
+            "sys.path.insert(0, %r)\n"
+            "import geosplatting_amd as gs\n"
+            "from tests.util import random_case, activated\n"
+            "sp, cam = random_case(20000, 320, view=1, seed=5)\n"
+            "m, q, s, o = activated(sp)\n"
+            "t = lambda a: torch.tensor(a, device='cuda')\n"
+            "r, a, meta = gs.rasterization(t(m), t(q), t(s), t(o), t(sp.colors.numpy()), cam.view_matrix.cuda()[None], cam.intrinsic_matrix.cuda()[None], 320, 320)\n"
+            "print(int(meta['isect_ids'].sum().item() %% 1000003), int((meta['flatten_ids'].long() * torch.arange(meta['flatten_ids'].numel(), device='cuda')).sum().item() %% 1000003), float(r.sum()))\n"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    for mode in ("3k", "onesweep"):
+        env = dict(os.environ, GEOSPLAT_RADIX=mode)
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs.append(res.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1], outs

@@ -559,6 +559,66 @@ tonemap_bwd_kernel(int64_t P, int mode, const float4* __restrict__ rgba, const f
     if (threadIdx.x == 0) gs_atomic_add(v_exposure, s[0] + s[1] + s[2] + s[3]);
 }
 
+// The same pair on the rasterizer's own layout: render [P,3] + alphas [P] in, image [P,4] out; and v_render [P,3] / v_alphas [P]
+// out of the backward -- no rgba concatenation, no strided copies in between (the engine's per-view glue).
+__global__ void __launch_bounds__(256)
+tonemap_fwd3_kernel(int64_t P, int mode, const float* __restrict__ render, const float* __restrict__ alphas,
+                    const float* __restrict__ exposure, float4* __restrict__ out)
+{
+    const float e = exposure[0];
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+        const float r = render[3 * p], g = render[3 * p + 1], b = render[3 * p + 2], a = alphas[p];
+        out[p] = make_float4(tone_fwd(mode, r * e), tone_fwd(mode, g * e), tone_fwd(mode, b * e), mode == GS_TONE_NONE ? a * e : a);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+tonemap_bwd3_kernel(int64_t P, int mode, const float* __restrict__ render, const float* __restrict__ alphas,
+                    const float* __restrict__ exposure, const float4* __restrict__ v_out, float* __restrict__ v_render,
+                    float* __restrict__ v_alphas, float* __restrict__ v_exposure)
+{
+    const float e = exposure[0];
+    float ve = 0.0f;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+        const float r = render[3 * p], gch = render[3 * p + 1], b = render[3 * p + 2], a = alphas[p];
+        const float4 g = v_out[p];
+        const float gx = g.x * tone_grad(mode, r * e), gy = g.y * tone_grad(mode, gch * e), gz = g.z * tone_grad(mode, b * e);
+        v_render[3 * p] = gx * e; v_render[3 * p + 1] = gy * e; v_render[3 * p + 2] = gz * e;
+        v_alphas[p] = mode == GS_TONE_NONE ? g.w * e : g.w;
+        ve += gx * r + gy * gch + gz * b + (mode == GS_TONE_NONE ? g.w * a : 0.0f);
+    }
+    ve = gs_wave_sum(ve);
+    __shared__ float s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = ve;
+    __syncthreads();
+    if (threadIdx.x == 0) gs_atomic_add(v_exposure, s[0] + s[1] + s[2] + s[3]);
+}
+
+extern "C" int gs_tonemap_fwd3(int64_t P, int mode, const float* render, const float* alphas, const float* exposure, float* out,
+                               void* stream)
+{
+    GS_CHECK_ARG(P >= 0 && mode >= 0 && mode <= 2, "bad P or mode");
+    if (P == 0) return GS_OK;
+    const int blocks = (int)((P + 255) / 256 < 2048 ? (P + 255) / 256 : 2048);
+    hipLaunchKernelGGL(tonemap_fwd3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, mode, render, alphas, exposure, (float4*)out);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
+extern "C" int gs_tonemap_bwd3(int64_t P, int mode, const float* render, const float* alphas, const float* exposure,
+                               const float* v_out, float* v_render, float* v_alphas, float* v_exposure, int accumulate, void* stream)
+{
+    GS_CHECK_ARG(P >= 0 && mode >= 0 && mode <= 2, "bad P or mode");
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) GS_CHECK_HIP(hipMemsetAsync(v_exposure, 0, sizeof(float), s));
+    if (P == 0) return GS_OK;
+    const int blocks = (int)((P + 255) / 256 < 1024 ? (P + 255) / 256 : 1024);
+    hipLaunchKernelGGL(tonemap_bwd3_kernel, dim3(blocks), dim3(256), 0, s, P, mode, render, alphas, exposure, (const float4*)v_out,
+                       v_render, v_alphas, v_exposure);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
 extern "C" int gs_tonemap_fwd(int64_t P, int mode, const float* rgba, const float* exposure, float* out, void* stream)
 {
     GS_CHECK_ARG(P >= 0 && mode >= 0 && mode <= 2, "bad P or mode");

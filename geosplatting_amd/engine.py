@@ -214,15 +214,13 @@ class RenderStep:
             if i + 2 < n_views:
                 proj.append(start_view(cameras[i + 2]))
             binned = bin_view(proj.pop(0)) if i + 1 < n_views else None
-            rgba = torch.cat((render, alphas.unsqueeze(-1)), dim=-1)
-            img = torch.empty_like(rgba)
+            img = torch.empty(H, W, 4, dtype=f32, device=dev)
             P = W * H
-            L.check(lib.gs_tonemap_fwd(L.i64(P), tone, L.ptr(rgba), L.ptr(exposure), L.ptr(img), st()), "gs_tonemap_fwd")
+            L.check(lib.gs_tonemap_fwd3(L.i64(P), tone, L.ptr(render), L.ptr(alphas), L.ptr(exposure), L.ptr(img), st()), "gs_tonemap_fwd3")
             v_img = upstream(i, img).contiguous()
-            v_rgba = torch.empty_like(rgba)
-            L.check(lib.gs_tonemap_bwd(L.i64(P), tone, L.ptr(rgba), L.ptr(exposure), L.ptr(v_img), L.ptr(v_rgba),
-                                       L.ptr(b["exposure"]), 1, st()), "gs_tonemap_bwd")
-            v_render = v_rgba[..., :3].contiguous(); v_alpha = v_rgba[..., 3].contiguous()
+            v_render = torch.empty(H, W, 3, dtype=f32, device=dev); v_alpha = torch.empty(H, W, dtype=f32, device=dev)
+            L.check(lib.gs_tonemap_bwd3(L.i64(P), tone, L.ptr(render), L.ptr(alphas), L.ptr(exposure), L.ptr(v_img), L.ptr(v_render),
+                                        L.ptr(v_alpha), L.ptr(b["exposure"]), 1, st()), "gs_tonemap_bwd3")
             v_packed = torch.empty(V, lib.gs_raster_grad_stride(3), dtype=f32, device=dev)
             rws = s["raster_ws"]
             L.check(lib.gs_raster_bwd(W, H, 16, 3, V, L.ptr(s["colors"]), None, L.i64(I), L.ptr(s["isect_offsets"]),

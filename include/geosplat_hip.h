@@ -215,6 +215,11 @@ int gs_shade_bwd(int N, const float* means, const float* normals, const float* k
 /* ------------------------------------------------------------------ S4 ----------------------------- */
 /* out[P,4] = tonemap(rgba[P,4] * exposure) ; exposure is a DEVICE scalar. */
 int gs_tonemap_fwd(int64_t P, int mode, const float* rgba, const float* exposure, float* out, void* stream);
+/* The same on the rasterizer's own layout (render [P,3] + alphas [P] -> image [P,4]; backward -> v_render [P,3], v_alphas [P]):
+ * no rgba concatenation / strided copies between the compositor and the tone map. */
+int gs_tonemap_fwd3(int64_t P, int mode, const float* render, const float* alphas, const float* exposure, float* out, void* stream);
+int gs_tonemap_bwd3(int64_t P, int mode, const float* render, const float* alphas, const float* exposure, const float* v_out,
+                    float* v_render, float* v_alphas, float* v_exposure, int accumulate, void* stream);
 /* v_exposure: device scalar, zeroed by the call (accumulate == 0) then accumulated into. */
 int gs_tonemap_bwd(int64_t P, int mode, const float* rgba, const float* exposure, const float* v_out,
                    float* v_rgba, float* v_exposure, int accumulate, void* stream);

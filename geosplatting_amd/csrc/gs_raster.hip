@@ -42,9 +42,21 @@ extern "C" int gs_raster_stats_read(unsigned long long* host8, int reset)
 }
 #define GS_STAT(i, v) do { const unsigned long long _sv = (unsigned long long)(v); if ((threadIdx.x & 63) == 0) atomicAdd(&g_raster_stats[i], _sv); } while (0)
 #define GS_STAT_ALL(i, v) atomicAdd(&g_raster_stats[i], (unsigned long long)(v))      /* every active lane adds */
+#ifdef GS_RASTER_PHASES            /* cycles of wave 0 of the LONGEST tile (block 0 in LPT order) per phase: overrides the counters above */
+#undef GS_STAT
+#undef GS_STAT_ALL
+#define GS_STAT(i, v) do { } while (0)
+#define GS_STAT_ALL(i, v) do { } while (0)
+#define GS_PHASE_BEGIN() const long long _ph0 = (blockIdx.x == 0 && threadIdx.x == 0) ? (long long)__builtin_readcyclecounter() : 0
+#define GS_PHASE_END(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_raster_stats[i], (unsigned long long)((long long)__builtin_readcyclecounter() - _ph0)); } while (0)
+#endif
 #else
 #define GS_STAT(i, v) do { } while (0)
 #define GS_STAT_ALL(i, v) do { } while (0)
+#endif
+#ifndef GS_PHASE_BEGIN
+#define GS_PHASE_BEGIN() do { } while (0)
+#define GS_PHASE_END(i) do { } while (0)
 #endif
 
 // ---------------------------------------------------------------------------------------------------
@@ -512,6 +524,9 @@ __device__ __forceinline__ void active_rect_i(unsigned long long act, int& xmin,
     ymin = __builtin_ctzll(act) >> 3; ymax = (63 - __builtin_clzll(act)) >> 3;
 }
 
+#ifndef GS_LANES_NPT
+#define GS_LANES_NPT 2            // candidates popped per lane and trip (independent fetch + alpha chains)
+#endif
 #ifndef GS_LANES_EXACT_MASK
 #define GS_LANES_EXACT_MASK 1
 #endif
@@ -603,6 +618,12 @@ raster_fwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
                         float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids)
 {
     extern __shared__ __align__(16) unsigned char gs_lds_raw[];
+#ifdef GS_EXP_SKIP_HEAVY          /* timing experiment: leave out the K longest tiles (LPT order) -- is the launch bound by its tail? */
+    if ((int)blockIdx.x < GS_EXP_SKIP_HEAVY) return;
+#endif
+#ifdef GS_EXP_ONLY_HEAVY
+    if ((int)blockIdx.x >= GS_EXP_ONLY_HEAVY) return;
+#endif
     const int tile = tile_order[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int tx = tile % tile_w, ty = tile / tile_w;
@@ -624,26 +645,35 @@ raster_fwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
 
     int qhead = 0, qcount = 0;                                    // wave-uniform
     int base = start;
-    Batch nxt = load_batch(rec0, rec1, rec2, start + lane, start + lane < end);
+    // THREE raw batches in flight: between two dense batches the fill loop consumes raw batches back to back (17-20 of 64
+    // records survive the cull), and with one batch of prefetch every iteration sat out a full memory latency -- on the
+    // silhouette tiles that bound the launch, ~110 raw batches x 1-2 us
+    Batch pf0 = load_batch(rec0, rec1, rec2, start + lane, start + lane < end);
+    Batch pf1 = load_batch(rec0, rec1, rec2, start + 64 + lane, start + 64 + lane < end);
+    Batch pf2 = load_batch(rec0, rec1, rec2, start + 128 + lane, start + 128 + lane < end);
     for (;;) {
         unsigned long long act = __ballot(!done);
         if (act == 0ull) break;
         // ---- fill: cull raw batches into the queue until a dense batch is available
+        { GS_PHASE_BEGIN();
         while (qcount < 64 && base < end) {
             float rx0, rx1, ry0, ry1;
             active_rect(act, qx0, qy0, rx0, rx1, ry0, ry1);
-            const Batch cur = nxt;
+            const Batch cur = pf0;
+            pf0 = pf1; pf1 = pf2;
             {
-                const int nidx = base + 64 + lane;
-                nxt = load_batch(rec0, rec1, rec2, nidx, nidx < end);
+                const int nidx = base + 192 + lane;
+                pf2 = load_batch(rec0, rec1, rec2, nidx, nidx < end);
             }
             GS_STAT(0, 1);
             qcount += lanes_cull_append(q, cur, base + lane, lane, rx0, rx1, ry0, ry1, qhead + qcount);
             base += 64;
         }
+        GS_PHASE_END(0); }
         if (qcount == 0) break;
         const int nb = qcount < 64 ? qcount : 64;
         lanes_lds_sync();
+        GS_PHASE_BEGIN();
         // ---- dense batch: lane j owns queue slot qhead + j
         int xmin, xmax, ymin, ymax;
         active_rect_i(act, xmin, xmax, ymin, ymax);
@@ -656,26 +686,49 @@ raster_fwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
         GS_STAT(1, nb);
         unsigned long long list = gs_bit_transpose64(pm, lane);
         if (done) list = 0ull;
+        GS_PHASE_END(1);
+        // The launch is bound by its TAIL: a silhouette tile walks ~7 000 records and its four waves take ~400 us whether or not
+        // anything else runs (removal experiment: the 100 longest tiles ALONE take 408 us of the 424), i.e. by the dependent-chain
+        // latency of one wave (LDS fetch -> sigma -> exp polynomial -> compare, ~400 cycles per trip).  So every lane pops
+        // GS_LANES_NPT candidates per trip: their fetches and alpha chains are independent (phase A), only the compositing
+        // recurrence is serial (phase B).
+        long long _pw0 = 0;
+#ifdef GS_RASTER_PHASES
+        if (blockIdx.x == 0 && threadIdx.x == 0) _pw0 = (long long)__builtin_readcyclecounter();
+#endif
         while (__ballot(list != 0ull) != 0ull) {
             GS_STAT(3, 1);
-            if (list != 0ull) {
-                const int j = __builtin_ctzll(list);
-                list &= list - 1ull;
+#ifdef GS_RASTER_PHASES
+            if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_raster_stats[3], 1ull);
+#endif
+            float alpha_u[GS_LANES_NPT]; bool ok_u[GS_LANES_NPT]; float4 col_u[GS_LANES_NPT]; int idx_u[GS_LANES_NPT];
+#pragma unroll
+            for (int u = 0; u < GS_LANES_NPT; ++u) {
+                const bool has = list != 0ull;
+                const int j = has ? __builtin_ctzll(list) : 0;               // lanes without a candidate re-read slot qhead (masked)
+                list = has ? (list & (list - 1ull)) : 0ull;
                 const int slot = (qhead + j) & (GS_LANES_Q - 1);
                 const float4 a = q.a[slot];
                 const float2 b = *reinterpret_cast<const float2*>(q.b + slot);
+                col_u[u] = q.c[slot];
+                idx_u[u] = q.idx[slot];
                 const float dx = a.x - px, dy = a.y - py;
                 const float t0 = a.z * dx, t1 = b.x * dy, t2 = a.w * dx;
                 const float sigma = fmaf(t0, dx, fmaf(t1, dy, t2 * dy));
-                const float alpha = fminf(0.999f, b.y * gs_exp_neg(sigma));
-                if (sigma >= 0.0f && alpha >= GS_ALPHA_MIN) {
+                alpha_u[u] = fminf(0.999f, b.y * gs_exp_neg(sigma));
+                ok_u[u] = has && sigma >= 0.0f && alpha_u[u] >= GS_ALPHA_MIN;
+            }
+#pragma unroll
+            for (int u = 0; u < GS_LANES_NPT; ++u) {
+                if (ok_u[u] && !done) {
                     GS_STAT_ALL(2, 1);
+                    const float alpha = alpha_u[u];
                     const float next_T = T * (1.0f - alpha);
                     if (next_T <= 1e-4f) {
                         done = true; list = 0ull;
                     } else {
                         const float vis = alpha * T;
-                        const float4 c = q.c[slot];
+                        const float4 c = col_u[u];
                         if (CD <= 3) {
                             pix[0] = fmaf(c.x, vis, pix[0]);
                             if (CD > 1) pix[1] = fmaf(c.y, vis, pix[1]);
@@ -686,11 +739,14 @@ raster_fwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
                             for (int k = 0; k < CD; ++k) if (k < D) pix[k] = fmaf(cg[k], vis, pix[k]);
                         }
                         T = next_T;
-                        cur_idx = q.idx[slot];
+                        cur_idx = idx_u[u];
                     }
                 }
             }
         }
+#ifdef GS_RASTER_PHASES
+        if (blockIdx.x == 0 && threadIdx.x == 0) { atomicAdd(&g_raster_stats[2], (unsigned long long)((long long)__builtin_readcyclecounter() - _pw0)); atomicAdd(&g_raster_stats[4], 1ull); }
+#endif
         lanes_lds_sync();                     // every lane is done reading these slots before the fill overwrites them
         qhead = (qhead + nb) & (GS_LANES_Q - 1);
         qcount -= nb;
@@ -763,14 +819,19 @@ raster_bwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
     if (top >= end) top = end - 1;
 
     int qhead = 0, qcount = 0;                                    // wave-uniform
-    Batch nxt = load_batch_pred(rec0, rec1, rec2, top - lane, top - lane >= start);
+    // three raw batches in flight, branch-free loads (see the forward kernel: the launch is bound by the memory latency of the
+    // fill loop on its longest tiles; a predicated load is waited for at the join, i.e. not prefetched at all)
+    Batch pf0 = load_batch(rec0, rec1, rec2, top - lane, top - lane >= start);
+    Batch pf1 = load_batch(rec0, rec1, rec2, top - 64 - lane, top - 64 - lane >= start);
+    Batch pf2 = load_batch(rec0, rec1, rec2, top - 128 - lane, top - 128 - lane >= start);
     for (;;) {
         // ---- fill: cull raw batches (walking DOWN the list) into the queue
         while (qcount < 64 && top >= start) {
-            const Batch cur = nxt;
+            const Batch cur = pf0;
+            pf0 = pf1; pf1 = pf2;
             {
-                const int nidx = top - 64 - lane;
-                nxt = load_batch_pred(rec0, rec1, rec2, nidx, nidx >= start);
+                const int nidx = top - 192 - lane;
+                pf2 = load_batch(rec0, rec1, rec2, nidx, nidx >= start);
             }
             // pixels whose last composited entry lies at or after this batch's lowest index can be valid in it
             const unsigned long long act = __ballot(bin_final >= top - 63);
@@ -968,14 +1029,19 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
     if (top >= end) top = end - 1;
 
     int qhead = 0, qcount = 0;                                    // wave-uniform
-    Batch nxt = load_batch_pred(rec0, rec1, rec2, top - lane, top - lane >= start);
+    // three raw batches in flight, branch-free loads (see the forward kernel: the launch is bound by the memory latency of the
+    // fill loop on its longest tiles; a predicated load is waited for at the join, i.e. not prefetched at all)
+    Batch pf0 = load_batch(rec0, rec1, rec2, top - lane, top - lane >= start);
+    Batch pf1 = load_batch(rec0, rec1, rec2, top - 64 - lane, top - 64 - lane >= start);
+    Batch pf2 = load_batch(rec0, rec1, rec2, top - 128 - lane, top - 128 - lane >= start);
     for (;;) {
         // ---- fill: cull raw batches (walking DOWN the list) into the queue
         while (qcount < 64 && top >= start) {
-            const Batch cur = nxt;
+            const Batch cur = pf0;
+            pf0 = pf1; pf1 = pf2;
             {
-                const int nidx = top - 64 - lane;
-                nxt = load_batch_pred(rec0, rec1, rec2, nidx, nidx >= start);
+                const int nidx = top - 192 - lane;
+                pf2 = load_batch(rec0, rec1, rec2, nidx, nidx >= start);
             }
             const unsigned long long act = __ballot(bin_final >= top - 63);
             if (act != 0ull) {

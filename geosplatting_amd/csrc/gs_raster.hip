@@ -571,6 +571,39 @@ __device__ __forceinline__ unsigned long long record_pixel_mask(bool ok, float m
     return ((unsigned long long)hi << 32) | lo;
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// index of the lowest set bit of a per-lane 64-bit list, which is cleared; an empty list yields 31 (a harmless in-range index)
+// and stays empty.  v_ffbl_b32 returns -1 for zero, which C's ctz leaves undefined -- hence the two asm statements.
+__device__ __forceinline__ int gs_pop_lowest(unsigned long long& list)
+{
+    unsigned lo = (unsigned)list, hi = (unsigned)(list >> 32), flo, fhi;
+    asm("v_ffbl_b32 %0, %1" : "=v"(flo) : "v"(lo));
+    asm("v_ffbl_b32 %0, %1" : "=v"(fhi) : "v"(hi));
+    list &= list - 1ull;
+    return (int)min(flo, fhi + 32u);
+}
+
+// gs_exp_neg for two candidates at once, for callers that discard results below 1/255: without the flush to zero below 2^-125
+// and the upper clamp (sigma < 0 is rejected by the caller), which changes no result that survives the alpha >= 1/255 test --
+// those have y >= -8.  The lower clamp stays: it turns an infinite or NaN y into -126 instead of a NaN that fminf would drop.
+__device__ __forceinline__ v2f gs_exp_neg_live2(v2f sigma)
+{
+#pragma clang fp contract(off)
+    v2f y = sigma * -1.44269504f;
+    y.x = fmaxf(y.x, -126.0f); y.y = fmaxf(y.y, -126.0f);
+    const v2f n = __builtin_elementwise_rint(y);
+    const v2f f = y - n;
+    v2f p = (v2f)(0x1.41a6fep-13f);
+    p = __builtin_elementwise_fma(p, f, (v2f)(0x1.5f44f0p-10f));
+    p = __builtin_elementwise_fma(p, f, (v2f)(0x1.3b2dfep-7f));
+    p = __builtin_elementwise_fma(p, f, (v2f)(0x1.c6aed6p-5f));
+    p = __builtin_elementwise_fma(p, f, (v2f)(0x1.ebfbdap-3f));
+    p = __builtin_elementwise_fma(p, f, (v2f)(0x1.62e430p-1f));
+    p = __builtin_elementwise_fma(p, f, (v2f)(1.0f));
+    return v2f{__builtin_ldexpf(p.x, (int)n.x), __builtin_ldexpf(p.y, (int)n.y)};
+}
+
 // wave-private LDS queue of culled records (ring of 128): appended in stream order, consumed 64 at a time
 struct LaneQueue {
     float4* a;      // {mx, my, 0.5a, b}
@@ -696,54 +729,81 @@ raster_fwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
 #ifdef GS_RASTER_PHASES
         if (blockIdx.x == 0 && threadIdx.x == 0) _pw0 = (long long)__builtin_readcyclecounter();
 #endif
+        int cur_slot = -1;                    // queue slot of the last candidate this pixel composited in this dense batch
         while (__ballot(list != 0ull) != 0ull) {
             GS_STAT(3, 1);
 #ifdef GS_RASTER_PHASES
             if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_raster_stats[3], 1ull);
 #endif
-            float alpha_u[GS_LANES_NPT]; bool ok_u[GS_LANES_NPT]; float4 col_u[GS_LANES_NPT]; int idx_u[GS_LANES_NPT];
-#pragma unroll
-            for (int u = 0; u < GS_LANES_NPT; ++u) {
-                const bool has = list != 0ull;
-                const int j = has ? __builtin_ctzll(list) : 0;               // lanes without a candidate re-read slot qhead (masked)
-                list = has ? (list & (list - 1ull)) : 0ull;
-                const int slot = (qhead + j) & (GS_LANES_Q - 1);
-                const float4 a = q.a[slot];
-                const float2 b = *reinterpret_cast<const float2*>(q.b + slot);
-                col_u[u] = q.c[slot];
-                idx_u[u] = q.idx[slot];
-                const float dx = a.x - px, dy = a.y - py;
-                const float t0 = a.z * dx, t1 = b.x * dy, t2 = a.w * dx;
-                const float sigma = fmaf(t0, dx, fmaf(t1, dy, t2 * dy));
-                alpha_u[u] = fminf(0.999f, b.y * gs_exp_neg(sigma));
-                ok_u[u] = has && sigma >= 0.0f && alpha_u[u] >= GS_ALPHA_MIN;
+            // phase A, two candidates side by side in packed fp32 (v_pk_*): same IEEE operations per component as the scalar form
+            const bool has0 = list != 0ull;
+            const int slot0 = (qhead + gs_pop_lowest(list)) & (GS_LANES_Q - 1);
+            const bool has1 = list != 0ull;
+            const int slot1 = (qhead + gs_pop_lowest(list)) & (GS_LANES_Q - 1);
+            const float4 a0 = q.a[slot0], a1 = q.a[slot1];
+            const float2 b0 = *reinterpret_cast<const float2*>(q.b + slot0), b1 = *reinterpret_cast<const float2*>(q.b + slot1);
+            const float4 c0 = q.c[slot0], c1 = q.c[slot1];
+            v2f sigma, alpha;
+            {
+#pragma clang fp contract(off)
+                const v2f dx = v2f{a0.x, a1.x} - px, dy = v2f{a0.y, a1.y} - py;
+                const v2f t0 = v2f{a0.z, a1.z} * dx, t1 = v2f{b0.x, b1.x} * dy, t2 = v2f{a0.w, a1.w} * dx;
+                sigma = __builtin_elementwise_fma(t0, dx, __builtin_elementwise_fma(t1, dy, t2 * dy));
+                alpha = __builtin_elementwise_min(v2f{b0.y, b1.y} * gs_exp_neg_live2(sigma), (v2f)(0.999f));
             }
+            const bool ok0 = has0 && sigma.x >= 0.0f && alpha.x >= GS_ALPHA_MIN;
+            const bool ok1 = has1 && sigma.y >= 0.0f && alpha.y >= GS_ALPHA_MIN;
+            // phase B, the serial recurrence, without branches: a rejected candidate composites with weight zero
+            bool stopped;
+            {
+                const float next_T = T * (1.0f - alpha.x);
+                const bool live = ok0 && !done;
+                const bool stop = live && next_T <= 1e-4f;
+                const bool acc = live && !stop;
+#ifdef GS_RASTER_STATS
+                if (acc) GS_STAT_ALL(2, 1);
+#endif
+                const float vis = acc ? alpha.x * T : 0.0f;
+                if (CD <= 3) {
+                    pix[0] = fmaf(c0.x, vis, pix[0]);
+                    if (CD > 1) pix[1] = fmaf(c0.y, vis, pix[1]);
+                    if (CD > 2) pix[2] = fmaf(c0.z, vis, pix[2]);
+                } else if (acc) {
+                    const float* cg = colors + (size_t)__float_as_int(c0.w) * D;
 #pragma unroll
-            for (int u = 0; u < GS_LANES_NPT; ++u) {
-                if (ok_u[u] && !done) {
-                    GS_STAT_ALL(2, 1);
-                    const float alpha = alpha_u[u];
-                    const float next_T = T * (1.0f - alpha);
-                    if (next_T <= 1e-4f) {
-                        done = true; list = 0ull;
-                    } else {
-                        const float vis = alpha * T;
-                        const float4 c = col_u[u];
-                        if (CD <= 3) {
-                            pix[0] = fmaf(c.x, vis, pix[0]);
-                            if (CD > 1) pix[1] = fmaf(c.y, vis, pix[1]);
-                            if (CD > 2) pix[2] = fmaf(c.z, vis, pix[2]);
-                        } else {
-                            const float* cg = colors + (size_t)__float_as_int(c.w) * D;
-#pragma unroll
-                            for (int k = 0; k < CD; ++k) if (k < D) pix[k] = fmaf(cg[k], vis, pix[k]);
-                        }
-                        T = next_T;
-                        cur_idx = idx_u[u];
-                    }
+                    for (int k = 0; k < CD; ++k) if (k < D) pix[k] = fmaf(cg[k], vis, pix[k]);
                 }
+                T = acc ? next_T : T;
+                cur_slot = acc ? slot0 : cur_slot;
+                done = done || stop;
+                stopped = stop;
             }
+            {
+                const float next_T = T * (1.0f - alpha.y);
+                const bool live = ok1 && !done;
+                const bool stop = live && next_T <= 1e-4f;
+                const bool acc = live && !stop;
+#ifdef GS_RASTER_STATS
+                if (acc) GS_STAT_ALL(2, 1);
+#endif
+                const float vis = acc ? alpha.y * T : 0.0f;
+                if (CD <= 3) {
+                    pix[0] = fmaf(c1.x, vis, pix[0]);
+                    if (CD > 1) pix[1] = fmaf(c1.y, vis, pix[1]);
+                    if (CD > 2) pix[2] = fmaf(c1.z, vis, pix[2]);
+                } else if (acc) {
+                    const float* cg = colors + (size_t)__float_as_int(c1.w) * D;
+#pragma unroll
+                    for (int k = 0; k < CD; ++k) if (k < D) pix[k] = fmaf(cg[k], vis, pix[k]);
+                }
+                T = acc ? next_T : T;
+                cur_slot = acc ? slot1 : cur_slot;
+                done = done || stop;
+                stopped = stopped || stop;
+            }
+            list = stopped ? 0ull : list;
         }
+        if (cur_slot >= 0) cur_idx = q.idx[cur_slot];
 #ifdef GS_RASTER_PHASES
         if (blockIdx.x == 0 && threadIdx.x == 0) { atomicAdd(&g_raster_stats[2], (unsigned long long)((long long)__builtin_readcyclecounter() - _pw0)); atomicAdd(&g_raster_stats[4], 1ull); }
 #endif
@@ -981,6 +1041,12 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
     constexpr int NV = 6 + CD;
     constexpr int RPI = 64 / NV;
     extern __shared__ __align__(16) unsigned char gs_lds_raw[];
+#ifdef GS_EXP_SKIP_HEAVY
+    if ((int)blockIdx.x < GS_EXP_SKIP_HEAVY) return;
+#endif
+#ifdef GS_EXP_ONLY_HEAVY
+    if ((int)blockIdx.x >= GS_EXP_ONLY_HEAVY) return;
+#endif
     const int tile = tile_order[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int tx = tile % tile_w, ty = tile / tile_w;

@@ -40,6 +40,23 @@ extern "C" int gs_raster_stats_read(unsigned long long* host8, int reset)
     if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_raster_stats), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
+// per-block timeline (diagnostic, -DGS_RASTER_PHASES): [3 * b] = first wave start, [3 * b + 1] = last wave end (100 MHz wall clock),
+// [3 * b + 2] = list length of the tile
+#define GS_TL_MAX 16384
+__device__ unsigned long long g_raster_tl[3 * GS_TL_MAX];
+extern "C" int gs_raster_timeline_read(unsigned long long* host, int n_blocks, int reset)
+{
+    if (n_blocks > GS_TL_MAX) return -1;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_raster_tl), sizeof(unsigned long long) * 3 * n_blocks) != hipSuccess) return -1;
+    if (reset) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_raster_tl)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned long long) * 3 * GS_TL_MAX) != hipSuccess) return -1; }
+    return 0;
+}
+#ifdef GS_RASTER_PHASES
+#define GS_TL_BEGIN(len) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < GS_TL_MAX) { const unsigned long long _t = wall_clock64(); \
+    unsigned long long* _e = g_raster_tl + 3 * blockIdx.x; if (threadIdx.x == 0) { _e[2] = (unsigned long long)(len); } \
+    atomicMax(_e, ~_t); } } while (0)
+#define GS_TL_END() do { if ((threadIdx.x & 63) == 0 && blockIdx.x < GS_TL_MAX) atomicMax(g_raster_tl + 3 * blockIdx.x + 1, wall_clock64()); } while (0)
+#endif
 #define GS_STAT(i, v) do { const unsigned long long _sv = (unsigned long long)(v); if ((threadIdx.x & 63) == 0) atomicAdd(&g_raster_stats[i], _sv); } while (0)
 #define GS_STAT_ALL(i, v) atomicAdd(&g_raster_stats[i], (unsigned long long)(v))      /* every active lane adds */
 #ifdef GS_RASTER_PHASES            /* cycles of wave 0 of the LONGEST tile (block 0 in LPT order) per phase: overrides the counters above */
@@ -53,6 +70,10 @@ extern "C" int gs_raster_stats_read(unsigned long long* host8, int reset)
 #else
 #define GS_STAT(i, v) do { } while (0)
 #define GS_STAT_ALL(i, v) do { } while (0)
+#endif
+#ifndef GS_TL_BEGIN
+#define GS_TL_BEGIN(len) do { } while (0)
+#define GS_TL_END() do { } while (0)
 #endif
 #ifndef GS_PHASE_BEGIN
 #define GS_PHASE_BEGIN() do { } while (0)
@@ -604,6 +625,20 @@ __device__ __forceinline__ v2f gs_exp_neg_live2(v2f sigma)
     return v2f{__builtin_ldexpf(p.x, (int)n.x), __builtin_ldexpf(p.y, (int)n.y)};
 }
 
+// 1 / x, correctly rounded, for x in [2^-10, 1] (here x = 1 - alpha in [0.001, 0.9961]): hardware reciprocal (1 ulp), one Newton
+// step, one Markstein correction -- all in packed fma.  No scaling or special cases are needed on this range; the oracle divides
+// (IEEE), and tests/test_gpu_rasterizer.py::test_rcp_exact_exhaustive checks every float of the range through gs_selftest_rcp.
+__device__ __forceinline__ v2f gs_rcp_exact2(v2f x)
+{
+#pragma clang fp contract(off)
+    const v2f r0 = v2f{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)};
+    const v2f one = (v2f)(1.0f);
+    const v2f e0 = __builtin_elementwise_fma(-x, r0, one);
+    const v2f r1 = __builtin_elementwise_fma(r0, e0, r0);
+    const v2f e1 = __builtin_elementwise_fma(-x, r1, one);
+    return __builtin_elementwise_fma(e1, r1, r1);
+}
+
 // wave-private LDS queue of culled records (ring of 128): appended in stream order, consumed 64 at a time
 struct LaneQueue {
     float4* a;      // {mx, my, 0.5a, b}
@@ -668,6 +703,7 @@ raster_fwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
 
     const int start = offsets[tile];
     const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    GS_TL_BEGIN(end - start);
 
     float T = 1.0f;
     int cur_idx = 0;
@@ -820,6 +856,7 @@ raster_fwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
         for (int k = 0; k < CD; ++k)
             if (k < D) render[pid * D + k] = background ? fmaf(T, background[k], pix[k]) : pix[k];
     }
+    GS_TL_END();
 }
 
 template <int CD>
@@ -1057,7 +1094,8 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
 
     const int start = offsets[tile];
     const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
-    if (end <= start) return;
+    GS_TL_BEGIN(end - start);
+    if (end <= start) { GS_TL_END(); return; }
 
     unsigned char* wbase = gs_lds_raw + (size_t)wave * LD::WAVE_BYTES;
     const LaneQueue q = lane_queue(wbase);
@@ -1087,6 +1125,7 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
         for (int k = 0; k < CD; ++k) if (k < D) bg_dot += background[k] * v_rc[k];
     }
     float T = T_final;
+    const float tail_k = T_final * v_a - T_final * bg_dot;        // d(render)/d(alpha) through the final transmittance, times (1 - alpha)
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
 
     int top = bin_final;
@@ -1102,6 +1141,7 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
     Batch pf2 = load_batch(rec0, rec1, rec2, top - 128 - lane, top - 128 - lane >= start);
     for (;;) {
         // ---- fill: cull raw batches (walking DOWN the list) into the queue
+        { GS_PHASE_BEGIN();
         while (qcount < 64 && top >= start) {
             const Batch cur = pf0;
             pf0 = pf1; pf1 = pf2;
@@ -1118,9 +1158,11 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
             }
             top -= 64;
         }
+        GS_PHASE_END(0); }
         if (qcount == 0) break;
         int nb = qcount < 64 ? qcount : 64;
         lanes_lds_sync();
+        GS_PHASE_BEGIN();
         // ---- dense batch: lane j owns queue slot qhead + j (stream indices DEcrease with j)
         const int idx_low = q.idx[(qhead + nb - 1) & (GS_LANES_Q - 1)];
         const bool live = bin_final >= idx_low;
@@ -1150,44 +1192,80 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
         unsigned long long list = gs_bit_transpose64(pm, lane);
         GS_STAT(5, nb);
         lanes_lds_sync();
+        GS_PHASE_END(1);
+        long long _pw0 = 0;
+#ifdef GS_RASTER_PHASES
+        if (blockIdx.x == 0 && threadIdx.x == 0) { _pw0 = (long long)__builtin_readcyclecounter(); atomicAdd(&g_raster_stats[6], 1ull); }
+#endif
+        // Two candidates per lane and trip.  Phase A (fetch, alpha, 1/(1 - alpha)) is independent per candidate and runs in packed
+        // fp32; phase B is the serial transmittance recurrence, without branches: a rejected candidate leaves T and the colour
+        // buffer unchanged and stores a zero pair.
         while (__ballot(list != 0ull) != 0ull) {
             GS_STAT(6, 1);
-            if (list != 0ull) {
-                const int j = __builtin_ctzll(list);
-                list &= list - 1ull;
-                const int slot = (qhead + j) & (GS_LANES_Q - 1);
-                const float4 a = q.a[slot];
-                const float2 b = *reinterpret_cast<const float2*>(q.b + slot);
-                const int idxj = q.idx[slot];
-                const int e = pbase[j] + __popcll(msk[j] & lane_lt);
-                const float ga = a.z, gb = a.w, gc = b.x, go = b.y;
-                const float dx = a.x - px, dy = a.y - py;
-                const float t0 = ga * dx, t1 = gc * dy, t2 = gb * dx;
-                const float sigma = fmaf(t0, dx, fmaf(t1, dy, t2 * dy));
-                const float vis = gs_exp_neg(sigma);
-                const float alpha = fminf(0.999f, go * vis);
-                float s_out = 0.0f, f_out = 0.0f;
-                if (idxj <= bin_final && sigma >= 0.0f && alpha >= GS_ALPHA_MIN) {
-                    GS_STAT_ALL(7, 1);
-                    const float4 c = q.c[slot];
-                    const float gcol[4] = { c.x, c.y, c.z, 0.0f };
-                    const float ra = 1.0f / (1.0f - alpha);        // correctly rounded (v_rcp_f32 alone drifts 1e-4 over a 1000-pair transmittance chain)
-                    T *= ra;
-                    const float fac = alpha * T;
-                    float v_alpha = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < CD; ++k) v_alpha += (gcol[k] * T - buffer[k] * ra) * v_rc[k];
-                    v_alpha += T_final * ra * v_a;
-                    if (background) v_alpha += -T_final * ra * bg_dot;
-                    if (go * vis <= 0.999f) s_out = -go * vis * v_alpha;
-                    f_out = fac;
-#pragma unroll
-                    for (int k = 0; k < CD; ++k) buffer[k] += gcol[k] * fac;
-                }
-                pairbuf[e] = make_float2(s_out, f_out);
+#ifdef GS_RASTER_PHASES
+            if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_raster_stats[5], 1ull);
+#endif
+            const bool has0 = list != 0ull;
+            const int j0 = gs_pop_lowest(list);
+            const bool has1 = list != 0ull;
+            const int j1 = gs_pop_lowest(list);
+            const int slot0 = (qhead + j0) & (GS_LANES_Q - 1), slot1 = (qhead + j1) & (GS_LANES_Q - 1);
+            const float4 a0 = q.a[slot0], a1 = q.a[slot1];
+            const float2 b0 = *reinterpret_cast<const float2*>(q.b + slot0), b1 = *reinterpret_cast<const float2*>(q.b + slot1);
+            const float4 c0 = q.c[slot0], c1 = q.c[slot1];
+            const int idx0 = q.idx[slot0], idx1 = q.idx[slot1];
+            const int e0 = pbase[j0] + __popcll(msk[j0] & lane_lt), e1 = pbase[j1] + __popcll(msk[j1] & lane_lt);
+            v2f sigma, ov, alpha, ra;
+            {
+#pragma clang fp contract(off)
+                const v2f dx = v2f{a0.x, a1.x} - px, dy = v2f{a0.y, a1.y} - py;
+                const v2f t0 = v2f{a0.z, a1.z} * dx, t1 = v2f{b0.x, b1.x} * dy, t2 = v2f{a0.w, a1.w} * dx;
+                sigma = __builtin_elementwise_fma(t0, dx, __builtin_elementwise_fma(t1, dy, t2 * dy));
+                ov = v2f{b0.y, b1.y} * gs_exp_neg_live2(sigma);
+                alpha = __builtin_elementwise_min(ov, (v2f)(0.999f));
+                ra = gs_rcp_exact2((v2f)(1.0f) - alpha);
+            }
+            const bool ok0 = has0 && idx0 <= bin_final && sigma.x >= 0.0f && alpha.x >= GS_ALPHA_MIN;
+            const bool ok1 = has1 && idx1 <= bin_final && sigma.y >= 0.0f && alpha.y >= GS_ALPHA_MIN;
+            {
+                const float Tn = T * ra.x;
+                const float fac = ok0 ? alpha.x * Tn : 0.0f;
+                float v_alpha = ra.x * tail_k;
+                v_alpha += (c0.x * Tn - buffer[0] * ra.x) * v_rc[0];
+                if (CD > 1) v_alpha += (c0.y * Tn - buffer[1] * ra.x) * v_rc[1];
+                if (CD > 2) v_alpha += (c0.z * Tn - buffer[2] * ra.x) * v_rc[2];
+                const float s_out = (ok0 && ov.x <= 0.999f) ? -ov.x * v_alpha : 0.0f;
+                buffer[0] = fmaf(c0.x, fac, buffer[0]);
+                if (CD > 1) buffer[1] = fmaf(c0.y, fac, buffer[1]);
+                if (CD > 2) buffer[2] = fmaf(c0.z, fac, buffer[2]);
+                T = ok0 ? Tn : T;
+#ifdef GS_RASTER_STATS
+                if (ok0) GS_STAT_ALL(7, 1);
+#endif
+                if (has0) pairbuf[e0] = make_float2(s_out, fac);
+            }
+            {
+                const float Tn = T * ra.y;
+                const float fac = ok1 ? alpha.y * Tn : 0.0f;
+                float v_alpha = ra.y * tail_k;
+                v_alpha += (c1.x * Tn - buffer[0] * ra.y) * v_rc[0];
+                if (CD > 1) v_alpha += (c1.y * Tn - buffer[1] * ra.y) * v_rc[1];
+                if (CD > 2) v_alpha += (c1.z * Tn - buffer[2] * ra.y) * v_rc[2];
+                const float s_out = (ok1 && ov.y <= 0.999f) ? -ov.y * v_alpha : 0.0f;
+                buffer[0] = fmaf(c1.x, fac, buffer[0]);
+                if (CD > 1) buffer[1] = fmaf(c1.y, fac, buffer[1]);
+                if (CD > 2) buffer[2] = fmaf(c1.z, fac, buffer[2]);
+                T = ok1 ? Tn : T;
+#ifdef GS_RASTER_STATS
+                if (ok1) GS_STAT_ALL(7, 1);
+#endif
+                if (has1) pairbuf[e1] = make_float2(s_out, fac);
             }
         }
         lanes_lds_sync();
+#ifdef GS_RASTER_PHASES
+        if (blockIdx.x == 0 && threadIdx.x == 0) { const long long _t = (long long)__builtin_readcyclecounter(); atomicAdd(&g_raster_stats[2], (unsigned long long)(_t - _pw0)); _pw0 = _t; }
+#endif
         // ---- reduction: lane j sums the pairs of record j over the set bits of its pixel mask (pixel order)
         float sum[NV];
 #pragma unroll
@@ -1197,6 +1275,9 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
             unsigned long long m = pm;
             int e = cum - cnt;
             while (__ballot(m != 0ull) != 0ull) {
+#ifdef GS_RASTER_PHASES
+                if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_raster_stats[7], 1ull);
+#endif
                 if (m != 0ull) {
                     const int p = __builtin_ctzll(m);
                     m &= m - 1ull;
@@ -1214,6 +1295,9 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
             }
         }
         lanes_lds_sync();                                          // pairbuf is dead: its space becomes the commit staging
+#ifdef GS_RASTER_PHASES
+        if (blockIdx.x == 0 && threadIdx.x == 0) { const long long _t = (long long)__builtin_readcyclecounter(); atomicAdd(&g_raster_stats[3], (unsigned long long)(_t - _pw0)); _pw0 = _t; }
+#endif
         {
             const float ga = ra4.z, gb = ra4.w, gc = rb4.x, go = rb4.y;
             const float M0 = sum[0], Mx = sum[1], My = sum[2];
@@ -1245,9 +1329,13 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
             }
         }
         lanes_lds_sync();
+#ifdef GS_RASTER_PHASES
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_raster_stats[4], (unsigned long long)((long long)__builtin_readcyclecounter() - _pw0));
+#endif
         qhead = (qhead + nb) & (GS_LANES_Q - 1);
         qcount -= nb;
     }
+    GS_TL_END();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1501,4 +1589,29 @@ static int raster_bwd_impl(int W, int H, int tile_size, int D, int V, const floa
     if (D <= 16) GS_BWD(16);
     GS_BWD(32);
 #undef GS_BWD
+}
+
+// ---------------------------------------------------------------------------------------------------
+// self-test hook: counts the floats with bit patterns in [lo_bits, hi_bits] for which gs_rcp_exact2 differs from IEEE division
+__global__ void __launch_bounds__(256) selftest_rcp_kernel(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* mismatches)
+{
+    const uint64_t n = (uint64_t)hi_bits - lo_bits + 1;
+    unsigned long long bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float(lo_bits + (uint32_t)i);
+        const v2f r = gs_rcp_exact2(v2f{x, x});
+        const float d = __fdiv_rn(1.0f, x);
+        bad += (__float_as_uint(r.x) != __float_as_uint(d)) + (__float_as_uint(r.y) != __float_as_uint(d));
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+extern "C" int gs_selftest_rcp(uint32_t lo_bits, uint32_t hi_bits, uint64_t* mismatches_dev, void* stream)
+{
+    GS_CHECK_ARG(mismatches_dev != nullptr && hi_bits >= lo_bits, "bad range");
+    hipStream_t s = (hipStream_t)stream;
+    GS_CHECK_HIP(hipMemsetAsync(mismatches_dev, 0, sizeof(uint64_t), s));
+    hipLaunchKernelGGL(selftest_rcp_kernel, dim3(4096), dim3(256), 0, s, lo_bits, hi_bits, (unsigned long long*)mismatches_dev);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
 }

@@ -163,6 +163,12 @@ int gs_raster_bwd_acc(int W, int H, int tile_size, int D, int V, const float* co
                       const float* v_render, const float* v_alphas, float* v_packed, const void* ws, size_t ws_bytes,
                       void* stream);
 
+/* Self-test of the compositor's reciprocal (hardware v_rcp_f32 + Newton + Markstein correction, which replaces the IEEE
+ * division 1 / (1 - alpha) of gsplat's rasterize_to_pixels backward): *mismatches_dev (device uint64) = number of floats
+ * with bit patterns in [lo_bits, hi_bits] whose result differs from the correctly rounded quotient (counted twice, once
+ * per packed component).  Test hook; no reference counterpart. */
+int gs_selftest_rcp(uint32_t lo_bits, uint32_t hi_bits, uint64_t* mismatches_dev, void* stream);
+
 /* ------------------------------------------------------------------ A7 ----------------------------- */
 /* Projection backward + gather backward from the packed records of gs_raster_bwd; dense outputs [N,*] are fully
  * written (zeros for culled Gaussians) -- no caller-side zeroing needed -- or, with accumulate != 0, ADDED to

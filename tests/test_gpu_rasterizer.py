@@ -294,3 +294,19 @@ def test_onesweep_passes_bit_identical(cuda):
         assert res.returncode == 0, res.stderr[-2000:]
         outs.append(res.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1], outs
+
+
+def test_rcp_exact_exhaustive(cuda):
+    """The compositor backward's 1 / (1 - alpha) is a hardware reciprocal plus two correction steps; the oracle (and
+    gsplat) divide.  Every float of [2^-11, 1] -- the range 1 - alpha can take is [0.001, 0.9961] -- must give the
+    correctly rounded quotient, so the two stay bit-identical."""
+    import ctypes as C
+    import struct
+    from geosplatting_amd import _lib as L
+    lo = struct.unpack("<I", struct.pack("<f", 2.0 ** -11))[0]
+    hi = struct.unpack("<I", struct.pack("<f", 1.0))[0]
+    bad = torch.zeros(1, dtype=torch.int64, device=cuda)
+    rc = L.lib().gs_selftest_rcp(C.c_uint32(lo), C.c_uint32(hi), C.c_void_p(bad.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, L.lib().gs_last_error()
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0

@@ -536,6 +536,8 @@ __device__ __forceinline__ unsigned long long gs_bit_transpose64(unsigned long l
     return ((unsigned long long)hi << 32) | lo;
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 // active rectangle of a quadrant wave in QUADRANT pixel indices (0..7)
 __device__ __forceinline__ void active_rect_i(unsigned long long act, int& xmin, int& xmax, int& ymin, int& ymax)
 {
@@ -573,26 +575,33 @@ __device__ __forceinline__ unsigned long long record_pixel_mask(bool ok, float m
         const unsigned long long rows = (~0ull >> (8 * (7 - y1))) & (~0ull << (8 * y0));
         return ((((unsigned long long)rep) << 32) | rep) & rows;
     }
-    const float tau = __logf(255.0f * op) + 0.004f;                         // slack >> rounding of sigma at a pixel
-    const float inv2a = 0.5f / ha;
+    // A superset with slack is all that is needed, so this runs on the raw hardware log2 / rcp / sqrt (1 ulp, no denormal or
+    // range fix-ups: the precise sqrtf / division / logf expansions made this function 410 instructions per dense batch, a fifth
+    // of the kernel), two pixel rows at a time in packed fp32.
+    const float tau = __builtin_amdgcn_logf(255.0f * op) * 0.69314718f + 0.004f;     // slack >> rounding of sigma at a pixel
+    const float inv2a = 0.5f * __builtin_amdgcn_rcpf(ha);
     const float k1 = cb * cb - 4.0f * ha * hc, k2 = 4.0f * ha * tau, k3 = cb * inv2a;
     const float mxo = mx - ox, dy0 = my - oy;
     unsigned lo = 0u, hi = 0u;
 #pragma unroll
-    for (int y = 0; y < 8; ++y) {
-        const float dy = dy0 - (float)y;
-        const float disc = fmaf(dy * dy, k1, k2);
-        const float w = sqrtf(fmaxf(disc, 0.0f)) * inv2a + 0.01f;
-        const float xc = fmaf(dy, k3, mxo);                                  // px - ox = mxo - dx,  dx centre = -k3 dy
-        const float xl = fmaxf(ceilf(xc - w), x0f), xh = fminf(floorf(xc + w), x1f);
-        const bool on = (y >= y0) && (y <= y1) && (disc >= 0.0f) && (xl <= xh);
-        const unsigned bits = on ? (((2u << (int)xh) - 1u) & ~((1u << (int)xl) - 1u)) : 0u;
-        if (y < 4) lo |= bits << (8 * y); else hi |= bits << (8 * (y - 4));
+    for (int y = 0; y < 8; y += 2) {
+        const v2f dy = (v2f)(dy0) - v2f{(float)y, (float)(y + 1)};
+        const v2f disc = __builtin_elementwise_fma(dy * dy, (v2f)(k1), (v2f)(k2));
+        const v2f root = v2f{__builtin_amdgcn_sqrtf(fmaxf(disc.x, 0.0f)), __builtin_amdgcn_sqrtf(fmaxf(disc.y, 0.0f))};
+        const v2f w = __builtin_elementwise_fma(root, (v2f)(inv2a), (v2f)(0.01f));
+        const v2f xc = __builtin_elementwise_fma(dy, (v2f)(k3), (v2f)(mxo));        // px - ox = mxo - dx,  dx centre = -k3 dy
+        const v2f xlo = xc - w, xhi = xc + w;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int yy = y + u;
+            const float xl = fmaxf(ceilf(u ? xlo.y : xlo.x), x0f), xh = fminf(floorf(u ? xhi.y : xhi.x), x1f);
+            const bool on = (yy >= y0) && (yy <= y1) && ((u ? disc.y : disc.x) >= 0.0f) && (xl <= xh);
+            const unsigned bits = on ? (((2u << (int)xh) - 1u) & (~0u << (int)xl)) : 0u;
+            if (yy < 4) lo |= bits << (8 * yy); else hi |= bits << (8 * (yy - 4));
+        }
     }
     return ((unsigned long long)hi << 32) | lo;
 }
-
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 // index of the lowest set bit of a per-lane 64-bit list, which is cleared; an empty list yields 31 (a harmless in-range index)
 // and stays empty.  v_ffbl_b32 returns -1 for zero, which C's ctz leaves undefined -- hence the two asm statements.

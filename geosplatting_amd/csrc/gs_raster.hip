@@ -520,12 +520,17 @@ __device__ __forceinline__ unsigned long long gs_bit_transpose64(unsigned long l
         const unsigned recv = gs_lane_xor<32>(up ? lo : hi);
         if (up) lo = recv; else hi = recv;
     }
+    // one exchange stage without divergence: the partner's word rotated right by K (upper lanes) or left by K (lower lanes;
+    // = right by 32 - K) lines its wanted bits up with the positions this lane gives away; the bits that wrap around fall
+    // outside the select mask.  2 VALU per word and stage (v_alignbit + v_bfi) -- the two-sided `up ? ... : ...` form made
+    // the compiler emit both sides under exec masks, ~150 instructions per transposition.
 #define GS_TR_STAGE(K, LOM)                                                                                        \
     {                                                                                                              \
         const bool up = (lane & K) != 0;                                                                           \
+        const unsigned rot = up ? (unsigned)K : (unsigned)(32 - K), take = up ? LOM : ~LOM;                        \
         const unsigned rl = gs_lane_xor<K>(lo), rh = gs_lane_xor<K>(hi);                                           \
-        lo = up ? ((lo & ~LOM) | ((rl & ~LOM) >> K)) : ((lo & LOM) | ((rl & LOM) << K));                           \
-        hi = up ? ((hi & ~LOM) | ((rh & ~LOM) >> K)) : ((hi & LOM) | ((rh & LOM) << K));                           \
+        lo = (__builtin_amdgcn_alignbit(rl, rl, rot) & take) | (lo & ~take);                                       \
+        hi = (__builtin_amdgcn_alignbit(rh, rh, rot) & take) | (hi & ~take);                                       \
     }
     GS_TR_STAGE(16, 0x0000ffffu)
     GS_TR_STAGE(8, 0x00ff00ffu)
@@ -665,12 +670,33 @@ __device__ __forceinline__ LaneQueue lane_queue(unsigned char* base)
     return q;
 }
 
-// cull one raw batch against the active rectangle (pixel-centre coordinates) and append the survivors; returns their number
-__device__ __forceinline__ int lanes_cull_append(const LaneQueue& q, const Batch& cur, int idx, int lane, float rx0, float rx1,
-                                                 float ry0, float ry1, int qtail)
+// Raw batch of the stream held in registers while its loads are in flight.  THREE are kept (r[0..2], consumed round-robin by
+// LANES_FILL below): rotating them through "pf0 = pf1; pf1 = pf2" cost 18 v_mov_b64 per raw batch, a quarter of the fill loop.
+struct RawBatch { float4 r0, r1, r2; };
+__device__ __forceinline__ void raw_load(RawBatch& b, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
+                                         const float4* __restrict__ rec2, int idx, bool in_range)
+{
+    const int safe = in_range ? idx : 0;          // no branch around the loads (see load_batch); out-of-range lanes are masked at the cull
+    b.r0 = rec0[safe]; b.r1 = rec1[safe]; b.r2 = rec2[safe];
+}
+
+// centre and half-extent (pixel-centre coordinates) of the bounding rectangle of the active lanes of a quadrant wave
+__device__ __forceinline__ void active_rect_c(unsigned long long act, int qx0, int qy0, float& cx, float& cy, float& ex, float& ey)
+{
+    int xmin, xmax, ymin, ymax;
+    active_rect_i(act, xmin, xmax, ymin, ymax);
+    cx = (float)qx0 + 0.5f + 0.5f * (float)(xmin + xmax); ex = 0.5f * (float)(xmax - xmin);
+    cy = (float)qy0 + 0.5f + 0.5f * (float)(ymin + ymax); ey = 0.5f * (float)(ymax - ymin);
+}
+
+// cull one raw batch against the active rectangle and append the survivors to the queue; returns their number (wave-uniform).
+// |mx - cx| <= hx + ex is the interval-overlap test (mx + hx >= x0 && mx - hx <= x1) in two instructions per axis; the extents
+// carry 0.02 px + 0.05 % of slack (alpha_extent), far above the rounding of either form.
+__device__ __forceinline__ int lanes_cull_append(const LaneQueue& q, const RawBatch& cur, bool in_range, int idx, int lane, float cx,
+                                                 float cy, float ex, float ey, int qtail)
 {
     const float mx = cur.r0.x, my = cur.r0.y, hx = cur.r1.z, hy = cur.r1.w;
-    const bool hit = cur.ok && (hx >= 0.0f) && (mx + hx >= rx0) && (mx - hx <= rx1) && (my + hy >= ry0) && (my - hy <= ry1);
+    const bool hit = in_range && (hx >= 0.0f) && (fabsf(mx - cx) <= hx + ex) && (fabsf(my - cy) <= hy + ey);
     const unsigned long long hmask = __ballot(hit);
     if (hit) {
         const int slot = (qtail + __popcll(hmask & ((1ull << lane) - 1ull))) & (GS_LANES_Q - 1);
@@ -678,6 +704,18 @@ __device__ __forceinline__ int lanes_cull_append(const LaneQueue& q, const Batch
     }
     return __popcll(hmask);
 }
+
+// The fill loop of the lanes kernels, unrolled over the three raw batches in flight.  CONT is the loop condition, STEP(B)
+// consumes batch B (cull + append + advance) and reloads it with the batch three steps ahead; `phase` (wave-uniform, kept
+// across dense batches) says which of the three is next.
+#define LANES_FILL(CONT, STEP)                                                                     \
+    while (CONT) {                                                                                 \
+        switch (phase) {                                                                           \
+        case 0: STEP(raw0); phase = 1; if (!(CONT)) break; [[fallthrough]];                        \
+        case 1: STEP(raw1); phase = 2; if (!(CONT)) break; [[fallthrough]];                        \
+        default: STEP(raw2); phase = 0;                                                            \
+        }                                                                                          \
+    }
 
 __device__ __forceinline__ void lanes_lds_sync()
 {
@@ -724,29 +762,29 @@ raster_fwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
     int qhead = 0, qcount = 0;                                    // wave-uniform
     int base = start;
     // THREE raw batches in flight: between two dense batches the fill loop consumes raw batches back to back (17-20 of 64
-    // records survive the cull), and with one batch of prefetch every iteration sat out a full memory latency -- on the
-    // silhouette tiles that bound the launch, ~110 raw batches x 1-2 us
-    Batch pf0 = load_batch(rec0, rec1, rec2, start + lane, start + lane < end);
-    Batch pf1 = load_batch(rec0, rec1, rec2, start + 64 + lane, start + 64 + lane < end);
-    Batch pf2 = load_batch(rec0, rec1, rec2, start + 128 + lane, start + 128 + lane < end);
+    // records survive the cull), and with one batch of prefetch every iteration sat out a full memory latency
+    RawBatch raw0, raw1, raw2;
+    raw_load(raw0, rec0, rec1, rec2, start + lane, start + lane < end);
+    raw_load(raw1, rec0, rec1, rec2, start + 64 + lane, start + 64 + lane < end);
+    raw_load(raw2, rec0, rec1, rec2, start + 128 + lane, start + 128 + lane < end);
+    int phase = 0;
     for (;;) {
         unsigned long long act = __ballot(!done);
         if (act == 0ull) break;
         // ---- fill: cull raw batches into the queue until a dense batch is available
         { GS_PHASE_BEGIN();
-        while (qcount < 64 && base < end) {
-            float rx0, rx1, ry0, ry1;
-            active_rect(act, qx0, qy0, rx0, rx1, ry0, ry1);
-            const Batch cur = pf0;
-            pf0 = pf1; pf1 = pf2;
-            {
-                const int nidx = base + 192 + lane;
-                pf2 = load_batch(rec0, rec1, rec2, nidx, nidx < end);
-            }
-            GS_STAT(0, 1);
-            qcount += lanes_cull_append(q, cur, base + lane, lane, rx0, rx1, ry0, ry1, qhead + qcount);
-            base += 64;
+        float rcx, rcy, rex, rey;
+        active_rect_c(act, qx0, qy0, rcx, rcy, rex, rey);
+#define FWD_FILL_STEP(B)                                                                                               \
+        {                                                                                                              \
+            GS_STAT(0, 1);                                                                                             \
+            const int n_hit = lanes_cull_append(q, B, base + lane < end, base + lane, lane, rcx, rcy, rex, rey, qhead + qcount); \
+            raw_load(B, rec0, rec1, rec2, base + 192 + lane, base + 192 + lane < end);                                 \
+            qcount += n_hit;                                                                                           \
+            base += 64;                                                                                                \
         }
+        LANES_FILL(qcount < 64 && base < end, FWD_FILL_STEP)
+#undef FWD_FILL_STEP
         GS_PHASE_END(0); }
         if (qcount == 0) break;
         const int nb = qcount < 64 ? qcount : 64;
@@ -925,30 +963,34 @@ raster_bwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
     if (top >= end) top = end - 1;
 
     int qhead = 0, qcount = 0;                                    // wave-uniform
-    // three raw batches in flight, branch-free loads (see the forward kernel: the launch is bound by the memory latency of the
-    // fill loop on its longest tiles; a predicated load is waited for at the join, i.e. not prefetched at all)
-    Batch pf0 = load_batch(rec0, rec1, rec2, top - lane, top - lane >= start);
-    Batch pf1 = load_batch(rec0, rec1, rec2, top - 64 - lane, top - 64 - lane >= start);
-    Batch pf2 = load_batch(rec0, rec1, rec2, top - 128 - lane, top - 128 - lane >= start);
+    // three raw batches in flight, branch-free loads, consumed round-robin (see the forward kernel)
+    top = __builtin_amdgcn_readfirstlane(top);
+    RawBatch raw0, raw1, raw2;
+    raw_load(raw0, rec0, rec1, rec2, top - lane, top - lane >= start);
+    raw_load(raw1, rec0, rec1, rec2, top - 64 - lane, top - 64 - lane >= start);
+    raw_load(raw2, rec0, rec1, rec2, top - 128 - lane, top - 128 - lane >= start);
+    int phase = 0;
     for (;;) {
         // ---- fill: cull raw batches (walking DOWN the list) into the queue
-        while (qcount < 64 && top >= start) {
-            const Batch cur = pf0;
-            pf0 = pf1; pf1 = pf2;
-            {
-                const int nidx = top - 192 - lane;
-                pf2 = load_batch(rec0, rec1, rec2, nidx, nidx >= start);
-            }
-            // pixels whose last composited entry lies at or after this batch's lowest index can be valid in it
-            const unsigned long long act = __ballot(bin_final >= top - 63);
-            if (act != 0ull) {
-                float rx0, rx1, ry0, ry1;
-                active_rect(act, qx0, qy0, rx0, rx1, ry0, ry1);
-                GS_STAT(4, 1);
-                qcount += lanes_cull_append(q, cur, top - lane, lane, rx0, rx1, ry0, ry1, qhead + qcount);
-            }
-            top -= 64;
+        { GS_PHASE_BEGIN();
+        // pixels whose last composited entry lies at or after a batch's lowest index can be valid in it
+#define BWD_FILL_STEP(B)                                                                                               \
+        {                                                                                                              \
+            const unsigned long long act_b = __ballot(bin_final >= top - 63);                                          \
+            int n_hit = 0;                                                                                             \
+            if (act_b != 0ull) {                                                                                       \
+                float rcx, rcy, rex, rey;                                                                              \
+                active_rect_c(act_b, qx0, qy0, rcx, rcy, rex, rey);                                                    \
+                GS_STAT(4, 1);                                                                                         \
+                n_hit = lanes_cull_append(q, B, top - lane >= start, top - lane, lane, rcx, rcy, rex, rey, qhead + qcount); \
+            }                                                                                                          \
+            raw_load(B, rec0, rec1, rec2, top - 192 - lane, top - 192 - lane >= start);                                \
+            qcount += n_hit;                                                                                           \
+            top -= 64;                                                                                                 \
         }
+        LANES_FILL(qcount < 64 && top >= start, BWD_FILL_STEP)
+#undef BWD_FILL_STEP
+        GS_PHASE_END(0); }
         if (qcount == 0) break;
         const int nb = qcount < 64 ? qcount : 64;
         lanes_lds_sync();
@@ -1143,30 +1185,33 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
     if (top >= end) top = end - 1;
 
     int qhead = 0, qcount = 0;                                    // wave-uniform
-    // three raw batches in flight, branch-free loads (see the forward kernel: the launch is bound by the memory latency of the
-    // fill loop on its longest tiles; a predicated load is waited for at the join, i.e. not prefetched at all)
-    Batch pf0 = load_batch(rec0, rec1, rec2, top - lane, top - lane >= start);
-    Batch pf1 = load_batch(rec0, rec1, rec2, top - 64 - lane, top - 64 - lane >= start);
-    Batch pf2 = load_batch(rec0, rec1, rec2, top - 128 - lane, top - 128 - lane >= start);
+    // three raw batches in flight, branch-free loads, consumed round-robin (see the forward kernel)
+    top = __builtin_amdgcn_readfirstlane(top);
+    RawBatch raw0, raw1, raw2;
+    raw_load(raw0, rec0, rec1, rec2, top - lane, top - lane >= start);
+    raw_load(raw1, rec0, rec1, rec2, top - 64 - lane, top - 64 - lane >= start);
+    raw_load(raw2, rec0, rec1, rec2, top - 128 - lane, top - 128 - lane >= start);
+    int phase = 0;
     for (;;) {
         // ---- fill: cull raw batches (walking DOWN the list) into the queue
         { GS_PHASE_BEGIN();
-        while (qcount < 64 && top >= start) {
-            const Batch cur = pf0;
-            pf0 = pf1; pf1 = pf2;
-            {
-                const int nidx = top - 192 - lane;
-                pf2 = load_batch(rec0, rec1, rec2, nidx, nidx >= start);
-            }
-            const unsigned long long act = __ballot(bin_final >= top - 63);
-            if (act != 0ull) {
-                float rx0, rx1, ry0, ry1;
-                active_rect(act, qx0, qy0, rx0, rx1, ry0, ry1);
-                GS_STAT(4, 1);
-                qcount += lanes_cull_append(q, cur, top - lane, lane, rx0, rx1, ry0, ry1, qhead + qcount);
-            }
-            top -= 64;
+        // pixels whose last composited entry lies at or after a batch's lowest index can be valid in it
+#define BWD_FILL_STEP(B)                                                                                               \
+        {                                                                                                              \
+            const unsigned long long act_b = __ballot(bin_final >= top - 63);                                          \
+            int n_hit = 0;                                                                                             \
+            if (act_b != 0ull) {                                                                                       \
+                float rcx, rcy, rex, rey;                                                                              \
+                active_rect_c(act_b, qx0, qy0, rcx, rcy, rex, rey);                                                    \
+                GS_STAT(4, 1);                                                                                         \
+                n_hit = lanes_cull_append(q, B, top - lane >= start, top - lane, lane, rcx, rcy, rex, rey, qhead + qcount); \
+            }                                                                                                          \
+            raw_load(B, rec0, rec1, rec2, top - 192 - lane, top - 192 - lane >= start);                                \
+            qcount += n_hit;                                                                                           \
+            top -= 64;                                                                                                 \
         }
+        LANES_FILL(qcount < 64 && top >= start, BWD_FILL_STEP)
+#undef BWD_FILL_STEP
         GS_PHASE_END(0); }
         if (qcount == 0) break;
         int nb = qcount < 64 ? qcount : 64;

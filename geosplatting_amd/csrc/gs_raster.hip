@@ -565,17 +565,16 @@ __device__ __forceinline__ void active_rect_i(unsigned long long act, int& xmin,
 //   sigma(dx, dy) = ha dx^2 + cb dx dy + hc dy^2 <= tau := log(255 op)     (ha = a/2, hc = c/2, dx = mx - px)
 // per pixel row (fixed dy):  dx in [xc - w, xc + w],  xc = -cb dy / (2 ha),  w = sqrt(dy^2 (cb^2 - 4 ha hc) + 4 ha tau) / (2 ha).
 __device__ __forceinline__ unsigned long long record_pixel_mask(bool ok, float mx, float my, float ha, float cb, float hc, float op,
-                                                                float hx, float hy, int qx0, int qy0, int xmin, int xmax, int ymin,
-                                                                int ymax)
+                                                                int qx0, int qy0, int xmin, int xmax, int ymin, int ymax)
 {
+    // (the extents hx, hy of the stream record are not consulted: the per-row intervals bound the ellipse in both directions, and
+    // the queue need not carry them -- 1 KB of LDS per wave)
     const float ox = (float)qx0 + 0.5f, oy = (float)qy0 + 0.5f;
-    const float x0f = fmaxf(ceilf(mx - hx - ox), (float)xmin), x1f = fminf(floorf(mx + hx - ox), (float)xmax);
-    const float y0f = fmaxf(ceilf(my - hy - oy), (float)ymin), y1f = fminf(floorf(my + hy - oy), (float)ymax);
-    if (!(ok && hx >= 0.0f && x0f <= x1f && y0f <= y1f)) return 0ull;
-    const int y0 = (int)y0f, y1 = (int)y1f;
-    if (!GS_LANES_EXACT_MASK || !(ha > 1e-12f) || !(hx < 1e20f)) {          // bounding rectangle (degenerate conics)
-        const int x0 = (int)x0f, x1 = (int)x1f;
-        const unsigned colmask = ((2u << x1) - 1u) & ~((1u << x0) - 1u);
+    const float x0f = (float)xmin, x1f = (float)xmax;
+    if (!ok) return 0ull;
+    const int y0 = ymin, y1 = ymax;
+    if (!GS_LANES_EXACT_MASK || !(ha > 1e-12f)) {                            // the active rectangle (degenerate conics)
+        const unsigned colmask = ((2u << xmax) - 1u) & ~((1u << xmin) - 1u);
         const unsigned rep = colmask * 0x01010101u;
         const unsigned long long rows = (~0ull >> (8 * (7 - y1))) & (~0ull << (8 * y0));
         return ((((unsigned long long)rep) << 32) | rep) & rows;
@@ -656,17 +655,17 @@ __device__ __forceinline__ v2f gs_rcp_exact2(v2f x)
 // wave-private LDS queue of culled records (ring of 128): appended in stream order, consumed 64 at a time
 struct LaneQueue {
     float4* a;      // {mx, my, 0.5a, b}
-    float4* b;      // {0.5c, opacity, hx, hy}
+    float2* b;      // {0.5c, opacity}   (the extents hx, hy of the stream record serve the cull only)
     float4* c;      // {c0, c1, c2, bits(g)}
     int* idx;       // stream index
 };
 static constexpr int GS_LANES_Q = 128;
-static constexpr int GS_LANES_Q_BYTES = GS_LANES_Q * (16 + 16 + 16 + 4);   // per wave
+static constexpr int GS_LANES_Q_BYTES = GS_LANES_Q * (16 + 16 + 8 + 4);    // per wave
 
 __device__ __forceinline__ LaneQueue lane_queue(unsigned char* base)
 {
     LaneQueue q;
-    q.a = (float4*)base; q.b = q.a + GS_LANES_Q; q.c = q.b + GS_LANES_Q; q.idx = (int*)(q.c + GS_LANES_Q);
+    q.a = (float4*)base; q.c = q.a + GS_LANES_Q; q.b = (float2*)(q.c + GS_LANES_Q); q.idx = (int*)(q.b + GS_LANES_Q);
     return q;
 }
 
@@ -700,7 +699,7 @@ __device__ __forceinline__ int lanes_cull_append(const LaneQueue& q, const RawBa
     const unsigned long long hmask = __ballot(hit);
     if (hit) {
         const int slot = (qtail + __popcll(hmask & ((1ull << lane) - 1ull))) & (GS_LANES_Q - 1);
-        q.a[slot] = cur.r0; q.b[slot] = cur.r1; q.c[slot] = cur.r2; q.idx[slot] = idx;
+        q.a[slot] = cur.r0; q.b[slot] = make_float2(cur.r1.x, cur.r1.y); q.c[slot] = cur.r2; q.idx[slot] = idx;
     }
     return __popcll(hmask);
 }
@@ -796,8 +795,9 @@ raster_fwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
         unsigned long long pm;
         {
             const int slot = (qhead + lane) & (GS_LANES_Q - 1);
-            const float4 a = q.a[slot], b = q.b[slot];
-            pm = record_pixel_mask(lane < nb, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, qx0, qy0, xmin, xmax, ymin, ymax);
+            const float4 a = q.a[slot];
+            const float2 b = q.b[slot];
+            pm = record_pixel_mask(lane < nb, a.x, a.y, a.z, a.w, b.x, b.y, qx0, qy0, xmin, xmax, ymin, ymax);
         }
         GS_STAT(1, nb);
         unsigned long long list = gs_bit_transpose64(pm, lane);
@@ -824,7 +824,7 @@ raster_fwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
             const bool has1 = list != 0ull;
             const int slot1 = (qhead + gs_pop_lowest(list)) & (GS_LANES_Q - 1);
             const float4 a0 = q.a[slot0], a1 = q.a[slot1];
-            const float2 b0 = *reinterpret_cast<const float2*>(q.b + slot0), b1 = *reinterpret_cast<const float2*>(q.b + slot1);
+            const float2 b0 = q.b[slot0], b1 = q.b[slot1];
             const float4 c0 = q.c[slot0], c1 = q.c[slot1];
             v2f sigma, alpha;
             {
@@ -1003,8 +1003,9 @@ raster_bwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
             int xmin, xmax, ymin, ymax;
             active_rect_i(act, xmin, xmax, ymin, ymax);
             const int slot = (qhead + lane) & (GS_LANES_Q - 1);
-            const float4 a = q.a[slot], b = q.b[slot];
-            const unsigned long long pm = record_pixel_mask(lane < nb, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, qx0, qy0, xmin, xmax,
+            const float4 a = q.a[slot];
+            const float2 b = q.b[slot];
+            const unsigned long long pm = record_pixel_mask(lane < nb, a.x, a.y, a.z, a.w, b.x, b.y, qx0, qy0, xmin, xmax,
                                                             ymin, ymax);
             list = gs_bit_transpose64(pm, lane);
             if (!live) list = 0ull;
@@ -1017,7 +1018,7 @@ raster_bwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
                 list &= list - 1ull;
                 const int slot = (qhead + j) & (GS_LANES_Q - 1);
                 const float4 a = q.a[slot];
-                const float2 b = *reinterpret_cast<const float2*>(q.b + slot);
+                const float2 b = q.b[slot];
                 const int idxj = q.idx[slot];
                 const float ga = a.z, gb = a.w, gc = b.x, go = b.y;
                 const float dx = a.x - px, dy = a.y - py;
@@ -1103,14 +1104,16 @@ raster_bwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
 // registers (dx = mx - px is a function of the pixel index), from which the nine gradients follow:
 //     v_xy = (2 ha Mx + b My, b Mx + 2 hc My),  v_conic = (Mxx/2, Mxy, Myy/2),  v_opacity = -M0 / opacity.
 // The sums are exact per-lane fp32 FMAs in pixel order: the per-(quadrant, Gaussian) result is deterministic.
-static constexpr int GS_PAIR_CAP = 512;                       // pair slots per dense batch (records beyond wait for the next one)
+#ifndef GS_PAIR_CAP_N
+#define GS_PAIR_CAP_N 448
+#endif
+static constexpr int GS_PAIR_CAP = GS_PAIR_CAP_N;                       // pair slots per dense batch (records beyond wait for the next one)
 template <int CD>
 struct Lanes2Lds {
     static constexpr int NV = 6 + CD;
     static constexpr int OFF_MSK = GS_LANES_Q_BYTES;
     static constexpr int OFF_BASE = OFF_MSK + 64 * 8;
-    static constexpr int OFF_PIX = OFF_BASE + 64 * 4;
-    static constexpr int OFF_PAIR = OFF_PIX + 64 * 16;
+    static constexpr int OFF_PAIR = OFF_BASE + 64 * 4;
     static constexpr int PAIR_BYTES = GS_PAIR_CAP * 8 > 64 * NV * 4 ? GS_PAIR_CAP * 8 : 64 * NV * 4;
     static constexpr int WAVE_BYTES = OFF_PAIR + PAIR_BYTES;
 };
@@ -1152,7 +1155,6 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
     const LaneQueue q = lane_queue(wbase);
     unsigned long long* msk = (unsigned long long*)(wbase + LD::OFF_MSK);
     int* pbase = (int*)(wbase + LD::OFF_BASE);
-    float4* pix = (float4*)(wbase + LD::OFF_PIX);
     float2* pairbuf = (float2*)(wbase + LD::OFF_PAIR);
     float* stage = (float*)(wbase + LD::OFF_PAIR);              // aliases pairbuf (separated by wave syncs)
 
@@ -1169,7 +1171,6 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
 #pragma unroll
         for (int k = 0; k < CD; ++k) if (k < D) v_rc[k] = v_render[pid * D + k];
     }
-    pix[lane] = make_float4(v_rc[0], CD > 1 ? v_rc[1] : 0.0f, CD > 2 ? v_rc[2] : 0.0f, CD > 3 ? v_rc[3] : 0.0f);
     float bg_dot = 0.0f;
     if (background) {
 #pragma unroll
@@ -1226,12 +1227,13 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
         const bool live = bin_final >= idx_low;
         const unsigned long long act = __ballot(live);
         const int myslot = (qhead + lane) & (GS_LANES_Q - 1);
-        const float4 ra4 = q.a[myslot], rb4 = q.b[myslot];       // the record this lane OWNS in the reduction
+        const float4 ra4 = q.a[myslot];                           // the record this lane OWNS in the reduction
+        const float2 rb4 = q.b[myslot];
         unsigned long long pm = 0ull;
         if (act != 0ull) {
             int xmin, xmax, ymin, ymax;
             active_rect_i(act, xmin, xmax, ymin, ymax);
-            pm = record_pixel_mask(lane < nb, ra4.x, ra4.y, ra4.z, ra4.w, rb4.x, rb4.y, rb4.z, rb4.w, qx0, qy0, xmin, xmax, ymin, ymax) & act;
+            pm = record_pixel_mask(lane < nb, ra4.x, ra4.y, ra4.z, ra4.w, rb4.x, rb4.y, qx0, qy0, xmin, xmax, ymin, ymax) & act;
         }
         // pair slots: exclusive scan of the mask sizes; records whose pairs do not fit wait for the next dense batch
         const int cnt = __popcll(pm);
@@ -1269,7 +1271,7 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
             const int j1 = gs_pop_lowest(list);
             const int slot0 = (qhead + j0) & (GS_LANES_Q - 1), slot1 = (qhead + j1) & (GS_LANES_Q - 1);
             const float4 a0 = q.a[slot0], a1 = q.a[slot1];
-            const float2 b0 = *reinterpret_cast<const float2*>(q.b + slot0), b1 = *reinterpret_cast<const float2*>(q.b + slot1);
+            const float2 b0 = q.b[slot0], b1 = q.b[slot1];
             const float4 c0 = q.c[slot0], c1 = q.c[slot1];
             const int idx0 = q.idx[slot0], idx1 = q.idx[slot1];
             const int e0 = pbase[j0] + __popcll(msk[j0] & lane_lt), e1 = pbase[j1] + __popcll(msk[j1] & lane_lt);
@@ -1336,7 +1338,8 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
                 const bool has = m != 0ull;
                 const int p = gs_pop_lowest(m);
                 const float2 sfr = pairbuf[has ? e : 0];
-                const float4 vr = pix[p];
+                float4 vr;                                             // v_render of pixel p: from that lane's registers (ds_bpermute, no LDS storage)
+                vr.x = __shfl(v_rc[0], p, 64); vr.y = CD > 1 ? __shfl(v_rc[1], p, 64) : 0.0f; vr.z = CD > 2 ? __shfl(v_rc[2], p, 64) : 0.0f; vr.w = 0.0f;
                 e += has ? 1 : 0;
                 const float s_w = has ? sfr.x : 0.0f, f_w = has ? sfr.y : 0.0f;
                 const v2f d = v2f{X, Y} - v2f{(float)(p & 7), (float)(p >> 3)};

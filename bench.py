@@ -260,6 +260,11 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    # capacity protocol: the timed steps ran without any (V, I) read-back if a capacity was known before them (default: learnt in
+    # the warm-up); an overflow in any of them would make the number invalid -- checked here, outside the timed region
+    cap_ok = step.poll_capacity(wait=True)
+    capacity = {"mode": "device-side counts, no host synchronisation inside a step" if step._i_cap is not None else "exact (one read-back per view)",
+                "n_isects_cap": step._i_cap, "overflow_in_timed_steps": (not cap_ok)}
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -346,6 +351,7 @@ def main():
                               "achieved_GBs": view_bytes * views_per_s / world / 1e9,
                               "frac_of_8TBs": view_bytes * views_per_s / world / 1e9 / HBM_PEAK_GBS},
             "gpu_view_ms_without_prefilter": view_ms,
+            "capacity_protocol": capacity,
         }
         if cb is not None:
             result["parity"] = cb.pop("parity", None)

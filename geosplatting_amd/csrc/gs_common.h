@@ -28,6 +28,19 @@ void gs_set_error(const char* fmt, ...);
 
 static inline int gs_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// A size that is either known on the host (dev == NULL: n itself) or lives in device memory (capacity protocol: n is the
+// caller's CAPACITY -- grids and buffers are sized by it -- and the kernels read the actual count, clamped to the capacity).
+struct GsCount {
+    long long n;
+    const long long* dev;
+};
+__device__ __forceinline__ long long gs_count(const GsCount& c)
+{
+    if (c.dev == nullptr) return c.n;
+    const long long v = *c.dev;
+    return v < 0 ? 0 : (v < c.n ? v : c.n);
+}
+
 // ---- wave64 cross-lane helpers -------------------------------------------------------------------
 __device__ __forceinline__ float gs_readlane(float v, int lane)
 {

@@ -433,9 +433,12 @@ extern "C" int gs_isect_emit(int V, const float* means2d, const int32_t* radii, 
 // ---------------------------------------------------------------------------------------------------
 // A4 offsets: offsets[t] = first sorted position whose tile id >= t.
 __global__ void __launch_bounds__(256)
-isect_offsets_kernel(int64_t n, const int64_t* __restrict__ ids, int n_tiles, int32_t* __restrict__ offsets)
+isect_offsets_kernel(GsCount nc, const int64_t* __restrict__ ids, int n_tiles, int32_t* __restrict__ offsets)
 {
+    const int64_t n = gs_count(nc);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n == 0 && i == 0)                                  // (only reachable with a device-side count: the host path memsets)
+        for (int t = 0; t < n_tiles; ++t) offsets[t] = 0;
     if (i >= n) return;
     const int cur = (int)(((uint64_t)ids[i]) >> 32);
     if (i == 0) {
@@ -457,8 +460,18 @@ extern "C" int gs_isect_offsets(int64_t n_isects, const int64_t* isect_ids_sorte
         GS_CHECK_HIP(hipMemsetAsync(offsets, 0, sizeof(int32_t) * (size_t)n_tiles, s));
         return GS_OK;
     }
-    hipLaunchKernelGGL(isect_offsets_kernel, dim3(gs_cdiv(n_isects, 256)), dim3(256), 0, s, n_isects,
+    hipLaunchKernelGGL(isect_offsets_kernel, dim3(gs_cdiv(n_isects, 256)), dim3(256), 0, s, GsCount{ n_isects, nullptr },
                        isect_ids_sorted, n_tiles, offsets);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
+extern "C" int gs_isect_offsets_cap(int64_t n_isects_cap, const int64_t* counts_dev, const int64_t* isect_ids_sorted, int n_tiles,
+                                    int32_t* offsets, void* stream)
+{
+    GS_CHECK_ARG(n_isects_cap > 0 && n_tiles > 0 && counts_dev != nullptr, "bad sizes");
+    hipLaunchKernelGGL(isect_offsets_kernel, dim3(gs_cdiv(n_isects_cap, 256)), dim3(256), 0, (hipStream_t)stream,
+                       GsCount{ n_isects_cap, (const long long*)counts_dev + 1 }, isect_ids_sorted, n_tiles, offsets);
     GS_CHECK_LAUNCH();
     return GS_OK;
 }
@@ -480,7 +493,7 @@ __device__ __forceinline__ int find_slot(const int32_t* __restrict__ gids, int V
 }
 
 __global__ void __launch_bounds__(256)
-project_bwd_kernel(int N, int V, int D, const float* __restrict__ means, const float* __restrict__ quats,
+project_bwd_kernel(int N, GsCount vc, int D, const float* __restrict__ means, const float* __restrict__ quats,
                    const float* __restrict__ scales, const float* __restrict__ opacities,
                    const float* __restrict__ viewmat, const float* __restrict__ K, int W, int H, float eps2d,
                    const int32_t* __restrict__ gaussian_ids, const float* __restrict__ conics,
@@ -491,6 +504,7 @@ project_bwd_kernel(int N, int V, int D, const float* __restrict__ means, const f
 {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
+    const int V = (int)gs_count(vc);
     const int v = find_slot(gaussian_ids, V, N, n);
     float g_mean[3] = { 0, 0, 0 }, g_quat[4] = { 0, 0, 0, 0 }, g_scale[3] = { 0, 0, 0 }, g_op = 0.0f;
     if (v >= 0) {
@@ -657,6 +671,22 @@ project_bwd_kernel(int N, int V, int D, const float* __restrict__ means, const f
     }
 }
 
+static int project_bwd_impl(int N, GsCount vc, int D, const float* means, const float* quats, const float* scales,
+                            const float* opacities, const float* viewmat, const float* K, int W, int H,
+                            float eps2d, const int32_t* gaussian_ids, const float* conics,
+                            const float* compensations, const float* v_packed, int rec_stride,
+                            const float* v_depths, float* v_means, float* v_quats, float* v_scales, float* v_opacities, float* v_colors,
+                            int accumulate, void* stream)
+{
+    if (N == 0) return GS_OK;
+    hipLaunchKernelGGL(project_bwd_kernel, dim3(gs_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, N, vc, D, means,
+                       quats, scales, opacities, viewmat, K, W, H, eps2d, gaussian_ids, conics, compensations,
+                       v_packed, rec_stride > 0 ? rec_stride : ((6 + D) + 15) / 16 * 16, v_depths, v_means, v_quats,
+                       v_scales, v_opacities, v_colors, accumulate);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
 extern "C" int gs_project_bwd(int N, int V, int D, const float* means, const float* quats, const float* scales,
                               const float* opacities, const float* viewmat, const float* K, int W, int H,
                               float eps2d, const int32_t* gaussian_ids, const float* conics,
@@ -665,11 +695,20 @@ extern "C" int gs_project_bwd(int N, int V, int D, const float* means, const flo
                               int accumulate, void* stream)
 {
     GS_CHECK_ARG(N >= 0 && V >= 0 && V <= N, "bad sizes");
-    if (N == 0) return GS_OK;
-    hipLaunchKernelGGL(project_bwd_kernel, dim3(gs_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, N, V, D, means,
-                       quats, scales, opacities, viewmat, K, W, H, eps2d, gaussian_ids, conics, compensations,
-                       v_packed, rec_stride > 0 ? rec_stride : ((6 + D) + 15) / 16 * 16, v_depths, v_means, v_quats,
-                       v_scales, v_opacities, v_colors, accumulate);
-    GS_CHECK_LAUNCH();
-    return GS_OK;
+    return project_bwd_impl(N, GsCount{ V, nullptr }, D, means, quats, scales, opacities, viewmat, K, W, H, eps2d, gaussian_ids, conics,
+                            compensations, v_packed, rec_stride, v_depths, v_means, v_quats, v_scales, v_opacities, v_colors, accumulate,
+                            stream);
+}
+
+extern "C" int gs_project_bwd_cap(int N, const int64_t* counts_dev, int D, const float* means, const float* quats, const float* scales,
+                                  const float* opacities, const float* viewmat, const float* K, int W, int H,
+                                  float eps2d, const int32_t* gaussian_ids, const float* conics,
+                                  const float* compensations, const float* v_packed, int rec_stride,
+                                  const float* v_depths, float* v_means, float* v_quats, float* v_scales, float* v_opacities,
+                                  float* v_colors, int accumulate, void* stream)
+{
+    GS_CHECK_ARG(N >= 0 && counts_dev != nullptr, "bad sizes");
+    return project_bwd_impl(N, GsCount{ N, (const long long*)counts_dev }, D, means, quats, scales, opacities, viewmat, K, W, H, eps2d,
+                            gaussian_ids, conics, compensations, v_packed, rec_stride, v_depths, v_means, v_quats, v_scales, v_opacities,
+                            v_colors, accumulate, stream);
 }

@@ -84,11 +84,12 @@ extern "C" int gs_raster_timeline_read(unsigned long long* host, int n_blocks, i
 // stream build: rec0 = {mx, my, 0.5a, b}, rec1 = {0.5c, opacity, hx, hy}, rec2 = {c0, c1, c2, bits(g)}
 // (hx < 0 marks "can never reach alpha_min").  One thread per sorted intersection.
 __global__ void __launch_bounds__(256)
-build_stream_kernel(int n_isects, int D, const int32_t* __restrict__ flatten_ids, const float* __restrict__ means2d,
+build_stream_kernel(GsCount ic, int D, const int32_t* __restrict__ flatten_ids, const float* __restrict__ means2d,
                     const float* __restrict__ conics, const float* __restrict__ opacities,
                     const float* __restrict__ colors, float4* __restrict__ rec0, float4* __restrict__ rec1,
                     float4* __restrict__ rec2)
 {
+    const int n_isects = (int)gs_count(ic);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_isects) return;
     const int g = flatten_ids[i];
@@ -111,9 +112,10 @@ build_stream_kernel(int n_isects, int D, const int32_t* __restrict__ flatten_ids
 // Same stream from the PACKED per-visible records written by gs_pack_visible (3 aligned 16-byte gathers per
 // intersection instead of 8 scalar ones: the gather, not the 48-byte store, bounds this kernel).
 __global__ void __launch_bounds__(256)
-build_stream_packed_kernel(int n_isects, const int32_t* __restrict__ flatten_ids, const float4* __restrict__ vis,
+build_stream_packed_kernel(GsCount ic, const int32_t* __restrict__ flatten_ids, const float4* __restrict__ vis,
                            float4* __restrict__ rec0, float4* __restrict__ rec1, float4* __restrict__ rec2)
 {
+    const int n_isects = (int)gs_count(ic);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_isects) return;
     const int g = flatten_ids[i];
@@ -148,8 +150,9 @@ pack_visible_kernel(int V, int D, const float* __restrict__ means2d, const float
 // ---------------------------------------------------------------------------------------------------
 // LPT tile order: bucket tiles by floor(log2(count)) descending (single block).
 __global__ void __launch_bounds__(1024)
-tile_order_kernel(int n_tiles, int n_isects, const int32_t* __restrict__ offsets, int32_t* __restrict__ order)
+tile_order_kernel(int n_tiles, GsCount ic, const int32_t* __restrict__ offsets, int32_t* __restrict__ order)
 {
+    const int n_isects = (int)gs_count(ic);
     __shared__ int hist[32];
     __shared__ int base[32];
     if (threadIdx.x < 32) hist[threadIdx.x] = 0;
@@ -224,10 +227,11 @@ template <int CD>
 __global__ void __launch_bounds__(256)
 raster_fwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* __restrict__ tile_order,
                   const float4* __restrict__ rec0, const float4* __restrict__ rec1, const float4* __restrict__ rec2,
-                  const float* __restrict__ colors, const float* __restrict__ background, int n_isects,
+                  const float* __restrict__ colors, const float* __restrict__ background, GsCount ic,
                   const int32_t* __restrict__ offsets,
                   float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids)
 {
+    const int n_isects = (int)gs_count(ic);
     const int tile = tile_order[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPR
     const int tx = tile % tile_w, ty = tile / tile_w;
@@ -329,12 +333,13 @@ template <int CD>
 __global__ void __launch_bounds__(256)
 raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* __restrict__ tile_order,
                   const float4* __restrict__ rec0, const float4* __restrict__ rec1, const float4* __restrict__ rec2,
-                  const float* __restrict__ colors, const float* __restrict__ background, int n_isects,
+                  const float* __restrict__ colors, const float* __restrict__ background, GsCount ic,
                   const int32_t* __restrict__ offsets,
                   const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
                   const float* __restrict__ v_render, const float* __restrict__ v_alphas,
                   float* __restrict__ v_packed, int rec_stride)
 {
+    const int n_isects = (int)gs_count(ic);
     const int tile = tile_order[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPR
     const int tx = tile % tile_w, ty = tile / tile_w;
@@ -727,10 +732,11 @@ template <int CD>
 __global__ void __launch_bounds__(256)
 raster_fwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* __restrict__ tile_order,
                         const float4* __restrict__ rec0, const float4* __restrict__ rec1, const float4* __restrict__ rec2,
-                        const float* __restrict__ colors, const float* __restrict__ background, int n_isects,
+                        const float* __restrict__ colors, const float* __restrict__ background, GsCount ic,
                         const int32_t* __restrict__ offsets,
                         float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids)
 {
+    const int n_isects = (int)gs_count(ic);
     extern __shared__ __align__(16) unsigned char gs_lds_raw[];
 #ifdef GS_EXP_SKIP_HEAVY          /* timing experiment: leave out the K longest tiles (LPT order) -- is the launch bound by its tail? */
     if ((int)blockIdx.x < GS_EXP_SKIP_HEAVY) return;
@@ -910,12 +916,13 @@ template <int CD>
 __global__ void __launch_bounds__(256)
 raster_bwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* __restrict__ tile_order,
                         const float4* __restrict__ rec0, const float4* __restrict__ rec1, const float4* __restrict__ rec2,
-                        const float* __restrict__ colors, const float* __restrict__ background, int n_isects,
+                        const float* __restrict__ colors, const float* __restrict__ background, GsCount ic,
                         const int32_t* __restrict__ offsets,
                         const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
                         const float* __restrict__ v_render, const float* __restrict__ v_alphas,
                         float* __restrict__ v_packed, int rec_stride)
 {
+    const int n_isects = (int)gs_count(ic);
     constexpr int NV = 6 + CD;
     constexpr int RPI = 64 / NV;                                   // records committed per atomic instruction
     constexpr int WAVE_BYTES = GS_LANES_Q_BYTES + NV * 64 * 8;
@@ -1122,11 +1129,12 @@ template <int CD>
 __global__ void __launch_bounds__(256)
 raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* __restrict__ tile_order,
                          const float4* __restrict__ rec0, const float4* __restrict__ rec1, const float4* __restrict__ rec2,
-                         const float* __restrict__ background, int n_isects, const int32_t* __restrict__ offsets,
+                         const float* __restrict__ background, GsCount ic, const int32_t* __restrict__ offsets,
                          const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
                          const float* __restrict__ v_render, const float* __restrict__ v_alphas,
                          float* __restrict__ v_packed, int rec_stride)
 {
+    const int n_isects = (int)gs_count(ic);
     static_assert(CD <= 3, "colours come from the record stream (D <= 3)");
     using LD = Lanes2Lds<CD>;
     constexpr int NV = 6 + CD;
@@ -1450,6 +1458,15 @@ static RasterWs carve(void* ws, int64_t n_isects, int V, int tiles)
     return r;
 }
 
+// Capacity protocol: while a *_cap entry point is on the stack, the kernels launched by the functions below read the actual
+// intersection count from device memory (counts_dev = {V, I} as written by gs_project_fwd) and treat the scalar as a capacity.
+static thread_local const long long* t_counts_dev = nullptr;
+struct CountsScope {
+    explicit CountsScope(const int64_t* c) { t_counts_dev = (const long long*)c; }
+    ~CountsScope() { t_counts_dev = nullptr; }
+};
+static GsCount isect_count(int64_t n) { return GsCount{ (long long)n, t_counts_dev ? t_counts_dev + 1 : nullptr }; }
+
 template <int CD>
 static int launch_fwd(int W, int H, int D, const RasterWs& ws, const float* colors, const float* background,
                       int64_t n_isects, const int32_t* offsets, float* render, float* alphas, int32_t* last_ids,
@@ -1460,13 +1477,13 @@ static int launch_fwd(int W, int H, int D, const RasterWs& ws, const float* colo
         size_t lds = 4 * (size_t)GS_LANES_Q_BYTES;
         if (lds < gs_raster_lds_pad()) lds = gs_raster_lds_pad();
         hipLaunchKernelGGL(raster_fwd_lanes_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
-                           ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, (int)n_isects, offsets, render, alphas,
+                           ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, isect_count(n_isects), offsets, render, alphas,
                            last_ids);
         GS_CHECK_LAUNCH();
         return GS_OK;
     }
     hipLaunchKernelGGL(raster_fwd_kernel<CD>, dim3(tile_w * tile_h), dim3(256), gs_raster_lds_pad(), s, W, H, tile_w, tile_w * tile_h, D,
-                       ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, (int)n_isects, offsets, render, alphas,
+                       ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, isect_count(n_isects), offsets, render, alphas,
                        last_ids);
     GS_CHECK_LAUNCH();
     return GS_OK;
@@ -1524,11 +1541,11 @@ static int raster_prepare_impl(int W, int H, int tile_size, int D, int V, const 
             GS_CHECK_LAUNCH();
             vis = r.vis;
         }
-        hipLaunchKernelGGL(build_stream_packed_kernel, dim3(gs_cdiv(n_isects, 256)), dim3(256), 0, s, (int)n_isects, flatten_ids,
+        hipLaunchKernelGGL(build_stream_packed_kernel, dim3(gs_cdiv(n_isects, 256)), dim3(256), 0, s, isect_count(n_isects), flatten_ids,
                            vis, r.rec0, r.rec1, r.rec2);
         GS_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, tiles, (int)n_isects, offsets, r.order);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, tiles, isect_count(n_isects), offsets, r.order);
     GS_CHECK_LAUNCH();
     return GS_OK;
 }
@@ -1575,7 +1592,7 @@ static int launch_bwd(int W, int H, int D, const RasterWs& ws, const float* colo
             size_t lds = 4 * (size_t)Lanes2Lds<CD>::WAVE_BYTES;
             if (lds < gs_raster_lds_pad()) lds = gs_raster_lds_pad();
             hipLaunchKernelGGL(raster_bwd_lanes2_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
-                               ws.order, ws.rec0, ws.rec1, ws.rec2, background, (int)n_isects, offsets, alphas, last_ids,
+                               ws.order, ws.rec0, ws.rec1, ws.rec2, background, isect_count(n_isects), offsets, alphas, last_ids,
                                v_render, v_alphas, v_packed, rec_stride);
             GS_CHECK_LAUNCH();
             return GS_OK;
@@ -1590,13 +1607,13 @@ static int launch_bwd(int W, int H, int D, const RasterWs& ws, const float* colo
             attr_set = true;
         }
         hipLaunchKernelGGL(raster_bwd_lanes_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
-                           ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, (int)n_isects, offsets, alphas, last_ids,
+                           ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, isect_count(n_isects), offsets, alphas, last_ids,
                            v_render, v_alphas, v_packed, rec_stride);
         GS_CHECK_LAUNCH();
         return GS_OK;
     }
     hipLaunchKernelGGL(raster_bwd_kernel<CD>, dim3(tile_w * tile_h), dim3(256), gs_raster_lds_pad(), s, W, H, tile_w, tile_w * tile_h, D,
-                       ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, (int)n_isects, offsets, alphas, last_ids,
+                       ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, isect_count(n_isects), offsets, alphas, last_ids,
                        v_render, v_alphas, v_packed, rec_stride);
     GS_CHECK_LAUNCH();
     return GS_OK;
@@ -1651,6 +1668,39 @@ static int raster_bwd_impl(int W, int H, int tile_size, int D, int V, const floa
     if (D <= 16) GS_BWD(16);
     GS_BWD(32);
 #undef GS_BWD
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Capacity-protocol variants (include/geosplat_hip.h): V_cap / n_isects_cap size the workspace and the grids, the actual counts
+// are read on the device from counts_dev = {V, I}; nothing here needs the host to know them.
+extern "C" int gs_raster_prepare_vis_cap(int W, int H, int tile_size, int D, int V_cap, const float* vis_records, int64_t n_isects_cap,
+                                         const int64_t* counts_dev, const int32_t* offsets, const int32_t* flatten_ids, void* ws,
+                                         size_t ws_bytes, void* stream)
+{
+    GS_CHECK_ARG(counts_dev != nullptr, "counts_dev must not be NULL");
+    CountsScope sc(counts_dev);
+    return gs_raster_prepare_vis(W, H, tile_size, D, V_cap, vis_records, n_isects_cap, offsets, flatten_ids, ws, ws_bytes, stream);
+}
+
+extern "C" int gs_raster_composite_cap(int W, int H, int tile_size, int D, int V_cap, const float* colors, const float* background,
+                                       int64_t n_isects_cap, const int64_t* counts_dev, const int32_t* offsets, float* render,
+                                       float* alphas, int32_t* last_ids, const void* ws, size_t ws_bytes, void* stream)
+{
+    GS_CHECK_ARG(counts_dev != nullptr, "counts_dev must not be NULL");
+    CountsScope sc(counts_dev);
+    return gs_raster_composite(W, H, tile_size, D, V_cap, colors, background, n_isects_cap, offsets, render, alphas, last_ids, ws,
+                               ws_bytes, stream);
+}
+
+extern "C" int gs_raster_bwd_cap(int W, int H, int tile_size, int D, int V_cap, const float* colors, const float* background,
+                                 int64_t n_isects_cap, const int64_t* counts_dev, const int32_t* offsets, const float* alphas,
+                                 const int32_t* last_ids, const float* v_render, const float* v_alphas, float* v_packed, const void* ws,
+                                 size_t ws_bytes, void* stream)
+{
+    GS_CHECK_ARG(counts_dev != nullptr, "counts_dev must not be NULL");
+    CountsScope sc(counts_dev);
+    return gs_raster_bwd(W, H, tile_size, D, V_cap, colors, background, n_isects_cap, offsets, alphas, last_ids, v_render, v_alphas,
+                         v_packed, ws, ws_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

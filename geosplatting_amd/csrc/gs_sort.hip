@@ -83,8 +83,9 @@ struct FinalOut {                                                  // last tile 
 // ---- pass kernels --------------------------------------------------------------------------------------------------
 template <typename Item, typename In, typename Digit>
 __global__ void __launch_bounds__(RS_THREADS)
-radix_hist_kernel(int64_t n, In in, Digit digit, int nbins, int nblocks, unsigned* __restrict__ table)
+radix_hist_kernel(GsCount nc, In in, Digit digit, int nbins, int nblocks, unsigned* __restrict__ table)
 {
+    const int64_t n = gs_count(nc);
     __shared__ unsigned hist[256];
     hist[threadIdx.x] = 0u;
     __syncthreads();
@@ -158,9 +159,10 @@ small_scan_kernel(int total, unsigned* __restrict__ a)
 // digits straight from registers is 64 partial-sector stores).
 template <typename Item, typename In, typename Digit, typename Out, int NBITS>
 __global__ void __launch_bounds__(RS_THREADS)
-radix_scatter_kernel(int64_t n, In in, Digit digit, int nblocks, const unsigned* __restrict__ table,
+radix_scatter_kernel(GsCount nc, In in, Digit digit, int nblocks, const unsigned* __restrict__ table,
                      const unsigned* __restrict__ row_total, Out out)
 {
+    const int64_t n = gs_count(nc);
     constexpr int NB = 1 << NBITS;
     __shared__ unsigned cnt[RS_WAVES][NB];
     __shared__ unsigned dstart[NB];                              // start of digit d inside the block's sorted order
@@ -171,7 +173,7 @@ radix_scatter_kernel(int64_t n, In in, Digit digit, int nblocks, const unsigned*
     __syncthreads();
     const int64_t bbase = (int64_t)blockIdx.x * RS_TILE;
     const int64_t wbase = bbase + (int64_t)wave * RS_WCHUNK;
-    const int n_here = (int)((n - bbase) < RS_TILE ? (n - bbase) : RS_TILE);
+    const int n_here = (n - bbase) < RS_TILE ? (int)((n - bbase) > 0 ? (n - bbase) : 0) : RS_TILE;
     const u64 lane_lt = (1ull << lane) - 1ull;
     Item item[RS_ITEMS];
     unsigned dig[RS_ITEMS];
@@ -257,17 +259,18 @@ radix_scatter_kernel(int64_t n, In in, Digit digit, int nblocks, const unsigned*
 }
 
 template <typename Item, typename In, typename Digit, typename Out>
-static int radix_pass(int64_t n, In in, Digit digit, Out out, int nbits, unsigned* table, hipStream_t s)
+static int radix_pass(GsCount nc, In in, Digit digit, Out out, int nbits, unsigned* table, hipStream_t s)
 {
+    const int64_t n = nc.n;                                      // capacity: the grid and the table rows are sized by it
     const int nblocks = (int)((n + RS_TILE - 1) / RS_TILE);
     const int nbins = 1 << nbits;
     unsigned* row_total = table + (size_t)256 * nblocks;        // [256] + [256] behind the table
-    hipLaunchKernelGGL((radix_hist_kernel<Item, In, Digit>), dim3(nblocks), dim3(RS_THREADS), 0, s, n, in, digit, nbins, nblocks, table);
+    hipLaunchKernelGGL((radix_hist_kernel<Item, In, Digit>), dim3(nblocks), dim3(RS_THREADS), 0, s, nc, in, digit, nbins, nblocks, table);
     GS_CHECK_LAUNCH();
     hipLaunchKernelGGL(radix_rowscan_kernel, dim3(nbins), dim3(256), 0, s, nblocks, table, row_total);
     GS_CHECK_LAUNCH();
     switch (nbits) {
-#define RS_CASE(B) case B: hipLaunchKernelGGL((radix_scatter_kernel<Item, In, Digit, Out, B>), dim3(nblocks), dim3(RS_THREADS), 0, s, n, in, digit, nblocks, table, row_total, out); break;
+#define RS_CASE(B) case B: hipLaunchKernelGGL((radix_scatter_kernel<Item, In, Digit, Out, B>), dim3(nblocks), dim3(RS_THREADS), 0, s, nc, in, digit, nblocks, table, row_total, out); break;
         RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
 #undef RS_CASE
         default: gs_set_error("radix_pass: bad digit width %d", nbits); return GS_EINVAL;
@@ -475,7 +478,7 @@ extern "C" int gs_isect_sort(int64_t n_isects, const int64_t* isect_ids, const i
         const bool to_out = ((npass - 1 - pass) % 2) == 0;
         u64* dk = to_out ? (u64*)isect_ids_sorted : tk;
         int32_t* dv = to_out ? flatten_ids_sorted : tv;
-        const int rc = radix_pass<PairItem>(n_isects, PairIn{ src_k, src_v }, PairDigit{ shift, (1u << nbits) - 1u }, PairOut{ dk, dv }, nbits, table, s);
+        const int rc = radix_pass<PairItem>(GsCount{ n_isects, nullptr }, PairIn{ src_k, src_v }, PairDigit{ shift, (1u << nbits) - 1u }, PairOut{ dk, dv }, nbits, table, s);
         if (rc != GS_OK) return rc;
         src_k = dk; src_v = dv;
     }
@@ -506,9 +509,10 @@ __device__ __forceinline__ void tile_range_sorted(float mx, float my, int radius
 // tile rectangle of every visible Gaussian, packed (x0 | y0 << 16, x1 | y1 << 16): computed once in packed order (coalesced) so
 // that the two depth-order kernels below gather ONE 8-byte word per Gaussian instead of means2d + radii + tiles_per_gauss
 __global__ void __launch_bounds__(256)
-tile_rect_kernel(int V, const float* __restrict__ means2d, const int32_t* __restrict__ radii, int tile_size, int tile_w, int tile_h,
+tile_rect_kernel(GsCount vc, const float* __restrict__ means2d, const int32_t* __restrict__ radii, int tile_size, int tile_w, int tile_h,
                  uint2* __restrict__ rect)
 {
+    const int V = (int)gs_count(vc);
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
     const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)v);
@@ -525,8 +529,9 @@ __device__ __forceinline__ unsigned rect_count(uint2 q)
 
 // per-block totals of the tile counts in DEPTH order
 __global__ void __launch_bounds__(EM_THREADS)
-emit_blocksum_kernel(int V, const uint2* __restrict__ order, const uint2* __restrict__ rect, unsigned* __restrict__ blocksum)
+emit_blocksum_kernel(GsCount vc, const uint2* __restrict__ order, const uint2* __restrict__ rect, unsigned* __restrict__ blocksum)
 {
+    const int V = (int)gs_count(vc);
     __shared__ unsigned ws[EM_THREADS / 64];
     unsigned s = 0u;
 #pragma unroll
@@ -548,9 +553,11 @@ emit_blocksum_kernel(int V, const uint2* __restrict__ order, const uint2* __rest
 // thread r (depth rank) writes the (tile, index) items of its Gaussian, tiles row-major, at the exclusive prefix of the
 // tile counts in depth order
 __global__ void __launch_bounds__(EM_THREADS)
-emit_sorted_kernel(int V, const uint2* __restrict__ order, const uint2* __restrict__ rect, const unsigned* __restrict__ blockbase,
-                   int tile_w, uint2* __restrict__ items, int npass, int width, unsigned* __restrict__ tile_hist /*[npass][256] or NULL*/)
+emit_sorted_kernel(GsCount vc, const uint2* __restrict__ order, const uint2* __restrict__ rect, const unsigned* __restrict__ blockbase,
+                   int tile_w, uint2* __restrict__ items, unsigned item_cap, int npass, int width,
+                   unsigned* __restrict__ tile_hist /*[npass][256] or NULL*/)
 {
+    const int V = (int)gs_count(vc);
     __shared__ unsigned ws[EM_THREADS / 64];
     __shared__ unsigned th[2][256];                          // digit histograms of the tile ids this block emits (<= 2 passes)
     if (tile_hist) { th[0][threadIdx.x] = 0u; th[1][threadIdx.x] = 0u; }
@@ -585,7 +592,8 @@ emit_sorted_kernel(int V, const uint2* __restrict__ order, const uint2* __restri
         for (int i = y0; i < y1; ++i)
             for (int j = x0; j < x1; ++j) {
                 const unsigned t = (unsigned)(i * tile_w + j);
-                items[cur++] = make_uint2(t, (unsigned)v[k]);
+                if (cur < item_cap) items[cur] = make_uint2(t, (unsigned)v[k]);       // (capacity protocol: an overflowing view is reported, not written)
+                ++cur;
                 if (tile_hist) {
                     atomicAdd(&th[0][t & dmask], 1u);
                     if (npass > 1) atomicAdd(&th[1][(t >> width) & dmask], 1u);
@@ -614,10 +622,48 @@ extern "C" size_t gs_isect_bin_ws_bytes(int V, int64_t n_isects, int tile_w, int
     return tb + 3 * align256(v * 8) + align256(((v + EM_TILE - 1) / EM_TILE + 1) * 4) + 2 * align256(n * 8) + 256 + onesweep_bytes(V, n_isects);
 }
 
+// status word of the capacity protocol: {code, required n_isects}; written only on overflow (the caller zeroes it once)
+__global__ void capacity_check_kernel(const long long* __restrict__ counts, long long v_cap, long long i_cap, long long* __restrict__ status)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const long long V = counts[0], I = counts[1];
+    if (V > v_cap || I > i_cap) {
+        status[0] = GS_ENOSPC;
+        if (I > status[1]) status[1] = I;
+        if (V > status[2]) status[2] = V;
+    }
+}
+
+static int isect_bin_impl(int V, const float* means2d, const int32_t* radii, const float* depths, int64_t n_isects,
+                          const long long* counts_dev, int tile_size, int tile_w, int tile_h, int64_t* isect_ids_sorted,
+                          int32_t* flatten_ids_sorted, void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int gs_isect_bin(int V, const float* means2d, const int32_t* radii, const float* depths,
                             const int32_t* tiles_per_gauss, int64_t n_isects, int tile_size, int tile_w, int tile_h,
                             int64_t* isect_ids_sorted, int32_t* flatten_ids_sorted, void* ws, size_t ws_bytes, void* stream)
 {
+    (void)tiles_per_gauss;                                  // the counts are re-derived from the rectangles (same arithmetic as gs_project_fwd)
+    return isect_bin_impl(V, means2d, radii, depths, n_isects, nullptr, tile_size, tile_w, tile_h, isect_ids_sorted, flatten_ids_sorted,
+                          ws, ws_bytes, stream);
+}
+
+extern "C" int gs_isect_bin_cap(int V_cap, const float* means2d, const int32_t* radii, const float* depths, const int64_t* counts_dev,
+                                int64_t n_isects_cap, int tile_size, int tile_w, int tile_h, int64_t* isect_ids_sorted,
+                                int32_t* flatten_ids_sorted, void* ws, size_t ws_bytes, int64_t* status_dev, void* stream)
+{
+    GS_CHECK_ARG(counts_dev != nullptr && status_dev != nullptr, "counts_dev / status_dev must not be NULL");
+    hipLaunchKernelGGL(capacity_check_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const long long*)counts_dev, (long long)V_cap,
+                       (long long)n_isects_cap, (long long*)status_dev);
+    GS_CHECK_LAUNCH();
+    return isect_bin_impl(V_cap, means2d, radii, depths, n_isects_cap, (const long long*)counts_dev, tile_size, tile_w, tile_h,
+                          isect_ids_sorted, flatten_ids_sorted, ws, ws_bytes, stream);
+}
+
+static int isect_bin_impl(int V, const float* means2d, const int32_t* radii, const float* depths, int64_t n_isects,
+                          const long long* counts_dev, int tile_size, int tile_w, int tile_h, int64_t* isect_ids_sorted,
+                          int32_t* flatten_ids_sorted, void* ws, size_t ws_bytes, void* stream)
+{
+    const GsCount vc{ (long long)V, counts_dev }, ic{ (long long)n_isects, counts_dev ? counts_dev + 1 : nullptr };
     GS_CHECK_ARG(V >= 0 && n_isects >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0, "bad sizes");
     GS_CHECK_ARG(n_isects < (1ll << 31), "n_isects must fit int32");
     GS_CHECK_ARG((int64_t)tile_w * tile_h < (1ll << 24), "more than 2^24 tiles");
@@ -636,7 +682,8 @@ extern "C" int gs_isect_bin(int V, const float* means2d, const int32_t* radii, c
     uint2* ib = (uint2*)p; p += align256((size_t)n_isects * 8);
     // default: three kernels per pass.  GEOSPLAT_RADIX=onesweep selects the one-kernel look-back passes (bit-identical, measured
     // SLOWER on this workload: 265 vs 238 us of pass kernels per view)
-    static const bool three_kernel = [] { const char* e = getenv("GEOSPLAT_RADIX"); return !(e && !strcmp(e, "onesweep")); }();
+    static const bool three_kernel_env = [] { const char* e = getenv("GEOSPLAT_RADIX"); return !(e && !strcmp(e, "onesweep")); }();
+    const bool three_kernel = three_kernel_env || counts_dev != nullptr;   // (the look-back experiment sizes its state by the exact counts)
     int tb = 0;
     while ((1 << tb) < tile_w * tile_h) ++tb;
     if (tb < 1) tb = 1;
@@ -662,25 +709,24 @@ extern "C" int gs_isect_bin(int V, const float* means2d, const int32_t* radii, c
         if (rc != GS_OK) return rc;
     } else {
         // 1. depth order of the Gaussians: four stable 8-bit passes over (depth bits, index); the first reads the depth array
-        rc = radix_pass<uint2>((int64_t)V, DepthIn{ depths }, XDigit{ 0, 255u }, U2Out{ da }, 8, table, s);
+        rc = radix_pass<uint2>(vc, DepthIn{ depths }, XDigit{ 0, 255u }, U2Out{ da }, 8, table, s);
         if (rc != GS_OK) return rc;
-        rc = radix_pass<uint2>((int64_t)V, U2In{ da }, XDigit{ 8, 255u }, U2Out{ db }, 8, table, s);
+        rc = radix_pass<uint2>(vc, U2In{ da }, XDigit{ 8, 255u }, U2Out{ db }, 8, table, s);
         if (rc != GS_OK) return rc;
-        rc = radix_pass<uint2>((int64_t)V, U2In{ db }, XDigit{ 16, 255u }, U2Out{ da }, 8, table, s);
+        rc = radix_pass<uint2>(vc, U2In{ db }, XDigit{ 16, 255u }, U2Out{ da }, 8, table, s);
         if (rc != GS_OK) return rc;
-        rc = radix_pass<uint2>((int64_t)V, U2In{ da }, XDigit{ 24, 255u }, U2Out{ db }, 8, table, s);
+        rc = radix_pass<uint2>(vc, U2In{ da }, XDigit{ 24, 255u }, U2Out{ db }, 8, table, s);
         if (rc != GS_OK) return rc;
     }
     // 2. emission in depth order
     GS_CHECK_ARG(tile_w < 65536 && tile_h < 65536, "tile grid too large");
-    (void)tiles_per_gauss;                                  // the counts are re-derived from the rectangles (same arithmetic as gs_project_fwd)
-    hipLaunchKernelGGL(tile_rect_kernel, dim3(gs_cdiv(V, 256)), dim3(256), 0, s, V, means2d, radii, tile_size, tile_w, tile_h, rect);
+    hipLaunchKernelGGL(tile_rect_kernel, dim3(gs_cdiv(V, 256)), dim3(256), 0, s, vc, means2d, radii, tile_size, tile_w, tile_h, rect);
     GS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(emit_blocksum_kernel, dim3(eblocks), dim3(EM_THREADS), 0, s, V, db, rect, blocksum);
+    hipLaunchKernelGGL(emit_blocksum_kernel, dim3(eblocks), dim3(EM_THREADS), 0, s, vc, db, rect, blocksum);
     GS_CHECK_LAUNCH();
     hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(1024), 0, s, eblocks, blocksum);
     GS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(emit_sorted_kernel, dim3(eblocks), dim3(EM_THREADS), 0, s, V, db, rect, blocksum, tile_w, ia, npass, width,
+    hipLaunchKernelGGL(emit_sorted_kernel, dim3(eblocks), dim3(EM_THREADS), 0, s, vc, db, rect, blocksum, tile_w, ia, (unsigned)n_isects, npass, width,
                        onesweep ? thist : nullptr);
     GS_CHECK_LAUNCH();
     // 3. stable split by tile id: npass digits of `width` bits, the last one writes the sorted meta arrays
@@ -697,10 +743,10 @@ extern "C" int gs_isect_bin(int V, const float* means2d, const int32_t* radii, c
                 rc = onesweep_pass<uint2>(n_isects, U2In{ src }, XDigit{ shift, (1u << nbits) - 1u }, U2Out{ dst }, nbits, tickets + 4 + pass, st,
                                           thist + pass * 256, s);
         } else if (pass == npass - 1)
-            rc = radix_pass<uint2>(n_isects, U2In{ src }, XDigit{ shift, (1u << nbits) - 1u },
+            rc = radix_pass<uint2>(ic, U2In{ src }, XDigit{ shift, (1u << nbits) - 1u },
                                    FinalOut{ (u64*)isect_ids_sorted, flatten_ids_sorted, depths }, nbits, table, s);
         else
-            rc = radix_pass<uint2>(n_isects, U2In{ src }, XDigit{ shift, (1u << nbits) - 1u }, U2Out{ dst }, nbits, table, s);
+            rc = radix_pass<uint2>(ic, U2In{ src }, XDigit{ shift, (1u << nbits) - 1u }, U2Out{ dst }, nbits, table, s);
         if (rc != GS_OK) return rc;
         uint2* t = src; src = dst; dst = t;
     }

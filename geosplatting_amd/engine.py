@@ -24,7 +24,8 @@ import ctypes as C
 from . import _lib as L
 from .cameras import Camera
 from .parallel import GradBucket
-from .rasterization import _bin_stage, _composite_stage, _forward_stages, _prepare_stage, _project_stage
+from .rasterization import (_bin_stage, _bin_stage_cap, _composite_stage, _composite_stage_cap, _forward_stages, _prepare_stage,
+                            _prepare_stage_cap, _project_stage)
 from .shading import _MODE, _TONE, RenderableAttrs, _make_env, get_fg_lut, shade_private_copies
 from .splitsum import (CACHE_PAIR_WEIGHTS, TextureSplitSum, as_splitsum, as_splitsum_backward, as_splitsum_backward_sharded,
                        as_splitsum_sharded, can_shard_prefilter)
@@ -61,6 +62,14 @@ class RenderStep:
         self._side_stream = None
         self._tail_stream = None
         self._pre_stream = None
+        # capacity protocol state (see _step_fused / poll_capacity)
+        self._use_capacity = os.environ.get("GEOSPLAT_CAPACITY", "1") != "0"
+        self._i_cap = None                 # intersection capacity per view; None = exact mode (one (V, I) read-back per view)
+        self._status = None                # device int64[3]: {GS_ENOSPC or 0, max required I, max required V}
+        self._status_host = None
+        self._status_event = None
+        self._seen_counts = []
+        self._exact_max_i = 0              # largest intersection count read back by an exact-mode step
         self._pre_group = None
 
     def _prefilter_group(self):
@@ -190,11 +199,26 @@ class RenderStep:
                                     1e10, 0.0)
             return pr, col
 
-        def bin_view(item):                                  # A2-A4 on the side stream (host waits for that view's counts)
+        # Capacity protocol (include/geosplat_hip.h): once the engine has seen the intersection counts of a step, the later
+        # steps size every per-view buffer by (N, I_cap) and leave (V, I) on the device -- no read-back, no host wait inside
+        # the step.  The counts still travel to pinned memory asynchronously; poll_capacity() looks at them (and at the
+        # overflow status word) without blocking.
+        i_cap = self._i_cap if self._use_capacity else None
+        if i_cap is not None and self._status is None:
+            self._status = torch.zeros(3, dtype=torch.int64, device=dev)
+        seen = []                                            # (pinned counts, event) of this step's views
+
+        def bin_view(item):                                  # A2-A4 on the side stream (exact mode: host waits for that view's counts)
             pr, col = item
             with torch.cuda.stream(side):
-                state, V, I, D, whs = _bin_stage(pr)
-                state = _prepare_stage(state, V, I, D, whs)  # record stream: HBM-bound, belongs on this stream too
+                if i_cap is not None:
+                    seen.append((pr.host_counts, pr.event))       # read a step later by poll_capacity (never waited for here)
+                    state, V, I, D, whs = _bin_stage_cap(pr, i_cap, self._status)
+                    state = _prepare_stage_cap(state, V, I, D, whs)
+                else:
+                    state, V, I, D, whs = _bin_stage(pr)
+                    self._exact_max_i = max(self._exact_max_i, I)
+                    state = _prepare_stage(state, V, I, D, whs)  # record stream: HBM-bound, belongs on this stream too
                 ev = torch.cuda.Event(); ev.record(side)
             for t in list(state.values()) + [col] + list(pr.bufs):
                 if isinstance(t, torch.Tensor):
@@ -209,7 +233,10 @@ class RenderStep:
             W, H = cam.width, cam.height
             state, V, I, D, whs, ev, colors = binned
             main.wait_event(ev)
-            render, alphas, s, V, I = _composite_stage(state, V, I, D, whs, None)
+            if i_cap is not None:
+                render, alphas, s = _composite_stage_cap(state, V, I, D, whs, None)
+            else:
+                render, alphas, s, V, I = _composite_stage(state, V, I, D, whs, None)
             # keep the side stream two views ahead: A(i+2), then B1(i+1)
             if i + 2 < n_views:
                 proj.append(start_view(cameras[i + 2]))
@@ -223,9 +250,15 @@ class RenderStep:
                                         L.ptr(v_alpha), L.ptr(b["exposure"]), 1, st()), "gs_tonemap_bwd3")
             v_packed = torch.empty(V, lib.gs_raster_grad_stride(3), dtype=f32, device=dev)
             rws = s["raster_ws"]
-            L.check(lib.gs_raster_bwd(W, H, 16, 3, V, L.ptr(s["colors"]), None, L.i64(I), L.ptr(s["isect_offsets"]),
-                                      L.ptr(alphas), L.ptr(s["last_ids"]), L.ptr(v_render), L.ptr(v_alpha), L.ptr(v_packed),
-                                      L.ptr(rws), C.c_size_t(rws.numel()), st()), "gs_raster_bwd")
+            if i_cap is not None:
+                L.check(lib.gs_raster_bwd_cap(W, H, 16, 3, V, L.ptr(s["colors"]), None, L.i64(I), L.ptr(s["counts"]),
+                                              L.ptr(s["isect_offsets"]), L.ptr(alphas), L.ptr(s["last_ids"]), L.ptr(v_render),
+                                              L.ptr(v_alpha), L.ptr(v_packed), L.ptr(rws), C.c_size_t(rws.numel()), st()),
+                        "gs_raster_bwd_cap")
+            else:
+                L.check(lib.gs_raster_bwd(W, H, 16, 3, V, L.ptr(s["colors"]), None, L.i64(I), L.ptr(s["isect_offsets"]),
+                                          L.ptr(alphas), L.ptr(s["last_ids"]), L.ptr(v_render), L.ptr(v_alpha), L.ptr(v_packed),
+                                          L.ptr(rws), C.c_size_t(rws.numel()), st()), "gs_raster_bwd")
             # gradient tail of the view (A7 + S1-S3 backward: HBM / atomic-rate bound) on a third stream, so that it
             # overlaps the VALU-bound compositor of the next view; the tail kernels of successive views stay in order
             # on that stream (they accumulate into the same gradient buffers)
@@ -234,11 +267,19 @@ class RenderStep:
             eg = g_sets[0 if i < half else n_sets - 1][2]
             with torch.cuda.stream(tail):
                 tail.wait_event(ev_r)
-                L.check(lib.gs_project_bwd(N, V, 3, L.ptr(means), L.ptr(quats), L.ptr(scales_act), L.ptr(opac_act), L.ptr(vm),
-                                           L.ptr(K), W, H, L.f32(0.3), L.ptr(s["gaussian_ids_i32"]), L.ptr(s["conics"]),
-                                           L.ptr(s["compensations"]), L.ptr(v_packed), 0, None,
-                                           L.ptr(b["means"]), L.ptr(b["quats"]), L.ptr(g_scales_act), L.ptr(g_opac_act),
-                                           L.ptr(g_colors), 1, st()), "gs_project_bwd")
+                if i_cap is not None:
+                    L.check(lib.gs_project_bwd_cap(N, L.ptr(s["counts"]), 3, L.ptr(means), L.ptr(quats), L.ptr(scales_act),
+                                                   L.ptr(opac_act), L.ptr(vm), L.ptr(K), W, H, L.f32(0.3),
+                                                   L.ptr(s["gaussian_ids_i32"]), L.ptr(s["conics"]), L.ptr(s["compensations"]),
+                                                   L.ptr(v_packed), 0, None, L.ptr(b["means"]), L.ptr(b["quats"]),
+                                                   L.ptr(g_scales_act), L.ptr(g_opac_act), L.ptr(g_colors), 1, st()),
+                            "gs_project_bwd_cap")
+                else:
+                    L.check(lib.gs_project_bwd(N, V, 3, L.ptr(means), L.ptr(quats), L.ptr(scales_act), L.ptr(opac_act), L.ptr(vm),
+                                               L.ptr(K), W, H, L.f32(0.3), L.ptr(s["gaussian_ids_i32"]), L.ptr(s["conics"]),
+                                               L.ptr(s["compensations"]), L.ptr(v_packed), 0, None,
+                                               L.ptr(b["means"]), L.ptr(b["quats"]), L.ptr(g_scales_act), L.ptr(g_opac_act),
+                                               L.ptr(g_colors), 1, st()), "gs_project_bwd")
                 L.check(lib.gs_shade_bwd(N, L.ptr(means), L.ptr(normals), L.ptr(kd), L.ptr(ks), L.ptr(cam_pos),
                                          L.f32(self.min_roughness), L.f32(self.max_metallic), mode, C.byref(e), L.ptr(g_colors),
                                          L.ptr(b["means"]), L.ptr(b["normals"]), L.ptr(b["kd"]), L.ptr(b["ks"]), C.byref(eg), 1,
@@ -258,6 +299,12 @@ class RenderStep:
             if keep_images:
                 images.append(img)
         main.wait_stream(tail)
+        self._seen_counts = seen
+        if i_cap is not None:                                # the overflow word follows the step to the host, asynchronously
+            if self._status_host is None:
+                self._status_host = torch.zeros(3, dtype=torch.int64).pin_memory()
+            self._status_host.copy_(self._status, non_blocking=True)
+            self._status_event = torch.cuda.Event(); self._status_event.record()
         # chain the once-per-step activations; the per-Gaussian gradients are now final, so their all-reduce (RCCL on
         # the communication stream) overlaps the prefilter backward, whose cubemap gradient is reduced afterwards
         torch.mul(g_scales_act, scales_act, out=b["scales"])
@@ -293,11 +340,53 @@ class RenderStep:
         finish()
         return b, (images if keep_images else None)
 
+    def poll_capacity(self, wait: bool = False) -> bool:
+        """Host side of the capacity protocol; never blocks unless `wait`.  Looks at what the LAST step left in pinned memory:
+        the per-view (V, I) counts set / raise the intersection capacity (1.25 x the largest count seen, rounded up to 64 Ki),
+        and the overflow word tells whether a view of that step exceeded the capacity it ran with.  Returns False in that
+        case -- the step's gradients are then incomplete (memory-safe, a truncated view) and the caller should repeat it; the
+        capacity has already been raised.  RenderStep.__call__ polls before every step; a trainer that must not consume a
+        truncated step calls poll_capacity(wait=True) before its optimiser step (stage1.py does)."""
+        ok = True
+        max_i, self._exact_max_i = self._exact_max_i, 0
+        for hc, ev in self._seen_counts:
+            if hc is None:
+                continue
+            if wait:
+                ev.synchronize()
+            if ev.query():
+                max_i = max(max_i, int(hc[1]))
+        if self._status_event is not None:
+            if wait:
+                self._status_event.synchronize()
+            if self._status_event.query() and int(self._status_host[0]) != 0:
+                ok = False
+                max_i = max(max_i, int(self._status_host[1]))
+                self._status.zero_(); self._status_host.zero_()
+            if self._status_event.query():
+                self._status_event = None
+        from .rasterization import _pinned_pool
+        still = []
+        for hc, ev in self._seen_counts:
+            if hc is None:
+                continue
+            if ev.query():
+                _pinned_pool.append(hc)
+            else:
+                still.append((hc, ev))
+        self._seen_counts = still
+        if self._use_capacity and max_i > 0:
+            want = ((int(max_i * 1.25) + 65535) // 65536) * 65536
+            if self._i_cap is None or want > self._i_cap or max_i > self._i_cap:
+                self._i_cap = max(want, self._i_cap or 0)
+        return ok
+
     def __call__(self, cameras: List[Camera], upstream: Callable[[int, Tensor], Tensor], all_reduce: bool = True,
                  keep_images: bool = False):
         """Forward + backward for `cameras`; `upstream(i, image)` returns d(loss)/d(image) for local view i.
         Returns (grads dict of views into the flat bucket, images or None)."""
         if self.fused and self.mode == "pbr":
+            self.poll_capacity()                             # non-blocking: counts / overflow word of the previous step
             return self._step_fused(cameras, upstream, all_reduce, keep_images)
         p = self.p
         leaves = {k: v.detach().requires_grad_(True) for k, v in p.named().items()}

@@ -151,6 +151,55 @@ def _composite_stage(state, V: int, I: int, D: int, whs, background: Optional[Te
     return render, alphas, state, V, I
 
 
+# ---- capacity protocol (include/geosplat_hip.h): the same three stages without the (V, I) read-back --------------------------
+def _bin_stage_cap(pr: _Projected, I_cap: int, status: Tensor):
+    """A2-A4 with the counts left on the device: buffers, workspaces and grids are sized by (N, I_cap), the kernels read
+    (V, I) from pr's device counts; an overflow is reported in `status` (int64[3], sticky), never written out of bounds."""
+    lib = L.lib()
+    W, H, tile_size = pr.args
+    gids, radii, means2d, depths, conics, comps, opac_p, colors_p, tpg, cum, counts = pr.bufs
+    dev = means2d.device
+    N = means2d.shape[0]
+    tw, th = (W + tile_size - 1) // tile_size, (H + tile_size - 1) // tile_size
+    st = L.stream()
+    ids_s = torch.empty(I_cap, dtype=torch.int64, device=dev); flat_s = torch.empty(I_cap, dtype=torch.int32, device=dev)
+    bin_bytes = lib.gs_isect_bin_ws_bytes(N, L.i64(I_cap), tw, th)
+    bin_ws = torch.empty(max(bin_bytes, 1), dtype=torch.uint8, device=dev)
+    L.check(lib.gs_isect_bin_cap(N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(counts), L.i64(I_cap), tile_size, tw, th,
+                                 L.ptr(ids_s), L.ptr(flat_s), L.ptr(bin_ws), C.c_size_t(bin_bytes), L.ptr(status), st),
+            "gs_isect_bin_cap")
+    offsets = torch.empty(th * tw, dtype=torch.int32, device=dev)
+    L.check(lib.gs_isect_offsets_cap(L.i64(I_cap), L.ptr(counts), L.ptr(ids_s), tw * th, L.ptr(offsets), st), "gs_isect_offsets_cap")
+    state = dict(gaussian_ids_i32=gids, radii=radii, means2d=means2d, depths=depths, conics=conics, compensations=comps,
+                 opacities=opac_p, colors=colors_p, tiles_per_gauss=tpg, isect_ids=ids_s, flatten_ids=flat_s,
+                 isect_offsets=offsets, counts=counts, vis_records=pr.vis)
+    return state, N, I_cap, pr.D, (W, H, tile_size)
+
+
+def _prepare_stage_cap(state, V_cap: int, I_cap: int, D: int, whs):
+    lib = L.lib()
+    W, H, tile_size = whs
+    rws_bytes = lib.gs_raster_ws_bytes(L.i64(I_cap), V_cap, W, H, tile_size)
+    rws = torch.empty(rws_bytes, dtype=torch.uint8, device=state["means2d"].device)
+    L.check(lib.gs_raster_prepare_vis_cap(W, H, tile_size, D, V_cap, L.ptr(state["vis_records"]), L.i64(I_cap), L.ptr(state["counts"]),
+                                          L.ptr(state["isect_offsets"]), L.ptr(state["flatten_ids"]), L.ptr(rws),
+                                          C.c_size_t(rws_bytes), L.stream()), "gs_raster_prepare_vis_cap")
+    return dict({k: v for k, v in state.items() if k != "vis_records"}, raster_ws=rws)
+
+
+def _composite_stage_cap(state, V_cap: int, I_cap: int, D: int, whs, background: Optional[Tensor]):
+    lib = L.lib()
+    W, H, tile_size = whs
+    dev = state["means2d"].device
+    rws = state["raster_ws"]
+    render = torch.empty(H, W, D, dtype=torch.float32, device=dev); alphas = torch.empty(H, W, dtype=torch.float32, device=dev)
+    last_ids = torch.empty(H, W, dtype=torch.int32, device=dev)
+    L.check(lib.gs_raster_composite_cap(W, H, tile_size, D, V_cap, L.ptr(state["colors"]), L.ptr(background), L.i64(I_cap),
+                                        L.ptr(state["counts"]), L.ptr(state["isect_offsets"]), L.ptr(render), L.ptr(alphas),
+                                        L.ptr(last_ids), L.ptr(rws), C.c_size_t(rws.numel()), L.stream()), "gs_raster_composite_cap")
+    return render, alphas, dict(state, last_ids=last_ids)
+
+
 def _raster_stage(pr: _Projected, background: Optional[Tensor], depth_channel: bool = False):
     state, V, I, D, whs = _bin_stage(pr, depth_channel)
     return _composite_stage(state, V, I, D, whs, background)

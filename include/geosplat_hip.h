@@ -163,6 +163,37 @@ int gs_raster_bwd_acc(int W, int H, int tile_size, int D, int V, const float* co
                       const float* v_render, const float* v_alphas, float* v_packed, const void* ws, size_t ws_bytes,
                       void* stream);
 
+/* ------------------------------------------------------------------ capacity protocol --- */
+/* The data-dependent sizes of a view -- V visible Gaussians, I tile intersections -- exist only on the device after
+ * gs_project_fwd (counts = {V, I}, int64).  The entry points above take them as host scalars (gsplat's call shape: one
+ * read-back per view).  The *_cap variants below take CAPACITIES instead: V_cap (N always suffices) and n_isects_cap size
+ * the buffers, the workspaces and the launch grids; every kernel reads the actual count from counts_dev and clamps it to
+ * the capacity.  No host synchronisation, fixed launch shapes (capturable in a hipGraph).  If a view needs more than
+ * n_isects_cap, gs_isect_bin_cap sets status_dev = {GS_ENOSPC, max required n_isects, max required V} (int64[3], zeroed once by
+ * the caller, sticky) and that view is composited from the first n_isects_cap intersections in emission order: memory-safe,
+ * wrong image -- the caller polls status_dev at a convenient point (the engine: start of the next step), grows the capacity
+ * and repeats the step.  Workspace sizes: the *_ws_bytes functions with the capacities. */
+int gs_isect_bin_cap(int V_cap, const float* means2d, const int32_t* radii, const float* depths, const int64_t* counts_dev,
+                     int64_t n_isects_cap, int tile_size, int tile_w, int tile_h, int64_t* isect_ids_sorted,
+                     int32_t* flatten_ids_sorted, void* ws, size_t ws_bytes, int64_t* status_dev, void* stream);
+int gs_isect_offsets_cap(int64_t n_isects_cap, const int64_t* counts_dev, const int64_t* isect_ids_sorted, int n_tiles,
+                         int32_t* offsets, void* stream);
+int gs_raster_prepare_vis_cap(int W, int H, int tile_size, int D, int V_cap, const float* vis_records, int64_t n_isects_cap,
+                              const int64_t* counts_dev, const int32_t* offsets, const int32_t* flatten_ids, void* ws,
+                              size_t ws_bytes, void* stream);
+int gs_raster_composite_cap(int W, int H, int tile_size, int D, int V_cap, const float* colors, const float* background,
+                            int64_t n_isects_cap, const int64_t* counts_dev, const int32_t* offsets, float* render,
+                            float* alphas, int32_t* last_ids, const void* ws, size_t ws_bytes, void* stream);
+int gs_raster_bwd_cap(int W, int H, int tile_size, int D, int V_cap, const float* colors, const float* background,
+                      int64_t n_isects_cap, const int64_t* counts_dev, const int32_t* offsets, const float* alphas,
+                      const int32_t* last_ids, const float* v_render, const float* v_alphas, float* v_packed, const void* ws,
+                      size_t ws_bytes, void* stream);
+int gs_project_bwd_cap(int N, const int64_t* counts_dev, int D, const float* means, const float* quats, const float* scales,
+                       const float* opacities, const float* viewmat, const float* K, int W, int H, float eps2d,
+                       const int32_t* gaussian_ids, const float* conics, const float* compensations, const float* v_packed,
+                       int rec_stride, const float* v_depths, float* v_means, float* v_quats, float* v_scales,
+                       float* v_opacities, float* v_colors, int accumulate, void* stream);
+
 /* Self-test of the compositor's reciprocal (hardware v_rcp_f32 + Newton + Markstein correction, which replaces the IEEE
  * division 1 / (1 - alpha) of gsplat's rasterize_to_pixels backward): *mismatches_dev (device uint64) = number of floats
  * with bit patterns in [lo_bits, hi_bits] whose result differs from the correctly rounded quotient (counted twice, once

@@ -52,5 +52,72 @@ def test_two_ranks_equal_single_process(tmp_path):
         scale = w.abs().max().item() + 1e-30
         for r in range(2):
             err = (got[r][k] - w).abs().max().item() / scale
-            assert err < 2e-5, (k, r, err)            # different summation order over the views, nothing else
+            assert err < 5e-5, (k, r, err)            # different summation order over the views / of the float atomics, nothing else
         assert torch.equal(got[0][k], got[1][k]), k   # both ranks hold the same reduced buffer
+
+
+def _engine(dev):
+    import geosplatting_amd.synthetic as syn
+    from geosplatting_amd.engine import RenderStep, params_from_scene
+    sc = syn.sphere_scene(LEVEL, seed=2, cubemap_res=64)
+    cams = syn.blender_cameras(N_VIEWS, RES, RES)
+    step = RenderStep(params_from_scene(sc, dev, exposure=1.1))
+    ups = {i: (torch.rand(RES, RES, 4, generator=torch.Generator().manual_seed(50 + i)) * 2 - 1).to(dev) for i in range(N_VIEWS)}
+
+    global step_cams, step_up
+    step_cams, step_up = cams, (lambda j, img: ups[j].reshape(img.shape))
+
+    def run():
+        grads, images = step(cams, lambda j, img: ups[j].reshape(img.shape), all_reduce=False, keep_images=True)
+        torch.cuda.synchronize()
+        return {n: v.detach().cpu().clone() for n, v in grads.items()}, [im.detach().cpu().clone() for im in images]
+    return step, run
+
+
+def _same(ref, got):
+    for a, b in zip(ref[1], got[1]):
+        assert torch.equal(a, b)                                      # forward: same kernels on the same inputs
+    for k, w in ref[0].items():
+        scale = w.abs().max().item() + 1e-30
+        assert (got[0][k] - w).abs().max().item() / scale < 5e-5, k   # backward: order of the float atomics
+
+
+def test_capacity_protocol_equals_exact_mode():
+    """Capacity protocol (include/geosplat_hip.h): once the engine has seen the counts of a step it sizes the per-view
+    buffers by (N, I_cap) and never reads (V, I) back; images bit-identical to the exact mode, gradients equal up to the order
+    of the float atomics."""
+    step, run = _engine(torch.device("cuda", 0))
+    step._use_capacity = False
+    run()                                                             # (builds the cached prefilter tables)
+    ref = run()
+    assert step._i_cap is None
+    step._use_capacity = True
+    assert step.poll_capacity(wait=True) and step._i_cap is not None and step._i_cap % 65536 == 0
+    torch.cuda.set_sync_debug_mode("error")                           # any synchronising torch call inside the step raises
+    try:
+        grads, images = step(step_cams, step_up, all_reduce=False, keep_images=True)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    got = ({n: v.detach().cpu().clone() for n, v in grads.items()}, [im.detach().cpu().clone() for im in images])
+    assert step.poll_capacity(wait=True)                              # no overflow
+    _same(ref, got)
+
+
+def test_capacity_overflow_is_reported_and_recovered():
+    """A view that needs more intersections than the capacity is truncated (memory-safe), reported through the sticky status
+    word, and the capacity is raised so that the repeated step is complete."""
+    step, run = _engine(torch.device("cuda", 0))
+    step._use_capacity = False
+    run()
+    ref = run()
+    step._use_capacity = True
+    step._seen_counts = []; step._exact_max_i = 0                     # (forget what the exact steps learnt)
+    step._i_cap = 4096                                                # far below what a view needs
+    bad = run()
+    assert not step.poll_capacity(wait=True)                          # overflow seen ...
+    assert step._i_cap > 4096                                         # ... and the capacity raised to fit
+    assert not all(torch.equal(a, b) for a, b in zip(ref[1], bad[1])) # (the truncated step really was incomplete)
+    got = run()
+    assert step.poll_capacity(wait=True)
+    _same(ref, got)

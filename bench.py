@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--cubemap-res", type=int, default=512)
     ap.add_argument("--no-prefilter", action="store_true", help="diagnostic only: keep the pyramid fixed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", type=int, default=0, help="1: replay each step as one HIP graph (--gpus 1 only; measured 2 % slower than eager launches: the step is GPU-bound and a graph schedules the three streams less freely); 0 (default): eager launches")
     ap.add_argument("--kernel-iters", type=int, default=20)
     return ap.parse_args()
 
@@ -250,6 +251,15 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    graphed = None
+    if args.graph and world == 1 and len(cams) > 0:
+        # the whole step as ONE HIP graph (engine.RenderStep.capture): same kernels, same streams, no per-launch host work.
+        # Single-GPU only: the sharded prefilter and the gradient all-reduce (RCCL) stay eager.
+        torch.cuda.synchronize()
+        if step.poll_capacity(wait=True) and step._i_cap is not None:
+            graphed = step.capture(cams, lambda i, img: ups[i])
+            one_step = graphed
+            one_step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -262,9 +272,10 @@ def main():
     dt = time.perf_counter() - t0
     # capacity protocol: the timed steps ran without any (V, I) read-back if a capacity was known before them (default: learnt in
     # the warm-up); an overflow in any of them would make the number invalid -- checked here, outside the timed region
-    cap_ok = step.poll_capacity(wait=True)
+    cap_ok = graphed.check() if graphed is not None else step.poll_capacity(wait=True)
     capacity = {"mode": "device-side counts, no host synchronisation inside a step" if step._i_cap is not None else "exact (one read-back per view)",
-                "n_isects_cap": step._i_cap, "overflow_in_timed_steps": (not cap_ok)}
+                "n_isects_cap": step._i_cap, "overflow_in_timed_steps": (not cap_ok),
+                "hip_graph": graphed is not None}
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

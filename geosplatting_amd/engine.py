@@ -340,6 +340,58 @@ class RenderStep:
         finish()
         return b, (images if keep_images else None)
 
+    def capture(self, cameras: List[Camera], upstream: Callable[[int, Tensor], Tensor], keep_images: bool = False):
+        """One fused step over a FIXED camera list recorded into a HIP graph (torch.cuda.CUDAGraph): possible because in
+        capacity mode a step has fixed launch shapes and no host synchronisation.  Returns `replay() -> (grads, images)`:
+        the gradients land in this engine's bucket, exactly as after __call__(..., all_reduce=False); the caller reduces
+        them over the ranks itself (collectives stay outside the graph).  `upstream` is traced once: it must compute
+        d(loss)/d(image) with device-side operations on buffers that keep their addresses (update ground-truth images in
+        place between replays).  Parameters are read from the tensors bound at capture time (update them in place).
+        replay.check() synchronises and returns False if a view exceeded the capacity (then: poll_capacity, re-capture)."""
+        if not (self.fused and self.mode == "pbr"):
+            raise RuntimeError("capture() needs the fused path")
+        if self._i_cap is None:
+            raise RuntimeError("capture() needs a known capacity: run one eager step and poll_capacity(wait=True) first")
+        from .rasterization import _pinned_pool
+        dev = self.p.means.device
+        while len(_pinned_pool) < 2 * len(cameras) + 2:       # pinned buffers cannot be allocated while a stream is capturing
+            _pinned_pool.append(torch.empty(2, dtype=torch.int64).pin_memory())
+        if self._status is None:
+            self._status = torch.zeros(3, dtype=torch.int64, device=dev)
+        if self._status_host is None:
+            self._status_host = torch.zeros(3, dtype=torch.int64).pin_memory()
+        warm = torch.cuda.Stream(device=dev)
+        warm.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(warm):                          # (allocator warm-up on a side stream, as torch.cuda.graph asks)
+            self._step_fused(cameras, upstream, False, keep_images)
+        torch.cuda.current_stream(dev).wait_stream(warm)
+        torch.cuda.synchronize(dev)
+        self.poll_capacity()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self._step_fused(cameras, upstream, False, keep_images)
+        counts = [hc for hc, _ in self._seen_counts]          # refreshed by every replay (D2H copies are graph nodes)
+        self._seen_counts = []
+        self._status_event = None
+        cap = self._i_cap
+        status_host = self._status_host
+
+        def replay():
+            graph.replay()
+            return out
+
+        def check() -> bool:
+            torch.cuda.synchronize(dev)
+            worst = max([int(hc[1]) for hc in counts] + [0])
+            overflow = int(status_host[0]) != 0 or worst > cap
+            if overflow:
+                self._exact_max_i = max(self._exact_max_i, worst, int(status_host[1]))
+                self._status.zero_(); status_host.zero_()
+            return not overflow
+        replay.check = check
+        replay.graph = graph
+        return replay
+
     def poll_capacity(self, wait: bool = False) -> bool:
         """Host side of the capacity protocol; never blocks unless `wait`.  Looks at what the LAST step left in pinned memory:
         the per-view (V, I) counts set / raise the intersection capacity (1.25 x the largest count seen, rounded up to 64 Ki),

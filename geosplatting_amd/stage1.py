@@ -292,7 +292,23 @@ def train_step_fused(model: Stage1Model, cameras: Sequence[Camera], gt_rgba: Seq
     up = TrainerUpstream([gt_rgba[i] for i in mine], n_total, gt_is_srgb=gt_is_srgb, use_mask_loss=use_mask_loss,
                          train_bg=None if train_bg is None else [train_bg[i] for i in mine],
                          generator=model.bg_generator(rank), device=splats.means.device)   # `mine` may be empty (world > views)
-    g, _ = step([cameras[i] for i in mine], up, all_reduce=world_size > 1)
+    # capacity protocol (engine.RenderStep.poll_capacity): the step runs without (V, I) read-backs; a view that outgrew the
+    # intersection capacity (the extracted surface changes every iteration) is reported afterwards and the step repeated with
+    # the raised capacity -- collectively, since the per-Gaussian gradients were already reduced over the ranks
+    for attempt in range(4):
+        g, _ = step([cameras[i] for i in mine], up, all_reduce=world_size > 1)
+        ok = step.poll_capacity(wait=True)
+        if world_size > 1:
+            flag = torch.tensor([0.0 if ok else 1.0], device=splats.means.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            ok = float(flag.item()) == 0.0
+        if ok:
+            break
+        up = TrainerUpstream([gt_rgba[i] for i in mine], n_total, gt_is_srgb=gt_is_srgb, use_mask_loss=use_mask_loss,
+                             train_bg=None if train_bg is None else [train_bg[i] for i in mine],
+                             generator=model.bg_generator(rank), device=splats.means.device)
+    else:
+        raise RuntimeError("intersection capacity still exceeded after 4 attempts")
     heads = cut + [exposure]
     gh = [g["means"], g["scales"], g["quats"], g["opacities"], g["normals"], g["kd"], g["ks"], g["exposure"].reshape(1)]
     keep = [(h, gg) for h, gg in zip(heads, gh) if h.requires_grad]

@@ -121,3 +121,18 @@ def test_capacity_overflow_is_reported_and_recovered():
     got = run()
     assert step.poll_capacity(wait=True)
     _same(ref, got)
+
+
+def test_step_captured_in_hip_graph():
+    """With fixed launch shapes and no host synchronisation a whole step (8 views' worth of kernels on three streams, prefilter
+    forward and backward) is one HIP graph: replaying it must reproduce the eager step."""
+    step, run = _engine(torch.device("cuda", 0))
+    run()
+    assert step.poll_capacity(wait=True) and step._i_cap is not None
+    ref = run()
+    replay = step.capture(step_cams, step_up, keep_images=True)
+    for _ in range(3):
+        grads, images = replay()
+    assert replay.check()
+    got = ({n: v.detach().cpu().clone() for n, v in grads.items()}, [im.detach().cpu().clone() for im in images])
+    _same(ref, got)

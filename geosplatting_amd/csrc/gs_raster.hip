@@ -676,12 +676,38 @@ __device__ __forceinline__ LaneQueue lane_queue(unsigned char* base)
 
 // Raw batch of the stream held in registers while its loads are in flight.  THREE are kept (r[0..2], consumed round-robin by
 // LANES_FILL below): rotating them through "pf0 = pf1; pf1 = pf2" cost 18 v_mov_b64 per raw batch, a quarter of the fill loop.
-struct RawBatch { float4 r0, r1, r2; };
+typedef float v4f __attribute__((ext_vector_type(4)));
+struct RawBatch { v4f r0, r1, r2; };
+// The three loads are INLINE ASSEMBLY, and so is the wait for them (raw_wait): the compiler's wait-count insertion cannot see
+// through the dynamic `phase` of LANES_FILL and waited for (almost) everything in flight before every cull -- s_waitcnt
+// vmcnt(1) -- so each raw batch cost a full memory latency (~900 cycles; a third of the time of a silhouette tile).  The count
+// that is actually needed is static: whichever of the three batches is consumed, exactly two younger ones (6 loads) are in
+// flight, loads return in order, hence vmcnt(6).  Out-of-range lanes load record 0 so that the count holds at the list's end.
+// (Stores and atomics also count in vmcnt on gfx9 and may complete out of order with the loads: they can only make the wait
+// longer, never shorter than the three oldest loads -- see DESIGN.md section 4.)
 __device__ __forceinline__ void raw_load(RawBatch& b, const float4* __restrict__ rec0, const float4* __restrict__ rec1,
                                          const float4* __restrict__ rec2, int idx, bool in_range)
 {
-    const int safe = in_range ? idx : 0;          // no branch around the loads (see load_batch); out-of-range lanes are masked at the cull
-    b.r0 = rec0[safe]; b.r1 = rec1[safe]; b.r2 = rec2[safe];
+    const int safe = in_range ? idx : 0;
+    const float4 *p0 = rec0 + safe, *p1 = rec1 + safe, *p2 = rec2 + safe;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(b.r0) : "v"(p0) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(b.r1) : "v"(p1) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(b.r2) : "v"(p2) : "memory");
+}
+// Before a kernel leaves its batch loop: the last reloads are never consumed, so for the compiler their registers die at the load
+// and would be handed to other values while the data is still on its way -- which then lands on top of them.  Keep the nine
+// registers allocated until everything has arrived (free in practice: the last walk has run in between).
+__device__ __forceinline__ void raw_drain(RawBatch& a, RawBatch& b, RawBatch& c)
+{
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(a.r0), "+v"(a.r1), "+v"(a.r2), "+v"(b.r0), "+v"(b.r1), "+v"(b.r2), "+v"(c.r0), "+v"(c.r1), "+v"(c.r2) : : "memory");
+}
+__device__ __forceinline__ void raw_wait(RawBatch& b)
+{
+#ifndef GS_RAW_WAIT
+#define GS_RAW_WAIT "s_waitcnt vmcnt(6)"
+#endif
+    asm volatile(GS_RAW_WAIT : "+v"(b.r0), "+v"(b.r1), "+v"(b.r2) : : "memory");
 }
 
 // centre and half-extent (pixel-centre coordinates) of the bounding rectangle of the active lanes of a quadrant wave
@@ -704,7 +730,8 @@ __device__ __forceinline__ int lanes_cull_append(const LaneQueue& q, const RawBa
     const unsigned long long hmask = __ballot(hit);
     if (hit) {
         const int slot = (qtail + __popcll(hmask & ((1ull << lane) - 1ull))) & (GS_LANES_Q - 1);
-        q.a[slot] = cur.r0; q.b[slot] = make_float2(cur.r1.x, cur.r1.y); q.c[slot] = cur.r2; q.idx[slot] = idx;
+        q.a[slot] = make_float4(cur.r0.x, cur.r0.y, cur.r0.z, cur.r0.w); q.b[slot] = make_float2(cur.r1.x, cur.r1.y);
+        q.c[slot] = make_float4(cur.r2.x, cur.r2.y, cur.r2.z, cur.r2.w); q.idx[slot] = idx;
     }
     return __popcll(hmask);
 }
@@ -783,6 +810,7 @@ raster_fwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
 #define FWD_FILL_STEP(B)                                                                                               \
         {                                                                                                              \
             GS_STAT(0, 1);                                                                                             \
+            raw_wait(B);                                                                                               \
             const int n_hit = lanes_cull_append(q, B, base + lane < end, base + lane, lane, rcx, rcy, rex, rey, qhead + qcount); \
             raw_load(B, rec0, rec1, rec2, base + 192 + lane, base + 192 + lane < end);                                 \
             qcount += n_hit;                                                                                           \
@@ -900,6 +928,7 @@ raster_fwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
         qhead = (qhead + nb) & (GS_LANES_Q - 1);
         qcount -= nb;
     }
+    raw_drain(raw0, raw1, raw2);
 
     if (inside) {
         const size_t pid = (size_t)pyi * W + pxi;
@@ -985,6 +1014,7 @@ raster_bwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
         {                                                                                                              \
             const unsigned long long act_b = __ballot(bin_final >= top - 63);                                          \
             int n_hit = 0;                                                                                             \
+            raw_wait(B);                                                                                               \
             if (act_b != 0ull) {                                                                                       \
                 float rcx, rcy, rex, rey;                                                                              \
                 active_rect_c(act_b, qx0, qy0, rcx, rcy, rex, rey);                                                    \
@@ -1098,6 +1128,7 @@ raster_bwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
         qhead = (qhead + nb) & (GS_LANES_Q - 1);
         qcount -= nb;
     }
+    raw_drain(raw0, raw1, raw2);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1213,6 +1244,7 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
         {                                                                                                              \
             const unsigned long long act_b = __ballot(bin_final >= top - 63);                                          \
             int n_hit = 0;                                                                                             \
+            raw_wait(B);                                                                                               \
             if (act_b != 0ull) {                                                                                       \
                 float rcx, rcy, rex, rey;                                                                              \
                 active_rect_c(act_b, qx0, qy0, rcx, rcy, rex, rey);                                                    \
@@ -1405,6 +1437,7 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
         qhead = (qhead + nb) & (GS_LANES_Q - 1);
         qcount -= nb;
     }
+    raw_drain(raw0, raw1, raw2);
     GS_TL_END();
 }
 

@@ -327,8 +327,9 @@ def main():
         lane_util = None
         if stats and args.level == 7 and args.res == 800:
             key = "fwd" if dom == "raster_fwd_kernel" else "bwd"
-            lane_util = {"valid_pairs": stats[key]["valid_pairs"], "trips": stats[key]["trips"],
-                         "valid_lanes_per_trip_of_64": stats[key]["valid_pairs"] / max(1, stats[key]["trips"]),
+            cpt = int(stats.get("candidates_per_trip", 1))
+            lane_util = {"valid_pairs": stats[key]["valid_pairs"], "trips": stats[key]["trips"], "candidates_per_lane_and_trip": cpt,
+                         "frac_of_candidate_slots_used": stats[key]["valid_pairs"] / max(1, stats[key]["trips"] * 64 * cpt),
                          "source": "profiles/r02_raster_stats.json (scripts/raster_stats.py, -DGS_RASTER_STATS build of the same source)"}
         traffic = traffic_src = None
         if pmc and args.level == 7 and args.res == 800 and dom in pmc.get("kernels", {}):
@@ -346,7 +347,7 @@ def main():
                                    + f", prefilter fwd+bwd {'in' if not args.no_prefilter else 'EXCLUDED from'} every step",
                        "N": N, "V": V, "I": I, "P": P, "views_per_step_total": views_total,
                        "parallelism": f"dp{world} (views sharded, prefilter sharded, flat RCCL all-reduce of per-Gaussian grads)"},
-            "roofline": {"bound": "valu", "kernel": dom, "achieved": dom_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "valu", "kernel": dom, "launched_as": {"raster_fwd_kernel": "raster_fwd_lanes_kernel<3>", "raster_bwd_kernel": "raster_bwd_lanes2_kernel<3>"}[dom], "achieved": dom_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": None if dom_tf is None else dom_tf / VALU_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "pairs_valid": pairs_valid, "flops_per_pair": {"fwd": FLOPS_FWD_PER_PAIR, "bwd": FLOPS_BWD_PER_PAIR},

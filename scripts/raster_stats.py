@@ -32,7 +32,7 @@ if os.environ.get("GEOSPLAT_RASTER_LANES", "1") != "0":
         import hashlib, json
         src = os.path.join(B.CSRC, "gs_raster.hip")
         json.dump({"source_sha16": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16], "workload": f"icosphere level {level}, 800x800, view 0",
-                   "I": I, "fwd": {"raw_wave_batches": v[0], "culled_records": v[1], "trips": v[3], "valid_pairs": v[2]},
+                   "I": I, "candidates_per_trip": 2, "fwd": {"raw_wave_batches": v[0], "culled_records": v[1], "trips": v[3], "valid_pairs": v[2]},
                    "bwd": {"raw_wave_batches": v[4], "culled_records": v[5], "trips": v[6], "valid_pairs": v[7]}},
                   open(sys.argv[2], "w"), indent=1)
     print(f"I={I}  per-lane lists  fwd: raw wave-batches {v[0]}  culled records {v[1]} ({v[1]/max(v[0],1):.1f}/raw batch)  trips {v[3]} "

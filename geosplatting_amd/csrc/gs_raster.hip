@@ -232,6 +232,9 @@ raster_fwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
                   float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids)
 {
     const int n_isects = (int)gs_count(ic);
+#ifdef GS_EXP_PRIO
+    if ((int)blockIdx.x < GS_EXP_PRIO) __builtin_amdgcn_s_setprio(3);
+#endif
     const int tile = tile_order[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPR
     const int tx = tile % tile_w, ty = tile / tile_w;
@@ -340,6 +343,9 @@ raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* _
                   float* __restrict__ v_packed, int rec_stride)
 {
     const int n_isects = (int)gs_count(ic);
+#ifdef GS_EXP_PRIO
+    if ((int)blockIdx.x < GS_EXP_PRIO) __builtin_amdgcn_s_setprio(3);
+#endif
     const int tile = tile_order[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPR
     const int tx = tile % tile_w, ty = tile / tile_w;
@@ -557,8 +563,8 @@ __device__ __forceinline__ void active_rect_i(unsigned long long act, int& xmin,
     ymin = __builtin_ctzll(act) >> 3; ymax = (63 - __builtin_clzll(act)) >> 3;
 }
 
-#ifndef GS_LANES_NPT
-#define GS_LANES_NPT 2            // candidates popped per lane and trip (independent fetch + alpha chains)
+#ifndef GS_WALK_PAIRS
+#define GS_WALK_PAIRS 1           // packed candidate PAIRS popped per lane and trip in the forward walk
 #endif
 #ifndef GS_LANES_EXACT_MASK
 #define GS_LANES_EXACT_MASK 1
@@ -771,6 +777,9 @@ raster_fwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
 #ifdef GS_EXP_ONLY_HEAVY
     if ((int)blockIdx.x >= GS_EXP_ONLY_HEAVY) return;
 #endif
+#ifdef GS_EXP_PRIO
+    if ((int)blockIdx.x < GS_EXP_PRIO) __builtin_amdgcn_s_setprio(3);
+#endif
     const int tile = tile_order[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int tx = tile % tile_w, ty = tile / tile_w;
@@ -852,69 +861,54 @@ raster_fwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
 #ifdef GS_RASTER_PHASES
             if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_raster_stats[3], 1ull);
 #endif
-            // phase A, two candidates side by side in packed fp32 (v_pk_*): same IEEE operations per component as the scalar form
-            const bool has0 = list != 0ull;
-            const int slot0 = (qhead + gs_pop_lowest(list)) & (GS_LANES_Q - 1);
-            const bool has1 = list != 0ull;
-            const int slot1 = (qhead + gs_pop_lowest(list)) & (GS_LANES_Q - 1);
-            const float4 a0 = q.a[slot0], a1 = q.a[slot1];
-            const float2 b0 = q.b[slot0], b1 = q.b[slot1];
-            const float4 c0 = q.c[slot0], c1 = q.c[slot1];
-            v2f sigma, alpha;
-            {
+            // phase A, candidates in pairs side by side in packed fp32 (v_pk_*): same IEEE operations per component as the scalar
+            // form.  GS_WALK_PAIRS pairs per trip: independent chains for a wave that runs alone on its SIMD (the tail).
+            bool has[2 * GS_WALK_PAIRS]; int slot[2 * GS_WALK_PAIRS];
+            float4 ca[2 * GS_WALK_PAIRS], cc[2 * GS_WALK_PAIRS]; float2 cb[2 * GS_WALK_PAIRS];
+#pragma unroll
+            for (int u = 0; u < 2 * GS_WALK_PAIRS; ++u) {
+                has[u] = list != 0ull;
+                slot[u] = (qhead + gs_pop_lowest(list)) & (GS_LANES_Q - 1);
+            }
+#pragma unroll
+            for (int u = 0; u < 2 * GS_WALK_PAIRS; ++u) { ca[u] = q.a[slot[u]]; cb[u] = q.b[slot[u]]; cc[u] = q.c[slot[u]]; }
+            float alpha_u[2 * GS_WALK_PAIRS]; bool ok[2 * GS_WALK_PAIRS];
+#pragma unroll
+            for (int v = 0; v < GS_WALK_PAIRS; ++v) {
 #pragma clang fp contract(off)
+                const float4 a0 = ca[2 * v], a1 = ca[2 * v + 1];
+                const float2 b0 = cb[2 * v], b1 = cb[2 * v + 1];
                 const v2f dx = v2f{a0.x, a1.x} - px, dy = v2f{a0.y, a1.y} - py;
                 const v2f t0 = v2f{a0.z, a1.z} * dx, t1 = v2f{b0.x, b1.x} * dy, t2 = v2f{a0.w, a1.w} * dx;
-                sigma = __builtin_elementwise_fma(t0, dx, __builtin_elementwise_fma(t1, dy, t2 * dy));
-                alpha = __builtin_elementwise_min(v2f{b0.y, b1.y} * gs_exp_neg_live2(sigma), (v2f)(0.999f));
+                const v2f sigma = __builtin_elementwise_fma(t0, dx, __builtin_elementwise_fma(t1, dy, t2 * dy));
+                const v2f alpha = __builtin_elementwise_min(v2f{b0.y, b1.y} * gs_exp_neg_live2(sigma), (v2f)(0.999f));
+                alpha_u[2 * v] = alpha.x; alpha_u[2 * v + 1] = alpha.y;
+                ok[2 * v] = has[2 * v] && sigma.x >= 0.0f && alpha.x >= GS_ALPHA_MIN;
+                ok[2 * v + 1] = has[2 * v + 1] && sigma.y >= 0.0f && alpha.y >= GS_ALPHA_MIN;
             }
-            const bool ok0 = has0 && sigma.x >= 0.0f && alpha.x >= GS_ALPHA_MIN;
-            const bool ok1 = has1 && sigma.y >= 0.0f && alpha.y >= GS_ALPHA_MIN;
             // phase B, the serial recurrence, without branches: a rejected candidate composites with weight zero
-            bool stopped;
-            {
-                const float next_T = T * (1.0f - alpha.x);
-                const bool live = ok0 && !done;
+            bool stopped = false;
+#pragma unroll
+            for (int u = 0; u < 2 * GS_WALK_PAIRS; ++u) {
+                const float next_T = T * (1.0f - alpha_u[u]);
+                const bool live = ok[u] && !done;
                 const bool stop = live && next_T <= 1e-4f;
                 const bool acc = live && !stop;
 #ifdef GS_RASTER_STATS
                 if (acc) GS_STAT_ALL(2, 1);
 #endif
-                const float vis = acc ? alpha.x * T : 0.0f;
+                const float vis = acc ? alpha_u[u] * T : 0.0f;
                 if (CD <= 3) {
-                    pix[0] = fmaf(c0.x, vis, pix[0]);
-                    if (CD > 1) pix[1] = fmaf(c0.y, vis, pix[1]);
-                    if (CD > 2) pix[2] = fmaf(c0.z, vis, pix[2]);
+                    pix[0] = fmaf(cc[u].x, vis, pix[0]);
+                    if (CD > 1) pix[1] = fmaf(cc[u].y, vis, pix[1]);
+                    if (CD > 2) pix[2] = fmaf(cc[u].z, vis, pix[2]);
                 } else if (acc) {
-                    const float* cg = colors + (size_t)__float_as_int(c0.w) * D;
+                    const float* cg = colors + (size_t)__float_as_int(cc[u].w) * D;
 #pragma unroll
                     for (int k = 0; k < CD; ++k) if (k < D) pix[k] = fmaf(cg[k], vis, pix[k]);
                 }
                 T = acc ? next_T : T;
-                cur_slot = acc ? slot0 : cur_slot;
-                done = done || stop;
-                stopped = stop;
-            }
-            {
-                const float next_T = T * (1.0f - alpha.y);
-                const bool live = ok1 && !done;
-                const bool stop = live && next_T <= 1e-4f;
-                const bool acc = live && !stop;
-#ifdef GS_RASTER_STATS
-                if (acc) GS_STAT_ALL(2, 1);
-#endif
-                const float vis = acc ? alpha.y * T : 0.0f;
-                if (CD <= 3) {
-                    pix[0] = fmaf(c1.x, vis, pix[0]);
-                    if (CD > 1) pix[1] = fmaf(c1.y, vis, pix[1]);
-                    if (CD > 2) pix[2] = fmaf(c1.z, vis, pix[2]);
-                } else if (acc) {
-                    const float* cg = colors + (size_t)__float_as_int(c1.w) * D;
-#pragma unroll
-                    for (int k = 0; k < CD; ++k) if (k < D) pix[k] = fmaf(cg[k], vis, pix[k]);
-                }
-                T = acc ? next_T : T;
-                cur_slot = acc ? slot1 : cur_slot;
+                cur_slot = acc ? slot[u] : cur_slot;
                 done = done || stop;
                 stopped = stopped || stop;
             }
@@ -956,6 +950,9 @@ raster_bwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
     constexpr int RPI = 64 / NV;                                   // records committed per atomic instruction
     constexpr int WAVE_BYTES = GS_LANES_Q_BYTES + NV * 64 * 8;
     extern __shared__ __align__(16) unsigned char gs_lds_raw[];
+#ifdef GS_EXP_PRIO
+    if ((int)blockIdx.x < GS_EXP_PRIO) __builtin_amdgcn_s_setprio(3);
+#endif
     const int tile = tile_order[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int tx = tile % tile_w, ty = tile / tile_w;
@@ -1176,6 +1173,9 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
 #endif
 #ifdef GS_EXP_ONLY_HEAVY
     if ((int)blockIdx.x >= GS_EXP_ONLY_HEAVY) return;
+#endif
+#ifdef GS_EXP_PRIO
+    if ((int)blockIdx.x < GS_EXP_PRIO) __builtin_amdgcn_s_setprio(3);
 #endif
     const int tile = tile_order[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

@@ -98,3 +98,53 @@ def test_product_never_imports_oracle():
     legs = [q for q in parts if q.startswith("cpu_baseline")]
     assert legs and all("import oracle" in q for q in legs)
     assert all("import oracle" not in q for q in parts if not q.startswith("cpu_baseline"))
+
+
+def test_prefetch_registers_are_never_copied(tmp_path):
+    """The compositor kernels prefetch three raw batches with inline-assembly loads and wait for them with a static
+    `s_waitcnt vmcnt(6)` (csrc/gs_raster.hip: raw_load / raw_wait / raw_drain).  The compiler does not know that those registers
+    are in flight between the load and the wait: if its register allocator ever split such a live range (a `v_mov`, an AGPR or
+    scratch spill of the destination registers), the copy would read data that has not arrived.  This test disassembles the
+    shipped kernels and checks that, after the initial loads, no move / spill instruction has one of the prefetch registers as
+    its SOURCE -- the build is only valid while that holds (a register-pressure change in these kernels can break it)."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    from geosplatting_amd import build as B
+    out = tmp_path / "raster.s"
+    subprocess.check_call([hipcc, *[f for f in B.FLAGS if f not in ("-shared", "-fPIC")], "-S", "--cuda-device-only",
+                           os.path.join(B.CSRC, "gs_raster.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    src = out.read_text().split("\n")
+
+    def regs(tok):
+        m = re.match(r"v\[(\d+):(\d+)\]$", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.match(r"v(\d+)$", tok)
+        return {int(m.group(1))} if m else set()
+
+    checked = 0
+    for i, line in enumerate(src):
+        if not re.match(r"_Z2[34]raster_(fwd_lanes|bwd_lanes|bwd_lanes2)_kernelILi\d+E", line):
+            continue
+        end = next(j for j in range(i, len(src)) if "s_endpgm" in src[j])
+        body = [l.strip() for l in src[i:end] if l.strip() and not l.strip().startswith(";")]
+        loads = [k for k, l in enumerate(body) if l.startswith("global_load_dwordx4")]
+        if len(loads) < 9:
+            continue
+        raw = set()
+        for k in loads:
+            raw |= regs(body[k].split()[1].strip(","))
+        assert len(raw) == 36, (line, len(raw))                      # three batches x three 16-byte records, fixed registers
+        drain = next(k for k in range(loads[-1], len(body)) if body[k].startswith("s_waitcnt vmcnt(0)"))   # raw_drain: all arrived
+        for l in body[loads[8] + 1:drain]:
+            if not re.match(r"(v_mov_b32|v_mov_b64|v_accvgpr_write|scratch_store|buffer_store)", l):
+                continue
+            ops = [t.strip(",") for t in l.split()[1:]]
+            srcs = set().union(*[regs(t) for t in ops[1:]]) if len(ops) > 1 else set()
+            assert not (srcs & raw), f"{line.split(':')[0]}: prefetch register copied while possibly in flight: {l}"
+        checked += 1
+    assert checked >= 3

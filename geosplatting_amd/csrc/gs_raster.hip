@@ -1736,6 +1736,17 @@ extern "C" int gs_raster_bwd_cap(int W, int H, int tile_size, int D, int V_cap, 
                          v_packed, ws, ws_bytes, stream);
 }
 
+extern "C" int gs_raster_bwd_acc_cap(int W, int H, int tile_size, int D, int V_cap, const float* colors, const float* background,
+                                     int64_t n_isects_cap, const int64_t* counts_dev, const int32_t* offsets, const float* alphas,
+                                     const int32_t* last_ids, const float* v_render, const float* v_alphas, float* v_packed,
+                                     const void* ws, size_t ws_bytes, void* stream)
+{
+    GS_CHECK_ARG(counts_dev != nullptr, "counts_dev must not be NULL");
+    CountsScope sc(counts_dev);
+    return gs_raster_bwd_acc(W, H, tile_size, D, V_cap, colors, background, n_isects_cap, offsets, alphas, last_ids, v_render, v_alphas,
+                             v_packed, ws, ws_bytes, stream);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // self-test hook: counts the floats with bit patterns in [lo_bits, hi_bits] for which gs_rcp_exact2 differs from IEEE division
 __global__ void __launch_bounds__(256) selftest_rcp_kernel(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* mismatches)

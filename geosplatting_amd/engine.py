@@ -219,6 +219,9 @@ class RenderStep:
                     state, V, I, D, whs = _bin_stage(pr)
                     self._exact_max_i = max(self._exact_max_i, I)
                     state = _prepare_stage(state, V, I, D, whs)  # record stream: HBM-bound, belongs on this stream too
+                # the packed gradient records of this view, zeroed HERE (front stream, under the compositor of the previous view)
+                # instead of by a 126 MB memset in front of the compositor backward
+                state["v_packed"] = torch.zeros(V, lib.gs_raster_grad_stride(3), dtype=f32, device=dev)
                 ev = torch.cuda.Event(); ev.record(side)
             for t in list(state.values()) + [col] + list(pr.bufs):
                 if isinstance(t, torch.Tensor):
@@ -248,17 +251,17 @@ class RenderStep:
             v_render = torch.empty(H, W, 3, dtype=f32, device=dev); v_alpha = torch.empty(H, W, dtype=f32, device=dev)
             L.check(lib.gs_tonemap_bwd3(L.i64(P), tone, L.ptr(render), L.ptr(alphas), L.ptr(exposure), L.ptr(v_img), L.ptr(v_render),
                                         L.ptr(v_alpha), L.ptr(b["exposure"]), 1, st()), "gs_tonemap_bwd3")
-            v_packed = torch.empty(V, lib.gs_raster_grad_stride(3), dtype=f32, device=dev)
+            v_packed = s["v_packed"]
             rws = s["raster_ws"]
             if i_cap is not None:
-                L.check(lib.gs_raster_bwd_cap(W, H, 16, 3, V, L.ptr(s["colors"]), None, L.i64(I), L.ptr(s["counts"]),
+                L.check(lib.gs_raster_bwd_acc_cap(W, H, 16, 3, V, L.ptr(s["colors"]), None, L.i64(I), L.ptr(s["counts"]),
                                               L.ptr(s["isect_offsets"]), L.ptr(alphas), L.ptr(s["last_ids"]), L.ptr(v_render),
                                               L.ptr(v_alpha), L.ptr(v_packed), L.ptr(rws), C.c_size_t(rws.numel()), st()),
-                        "gs_raster_bwd_cap")
+                        "gs_raster_bwd_acc_cap")
             else:
-                L.check(lib.gs_raster_bwd(W, H, 16, 3, V, L.ptr(s["colors"]), None, L.i64(I), L.ptr(s["isect_offsets"]),
+                L.check(lib.gs_raster_bwd_acc(W, H, 16, 3, V, L.ptr(s["colors"]), None, L.i64(I), L.ptr(s["isect_offsets"]),
                                           L.ptr(alphas), L.ptr(s["last_ids"]), L.ptr(v_render), L.ptr(v_alpha), L.ptr(v_packed),
-                                          L.ptr(rws), C.c_size_t(rws.numel()), st()), "gs_raster_bwd")
+                                          L.ptr(rws), C.c_size_t(rws.numel()), st()), "gs_raster_bwd_acc")
             # gradient tail of the view (A7 + S1-S3 backward: HBM / atomic-rate bound) on a third stream, so that it
             # overlaps the VALU-bound compositor of the next view; the tail kernels of successive views stay in order
             # on that stream (they accumulate into the same gradient buffers)

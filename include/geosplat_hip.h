@@ -188,6 +188,12 @@ int gs_raster_bwd_cap(int W, int H, int tile_size, int D, int V_cap, const float
                       int64_t n_isects_cap, const int64_t* counts_dev, const int32_t* offsets, const float* alphas,
                       const int32_t* last_ids, const float* v_render, const float* v_alphas, float* v_packed, const void* ws,
                       size_t ws_bytes, void* stream);
+/* gs_raster_bwd_acc with the counts on the device: ADDS into a v_packed [V_cap, stride] the caller has zeroed (the engine
+ * zeroes it on its front stream, under the compositor of the previous view). */
+int gs_raster_bwd_acc_cap(int W, int H, int tile_size, int D, int V_cap, const float* colors, const float* background,
+                          int64_t n_isects_cap, const int64_t* counts_dev, const int32_t* offsets, const float* alphas,
+                          const int32_t* last_ids, const float* v_render, const float* v_alphas, float* v_packed, const void* ws,
+                          size_t ws_bytes, void* stream);
 int gs_project_bwd_cap(int N, const int64_t* counts_dev, int D, const float* means, const float* quats, const float* scales,
                        const float* opacities, const float* viewmat, const float* K, int W, int H, float eps2d,
                        const int32_t* gaussian_ids, const float* conics, const float* compensations, const float* v_packed,

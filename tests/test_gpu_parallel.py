@@ -21,7 +21,10 @@ def _free_port():
 def _step(dev, views, all_reduce):
     import geosplatting_amd.synthetic as syn
     from geosplatting_amd.engine import RenderStep, params_from_scene
-    sc = syn.sphere_scene(LEVEL, seed=2, cubemap_res=64)
+    from oracle import mesh_ref
+    # the CPU scene builder: every process must start from bit-identical Gaussians (the HIP vertex-normal kernel accumulates with
+    # float atomics, so two builds differ in the last bit -- and a stored-state backward amplifies that)
+    sc = syn.sphere_scene(LEVEL, seed=2, cubemap_res=64, mesh_to_splats_fn=mesh_ref.scene_builder)
     cams = syn.blender_cameras(N_VIEWS, RES, RES)
     step = RenderStep(params_from_scene(sc, dev, exposure=1.1))
     ups = {i: (torch.rand(RES, RES, 4, generator=torch.Generator().manual_seed(50 + i)) * 2 - 1).to(dev) for i in range(N_VIEWS)}

@@ -180,7 +180,7 @@ __device__ void cube_fetch(const float* __restrict__ tex, int R, const float* d,
 // (leader loop: broadcast the first pending address, ballot the matches, DPP-reduce, one lane commits);
 // incoherent lanes fall back to plain atomics after GS_AGG_ROUNDS leaders.
 #ifndef GS_AGG_ROUNDS
-#define GS_AGG_ROUNDS 1    // measured with the row-pair commit: 0 / 1 / 2 / 6 rounds = 0.807 / 0.802 / 0.833 / 0.846 ms (kernel + glue)
+#define GS_AGG_ROUNDS 0    // round 1 (permute commit): 0 / 1 / 2 / 6 rounds = 0.807 / 0.802 / 0.833 / 0.846 ms (kernel + glue); round 2 (LDS-staged commit, kernel alone): 0 / 1 rounds = 364 / 381 us
 #endif
 template <bool XCD_LOCAL>
 __device__ __forceinline__ void gs_add_scoped(float* p, float v)
@@ -246,6 +246,38 @@ __device__ __forceinline__ void wave_agg_add3(float* p /* nullptr = nothing to a
 // contiguous floats), so their six atomics are issued by SIX adjacent lanes of one instruction and merge into ONE
 // memory-side request (two when the 24 bytes straddle a cache line or, on a face edge, the second texel lives
 // elsewhere).  Halves the request count of the shading backward, which sits at the fabric's atomic request rate.
+// LDS-staged form of wave_commit6 (below): every lane writes its two pointers and six values into a wave-private
+// [10 words][64 lanes] tile, then reads the (pointer, value) pair it has to issue -- 8 writes + 12 reads per call instead of
+// 60 ds_bpermute, which made the LDS pipe of the CU (8.3 M LDS instructions per launch, 7.4 M of them permutes) a bottleneck
+// of the shading backward.  `stage` = 640 floats of LDS owned by this wave; all 64 lanes call together.
+template <bool XCD_LOCAL>
+__device__ __forceinline__ void wave_commit6_lds(float* stage, float* pa, float* pb, const float (&v)[6])
+{
+    const int lane = (int)(threadIdx.x & 63);
+    unsigned long long* sp = reinterpret_cast<unsigned long long*>(stage);       // [2][64] pointers, then [6][64] values
+    float* sv = stage + 256;
+    __builtin_amdgcn_wave_barrier();
+    sp[lane] = (unsigned long long)pa; sp[64 + lane] = (unsigned long long)pb;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) sv[c * 64 + lane] = v[c];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int q = 64 * k + lane;
+        const int src = q / 6, ch = q - 6 * src;
+        const bool second = ch >= 3;
+        float* base = (float*)sp[(second ? 64 : 0) + src];
+        const float val = sv[ch * 64 + src];
+#ifndef GS_EXPERIMENT_NO_GLOBAL_TEXEL_ATOMICS
+        if (base != nullptr) gs_add_scoped<XCD_LOCAL>(base + (second ? ch - 3 : ch), val);
+#else
+        if (base != nullptr && val == 123456.0f) base[0] = val;      /* timing experiment only */
+#endif
+    }
+}
+
 template <bool XCD_LOCAL>
 __device__ __forceinline__ void wave_commit6(float* pa, float* pb, const float (&v)[6])
 {
@@ -279,7 +311,7 @@ __device__ __forceinline__ void wave_commit6(float* pa, float* pb, const float (
 
 // aggregate lanes that hit the same row pair (same first AND second texel), then commit transposed
 template <bool XCD_LOCAL>
-__device__ __forceinline__ void wave_agg_add6(float* pa, float* pb, const float (&v)[6])
+__device__ __forceinline__ void wave_agg_add6(float* pa, float* pb, const float (&v)[6], float* stage = nullptr)
 {
     const int lane = (int)(threadIdx.x & 63);
     unsigned long long ka = (unsigned long long)pa;
@@ -314,12 +346,14 @@ __device__ __forceinline__ void wave_agg_add6(float* pa, float* pb, const float 
 #pragma unroll
         for (int c = 0; c < 6; ++c) pv[c] = v[c];
     }
-    wave_commit6<XCD_LOCAL>(enda, endb, pv);
+    if (stage) wave_commit6_lds<XCD_LOCAL>(stage, enda, endb, pv);
+    else wave_commit6<XCD_LOCAL>(enda, endb, pv);
 }
 
 // all 64 lanes of the wave must call this together (lanes without work pass valid == false)
 template <bool XCD_LOCAL>
-__device__ __forceinline__ void cube_scatter_wave(float* grad_tex, const CubeFp& fp, const float* g, float scale, bool valid)
+__device__ __forceinline__ void cube_scatter_wave(float* grad_tex, const CubeFp& fp, const float* g, float scale, bool valid,
+                                                  float* stage = nullptr)
 {
 #pragma unroll
     for (int row = 0; row < 2; ++row) {
@@ -332,7 +366,7 @@ __device__ __forceinline__ void cube_scatter_wave(float* grad_tex, const CubeFp&
             p[j] = on ? grad_tex + (size_t)fp.idx[i] * 3 : nullptr;
             v[3 * j] = g[0] * w; v[3 * j + 1] = g[1] * w; v[3 * j + 2] = g[2] * w;
         }
-        wave_agg_add6<XCD_LOCAL>(p[0], p[1], v);
+        wave_agg_add6<XCD_LOCAL>(p[0], p[1], v, stage);
     }
 }
 

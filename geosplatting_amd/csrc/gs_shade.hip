@@ -36,6 +36,7 @@ struct EnvGradDev {
     int lds_base;
     int lds_level[GS_MAX_LEVELS];
     int lds_floats;
+    int stage_off;                 // float offset of the per-wave commit staging (640 floats per wave) or -1
     // per-XCD private accumulators for the levels that do not fit LDS (XCD-local atomics, reduced afterwards):
     // copy x of level l lives at priv + x * priv_stride + priv_level[l] (floats); priv == nullptr -> device atomics
     float* priv;
@@ -229,6 +230,8 @@ shade_bwd_kernel(int N, const float* __restrict__ means, const float* __restrict
     // this block's XCD-private accumulator copy (device-scope fp32 atomics are resolved at the memory side of the
     // fabric -- a 32-byte write-through each, 0.6 GB per view here; XCD-local ones stay in the 4 MiB L2)
     float* const priv = PRIV ? eg.priv + (long long)gs_xcc_id() * eg.priv_stride : nullptr;
+    // wave-private commit staging behind the private texel copies (640 floats per wave, see wave_commit6_lds); -1 = permute form
+    float* const stage = eg.stage_off >= 0 ? s_grad + eg.stage_off + (threadIdx.x >> 6) * 640 : nullptr;
     const float cp[3] = { cam_pos[0], cam_pos[1], cam_pos[2] };
     // wave-uniform trip count: every lane of a wave reaches the wave-aggregated scatter together
     const int n_iter = (N + (int)(gridDim.x * blockDim.x) - 1) / (int)(gridDim.x * blockDim.x);
@@ -334,17 +337,17 @@ shade_bwd_kernel(int N, const float* __restrict__ means, const float* __restrict
             const bool lds0 = scatter && eg.lds_level[l0] >= 0;
             if (lds0) cube_scatter_lds(s_grad + eg.lds_level[l0], t.ls.fp0, v_ls, w0);
             cube_scatter_wave<PRIV>(scatter && !lds0 ? (PRIV ? priv + eg.priv_level[l0] : eg.levels[l0]) : nullptr, t.ls.fp0,
-                                    v_ls, w0, scatter && !lds0);
+                                    v_ls, w0, scatter && !lds0, stage);
             const bool has1 = scatter && l1 >= 0;
             const bool lds1 = has1 && eg.lds_level[has1 ? l1 : 0] >= 0;
             if (lds1) cube_scatter_lds(s_grad + eg.lds_level[l1], t.ls.fp1, v_ls, t.ls.f);
             cube_scatter_wave<PRIV>(has1 && !lds1 ? (PRIV ? priv + eg.priv_level[has1 ? l1 : 0] : eg.levels[l1]) : nullptr,
-                                    t.ls.fp1, v_ls, t.ls.f, has1 && !lds1);
+                                    t.ls.fp1, v_ls, t.ls.f, has1 && !lds1, stage);
         } else {
             const bool ldsb = scatter && eg.lds_base >= 0;
             if (ldsb) cube_scatter_lds(s_grad + eg.lds_base, t.ld_fp, v_ld, 1.0f);
             cube_scatter_wave<PRIV>(scatter && !ldsb ? (PRIV ? priv + eg.priv_base : eg.base) : nullptr, t.ld_fp, v_ld, 1.0f,
-                                    scatter && !ldsb);
+                                    scatter && !ldsb, stage);
         }
     }
     // ---- flush the private copies
@@ -460,6 +463,9 @@ extern "C" int gs_shade_bwd(int N, const float* means, const float* normals, con
         }
     }
     eg.lds_floats = used;
+    static const bool s_stage = [] { const char* v = getenv("GEOSPLAT_SHADE_COMMIT_LDS"); return !(v && v[0] == '0'); }();
+    eg.stage_off = s_stage ? ((used + 3) & ~3) : -1;
+    const int stage_floats = s_stage ? (eg.stage_off - used) + (s_block / 64) * 640 : 0;
     // XCD-private accumulators for the big levels (optional workspace)
     const size_t priv_floats = shade_bwd_priv_floats(e, mode, eg.priv_level, &eg.priv_base);
     const bool use_priv = ws != nullptr && priv_floats > 0;
@@ -468,10 +474,10 @@ extern "C" int gs_shade_bwd(int N, const float* means, const float* normals, con
     eg.priv_stride = (long long)priv_floats;
     if (N == 0) return GS_OK;
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds_bytes = (size_t)used * sizeof(float);
+    const size_t lds_bytes = (size_t)(used + stage_floats) * sizeof(float);
     int blocks = gs_cdiv(N, s_block);
     // persistent blocks when LDS copies have to be flushed at the end (one flush per block): as many as are resident at once
-    const int per_cu = used > 0 ? (int)fmin(8.0, fmax(1.0, floor(160.0 * 1024.0 / (double)(lds_bytes_of(used) + 1024)))) : 8;
+    const int per_cu = used > 0 ? (int)fmin(8.0, fmax(1.0, floor(160.0 * 1024.0 / (double)(lds_bytes + 1024)))) : 8;
     const int max_blocks = used > 0 ? 256 * per_cu : 2048;
     if (blocks > max_blocks) blocks = max_blocks;
     if (use_priv) {

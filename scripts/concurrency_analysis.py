@@ -1,0 +1,40 @@
+"""Concurrency of the three-stream engine over the LAST full step of a rocprofv3 kernel trace of bench.py (rocpd sqlite):
+how long is no kernel / exactly one kernel / several kernels in flight, and which kernels run alone."""
+import sqlite3, sys, collections
+c = sqlite3.connect(sys.argv[1])
+tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+kt = [t for t in tabs if 'kernel_dispatch' in t][0]
+ks = [t for t in tabs if t.startswith('rocpd_info_kernel_symbol')][0]
+rows = list(c.execute(f"select s.kernel_name, d.start, d.end from {kt} d join {ks} s on d.kernel_id=s.id order by d.start"))
+short = lambda n: n.split('(')[0].replace('void ', '')[:40]
+ap = [i for i, r in enumerate(rows) if 'specular_apply' in r[0]]
+rb = [i for i, r in enumerate(rows) if 'raster_bwd' in r[0]]
+groups = []                                               # runs of prefilter applies (one run = one direction of one step)
+for i in ap:
+    if groups and i - groups[-1][-1] <= 4:
+        groups[-1].append(i)
+    else:
+        groups.append([i])
+steps = [(a[0], b[-1]) for a, b in zip(groups[:-1], groups[1:]) if sum(1 for r in rb if a[-1] < r < b[0]) == 8]
+lo, hi = steps[-1]                                        # last engine step: prefilter forward ... views ... prefilter backward
+seg = rows[lo:hi + 1]
+t0, t1 = seg[0][1], max(r[2] for r in seg)
+ev = []
+for n, s, e in seg:
+    ev.append((s, 1, n)); ev.append((e, -1, n))
+ev.sort()
+live = collections.Counter(); depth_time = collections.Counter(); alone = collections.Counter(); last = t0
+for t, d, n in ev:
+    k = sum(live.values())
+    depth_time[k] += t - last
+    if k == 1:
+        alone[short(next(x for x, v in live.items() if v > 0))] += t - last
+    last = t
+    live[n] += d
+wall = t1 - t0
+print(f"last step: {len(seg)} kernels, wall {wall / 1e6:.2f} ms, sum of kernel durations {sum(r[2] - r[1] for r in seg) / 1e6:.2f} ms")
+for k in sorted(depth_time):
+    print(f"  {k} kernels in flight: {depth_time[k] / 1e6:7.3f} ms ({100.0 * depth_time[k] / wall:4.1f} %)")
+print("  alone on the GPU:")
+for n, v in alone.most_common(14):
+    print(f"    {v / 1e3:8.1f} us  {n}")

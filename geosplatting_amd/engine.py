@@ -64,6 +64,7 @@ class RenderStep:
         self._pre_stream = None
         # capacity protocol state (see _step_fused / poll_capacity)
         self._use_capacity = os.environ.get("GEOSPLAT_CAPACITY", "1") != "0"
+        self._cap_margin = float(os.environ.get("GEOSPLAT_CAPACITY_MARGIN", "1.25"))   # capacity = margin x the largest count seen
         self._i_cap = None                 # intersection capacity per view; None = exact mode (one (V, I) read-back per view)
         self._status = None                # device int64[3]: {GS_ENOSPC or 0, max required I, max required V}
         self._status_host = None
@@ -431,7 +432,7 @@ class RenderStep:
                 still.append((hc, ev))
         self._seen_counts = still
         if self._use_capacity and max_i > 0:
-            want = ((int(max_i * 1.25) + 65535) // 65536) * 65536
+            want = ((int(max_i * self._cap_margin) + 65535) // 65536) * 65536
             if self._i_cap is None or want > self._i_cap or max_i > self._i_cap:
                 self._i_cap = max(want, self._i_cap or 0)
         return ok

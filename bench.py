@@ -36,8 +36,8 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--level", type=int, default=7, help="icosphere level: 7 -> 1 966 080 Gaussians, 6 -> 491 520")
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--views", type=int, default=8, help="views per step per GPU (reference batch_size = 8)")

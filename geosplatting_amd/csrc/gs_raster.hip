@@ -1983,3 +1983,34 @@ extern "C" int gs_selftest_rcp(uint32_t lo_bits, uint32_t hi_bits, uint64_t* mis
     GS_CHECK_LAUNCH();
     return GS_OK;
 }
+
+// self-test hook for the canonical exponential (gs_common.h gs_exp_neg): over every float with bit pattern in [lo_bits, hi_bits]
+//   out[0] = sum_i bits(gs_exp_neg(sigma_i)) * (2 i + 1) mod 2^64   (the oracle's gso_exp_neg_check computes the same sum:
+//            equal sums <=> the two implementations agree bit for bit on the whole range)
+//   out[1] = bits of the largest relative error against the float64 exponential (a non-negative double orders like its bits)
+__global__ void __launch_bounds__(256) selftest_exp_kernel(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* out)
+{
+    const uint64_t n = (uint64_t)hi_bits - lo_bits + 1;
+    unsigned long long sum = 0;
+    double worst = 0.0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float(lo_bits + (uint32_t)i);
+        const float r = gs_exp_neg(x);
+        sum += (unsigned long long)__float_as_uint(r) * (2ull * i + 1ull);
+        const double ref = exp(-(double)x);
+        const double e = fabs((double)r - ref) / ref;
+        worst = e > worst ? e : worst;
+    }
+    atomicAdd(out, sum);
+    atomicMax(out + 1, (unsigned long long)__double_as_longlong(worst));
+}
+
+extern "C" int gs_selftest_exp(uint32_t lo_bits, uint32_t hi_bits, uint64_t* out_dev, void* stream)
+{
+    GS_CHECK_ARG(out_dev != nullptr && hi_bits >= lo_bits, "bad range");
+    hipStream_t s = (hipStream_t)stream;
+    GS_CHECK_HIP(hipMemsetAsync(out_dev, 0, 2 * sizeof(uint64_t), s));
+    hipLaunchKernelGGL(selftest_exp_kernel, dim3(4096), dim3(256), 0, s, lo_bits, hi_bits, (unsigned long long*)out_dev);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}

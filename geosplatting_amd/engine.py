@@ -72,6 +72,8 @@ class RenderStep:
         self._seen_counts = []
         self._exact_max_i = 0              # largest intersection count read back by an exact-mode step
         self._pre_group = None
+        self.truncated_steps = 0           # steps whose overflow word was seen set (each was composited from a truncated list)
+        self._overflow_unreported = False  # an overflow seen by the poll inside __call__ that no caller has been told about yet
 
     def _prefilter_group(self):
         """A second communicator for the prefilter exchange (25 MB all-reduce + two rounds of small all-gathers), so that it
@@ -90,19 +92,24 @@ class RenderStep:
 
     # ------------------------------------------------------------------------------------------------- fused path
     def _camera_tensors(self, cam: Camera):
-        """Device copies of (view matrix, K, camera position), cached by the camera's CONTENT (pose bytes + intrinsics):
-        a training loop that builds new Camera objects every step, or mutates one in place, can never be served another
-        camera's matrices (an id()-keyed cache could, after CPython recycles the id).  Bounded, oldest entry evicted."""
-        c2w = cam.c2w.detach().to("cpu", torch.float32).contiguous()
-        key = (c2w.numpy().tobytes(), float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy), int(cam.width), int(cam.height))
+        """Device copies of (view matrix, K, camera position) of a camera, cached per POSE TENSOR: the entry keeps a reference to
+        `cam.c2w` (so CPython cannot recycle its id while the entry lives) together with the tensor's version counter (an
+        in-place update of the pose bumps it) and the intrinsics -- a hit therefore costs no device-to-host copy and no
+        synchronisation, also for device-resident cameras and inside a graph capture; a training loop that builds new Camera
+        objects every step simply misses.  Bounded, oldest entry evicted."""
+        c2w = cam.c2w
+        key = id(c2w)
+        intr = (float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy), int(cam.width), int(cam.height))
         hit = self._cam_cache.get(key)
-        if hit is None:
-            dev = self.p.means.device
-            if len(self._cam_cache) >= 1024:
-                self._cam_cache.pop(next(iter(self._cam_cache)))
-            hit = self._cam_cache[key] = (cam.view_matrix.to(dev).contiguous(), cam.intrinsic_matrix.to(dev).contiguous(),
-                                          cam.c2w[:, 3].to(dev).contiguous())
-        return hit
+        if hit is not None and hit[0] is c2w and hit[1] == c2w._version and hit[2] == intr:
+            return hit[3]
+        dev = self.p.means.device
+        if len(self._cam_cache) >= 1024:
+            self._cam_cache.pop(next(iter(self._cam_cache)))
+        tensors = (cam.view_matrix.to(dev, torch.float32).contiguous(), cam.intrinsic_matrix.to(dev, torch.float32).contiguous(),
+                   c2w.detach()[:, 3].to(dev, torch.float32).contiguous())
+        self._cam_cache[key] = (c2w, c2w._version, intr, tensors)
+        return tensors
 
     def _step_fused(self, cameras, upstream, all_reduce, keep_images):
         """Same arithmetic as the autograd path, driven directly through the C-ABI: every per-view backward ADDS into
@@ -180,6 +187,8 @@ class RenderStep:
         # overlaps the compositor of view i on the CUs instead of queueing behind it, and the host's wait for the
         # (V, I) counts of a view never stalls the main stream.
         main = torch.cuda.current_stream(dev)
+        if self._use_capacity and self._status is None:      # zero-filled on the main stream BEFORE the side stream forks from it
+            self._status = torch.zeros(3, dtype=torch.int64, device=dev)
         side = self._side_stream
         if side is None:
             side = self._side_stream = torch.cuda.Stream(device=dev)
@@ -205,8 +214,6 @@ class RenderStep:
         # the step.  The counts still travel to pinned memory asynchronously; poll_capacity() looks at them (and at the
         # overflow status word) without blocking.
         i_cap = self._i_cap if self._use_capacity else None
-        if i_cap is not None and self._status is None:
-            self._status = torch.zeros(3, dtype=torch.int64, device=dev)
         seen = []                                            # (pinned counts, event) of this step's views
 
         def bin_view(item):                                  # A2-A4 on the side stream (exact mode: host waits for that view's counts)
@@ -288,8 +295,9 @@ class RenderStep:
                                          L.f32(self.min_roughness), L.f32(self.max_metallic), mode, C.byref(e), L.ptr(g_colors),
                                          L.ptr(b["means"]), L.ptr(b["normals"]), L.ptr(b["kd"]), L.ptr(b["ks"]), C.byref(eg), 1,
                                          L.ptr(ws) if ws_bytes else None, C.c_size_t(ws_bytes), st()), "gs_shade_bwd")
-            for t in (v_packed, g_colors, s["gaussian_ids_i32"], s["conics"], s["compensations"]):
-                t.record_stream(tail)
+            for t in (v_packed, g_colors, s["gaussian_ids_i32"], s["conics"], s["compensations"], s.get("counts")):
+                if t is not None:
+                    t.record_stream(tail)                    # (`counts` too: gs_project_bwd_cap reads {V, I} on the tail stream)
             if n_sets == 2 and i == half - 1:
                 # the first half of the texel gradients is complete: its prefilter backward (2.4 ms, latency-bound
                 # streaming) runs on its own stream under the compositor of the remaining views
@@ -303,7 +311,7 @@ class RenderStep:
             if keep_images:
                 images.append(img)
         main.wait_stream(tail)
-        self._seen_counts = seen
+        self._seen_counts.extend(seen)                       # entries of earlier steps the host has not looked at yet stay pending
         if i_cap is not None:                                # the overflow word follows the step to the host, asynchronously
             if self._status_host is None:
                 self._status_host = torch.zeros(3, dtype=torch.int64).pin_memory()
@@ -389,6 +397,7 @@ class RenderStep:
             worst = max([int(hc[1]) for hc in counts] + [0])
             overflow = int(status_host[0]) != 0 or worst > cap
             if overflow:
+                self.truncated_steps += 1
                 self._exact_max_i = max(self._exact_max_i, worst, int(status_host[1]))
                 self._status.zero_(); status_host.zero_()
             return not overflow
@@ -396,13 +405,15 @@ class RenderStep:
         replay.graph = graph
         return replay
 
-    def poll_capacity(self, wait: bool = False) -> bool:
-        """Host side of the capacity protocol; never blocks unless `wait`.  Looks at what the LAST step left in pinned memory:
+    def poll_capacity(self, wait: bool = False, _internal: bool = False) -> bool:
+        """Host side of the capacity protocol; never blocks unless `wait`.  Looks at what the earlier steps left in pinned memory:
         the per-view (V, I) counts set / raise the intersection capacity (1.25 x the largest count seen, rounded up to 64 Ki),
-        and the overflow word tells whether a view of that step exceeded the capacity it ran with.  Returns False in that
-        case -- the step's gradients are then incomplete (memory-safe, a truncated view) and the caller should repeat it; the
-        capacity has already been raised.  RenderStep.__call__ polls before every step; a trainer that must not consume a
-        truncated step calls poll_capacity(wait=True) before its optimiser step (stage1.py does)."""
+        and the overflow word tells whether a view exceeded the capacity it ran with.  Returns False in that case -- that step's
+        gradients are incomplete (memory-safe, a truncated view) and the caller should repeat it; the capacity has already been
+        raised.  An overflow is never lost: RenderStep.__call__ polls before every step (non-blocking) and, if IT sees the
+        word set, counts the step in `truncated_steps` and keeps the fact until the next poll_capacity() of the caller, which
+        then returns False.  A trainer that must not consume a truncated step calls poll_capacity(wait=True) before its optimiser
+        step (stage1.py does); bench.py reports `truncated_steps`."""
         ok = True
         max_i, self._exact_max_i = self._exact_max_i, 0
         for hc, ev in self._seen_counts:
@@ -417,6 +428,7 @@ class RenderStep:
                 self._status_event.synchronize()
             if self._status_event.query() and int(self._status_host[0]) != 0:
                 ok = False
+                self.truncated_steps += 1
                 max_i = max(max_i, int(self._status_host[1]))
                 self._status.zero_(); self._status_host.zero_()
             if self._status_event.query():
@@ -435,6 +447,10 @@ class RenderStep:
             want = ((int(max_i * self._cap_margin) + 65535) // 65536) * 65536
             if self._i_cap is None or want > self._i_cap or max_i > self._i_cap:
                 self._i_cap = max(want, self._i_cap or 0)
+        if _internal:
+            self._overflow_unreported = self._overflow_unreported or not ok
+        elif self._overflow_unreported:
+            ok, self._overflow_unreported = False, False
         return ok
 
     def __call__(self, cameras: List[Camera], upstream: Callable[[int, Tensor], Tensor], all_reduce: bool = True,
@@ -442,7 +458,8 @@ class RenderStep:
         """Forward + backward for `cameras`; `upstream(i, image)` returns d(loss)/d(image) for local view i.
         Returns (grads dict of views into the flat bucket, images or None)."""
         if self.fused and self.mode == "pbr":
-            self.poll_capacity()                             # non-blocking: counts / overflow word of the previous step
+            self.poll_capacity(_internal=True)               # non-blocking: counts / overflow word of the earlier steps (an overflow
+                                                             # seen here is kept for the caller's next poll_capacity())
             return self._step_fused(cameras, upstream, all_reduce, keep_images)
         p = self.p
         leaves = {k: v.detach().requires_grad_(True) for k, v in p.named().items()}

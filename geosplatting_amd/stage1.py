@@ -204,12 +204,15 @@ class Stage1Model:
         """:787-831 with sampling='face', smooth_type='jitter' -> (mesh, splats, attrs, regularisation)"""
         (v, f), reg = self.get_geometry()
         self.last_num_gaussians = f.shape[0] * 6
-        splats, attrs, _ = self.field.get_gaussians_from_face(v, f, self.kd_regualr_perturb_std, self.ks_regualr_perturb_std,
-                                                              scale=self.scale, initial_guess=self.initial_guess_bias,
-                                                              generator=self._jitter_gen)
-        if self.kd_regualr_perturb_std > 0 and self.kd_grad_weight > 0:
+        # the jittered encoder evaluations and their L1 terms exist for smooth_type == 'jitter' only (:800-801): under 'grad' /
+        # 'tv' the perturbation stds are zeroed, nothing is drawn from the jitter generator and no jitter term enters the loss
+        kd_std = self.kd_regualr_perturb_std if self.smooth_type == "jitter" else 0.0
+        ks_std = self.ks_regualr_perturb_std if self.smooth_type == "jitter" else 0.0
+        splats, attrs, _ = self.field.get_gaussians_from_face(v, f, kd_std, ks_std, scale=self.scale,
+                                                              initial_guess=self.initial_guess_bias, generator=self._jitter_gen)
+        if kd_std > 0 and self.kd_grad_weight > 0:
             reg = reg + self.kd_grad_weight * (attrs.kd_jitter - attrs.kd).abs().mean()
-        if self.ks_regualr_perturb_std > 0 and self.ks_grad_weight > 0:
+        if ks_std > 0 and self.ks_grad_weight > 0:
             reg = reg + self.ks_grad_weight * (attrs.ks_jitter - attrs.ks).abs().mean()
         return (v, f), splats, attrs, reg
 

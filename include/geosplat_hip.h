@@ -206,6 +206,13 @@ int gs_project_bwd_cap(int N, const int64_t* counts_dev, int D, const float* mea
  * per packed component).  Test hook; no reference counterpart. */
 int gs_selftest_rcp(uint32_t lo_bits, uint32_t hi_bits, uint64_t* mismatches_dev, void* stream);
 
+/* Self-test of the compositor's canonical exponential exp(-sigma) (one spelled-out operation order instead of gsplat's
+ * hardware `__expf`, so that the CPU oracle reproduces it bit for bit): over every float with bit pattern in
+ * [lo_bits, hi_bits], out_dev[0] (device uint64) = sum_i bits(result_i) * (2 i + 1) mod 2^64 -- an order-independent checksum the
+ * oracle computes from its own copy -- and out_dev[1] = the bit pattern of the largest relative error (a double) against the
+ * float64 exponential.  Test hook; no reference counterpart. */
+int gs_selftest_exp(uint32_t lo_bits, uint32_t hi_bits, uint64_t* out_dev, void* stream);
+
 /* ------------------------------------------------------------------ A7 ----------------------------- */
 /* Projection backward + gather backward from the packed records of gs_raster_bwd; dense outputs [N,*] are fully
  * written (zeros for culled Gaussians) -- no caller-side zeroing needed -- or, with accumulate != 0, ADDED to

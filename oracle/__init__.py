@@ -316,6 +316,15 @@ def diffuse_cubemap_bwd(v_out):
     return g
 
 
+def exp_neg_check(lo: float, hi: float) -> Tuple[float, int]:
+    """(max relative error vs float64 exp, order-independent checksum of the result bits) of the canonical exp(-sigma) the
+    compositor restatement uses (gs_oracle.c gso_exp_neg) over EVERY float in [lo, hi]."""
+    lo_b = int(np.float32(lo).view(np.uint32)); hi_b = int(np.float32(hi).view(np.uint32))
+    worst = C.c_double(0.0); cs = C.c_uint64(0)
+    lib().gso_exp_neg_check(C.c_uint32(lo_b), C.c_uint32(hi_b), C.byref(worst), C.byref(cs))
+    return float(worst.value), int(cs.value)
+
+
 def ndf_cutoff(roughness: float, cutoff: float = 0.99, n_samples: int = 1000000) -> float:
     """cos(theta) that retains `cutoff` of the GGX NDF energy
     (rfstudio/graphics/_mesh/_splitsum/_wrap.py:120-135, float64 numpy like the reference)."""

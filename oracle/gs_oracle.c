@@ -331,6 +331,36 @@ static inline float gso_exp_neg(float sigma)
     return (y >= -125.0f) ? r : 0.0f;           /* underflow (and NaN): such a pair is far below 1/255 anyway */
 }
 
+/* Test hook for the canonical exponential: over every float whose bit pattern lies in [lo_bits, hi_bits] (sigma >= 0)
+ *   max_rel   = max |gso_exp_neg(sigma) - exp(-sigma)| / exp(-sigma) against the float64 libm exponential,
+ *   checksum  = sum_i bits(gso_exp_neg(sigma_i)) * (2 i + 1)  mod 2^64   (order-independent; the HIP self-test
+ *               gs_selftest_exp computes the same sum from gs_exp_neg, so equal sums <=> equal bits on the whole range). */
+GSO_API void gso_exp_neg_check(uint32_t lo_bits, uint32_t hi_bits, double* max_rel, uint64_t* checksum)
+{
+    const int64_t n = (int64_t)hi_bits - (int64_t)lo_bits + 1;
+    double worst = 0.0;
+    uint64_t sum = 0;
+#pragma omp parallel
+    {
+        double w = 0.0;
+        uint64_t s = 0;
+#pragma omp for schedule(static) nowait
+        for (int64_t i = 0; i < n; ++i) {
+            union { uint32_t u; float f; } in, out;
+            in.u = lo_bits + (uint32_t)i;
+            out.f = gso_exp_neg(in.f);
+            s += (uint64_t)out.u * (2ull * (uint64_t)i + 1ull);
+            const double ref = exp(-(double)in.f);
+            const double e = fabs((double)out.f - ref) / ref;
+            if (e > w) w = e;
+        }
+#pragma omp critical
+        { if (w > worst) worst = w; sum += s; }
+    }
+    if (max_rel) *max_rel = worst;
+    if (checksum) *checksum = sum;
+}
+
 GSO_API void gso_raster_fwd(int W, int H, int tile_size, int D,
                             const float* means2d, const float* conics, const float* opacities,
                             const float* colors, const float* background /* nullable [D] */,

@@ -92,9 +92,14 @@ def test_prefilter_fullsize_subset(cuda):
     assert mx < TOL and fr < ELEM_FRAC_MAX
 
 
-@pytest.mark.parametrize("level", [6, 7])
-def test_view_fullsize_vs_oracle(cuda, level):
-    """One whole view at 491 520 / 1 966 080 Gaussians, 800^2, against the oracle: indices bit-exact, image and all gradients."""
+@pytest.mark.parametrize("level,activations", [(6, "device"), (7, "device"), (7, "host")])
+def test_view_fullsize_vs_oracle(cuda, level, activations):
+    """One whole view at 491 520 / 1 966 080 Gaussians, 800^2, against the oracle: indices bit-exact, image and all gradients.
+
+    activations="device": exp / sigmoid of the raw parameters evaluated once (torch on the GPU, what the product runs) and handed
+    to the oracle -- identical inputs on both sides.  activations="host": the oracle starts from the RAW parameters with the
+    host's libm, as a reference run would -- the inputs of the two compositors then differ by an ulp in a few scales, and the
+    stored-state backward amplifies that (see below); the run keeps that sensitivity a tracked, bounded number."""
     import geosplatting_amd as gs
     sc, cam = sphere_case(level, 800, view=1, cubemap_res=512)
     N = sc.splats.num
@@ -112,8 +117,12 @@ def test_view_fullsize_vs_oracle(cuda, level):
     # bit of a few scales, which moves alpha of a nearly saturated pixel by one ulp of 1.0 -- and the stored-state backward
     # restarts from T_final = 1 - alpha, so that ulp is 6e-4 of a transmittance of 1e-4 and of every gradient term behind it
     # (measured: 1.2e-4 max-norm on kd with host-side activations, <1e-6 with shared ones; scripts/debug_fullsize.py).
-    scales = sc.splats.scales.to(cuda).exp().cpu().numpy()
-    opac = torch.sigmoid(sc.splats.opacities.to(cuda)).squeeze(-1).cpu().numpy()
+    if activations == "device":
+        scales = sc.splats.scales.to(cuda).exp().cpu().numpy()
+        opac = torch.sigmoid(sc.splats.opacities.to(cuda)).squeeze(-1).cpu().numpy()
+    else:
+        _, _, scales, opac = activated(sc.splats)
+    shared = activations == "device"
     cam_pos = cam.c2w[:, 3].numpy()
     lv = [l.numpy() for l in levels]
     vm, K = cam.view_matrix.numpy(), cam.intrinsic_matrix.numpy()
@@ -123,11 +132,10 @@ def test_view_fullsize_vs_oracle(cuda, level):
     m = oracle.rasterization(means, quats, scales, opac, col, vm, K, W, H)
     rgba = np.concatenate([m["render"], m["alphas"][..., None]], -1)
     img_ref = oracle.tonemap_fwd(rgba, exposure, "naive")
-    amb = m["ambiguous"]
 
     # ---- HIP: indices of the rasterizer on the oracle's colours (indices do not depend on them)
     t = lambda a: torch.tensor(a, device=cuda)
-    _, _, meta = gs.rasterization(t(means), t(quats), t(scales), t(opac), t(col), t(vm)[None], t(K)[None], W, H)
+    _r, _a, meta = gs.rasterization(t(means), t(quats), t(scales), t(opac), t(col), t(vm)[None], t(K)[None], W, H)
     for key in ("gaussian_ids", "radii", "tiles_per_gauss", "isect_ids", "flatten_ids"):
         got = meta[key].cpu().numpy()
         assert got.shape == m[key].shape, key
@@ -136,11 +144,12 @@ def test_view_fullsize_vs_oracle(cuda, level):
     assert np.array_equal(meta["depths"].cpu().numpy().view(np.int32), m["depths"].view(np.int32))
     assert np.array_equal(meta["means2d"].cpu().numpy(), m["means2d"])
     last = meta["last_ids"][0].cpu().numpy()
-    mism = (last != m["last_ids"]) & ~amb
-    print(f"\n  N={N} V={len(m['gaussian_ids'])} I={len(m['flatten_ids'])}  ambiguous pixels {int(amb.sum())}  "
-          f"last_ids mismatches outside the band {int(mism.sum())}")
-    assert mism.mean() < 1e-4
-    del meta
+    print(f"\n  N={N} V={len(m['gaussian_ids'])} I={len(m['flatten_ids'])}  activations: {activations}")
+    # the compositor on the oracle's colours: image, alpha and last index BIT-IDENTICAL (same inputs on both sides here in
+    # either mode: the rasterizer is handed the activated values the oracle used)
+    assert np.array_equal(last, m["last_ids"]), f"last_ids differ on {(last != m['last_ids']).sum()} pixels"
+    assert np.array_equal(_r[0].cpu().numpy(), m["render"]) and np.array_equal(_a[0, ..., 0].cpu().numpy(), m["alphas"])
+    del meta, _r, _a
 
     # ---- HIP: the shaded-splat boundary, forward + backward
     d = lambda x: x.clone().to(cuda).requires_grad_(True)
@@ -154,15 +163,16 @@ def test_view_fullsize_vs_oracle(cuda, level):
     et = torch.tensor(exposure, device=cuda, requires_grad=True)
     img = attrs.splat(gsn, [cam], exposure=et, envmap=gs.TextureSplitSum(tb, tl), min_roughness=0.1, max_metallic=1.0)
     assert img.shape == (H, W, 4)
-    ok = ~(amb | mism)
-    mx, fr = _report("image", img.detach().cpu().numpy()[ok], img_ref[ok])
-    assert mx < 1e-6 and fr == 0.0            # the compositor is bit-identical to the oracle; the tone map differs in libm's last bit
-    mse = float(((img.detach().cpu().numpy()[..., :3][ok] - img_ref[..., :3][ok]).astype(np.float64) ** 2).mean())
+    mx, fr = _report("image", img.detach().cpu().numpy(), img_ref)
+    if shared:
+        assert mx < 1e-6 and fr == 0.0        # the compositor is bit-identical to the oracle; the tone map differs in libm's last bit
+    else:
+        assert mx < 1e-4                      # host exp / sigmoid: a few inputs differ by an ulp, a handful of last_ids move
+    mse = float(((img.detach().cpu().numpy()[..., :3] - img_ref[..., :3]).astype(np.float64) ** 2).mean())
     print(f"  PSNR vs oracle image {10 * np.log10(1.0 / max(mse, 1e-30)):.1f} dB")
 
     g = torch.Generator().manual_seed(3)
     v = torch.rand(H, W, 4, generator=g) * 2 - 1
-    v[torch.tensor(~ok)] = 0
     (img * v.to(cuda)).sum().backward()
     v_rgba, v_e = oracle.tonemap_bwd(rgba, exposure, v.numpy(), "naive")
     gr = oracle.rasterization_bwd(means, quats, scales, opac, col, vm, K, W, H, m, v_rgba[..., :3], v_rgba[..., 3])
@@ -171,7 +181,7 @@ def test_view_fullsize_vs_oracle(cuda, level):
     v_means = gr["v_means"] + gsh["v_means"]
     v_logscale = gr["v_scales"] * scales
     v_logit = (gr["v_opacities"] * opac * (1 - opac))[:, None]
-    assert abs(et.grad.item() - v_e) < 1e-5 * max(1.0, abs(v_e)), (et.grad.item(), v_e)
+    assert abs(et.grad.item() - v_e) < (1e-5 if shared else 2e-4) * max(1.0, abs(v_e)), (et.grad.item(), v_e)
     print(f"  exposure     {et.grad.item():.6e} vs {v_e:.6e}")
     worst = {}
     for name, got, want in (("means", gsn.means.grad, v_means), ("scales", gsn.scales.grad, v_logscale),
@@ -187,6 +197,15 @@ def test_view_fullsize_vs_oracle(cuda, level):
         # absolute floor of its element-wise figure is the rounding of that cancelling sum, 1e-5 of the largest texel gradient
         worst[f"level{i}"] = _report(f"v_level{i}", a.grad.cpu().numpy(), b, atol_rel=1e-5)
     assert tb.grad is None or float(tb.grad.abs().max()) == 0.0     # 'pbr' never uses the diffuse lookup
+    if not shared:
+        # HOST activations: glibc's expf / the sigmoid differ from the device's in the last bit of a few scales / opacities; that
+        # moves alpha of a nearly saturated pixel by an ulp of 1.0, and the stored-state backward restarts from T_final = 1 - alpha
+        # (gsplat's algorithm): 6e-4 of a transmittance of 1e-4 and of every gradient term behind it.  Measured 1.2e-4 max-norm
+        # on kd; the tracked bound is 2e-4 for everything (two CORRECT implementations fed inputs one ulp apart differ by this).
+        for name, (mx, fr) in worst.items():
+            assert mx < (5e-4 if name in ("quats", "scales") else 2e-4), f"{name} (host activations): max-norm {mx:.3e}"
+            assert fr < ELEM_FRAC_MAX, f"{name} (host activations): element-wise outliers {fr:.3e}"
+        return
     for name, (mx, fr) in worst.items():
         # measured <= 1.3e-6 (5e-6 / 2e-5 for the scales / quats of FLAT disks, 3rd scale e^-10, whose projection backward cancels:
         # the fp32 oracle itself is ~2e-4 from float64 autograd there, tests/test_oracle_cpu.py); bars with a 10x margin

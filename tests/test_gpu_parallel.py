@@ -29,7 +29,7 @@ def _step(dev, views, all_reduce):
     step = RenderStep(params_from_scene(sc, dev, exposure=1.1))
     ups = {i: (torch.rand(RES, RES, 4, generator=torch.Generator().manual_seed(50 + i)) * 2 - 1).to(dev) for i in range(N_VIEWS)}
     local = [cams[i] for i in views]
-    for _ in range(3):      # the third step runs on the capacity protocol with the first views' geometry prefetched under the prefilter
+    for _ in range(3):      # the first step is exact (one (V, I) read-back per view); the later ones run on the capacity protocol
         grads, _ = step(local, lambda j, img: ups[views[j]].reshape(img.shape), all_reduce=all_reduce)
         torch.cuda.synchronize()
     assert step._i_cap is not None or not local
@@ -125,6 +125,26 @@ def test_capacity_overflow_is_reported_and_recovered():
     assert not all(torch.equal(a, b) for a, b in zip(ref[1], bad[1])) # (the truncated step really was incomplete)
     got = run()
     assert step.poll_capacity(wait=True)
+    _same(ref, got)
+
+
+def test_capacity_overflow_seen_inside_call_is_not_lost():
+    """RenderStep.__call__ polls (non-blocking) before every step.  If THAT poll is the one that sees the overflow word of an
+    earlier step, the fact must survive until the caller asks: `truncated_steps` counts it and the caller's next
+    poll_capacity() returns False once."""
+    step, run = _engine(torch.device("cuda", 0))
+    step._use_capacity = False
+    run(); ref = run()
+    step._use_capacity = True
+    step._seen_counts = []; step._exact_max_i = 0
+    step._i_cap = 4096
+    assert step.truncated_steps == 0
+    run()                                                             # truncated; run() synchronises, so the word is on the host
+    run()                                                             # __call__'s own poll sees it (and raises the capacity) ...
+    assert step.truncated_steps >= 1 and step._i_cap > 4096
+    assert not step.poll_capacity(wait=True)                          # ... and the caller still learns about it
+    got = run()
+    assert step.poll_capacity(wait=True)                              # reported once; this step was complete
     _same(ref, got)
 
 

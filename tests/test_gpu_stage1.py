@@ -146,6 +146,15 @@ def test_smoothing_branches(cuda):
         m.smooth_type, m.kd_grad_weight, m.ks_grad_weight, m.normal_grad_weight = mode, kw, 0.5 * kw, kn
         for p in m.parameters():
             p.grad = None
+        # perturbation stds > 0 must be IGNORED outside smooth_type == 'jitter' (rfstudio/model/geosplat.py:800-801): no jittered
+        # encoder evaluation, no |kd_jitter - kd| term, nothing drawn from the jitter generator
+        m.kd_regualr_perturb_std = m.ks_regualr_perturb_std = 0.0
+        _, _, _, reg0 = m.get_gsplat()
+        m.kd_regualr_perturb_std = m.ks_regualr_perturb_std = 0.05
+        rng_before = m._jitter_gen.get_state().clone()
+        _, _, attrs_j, reg1 = m.get_gsplat()
+        assert attrs_j.kd_jitter is None and attrs_j.ks_jitter is None
+        assert float(reg1) == float(reg0) and torch.equal(m._jitter_gen.get_state(), rng_before)
         _, _, reg = m.render_report(cams, gts)
         smooth = m._last_smoothing
         assert float(smooth) > 0

@@ -61,6 +61,33 @@ def test_golden_tonemap():
         assert rel_err(t(torch.tensor(g["rgba"]), torch.tensor(float(g["exposure"]))).numpy(), g[mode]) < 2e-6
 
 
+def test_golden_ndf_cutoff():
+    """The lobe cut-off cosines of the split-sum prefilter: the reference's own `__ndfBounds`
+    (rfstudio/graphics/_mesh/_splitsum/_wrap.py:120-135, run unchanged by scripts/make_golden_ndf.py with `_get_plugin` stubbed)
+    against the oracle's and the product's restatement -- float64 NumPy on all three sides, so the values must be EQUAL."""
+    g = gold("ref_ndf_cutoff.npz")
+    assert len(g["res"]) >= 12
+    for rough, cutoff, want in zip(g["roughness"], g["cutoff"], g["costheta"]):
+        assert oracle.ndf_cutoff(float(rough), float(cutoff)) == float(want), (rough, cutoff)
+        assert ss.ndf_cutoff(float(rough), float(cutoff)) == float(want), (rough, cutoff)
+    # the six levels of a 512^2 environment are the first six rows
+    assert list(g["res"][:6]) == [512, 256, 128, 64, 32, 16]
+    assert np.allclose(g["roughness"][:6], oracle.splitsum_roughness(6), rtol=0, atol=0)
+
+
+def test_canonical_exp_accuracy():
+    """gso_exp_neg (the spelled-out exp(-sigma) shared with the HIP compositor, gs_oracle.c) against the float64 exponential on
+    EVERY float of [0, 16].  gsplat evaluates `__expf(-sigma)` = ex2.approx(-sigma * log2 e), documented at 2 + floor(|1.16 x|) ulp:
+    the argument product is rounded once there as here, so the error grows with sigma in both -- measured 4.3e-7 on the live
+    range (a pair with alpha < 1/255, i.e. sigma > ln 255 = 5.54, is skipped) and 9.3e-7 at sigma = 16; the bar is 1e-4."""
+    live, _ = oracle.exp_neg_check(0.0, 5.55)
+    assert live < 5e-7, live
+    full, cs = oracle.exp_neg_check(0.0, 16.0)
+    assert full < 1e-6, full
+    assert oracle.exp_neg_check(1.0, 2.0)[1] == oracle.exp_neg_check(1.0, 2.0)[1]      # the checksum is deterministic (threads, order)
+    assert oracle.exp_neg_check(0.0, 0.0) == (0.0, 0x3f800000)     # exp(-0) == 1 exactly; checksum of one item = its bits
+
+
 def test_tonemap_none_scales_alpha_too():
     """tone_type='none' is `render_rgba * exposure` (rfstudio/model/geosplat.py:123-124): alpha is scaled with the colours and
     the exposure gradient carries the alpha term"""

@@ -33,8 +33,8 @@ SYMBOLS = [
     "gs_isect_sort", "gs_isect_bin_ws_bytes", "gs_isect_bin", "gs_isect_offsets", "gs_raster_ws_bytes", "gs_raster_fwd", "gs_raster_prepare", "gs_raster_prepare_vis", "gs_raster_composite", "gs_raster_grad_stride", "gs_raster_bwd", "gs_raster_bwd_acc", "gs_selftest_rcp", "gs_selftest_exp", "gs_isect_bin_cap", "gs_isect_offsets_cap", "gs_raster_prepare_vis_cap", "gs_raster_composite_cap", "gs_raster_bwd_cap", "gs_raster_bwd_acc_cap", "gs_project_bwd_cap", "gs_project_bwd", "gs_shade_fwd",
     "gs_shade_bwd_ws_bytes", "gs_shade_bwd", "gs_tonemap_fwd", "gs_tonemap_bwd", "gs_tonemap_fwd3", "gs_tonemap_bwd3", "gs_cubemap_mip_fwd", "gs_cube_sample_linear",
     "gs_cubemap_mip_bwd", "gs_diffuse_cubemap_fwd", "gs_diffuse_cubemap_bwd", "gs_specular_bounds", "gs_cube_dir_table",
-    "gs_specular_cubemap_fwd", "gs_specular_cubemap_bwd", "gs_specular_patch_count", "gs_specular_weights_build",
-    "gs_specular_apply", "gs_specular_apply_range", "gs_mgadapter_fwd", "gs_mgadapter_bwd", "gs_vertex_normals_fwd",
+    "gs_specular_cubemap_fwd", "gs_specular_cubemap_bwd", "gs_specular_tiles_count", "gs_specular_tiles_fill",
+    "gs_specular_tiles_check", "gs_specular_tiles_apply", "gs_mgadapter_fwd", "gs_mgadapter_bwd", "gs_vertex_normals_fwd",
     "gs_vertex_normals_bwd", "gs_photo_loss_ws_bytes", "gs_photo_loss", "gs_hashgrid_fwd", "gs_hashgrid_bwd_ws_bytes", "gs_hashgrid_bwd", "gs_hashgrid_bwd_fixed_ws_bytes", "gs_hashgrid_bwd_fixed", "gs_mlp_wgrad_ws_bytes", "gs_mlp_wgrad",
     "gs_flexicubes_ws_bytes", "gs_flexicubes_count", "gs_flexicubes_fwd", "gs_flexicubes_bwd", "gs_flexicubes_entropy_fwd",
     "gs_flexicubes_entropy_bwd",

@@ -15,6 +15,11 @@
 // (these kernels are memory-bound; the lost FMAs cost nothing measurable).
 #pragma clang fp contract(off)
 #include "gs_cube.h"
+#include "gs_splitsum_math.h"
+
+// backward gathers look for the outputs that include a source texel inside the source's OWN lobe box grown by this margin
+// (membership `ldv >= cutoff` is symmetric; the boxes, built from culled 16x16 tiles, are so only up to rare one-texel differences)
+#define GS_SPECULAR_BWD_MARGIN 2
 
 __device__ __forceinline__ float pixel_area(int x, int y, int N)
 {
@@ -36,15 +41,6 @@ __device__ __forceinline__ void cube_to_dir(int x, int y, int side, int N, float
     face_point(side, fx, fy, d);
     const float l = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
     if (l > 0.0f) { d[0] /= l; d[1] /= l; d[2] /= l; } else { d[0] = d[1] = d[2] = 0.0f; }
-}
-
-__device__ __forceinline__ float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-
-__device__ __forceinline__ float ndfGGX(float alphaSqr, float cosTheta)
-{
-    const float c = fminf(fmaxf(cosTheta, 0.0f), 1.0f);
-    const float d = (c * alphaSqr - c) * c + 1.0f;
-    return alphaSqr / (d * d * 3.14159265358979323846f);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -280,10 +276,21 @@ specular_kernel(int R, const float* __restrict__ src /*cubemap (fwd) | v_out rgb
     const float alphaSqr = alpha * alpha;
     const int lx = lane & 7, ly = lane >> 3;
     float wsum = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    const int own_s = t / (R * R), own_y = (t / R) % R, own_x = t % R;
     for (int s = 0; s < 6; ++s) {
         const float4 b = *reinterpret_cast<const float4*>(bounds + (size_t)t * 24 + s * 4);
-        const int xmin = (int)b.x, xmax = (int)b.y, ymin = (int)b.z, ymax = (int)b.w;
-        if (xmin > xmax) continue;
+        int xmin = (int)b.x, xmax = (int)b.y, ymin = (int)b.z, ymax = (int)b.w;
+        if (BWD && R < 64) {
+            // small levels: one or four 16x16 tiles per face, where the reference's tile culling (whose boxes these are) is far
+            // from symmetric -- every texel of every face is a candidate output, the pair test below decides
+            xmin = ymin = 0; xmax = ymax = R - 1;
+        } else {
+            if (xmin > xmax) continue;
+            if (BWD) {  // candidate outputs: this texel's own box plus a margin
+                xmin = max(xmin - GS_SPECULAR_BWD_MARGIN, 0); xmax = min(xmax + GS_SPECULAR_BWD_MARGIN, R - 1);
+                ymin = max(ymin - GS_SPECULAR_BWD_MARGIN, 0); ymax = min(ymax + GS_SPECULAR_BWD_MARGIN, R - 1);
+            }
+        }
         for (int by = ymin; by <= ymax; by += 8)
             for (int bx = xmin; bx <= xmax; bx += 8) {
                 const int x = bx + lx, y = by + ly;
@@ -294,14 +301,16 @@ specular_kernel(int R, const float* __restrict__ src /*cubemap (fwd) | v_out rgb
                 const float* L = BWD ? own : other;
                 const float* VNR = BWD ? other : own;
                 const float ldv = dot3(L, VNR);
-                if (ldv >= cutoff) {
-                    float Hv[3] = { L[0] + VNR[0], L[1] + VNR[1], L[2] + VNR[2] };
-                    const float hl = sqrtf(dot3(Hv, Hv));
-                    if (hl > 0.0f) { Hv[0] /= hl; Hv[1] /= hl; Hv[2] /= hl; } else { Hv[0] = Hv[1] = Hv[2] = 0.0f; }
-                    const float wiDotN = fmaxf(ldv, 0.0f);
-                    const float VNRDotH = fmaxf(dot3(VNR, Hv), 0.0f);
+                bool in = ldv >= cutoff;
+                if (BWD && in) {
+                    // exact adjoint of the forward: output `ti` gathers THIS texel only if it lies inside ti's box on this face
+                    // (the reference's backward is the forward loop with a scatter, cubemap.cu:300-350)
+                    const float4 ob = *reinterpret_cast<const float4*>(bounds + ti * 24 + own_s * 4);
+                    in = own_x >= (int)ob.x && own_x <= (int)ob.y && own_y >= (int)ob.z && own_y <= (int)ob.w;
+                }
+                if (in) {
                     const float area = BWD ? own_area : o4.w;
-                    const float w = wiDotN * ndfGGX(alphaSqr, VNRDotH) * area / 4.0f;
+                    const float w = specular_pair_g(L, VNR, ldv, alphaSqr) * area / 4.0f;
                     c0 += src[ti * 3] * w; c1 += src[ti * 3 + 1] * w; c2 += src[ti * 3 + 2] * w;
                     wsum += w;
                 }
@@ -317,271 +326,6 @@ specular_kernel(int R, const float* __restrict__ src /*cubemap (fwd) | v_out rgb
             *reinterpret_cast<float4*>(dst + (size_t)t * 4) = make_float4(c0, c1, c2, wsum);
         }
     }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Cached pair weights.  w(o,i) depends on (R, roughness, cutoff) only -- never on the cubemap -- and the cubemap
-// is re-filtered every training step.  With 288 GB of HBM the weights are worth keeping: for every texel t the
-// 8x8 patches of its face AABBs are stored as 64 contiguous floats in the traversal order of specular_kernel
-// (0 outside the lobe / outside the AABB).  Applying the filter then is a pure stream: one coalesced 256-byte
-// weight read per patch plus L2-resident texel gathers -- HBM-bound instead of division/sqrt-bound -- and the
-// numbers are bit-identical to the direct kernel because the same kernel code fills the table.
-// Two tables per level: forward (t = output texel) and backward (t = input texel, see specular_kernel<BWD>).
-__global__ void __launch_bounds__(256)
-specular_patch_count_kernel(int R, const float* __restrict__ bounds, int32_t* __restrict__ counts)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 6 * R * R) return;
-    int n = 0;
-    for (int s = 0; s < 6; ++s) {
-        const float4 b = *reinterpret_cast<const float4*>(bounds + (size_t)t * 24 + s * 4);
-        const int xmin = (int)b.x, xmax = (int)b.y, ymin = (int)b.z, ymax = (int)b.w;
-        if (xmin > xmax) continue;
-        n += ((xmax - xmin) / 8 + 1) * ((ymax - ymin) / 8 + 1);
-    }
-    counts[t] = n;
-}
-
-extern "C" int gs_specular_patch_count(int R, const float* bounds, int32_t* counts, void* stream)
-{
-    GS_CHECK_ARG(R >= 1, "bad R");
-    hipLaunchKernelGGL(specular_patch_count_kernel, dim3(gs_cdiv(6 * R * R, 256)), dim3(256), 0, (hipStream_t)stream, R,
-                       bounds, counts);
-    GS_CHECK_LAUNCH();
-    return GS_OK;
-}
-
-// MODE 0: fill the weight table (and wsum in the forward orientation); MODE 1: apply a filled table.
-template <bool BWD, int MODE>
-__global__ void __launch_bounds__(256)
-specular_table_kernel(int R, const float* __restrict__ src, const float* __restrict__ bounds,
-                      const float4* __restrict__ table, const int64_t* __restrict__ patch_offsets,
-                      float roughness, float cutoff, float* __restrict__ weights, float* __restrict__ wsum_out,
-                      float* __restrict__ dst, int dst_stride, int accumulate, int32_t* __restrict__ patch_desc)
-{
-    const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= 6 * R * R) return;
-    const int lx = lane & 7, ly = lane >> 3;
-    float own[3] = { 0.f, 0.f, 0.f }, own_area = 0.0f, alphaSqr = 0.0f;
-    if (MODE == 0) {
-        const float4 own4 = table[t];
-        own[0] = own4.x; own[1] = own4.y; own[2] = own4.z; own_area = own4.w;
-        const float alpha = roughness * roughness;
-        alphaSqr = alpha * alpha;
-    }
-    float* wp = weights + (size_t)patch_offsets[t] * 64 + lane;
-    int32_t* dp = (MODE == 0 && patch_desc) ? patch_desc + patch_offsets[t] : nullptr;
-    float wsum = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
-    for (int s = 0; s < 6; ++s) {
-        const float4 b = *reinterpret_cast<const float4*>(bounds + (size_t)t * 24 + s * 4);
-        const int xmin = (int)b.x, xmax = (int)b.y, ymin = (int)b.z, ymax = (int)b.w;
-        if (xmin > xmax) continue;
-        for (int by = ymin; by <= ymax; by += 8)
-            for (int bx = xmin; bx <= xmax; bx += 8, wp += 64) {
-                const int x = bx + lx, y = by + ly;
-                const bool in_box = (x <= xmax && y <= ymax);
-                const size_t ti = ((size_t)s * R + y) * R + x;
-                if (MODE == 0) {
-                    float w = 0.0f;
-                    if (in_box) {
-                        const float4 o4 = table[ti];
-                        const float other[3] = { o4.x, o4.y, o4.z };
-                        const float* L = BWD ? own : other;
-                        const float* VNR = BWD ? other : own;
-                        const float ldv = dot3(L, VNR);
-                        if (ldv >= cutoff) {
-                            float Hv[3] = { L[0] + VNR[0], L[1] + VNR[1], L[2] + VNR[2] };
-                            const float hl = sqrtf(dot3(Hv, Hv));
-                            if (hl > 0.0f) { Hv[0] /= hl; Hv[1] /= hl; Hv[2] /= hl; } else { Hv[0] = Hv[1] = Hv[2] = 0.0f; }
-                            const float wiDotN = fmaxf(ldv, 0.0f);
-                            const float VNRDotH = fmaxf(dot3(VNR, Hv), 0.0f);
-                            const float area = BWD ? own_area : o4.w;
-                            w = wiDotN * ndfGGX(alphaSqr, VNRDotH) * area / 4.0f;
-                        }
-                    }
-                    *wp = w;
-                    wsum += w;
-                    if (dp) { if (lane == 0) *dp = (s << 24) | (by << 12) | bx; ++dp; }
-                } else {
-                    const float w = *wp;
-                    if (w != 0.0f) { c0 += src[ti * 3] * w; c1 += src[ti * 3 + 1] * w; c2 += src[ti * 3 + 2] * w; }
-                }
-            }
-    }
-    if (MODE == 0) {
-        if (wsum_out) { wsum = gs_wave_sum(wsum); if (lane == 0) wsum_out[t] = wsum; }
-    } else {
-        c0 = gs_wave_sum(c0); c1 = gs_wave_sum(c1); c2 = gs_wave_sum(c2);
-        if (lane == 0) {
-            float* p = dst + (size_t)t * dst_stride;
-            if (accumulate) { p[0] += c0; p[1] += c1; p[2] += c2; } else { p[0] = c0; p[1] = c1; p[2] = c2; }
-        }
-    }
-}
-
-extern "C" int gs_specular_weights_build(int R, const float* bounds, const float* dir_table, const int64_t* patch_offsets,
-                                         float roughness, float costheta_cutoff, int backward, float* weights,
-                                         float* wsum, int32_t* patch_desc, void* stream)
-{
-    GS_CHECK_ARG(R >= 1 && R < 4096 && dir_table && patch_offsets && weights, "bad arguments");
-    const dim3 grid(gs_cdiv(6 * R * R, 4)), block(256);
-    if (backward)
-        hipLaunchKernelGGL((specular_table_kernel<true, 0>), grid, block, 0, (hipStream_t)stream, R, nullptr, bounds,
-                           (const float4*)dir_table, patch_offsets, roughness, costheta_cutoff, weights, wsum, nullptr, 0, 0, patch_desc);
-    else
-        hipLaunchKernelGGL((specular_table_kernel<false, 0>), grid, block, 0, (hipStream_t)stream, R, nullptr, bounds,
-                           (const float4*)dir_table, patch_offsets, roughness, costheta_cutoff, weights, wsum, nullptr, 0, 0, patch_desc);
-    GS_CHECK_LAUNCH();
-    return GS_OK;
-}
-
-// Streaming application of a weight table: the patches of texel t are a flat list (descriptor = face|by|bx),
-// so four patches' weights and texels are requested before any is consumed (memory-level parallelism; the direct
-// kernel's nested AABB loops serialise one patch's latency after the other).
-// One load per lane and patch: three strided dword gathers bounded the first version (texture-addresser cycles, not HBM).
-// SRC4 = float4-padded source [6,R,R,4], one 16-byte load; !SRC4 = the packed [6,R,R,3] map itself, one 12-byte load
-// (dwordx3, 4-byte aligned) -- the default: a patch row of 8 texels is 96 instead of 128 bytes, i.e. fewer cache lines
-// per tap instruction (1.67 vs 1.75 ms per direction), and the padded copy per level and direction disappears.
-#ifndef GS_APPLY_XCD
-#define GS_APPLY_XCD 1
-#endif
-#ifndef GS_APPLY_NT
-#define GS_APPLY_NT 1
-#endif
-#if GS_APPLY_NT
-#define GS_STREAM_LOAD(p) __builtin_nontemporal_load(p)
-#else
-#define GS_STREAM_LOAD(p) (*(p))
-#endif
-#ifndef GS_APPLY_UNROLL
-#define GS_APPLY_UNROLL 4          // patches in flight per texel and wave (x GS_APPLY_TPW texels)
-#endif
-#ifndef GS_APPLY_WAVES
-#define GS_APPLY_WAVES 4            // texels (waves) per workgroup
-#endif
-#ifndef GS_APPLY_LDS
-#define GS_APPLY_LDS 0              // dynamic LDS request (occupancy cap experiment)
-#endif
-#ifndef GS_APPLY_TPW
-#define GS_APPLY_TPW 2              // texels per wave, processed INTERLEAVED (their latency chains overlap)
-#endif
-// TPW texels per wave, interleaved: the offset loads, the weight batches and the tap batches of all TPW texels are
-// issued together, so one wave carries TPW independent latency chains (offsets -> weights (HBM) -> taps -> sum); the taps
-// are branch-free (zero-weight taps read texel 0 and are masked: a branch around a load makes the compiler wait for each
-// tap before it issues the next -- the first version ran its 12 taps strictly one after the other).
-// Measured (scripts/apply_experiment.py, ms per direction over the 6 levels): 12 serial taps 2.04; branch-free U=6 1.88;
-// TPW=2 x U=4 1.76 (default); TPW=2 x 6 1.88; TPW=4 x 3 1.82.  What bounds it (scripts/run_pmc_apply.sh): the weight
-// stream ALONE runs at 5.9-6.6 TB/s in this structure (a plain dword-per-lane stream: 7 TB/s, scripts/micro), the taps
-// hit L1 (1.1 L2 requests per patch) but every tap instruction is 8+ cache-line accesses in the CU's in-order
-// vector-memory pipeline behind the HBM-latency weight loads (latency-FIFO / pending stalls 30 % of the time, waves
-// cannot issue 1/3 of their cycles): the two costs add instead of overlapping.  Dead ends: 16-byte loads throughout (one
-// lane = 4 adjacent taps, 1 instead of 2 memory instructions per patch: 2.09-2.20), source regions staged through LDS
-// per 16-texel workgroup so that only the weight stream uses the memory pipeline (2.63: the three-barrier prologue and
-// the 58 staged texels per output texel cost more than the 211 taps they replace), workgroups of 8 / 16 waves (no L1
-// gain), taps addressed independently of the weights (more lanes fetch: slower at 256^2).
-template <bool SRC4>
-__global__ void __launch_bounds__(64 * GS_APPLY_WAVES)
-specular_apply_kernel(int R, const float* __restrict__ src, const int64_t* __restrict__ patch_offsets, int64_t total_patches,
-                      const int32_t* __restrict__ patch_desc, const float* __restrict__ weights,
-                      float* __restrict__ dst, int dst_stride, int accumulate, int t_begin, int t_end)
-{
-    constexpr int TPW = GS_APPLY_TPW, U = GS_APPLY_UNROLL;
-    const int lane = threadIdx.x & 63;
-#if GS_APPLY_XCD
-    const int per = gridDim.x / 8;
-    const int grp = (blockIdx.x % 8) * per + blockIdx.x / 8;
-#else
-    const int grp = blockIdx.x;
-#endif
-    // texels [t_begin, t_end) of the level: the whole level on one GPU, this rank's share when the prefilter is sharded
-    const int t0 = t_begin + __builtin_amdgcn_readfirstlane((grp * GS_APPLY_WAVES + (int)(threadIdx.x >> 6)) * TPW);
-    const int n = t_end;
-    const int n_all = 6 * R * R;
-    if (t0 >= n) return;
-    const int lx = lane & 7, ly = lane >> 3;
-    int64_t pb[TPW], pe[TPW];
-#pragma unroll
-    for (int j = 0; j < TPW; ++j) {
-        const int t = min(t0 + j, n - 1);
-        pb[j] = patch_offsets[t];
-        pe[j] = (t + 1 < n_all) ? patch_offsets[t + 1] : total_patches;
-        if (t0 + j >= n) pe[j] = pb[j];
-    }
-    int64_t longest = 0;
-#pragma unroll
-    for (int j = 0; j < TPW; ++j) longest = max(longest, pe[j] - pb[j]);
-    float c[TPW][3];
-#pragma unroll
-    for (int j = 0; j < TPW; ++j) c[j][0] = c[j][1] = c[j][2] = 0.0f;
-    for (int64_t o = 0; o < longest; o += U) {
-        float w[TPW][U]; unsigned ti[TPW][U];
-#pragma unroll
-        for (int j = 0; j < TPW; ++j)
-#pragma unroll
-            for (int k = 0; k < U; ++k) {
-                const int64_t p = pb[j] + o + k;
-                const bool on = p < pe[j];
-                const int d = on ? patch_desc[p] : 0;
-                w[j][k] = on ? GS_STREAM_LOAD(weights + (size_t)p * 64 + lane) : 0.0f;
-                const int sf = d >> 24, by = (d >> 12) & 0xfff, bx = d & 0xfff;
-                ti[j][k] = (unsigned)(((sf * R + (by + ly)) * R + (bx + lx)) * (SRC4 ? 4 : 3));
-            }
-#pragma unroll
-        for (int j = 0; j < TPW; ++j) {
-            float v[U][3];
-#pragma unroll
-            for (int k = 0; k < U; ++k) {
-                const bool nz = w[j][k] != 0.0f;                     // zero-weight taps (outside the lobe / the face) read
-                const unsigned a = nz ? ti[j][k] : 0u;               // texel 0 and are masked: no branch around the load
-                if (SRC4) {
-                    const float4 q = *reinterpret_cast<const float4*>(src + a);
-                    v[k][0] = nz ? q.x : 0.0f; v[k][1] = nz ? q.y : 0.0f; v[k][2] = nz ? q.z : 0.0f;
-                } else {
-                    struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };     // one 12-byte load (dwordx3), 4-byte aligned
-                    const F3 q = *reinterpret_cast<const F3*>(src + a);
-                    v[k][0] = nz ? q.x : 0.0f; v[k][1] = nz ? q.y : 0.0f; v[k][2] = nz ? q.z : 0.0f;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < U; ++k) { c[j][0] += v[k][0] * w[j][k]; c[j][1] += v[k][1] * w[j][k]; c[j][2] += v[k][2] * w[j][k]; }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < TPW; ++j) {
-        const float s0 = gs_wave_sum(c[j][0]), s1 = gs_wave_sum(c[j][1]), s2 = gs_wave_sum(c[j][2]);
-        if (lane == 0 && t0 + j < n) {
-            float* q = dst + (size_t)(t0 + j) * dst_stride;
-            if (accumulate) { q[0] += s0; q[1] += s1; q[2] += s2; } else { q[0] = s0; q[1] = s1; q[2] = s2; }
-        }
-    }
-}
-
-extern "C" int gs_specular_apply_range(int R, const float* src, int src_stride, const int64_t* patch_offsets,
-                                       int64_t total_patches, const int32_t* patch_desc, const float* weights, float* dst,
-                                       int dst_stride, int accumulate, int t_begin, int t_end, void* stream)
-{
-    GS_CHECK_ARG(R >= 1 && src && patch_offsets && patch_desc && weights && dst && dst_stride >= 3, "bad arguments");
-    GS_CHECK_ARG(src_stride == 3 || src_stride == 4, "src_stride must be 3 or 4");
-    GS_CHECK_ARG(t_begin >= 0 && t_begin <= t_end && t_end <= 6 * R * R, "texel range outside [0, 6 R^2]");
-    if (t_begin == t_end) return GS_OK;
-    const int groups = (gs_cdiv(t_end - t_begin, GS_APPLY_WAVES * GS_APPLY_TPW) + 7) / 8 * 8;   // multiple of 8: one contiguous share per XCD
-    if (src_stride == 4)
-        hipLaunchKernelGGL(specular_apply_kernel<true>, dim3(groups), dim3(64 * GS_APPLY_WAVES), GS_APPLY_LDS, (hipStream_t)stream, R, src,
-                           patch_offsets, total_patches, patch_desc, weights, dst, dst_stride, accumulate, t_begin, t_end);
-    else
-        hipLaunchKernelGGL(specular_apply_kernel<false>, dim3(groups), dim3(64 * GS_APPLY_WAVES), GS_APPLY_LDS, (hipStream_t)stream, R, src,
-                           patch_offsets, total_patches, patch_desc, weights, dst, dst_stride, accumulate, t_begin, t_end);
-    GS_CHECK_LAUNCH();
-    return GS_OK;
-}
-
-extern "C" int gs_specular_apply(int R, const float* src, int src_stride, const int64_t* patch_offsets,
-                                 int64_t total_patches, const int32_t* patch_desc, const float* weights, float* dst,
-                                 int dst_stride, int accumulate, void* stream)
-{
-    return gs_specular_apply_range(R, src, src_stride, patch_offsets, total_patches, patch_desc, weights, dst, dst_stride,
-                                   accumulate, 0, 6 * R * R, stream);
 }
 
 extern "C" int gs_specular_cubemap_fwd(int R, const float* cubemap, const float* bounds, const float* dir_table,

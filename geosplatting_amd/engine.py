@@ -27,7 +27,7 @@ from .parallel import GradBucket
 from .rasterization import (_bin_stage, _bin_stage_cap, _composite_stage, _composite_stage_cap, _forward_stages, _prepare_stage,
                             _prepare_stage_cap, _project_stage)
 from .shading import _MODE, _TONE, RenderableAttrs, _make_env, get_fg_lut, shade_private_copies
-from .splitsum import (CACHE_PAIR_WEIGHTS, TextureSplitSum, as_splitsum, as_splitsum_backward, as_splitsum_backward_sharded,
+from .splitsum import (TextureSplitSum, as_splitsum, as_splitsum_backward, as_splitsum_backward_sharded,
                        as_splitsum_sharded, can_shard_prefilter)
 from .splats import SplatSet
 
@@ -126,7 +126,7 @@ class RenderStep:
         mode, tone = _MODE[self.mode], _TONE[self.tone_type]
         # explicit prefilter backward (as_splitsum_backward) instead of autograd: it can then be split in two halves and
         # the first half placed on its own stream, under the compositor of the remaining views
-        explicit_pre = self.prefilter and CACHE_PAIR_WEIGHTS
+        explicit_pre = self.prefilter
         cubemap = p.cubemap.detach().requires_grad_(self.prefilter and not explicit_pre)
         import torch.distributed as dist
         world = dist.get_world_size() if (all_reduce and dist.is_available() and dist.is_initialized()) else 1

@@ -61,54 +61,163 @@ def dir_table(res: int, device: torch.device) -> Tensor:
     return _dir_table_cache[key]
 
 
-_weights_cache: Dict[Tuple[int, float, float, int], Dict[str, Tensor]] = {}
-CACHE_PAIR_WEIGHTS = os.environ.get("GEOSPLAT_PREFILTER_CACHE", "1") != "0"
+# ----------------------------------------------------------------------------- tiled pair-weight tables (levels with R >= 64)
+TILED_PREFILTER = os.environ.get("GEOSPLAT_PREFILTER_TILES", "1") != "0"     # 0: every level through the direct kernels
+BWD_MARGIN = 2                    # candidate outputs of a source texel: its own lobe box grown by this (csrc GS_SPECULAR_BWD_MARGIN)
+_ROW_PAD = 8                      # csrc GS_TILE_ROW_PAD
 
 
-def specular_weights(res: int, roughness: float, cutoff: float, device: torch.device) -> Dict[str, Tensor]:
-    """Cached pair weights of one pyramid level (forward + transposed orientation, ~10 GB in total for a 512^2
-    pyramid -- sized for the 288 GB of an MI355X).  They depend on (res, roughness, cutoff) only, while the cubemap
-    changes every training step."""
+def _bwd_margin(res: int) -> int:
+    """levels below 64^2 have one or four 16x16 culling tiles per face -- the reference's boxes are far from symmetric there:
+    every texel of every face is a candidate output (margin >= R), the pair test decides"""
+    return BWD_MARGIN if res >= 64 else res
+
+
+def tile_geometry(res: int) -> Tuple[int, int]:
+    """(bw, nb): blocks per tile row, blocks per tile, for the 16 waves of a workgroup.  Large tiles where the lobes are small
+    against the face (the staged rectangle grows by the lobe diameter once per tile), one 8x8 block split over all 16 waves
+    where a lobe covers most of a face and the level has few texels."""
+    if res >= 512:
+        return 4, 16          # 32 x 32 texels, one wave per block
+    if res >= 256:
+        return 4, 8           # 32 x 16, two waves per block
+    if res >= 128:
+        return 2, 4           # 16 x 16, four waves per block
+    return 1, 1               # 8 x 8, sixteen waves on the block
+_tiles_cache: Dict[Tuple[int, float, float, int], Optional[Dict]] = {}
+
+
+def tiles_eligible(res: int) -> bool:
+    return TILED_PREFILTER and res >= 16 and res % 16 == 0
+
+
+def _build_direction(res: int, roughness: float, ct: float, bounds: Tensor, table: Tensor, tiles: Tensor, backward: int, bw: int,
+                     nb: int) -> Dict:
+    lib = L.lib()
+    dev = bounds.device
+    nt = tiles.shape[0]
+    ns = 6 * nb                                                            # slots per tile
+    margin = _bwd_margin(res)
+    cnt = torch.zeros(nt * ns, dtype=torch.int32, device=dev)
+    ext = torch.zeros(nt * ns, 4, dtype=torch.int32, device=dev)
+    pairs = torch.zeros(1, dtype=torch.int64, device=dev)
+    L.check(lib.gs_specular_tiles_count(res, L.f32(roughness), L.f32(ct), backward, margin, bw, nb, L.ptr(bounds), L.ptr(table),
+                                        L.ptr(tiles), nt, L.ptr(cnt), L.ptr(ext), L.ptr(pairs), L.stream()), "gs_specular_tiles_count")
+    cnt_pad = ((cnt.long() + (_ROW_PAD - 1)) // _ROW_PAD) * _ROW_PAD
+    csum = torch.cumsum(cnt_pad, 0)
+    row_begin = (csum - cnt_pad).contiguous()
+    total = int(csum[-1].item())
+    # per (tile, face): the source rectangle its four blocks can address, staged in LDS with a pitch = 8 (mod 16) texels
+    # (conflict-free ds_read_b128 for the 8x8 lane arrangement: 16-lane groups cover 64 distinct banks)
+    c4 = cnt.view(nt, 6, nb)
+    e4 = ext.view(nt, 6, nb, 4).long()
+    on = c4 > 0
+    big = 1 << 30
+    x0 = torch.where(on, e4[..., 0], torch.full_like(e4[..., 0], big)).amin(-1)
+    x1 = torch.where(on, e4[..., 1], torch.full_like(e4[..., 1], -big)).amax(-1)
+    y0 = torch.where(on, e4[..., 2], torch.full_like(e4[..., 2], big)).amin(-1)
+    y1 = torch.where(on, e4[..., 3], torch.full_like(e4[..., 3], -big)).amax(-1)
+    some = on.any(-1)
+    rw = torch.where(some, x1 - x0 + 1, torch.zeros_like(x0))
+    rh = torch.where(some, y1 - y0 + 1, torch.zeros_like(x0))
+    pitch = torch.where(some, rw + ((8 - rw) % 16), torch.zeros_like(rw))
+    seg = torch.stack((torch.where(some, x0, torch.zeros_like(x0)), torch.where(some, y0, torch.zeros_like(y0)), rh, pitch), -1).int().contiguous()
+    lds_bytes = int((rh * pitch).max().item()) * 16
+    desc = torch.zeros(max(total, 2 * _ROW_PAD), dtype=torch.int32, device=dev)
+    weights = torch.zeros(max(total, 2 * _ROW_PAD) * 64, dtype=torch.float32, device=dev)
+    L.check(lib.gs_specular_tiles_fill(res, L.f32(roughness), L.f32(ct), backward, margin, bw, nb, L.ptr(bounds), L.ptr(table),
+                                       L.ptr(tiles), nt, L.ptr(row_begin), L.ptr(seg), L.ptr(desc), L.ptr(weights), L.stream()),
+            "gs_specular_tiles_fill")
+    rows_per_tile = cnt_pad.view(nt, ns).sum(-1)
+    return {"cnt": cnt_pad.int().view(nt, ns).contiguous(), "row_begin": row_begin.view(nt, ns).contiguous(), "seg": seg, "desc": desc,
+            "weights": weights, "rows": total, "kept_rows": int(cnt.sum().item()), "pairs": int(pairs.item()), "lds_bytes": lds_bytes,
+            "rows_per_tile": rows_per_tile}
+
+
+def specular_tiles(res: int, roughness: float, cutoff: float, device: torch.device) -> Optional[Dict]:
+    """Tiled pair-weight tables of one pyramid level (csrc/gs_splitsum_tiles.hip), built once per (res, roughness, cutoff, device)
+    -- they do not depend on the cubemap.  With exact mirror symmetry (checked on the device) the tables cover ONE octant of
+    the cube and every row serves eight reflections: ~1.4 GB for a 512^2 pyramid (round 2's per-texel tables: 13 GB).  Returns
+    None when the level is not eligible (R not a multiple of 16: the direct kernels run)."""
     key = (res, float(roughness), float(cutoff), device.index or 0)
-    if key not in _weights_cache:
-        lib = L.lib()
-        ct, bounds = specular_bounds(res, roughness, cutoff, device)
-        table = dir_table(res, device)
-        n = 6 * res * res
-        counts = torch.empty(n, dtype=torch.int32, device=device)
-        L.check(lib.gs_specular_patch_count(res, L.ptr(bounds), L.ptr(counts), L.stream()), "gs_specular_patch_count")
-        csum = torch.cumsum(counts.long(), 0)
-        offsets = (csum - counts.long()).contiguous()
-        total = int(csum[-1].item())
-        desc = torch.empty(max(total, 1), dtype=torch.int32, device=device)
-        entry = {"offsets": offsets, "ct": ct, "bounds": bounds, "desc": desc, "total": total}
-        for name, bwd in (("fwd", 0), ("bwd", 1)):
-            w = torch.empty(max(total, 1) * 64, dtype=torch.float32, device=device)
-            wsum = torch.empty(n, dtype=torch.float32, device=device) if not bwd else None
-            L.check(lib.gs_specular_weights_build(res, L.ptr(bounds), L.ptr(table), L.ptr(offsets), L.f32(roughness), L.f32(ct),
-                                                  bwd, L.ptr(w), L.ptr(wsum), L.ptr(desc), L.stream()),
-                    "gs_specular_weights_build")
-            entry[name] = w
-            if wsum is not None:
-                entry["wsum"] = wsum.view(6, res, res, 1)
-        if DROP_EMPTY_PATCHES and total > 0:
-            # 8x8 patches tile each face AABB of the lobe; the ones in the AABB corners hold no texel inside the lobe.
-            # Membership (dot >= cutoff) is the same in both orientations, so one mask compacts fwd, bwd and the descriptors.
-            keep = (entry["fwd"].view(total, 64) != 0).any(dim=1)
-            csum_k = torch.cumsum(keep.long(), 0)
-            new_total = int(csum_k[-1].item())
-            before = torch.cat((csum_k.new_zeros(1), csum_k))             # kept patches in front of old patch p
-            entry["offsets"] = before[offsets].contiguous()
-            for name in ("fwd", "bwd"):
-                entry[name] = entry[name].view(total, 64)[keep].reshape(-1).contiguous()
-            entry["desc"] = desc[:total][keep].contiguous()
-            entry["total"] = new_total
-            entry["dropped"] = total - new_total
-        _weights_cache[key] = entry
-    return _weights_cache[key]
+    if key in _tiles_cache:
+        return _tiles_cache[key]
+    if not tiles_eligible(res):
+        _tiles_cache[key] = None
+        return None
+    lib = L.lib()
+    ct, bounds = specular_bounds(res, roughness, cutoff, device)
+    table = dir_table(res, device)
+    chk = torch.zeros(2, dtype=torch.int64, device=device)
+    L.check(lib.gs_specular_tiles_check(res, L.ptr(bounds), L.ptr(table), L.ptr(chk), L.stream()), "gs_specular_tiles_check")
+    bad_dir, bad_box = (int(v) for v in chk.tolist())
+    bw, nb = tile_geometry(res)
+    tw, th = 8 * bw, 8 * (nb // bw)                                       # tile size in texels
+    half = res // 2
+    sym = (bad_dir == 0 and bad_box == 0 and half % tw == 0 and half % th == 0 and os.environ.get("GEOSPLAT_PREFILTER_SYMMETRY", "1") != "0")
+    if sym:      # one quadrant of the faces +x, +y, +z = one texel of every orbit of the three reflections
+        coords = [(s, tw * i, th * j) for s in (0, 2, 4) for j in range(half // th) for i in range(half // tw)]
+    else:
+        if res % tw or res % th:
+            bw, nb = 1, 1
+            tw = th = 8
+        coords = [(s, tw * i, th * j) for s in range(6) for j in range(res // th) for i in range(res // tw)]
+    tiles = torch.tensor([(s, x, y, 0) for s, x, y in coords], dtype=torch.int32, device=device)
+    entry = {"res": res, "ct": ct, "bounds": bounds, "table": table, "tiles": tiles, "n_tiles": len(coords), "n_mirrors": 8 if sym else 1,
+             "symmetry_check": (bad_dir, bad_box), "orders": {}, "bw": bw, "nb": nb, "tile_texels": tw * th}
+    for name, bwd in (("fwd", 0), ("bwd", 1)):
+        entry[name] = _build_direction(res, roughness, ct, bounds, table, tiles, bwd, bw, nb)
+    # every pair of the forward tables must appear exactly once in the transposed ones
+    if entry["fwd"]["pairs"] != entry["bwd"]["pairs"]:
+        raise L.GeoSplatHipError(f"specular tiles R={res}: {entry['fwd']['pairs']} forward pairs but {entry['bwd']['pairs']} transposed "
+                                 f"pairs (candidate margin {BWD_MARGIN} too small?)")
+    # sum of the pair weights per output texel (needs pixel_area of the actual sources: not mirror symmetric) -- the direct kernel on ones
+    ones = torch.ones(6, res, res, 3, dtype=torch.float32, device=device)
+    raw = torch.empty(6, res, res, 4, dtype=torch.float32, device=device)
+    L.check(lib.gs_specular_cubemap_fwd(res, L.ptr(ones), L.ptr(bounds), L.ptr(table), L.f32(roughness), L.f32(ct), L.ptr(raw), L.stream()),
+            "gs_specular_cubemap_fwd")
+    entry["wsum"] = raw[..., 3].contiguous()
+    entry["inv_wsum"] = (1.0 / entry["wsum"]).contiguous()                # scale of the staged d loss / d level texels (backward)
+    entry["area4"] = (table[..., 3] * 0.25).contiguous()                  # pixel_area / 4: scale of the staged sources (forward)
+    _tiles_cache[key] = entry
+    return entry
 
 
-# ----------------------------------------------------------------------------- autograd pieces
+def shard_tiles(n_tiles: int, rank: int, world: int) -> Tuple[int, int]:
+    """Share [begin, end) of a level's tile list for `rank`: the list is the longest-first order dealt round-robin (rank r gets
+    sorted tiles r, r + world, ...), stored rank after rank -- contiguous shares whose sizes differ by at most one."""
+    sizes = [(n_tiles - q + world - 1) // world for q in range(world)]
+    begin = sum(sizes[:rank])
+    return begin, begin + sizes[rank]
+
+
+def _ordered(entry: Dict, direction: str, world: int) -> Dict:
+    """Tile metadata of one direction in launch order: longest tile first (the lobes of tiles at the cube's corners are 3x the
+    mean); for `world` ranks the sorted list is dealt round-robin and stored share after share (shard_tiles)."""
+    key = (direction, world)
+    if key not in entry["orders"]:
+        d = entry[direction]
+        order = torch.argsort(d["rows_per_tile"], descending=True, stable=True)
+        if world > 1:
+            order = torch.cat([order[r::world] for r in range(world)])
+        entry["orders"][key] = {"tiles": entry["tiles"][order].contiguous(), "seg": d["seg"][order].contiguous(),
+                                "row_begin": d["row_begin"][order].contiguous(), "cnt": d["cnt"][order].contiguous()}
+    return entry["orders"][key]
+
+
+def _tiles_apply(entry: Dict, direction: str, src: Tensor, dst: Tensor, tile_begin: int = 0, tile_end: Optional[int] = None,
+                 world: int = 1) -> None:
+    d = entry[direction]
+    o = _ordered(entry, direction, world)
+    te = entry["n_tiles"] if tile_end is None else tile_end
+    bwd = direction == "bwd"
+    L.check(L.lib().gs_specular_tiles_apply(entry["res"], 1 if bwd else 0, entry["n_mirrors"], _bwd_margin(entry["res"]), entry["bw"],
+                                            entry["nb"], L.ptr(src), L.ptr(entry["inv_wsum"] if bwd else entry["area4"]),
+                                            L.ptr(entry["area4"]) if bwd else None, L.ptr(entry["bounds"]), L.ptr(o["tiles"]),
+                                            L.ptr(o["seg"]), L.ptr(o["row_begin"]), L.ptr(o["cnt"]), L.ptr(d["desc"]), L.ptr(d["weights"]),
+                                            L.ptr(dst), tile_begin, te, C.c_size_t(d["lds_bytes"]), L.stream()), "gs_specular_tiles_apply")
+
+
 class _CubeMapMip(torch.autograd.Function):
     """rfstudio/graphics/_mesh/_texture.py:199-226"""
 
@@ -180,38 +289,24 @@ class _SpecularCubemap(torch.autograd.Function):
         return g, None, None, None
 
 
-DROP_EMPTY_PATCHES = os.environ.get("GEOSPLAT_DROP_EMPTY_PATCHES", "1") != "0"
-APPLY_PACKED_SRC = os.environ.get("GEOSPLAT_APPLY_SRC", "3") == "3"   # 3: taps read the packed [6,R,R,3] map (one 12-byte load), 4: float4-padded copy
-
-
-def _apply_src(t: Tensor):
-    """(tensor, stride) of the tap source for gs_specular_apply"""
-    if APPLY_PACKED_SRC:
-        return t.contiguous(), 3
-    return torch.nn.functional.pad(t, (0, 1)).contiguous(), 4
-
-
-class _SpecularCubemapCached(torch.autograd.Function):
-    """Same operator through the cached pair-weight tables (bit-identical weights, streamed instead of recomputed)."""
+class _SpecularCubemapTiled(torch.autograd.Function):
+    """The same operator through the tiled pair-weight tables (specular_tiles): normalisation by the weight sums fused into the
+    kernels, backward = the transposed tables as a gather."""
 
     @staticmethod
     def forward(ctx, cubemap: Tensor, res: int, roughness: float, cutoff: float) -> Tensor:
-        e = specular_weights(res, roughness, cutoff, cubemap.device)
-        src4, stride = _apply_src(cubemap)
-        rgb = torch.empty(6, res, res, 3, dtype=torch.float32, device=cubemap.device)
-        L.check(L.lib().gs_specular_apply(res, L.ptr(src4), stride, L.ptr(e["offsets"]), L.i64(e["total"]), L.ptr(e["desc"]),
-                                          L.ptr(e["fwd"]), L.ptr(rgb), 3, 0, L.stream()), "gs_specular_apply")
+        e = specular_tiles(res, roughness, cutoff, cubemap.device)
+        out = torch.empty(6, res, res, 3, dtype=torch.float32, device=cubemap.device)
+        _tiles_apply(e, "fwd", cubemap.contiguous(), out)
         ctx.cfg = (res, roughness, cutoff)
-        return rgb / e["wsum"]
+        return out
 
     @staticmethod
     def backward(ctx, dout: Tensor):
         res, roughness, cutoff = ctx.cfg
-        e = specular_weights(res, roughness, cutoff, dout.device)
-        v4, stride = _apply_src(dout / e["wsum"])
-        g = torch.empty_like(dout, memory_format=torch.contiguous_format)
-        L.check(L.lib().gs_specular_apply(res, L.ptr(v4), stride, L.ptr(e["offsets"]), L.i64(e["total"]), L.ptr(e["desc"]),
-                                          L.ptr(e["bwd"]), L.ptr(g), 3, 0, L.stream()), "gs_specular_apply")
+        e = specular_tiles(res, roughness, cutoff, dout.device)
+        g = torch.empty(6, res, res, 3, dtype=torch.float32, device=dout.device)
+        _tiles_apply(e, "bwd", dout.contiguous(), g)
         return g, None, None, None
 
 
@@ -220,13 +315,46 @@ def diffuse_cubemap(cubemap: Tensor) -> Tensor:
 
 
 def specular_cubemap(cubemap: Tensor, roughness: float, cutoff: float = 0.99, cached: Optional[bool] = None) -> Tensor:
-    """specular_cubemap of _wrap.py:138-157.  cached=True streams the pair weights from the per-level table
-    (default, GEOSPLAT_PREFILTER_CACHE=0 disables), cached=False recomputes them in the kernel."""
-    use_cache = CACHE_PAIR_WEIGHTS if cached is None else cached
-    if use_cache:
-        return _SpecularCubemapCached.apply(cubemap, int(cubemap.shape[1]), float(roughness), float(cutoff))
-    ct, bounds = specular_bounds(cubemap.shape[1], roughness, cutoff, cubemap.device)
+    """specular_cubemap of _wrap.py:138-157.  cached=True (default where the level is eligible: R >= 64, a multiple of 16) applies
+    the tiled pair-weight tables, cached=False evaluates every pair weight in the kernel (the reference's call shape)."""
+    res = int(cubemap.shape[1])
+    use_tables = tiles_eligible(res) if cached is None else (cached and tiles_eligible(res))
+    if use_tables:
+        return _SpecularCubemapTiled.apply(cubemap, res, float(roughness), float(cutoff))
+    ct, bounds = specular_bounds(res, roughness, cutoff, cubemap.device)
     return _SpecularCubemap.apply(cubemap, float(roughness), ct, bounds)
+
+
+def _specular_level_backward(gl: Tensor, rough: float, cutoff: float) -> Tensor:
+    """d loss / d (mip level) from d loss / d (prefiltered level), on the current stream, without an autograd graph."""
+    res = gl.shape[1]
+    g = torch.empty(6, res, res, 3, dtype=torch.float32, device=gl.device)
+    e = specular_tiles(res, rough, cutoff, gl.device)
+    if e is not None:
+        _tiles_apply(e, "bwd", gl.contiguous(), g)
+        return g
+    ct, bounds = specular_bounds(res, rough, cutoff, gl.device)
+    wsum = _direct_wsum(res, rough, cutoff, gl.device)
+    v = (gl / wsum).contiguous()
+    L.check(L.lib().gs_specular_cubemap_bwd(res, L.ptr(bounds), L.ptr(dir_table(res, gl.device)), L.ptr(v), L.f32(rough), L.f32(ct),
+                                            L.ptr(g), 0, L.stream()), "gs_specular_cubemap_bwd")
+    return g
+
+
+_wsum_cache: Dict[Tuple[int, float, float, int], Tensor] = {}
+
+
+def _direct_wsum(res: int, roughness: float, cutoff: float, device: torch.device) -> Tensor:
+    """[6,R,R,1] sums of the pair weights per output texel (they do not depend on the cubemap): the direct kernel on ones."""
+    key = (res, float(roughness), float(cutoff), device.index or 0)
+    if key not in _wsum_cache:
+        ct, bounds = specular_bounds(res, roughness, cutoff, device)
+        ones = torch.ones(6, res, res, 3, dtype=torch.float32, device=device)
+        raw = torch.empty(6, res, res, 4, dtype=torch.float32, device=device)
+        L.check(L.lib().gs_specular_cubemap_fwd(res, L.ptr(ones), L.ptr(bounds), L.ptr(dir_table(res, device)), L.f32(roughness),
+                                                L.f32(ct), L.ptr(raw), L.stream()), "gs_specular_cubemap_fwd")
+        _wsum_cache[key] = raw[..., 3:].contiguous()
+    return _wsum_cache[key]
 
 
 # ----------------------------------------------------------------------------- atlas packing (reference layout)
@@ -282,36 +410,28 @@ class TextureSplitSum:
         return cls(base, split_mipmaps(mipmaps, num_mipmaps), float(min_roughness), float(max_roughness))
 
 
-def as_splitsum_backward(g_base: Tensor, g_levels: List[Tensor], *, cutoff: float = 0.99, min_roughness: float = 0.08,
-                         max_roughness: float = 0.5) -> Tensor:
-    """Explicit backward of `as_splitsum` on the CURRENT stream (no autograd graph, so a caller can place it on any HIP
-    stream -- the autograd engine would run it on the stream of the forward): texel gradients of the base map and of
-    the n levels -> gradient of the cubemap.  Same kernels as the autograd path."""
-    n = len(g_levels)
-    roughs = [(idx / (n - 2)) * (max_roughness - min_roughness) + min_roughness for idx in range(n - 1)] + [1.0]
-    g_mips = []
-    for gl, rough in zip(g_levels, roughs):
-        res = gl.shape[1]
-        if CACHE_PAIR_WEIGHTS:
-            e = specular_weights(res, rough, cutoff, gl.device)
-            v4, stride = _apply_src(gl / e["wsum"])
-            g = torch.empty(6, res, res, 3, dtype=torch.float32, device=gl.device)
-            L.check(L.lib().gs_specular_apply(res, L.ptr(v4), stride, L.ptr(e["offsets"]), L.i64(e["total"]), L.ptr(e["desc"]),
-                                              L.ptr(e["bwd"]), L.ptr(g), 3, 0, L.stream()), "gs_specular_apply")
-        else:
-            raise L.GeoSplatHipError("as_splitsum_backward needs the cached pair weights (GEOSPLAT_PREFILTER_CACHE=1)")
-        g_mips.append(g)
+def _mip_chain_backward(g_mips: List[Tensor], g_base: Tensor) -> Tensor:
     gd = g_base.contiguous()
     gdb = torch.empty_like(gd)
     L.check(L.lib().gs_diffuse_cubemap_bwd(gd.shape[1], L.ptr(gd), L.ptr(gdb), 0, L.stream()), "gs_diffuse_cubemap_bwd")
     g_mips[-1] = g_mips[-1] + gdb
-    for idx in range(n - 1, 0, -1):
+    for idx in range(len(g_mips) - 1, 0, -1):
         dout = g_mips[idx].contiguous()
         R = dout.shape[1]
         up = torch.empty(6, 2 * R, 2 * R, 3, dtype=torch.float32, device=dout.device)
         L.check(L.lib().gs_cubemap_mip_bwd(R, L.ptr(dout), L.ptr(up), 0, L.stream()), "gs_cubemap_mip_bwd")
         g_mips[idx - 1] = g_mips[idx - 1] + up
     return g_mips[0]
+
+
+def as_splitsum_backward(g_base: Tensor, g_levels: List[Tensor], *, cutoff: float = 0.99, min_roughness: float = 0.08,
+                         max_roughness: float = 0.5) -> Tensor:
+    """Explicit backward of `as_splitsum` on the CURRENT stream (no autograd graph, so a caller can place it on any HIP
+    stream -- the autograd engine would run it on the stream of the forward): texel gradients of the base map and of
+    the n levels -> gradient of the cubemap.  Same kernels as the autograd path."""
+    n = len(g_levels)
+    g_mips = [_specular_level_backward(gl, rough, cutoff) for gl, rough in zip(g_levels, _level_roughness(n, min_roughness, max_roughness))]
+    return _mip_chain_backward(g_mips, g_base)
 
 
 def as_splitsum(cubemap: Tensor, *, cutoff: float = 0.99, min_resolution: int = 16, min_roughness: float = 0.08,
@@ -334,55 +454,32 @@ def as_splitsum(cubemap: Tensor, *, cutoff: float = 0.99, min_resolution: int = 
 
 # ----------------------------------------------------------------------------- sharded prefilter (multi-GPU)
 # The reference prefilters the environment once per step on its one device (rfstudio/model/geosplat.py:780-785); with one
-# view per GPU that replicated 3.9 ms would sit beside a ~2.5 ms view on every rank (Amdahl).  The operator is independent
-# per OUTPUT texel in both directions (forward: a level texel gathers cubemap texels; backward: a cubemap texel gathers
-# level-gradient texels through the transposed tables), so rank r applies texels [r n/G, (r+1) n/G) of every level and the
-# ranks all-gather in place:
-#   forward : G x (1/G of the 12 GB weight stream)  + all-gather of the 25 MB pyramid
-#   backward: all-reduce of the 25 MB texel gradients (they are sums over the views of ALL ranks), 1/G of the transposed
-#             stream per rank, all-gather of the per-level cubemap-gradient pieces; the mip chain / diffuse backward are
-#             cheap and replicated, so every rank ends with the same cubemap gradient and NO all-reduce of it is needed.
+# view per GPU the replicated prefilter would sit beside a ~2 ms view on every rank (Amdahl).  The tiled operator is independent
+# per tile of output texels in both directions, so rank r applies its share of every tiled level's tile list (shard_tiles) into
+# a zero-filled level and the ranks SUM (disjoint supports: x + 0, exact and identical everywhere):
+#   forward : one all-reduce over the flat pyramid (25 MB for a 512^2 map)
+#   backward: all-reduce of the 25 MB texel gradients (they are sums over the views of ALL ranks), then one all-reduce of the
+#             per-level cubemap-gradient pieces; the mip chain / diffuse backward and the levels below 64^2 (direct kernels,
+#             tens of microseconds) are replicated, so every rank ends with the same cubemap gradient and NO all-reduce of it
+#             is needed.
 def _level_roughness(n: int, min_roughness: float, max_roughness: float) -> List[float]:
     return [(idx / (n - 2)) * (max_roughness - min_roughness) + min_roughness for idx in range(n - 1)] + [1.0]
 
 
-def shard_texels(n_texels: int, rank: int, world: int) -> Tuple[int, int]:
-    """Contiguous share of a level's 6 R^2 texels; equal sizes (6 * 16^2 = 1536 divides by 2, 3, 4, 6, 8, ...)."""
-    if n_texels % world != 0:
-        raise L.GeoSplatHipError(f"{n_texels} texels do not split evenly over {world} ranks")
-    per = n_texels // world
-    return rank * per, (rank + 1) * per
-
-
 def can_shard_prefilter(cubemap_res: int, world: int, min_resolution: int = 16) -> bool:
-    return world > 1 and CACHE_PAIR_WEIGHTS and (6 * min_resolution * min_resolution) % world == 0 and cubemap_res >= 4 * min_resolution
+    return world > 1 and tiles_eligible(cubemap_res) and cubemap_res >= 4 * min_resolution
 
 
-def _all_gather_inplace(full: Tensor, t0: int, t1: int, group) -> None:
-    """full: [n, 3] contiguous; rows [t0, t1) hold this rank's share -> every rank's share lands in place."""
-    import torch.distributed as dist
-    flat = full.view(-1)
-    mine = flat[t0 * 3:t1 * 3]
-    if dist.get_backend(group) == "nccl":
-        dist.all_gather_into_tensor(flat, mine, group=group)             # in place: input is the rank-th slice of the output
-    else:
-        world = dist.get_world_size(group)
-        per = (t1 - t0) * 3
-        parts = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine.clone(), group=group)
-        for r, part in enumerate(parts):
-            flat[r * per:(r + 1) * per].copy_(part)
-
-
-def _apply_range(e, table: str, src: Tensor, dst: Tensor, t0: int, t1: int, res: int) -> None:
-    src_t, stride = _apply_src(src)
-    L.check(L.lib().gs_specular_apply_range(res, L.ptr(src_t), stride, L.ptr(e["offsets"]), L.i64(e["total"]), L.ptr(e["desc"]),
-                                            L.ptr(e[table]), L.ptr(dst), 3, 0, t0, t1, L.stream()), "gs_specular_apply_range")
+def _flat_levels(res_list: List[int], device) -> Tuple[Tensor, List[Tensor]]:
+    sizes = [6 * r * r * 3 for r in res_list]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=device)
+    return flat, [q.view(6, r, r, 3) for q, r in zip(torch.split(flat, sizes), res_list)]
 
 
 def as_splitsum_sharded(cubemap: Tensor, rank: int, world: int, group=None, *, cutoff: float = 0.99, min_resolution: int = 16,
                         min_roughness: float = 0.08, max_roughness: float = 0.5) -> TextureSplitSum:
-    """`as_splitsum` (no autograd graph) with the specular levels computed 1/world per rank and all-gathered."""
+    """`as_splitsum` (no autograd graph) with the tiled levels computed 1/world per rank and summed."""
+    import torch.distributed as dist
     L.require_cuda(cubemap)
     with torch.no_grad():
         mips = [cubemap.detach().float().contiguous()]
@@ -390,41 +487,40 @@ def as_splitsum_sharded(cubemap: Tensor, rank: int, world: int, group=None, *, c
             mips.append(_CubeMapMip.apply(mips[-1]))
         assert len(mips) > 2, "Min resolution is too large."
         base = diffuse_cubemap(mips[-1])
-        levels = []
-        for mip, rough in zip(mips, _level_roughness(len(mips), min_roughness, max_roughness)):
-            res = mip.shape[1]
-            e = specular_weights(res, rough, cutoff, mip.device)
-            t0, t1 = shard_texels(6 * res * res, rank, world)
-            out = torch.empty(6, res, res, 3, dtype=torch.float32, device=mip.device)
-            _apply_range(e, "fwd", mip, out, t0, t1, res)
-            o2 = out.view(-1, 3)
-            o2[t0:t1].div_(e["wsum"].view(-1, 1)[t0:t1])
-            _all_gather_inplace(o2, t0, t1, group)
-            levels.append(out)
+        roughs = _level_roughness(len(mips), min_roughness, max_roughness)
+        tiled = [i for i, m in enumerate(mips) if tiles_eligible(m.shape[1])]
+        flat, parts = _flat_levels([mips[i].shape[1] for i in tiled], cubemap.device)
+        levels: List[Optional[Tensor]] = [None] * len(mips)
+        for out, i in zip(parts, tiled):
+            e = specular_tiles(mips[i].shape[1], roughs[i], cutoff, cubemap.device)
+            t0, t1 = shard_tiles(e["n_tiles"], rank, world)
+            _tiles_apply(e, "fwd", mips[i], out, t0, t1, world)
+            levels[i] = out
+        if tiled:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        for i, m in enumerate(mips):
+            if levels[i] is None:
+                levels[i] = specular_cubemap(m, roughs[i], cutoff)          # small levels: replicated
     return TextureSplitSum(base, levels, min_roughness, max_roughness)
 
 
 def as_splitsum_backward_sharded(g_base: Tensor, g_levels: List[Tensor], rank: int, world: int, group=None, *, cutoff: float = 0.99,
                                  min_roughness: float = 0.08, max_roughness: float = 0.5) -> Tensor:
     """Cubemap gradient from texel gradients that are ALREADY summed over the ranks; identical result on every rank."""
+    import torch.distributed as dist
     n = len(g_levels)
-    g_mips = []
-    for gl, rough in zip(g_levels, _level_roughness(n, min_roughness, max_roughness)):
-        res = gl.shape[1]
-        e = specular_weights(res, rough, cutoff, gl.device)
-        t0, t1 = shard_texels(6 * res * res, rank, world)
-        g = torch.empty(6, res, res, 3, dtype=torch.float32, device=gl.device)
-        _apply_range(e, "bwd", gl / e["wsum"], g, t0, t1, res)
-        _all_gather_inplace(g.view(-1, 3), t0, t1, group)
-        g_mips.append(g)
-    gd = g_base.contiguous()
-    gdb = torch.empty_like(gd)
-    L.check(L.lib().gs_diffuse_cubemap_bwd(gd.shape[1], L.ptr(gd), L.ptr(gdb), 0, L.stream()), "gs_diffuse_cubemap_bwd")
-    g_mips[-1] = g_mips[-1] + gdb
-    for idx in range(n - 1, 0, -1):
-        dout = g_mips[idx].contiguous()
-        R = dout.shape[1]
-        up = torch.empty(6, 2 * R, 2 * R, 3, dtype=torch.float32, device=dout.device)
-        L.check(L.lib().gs_cubemap_mip_bwd(R, L.ptr(dout), L.ptr(up), 0, L.stream()), "gs_cubemap_mip_bwd")
-        g_mips[idx - 1] = g_mips[idx - 1] + up
-    return g_mips[0]
+    roughs = _level_roughness(n, min_roughness, max_roughness)
+    tiled = [i for i, gl in enumerate(g_levels) if tiles_eligible(gl.shape[1])]
+    flat, parts = _flat_levels([g_levels[i].shape[1] for i in tiled], g_base.device)
+    g_mips: List[Optional[Tensor]] = [None] * n
+    for out, i in zip(parts, tiled):
+        e = specular_tiles(g_levels[i].shape[1], roughs[i], cutoff, g_base.device)
+        t0, t1 = shard_tiles(e["n_tiles"], rank, world)
+        _tiles_apply(e, "bwd", g_levels[i].contiguous(), out, t0, t1, world)
+        g_mips[i] = out
+    if tiled:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    for i in range(n):
+        if g_mips[i] is None:
+            g_mips[i] = _specular_level_backward(g_levels[i], roughs[i], cutoff)
+    return _mip_chain_backward(g_mips, g_base)

@@ -291,31 +291,49 @@ int gs_cube_dir_table(int R, float* table, void* stream);
 /* out[6,R,R,4] = (sum rgb*w, sum w) */
 int gs_specular_cubemap_fwd(int R, const float* cubemap, const float* bounds, const float* dir_table,
                             float roughness, float costheta_cutoff, float* out, void* stream);
-/* v_out_rgb[6,R,R,3] = gradient w.r.t. the un-normalised rgb sums; v_cubemap written (or accumulated).
- * Atomic-free gather (lobe membership is symmetric). */
+/* v_out_rgb[6,R,R,3] = gradient w.r.t. the un-normalised rgb sums; v_cubemap written (or accumulated).  Atomic-free gather:
+ * a source texel visits the outputs inside its own box grown by a margin (every texel for R < 64) and keeps those whose box
+ * contains it -- the exact adjoint of gs_specular_cubemap_fwd (the reference scatters with atomicAdd, cubemap.cu:300-350). */
 int gs_specular_cubemap_bwd(int R, const float* bounds, const float* dir_table, const float* v_out_rgb,
                             float roughness, float costheta_cutoff, float* v_cubemap, int accumulate, void* stream);
 
-/* Cached pair weights of the specular prefilter (functions of R / roughness / cutoff only; the cubemap is
- * re-filtered every step).  Per texel the 8x8 patches of its face AABBs are stored as 64 contiguous floats:
- *   gs_specular_patch_count  -> counts[6*R*R] patches per texel; the caller builds patch_offsets[6*R*R] =
- *                               exclusive cumsum (int64) and allocates weights[total_patches * 64];
- *   gs_specular_weights_build-> fills weights (backward != 0: the transposed orientation used by the
- *                               atomic-free backward gather) and, if wsum != NULL, wsum[6*R*R];
- *   gs_specular_apply        -> dst[t*dst_stride + 0..2] (+)= sum_k weights[t][k] * src[texel_k][0..2]
- *                               (flat patch list + descriptors: four patches in flight per wave). */
-int gs_specular_patch_count(int R, const float* bounds, int32_t* counts, void* stream);
-int gs_specular_weights_build(int R, const float* bounds, const float* dir_table, const int64_t* patch_offsets,
-                              float roughness, float costheta_cutoff, int backward, float* weights, float* wsum,
-                              int32_t* patch_desc /* [total_patches]: face<<24 | by<<12 | bx */, void* stream);
-int gs_specular_apply(int R, const float* src, int src_stride /* 3, or 4 = float4-padded texels (faster) */,
-                      const int64_t* patch_offsets, int64_t total_patches, const int32_t* patch_desc,
-                      const float* weights, float* dst, int dst_stride, int accumulate, void* stream);
-/* The same operator on the output texels [t_begin, t_end) only (flat index (s*R + y)*R + x): the prefilter is independent per
- * output texel, so G ranks each apply 1/G of every level and all-gather (geosplatting_amd/splitsum.py, sharded S5). */
-int gs_specular_apply_range(int R, const float* src, int src_stride, const int64_t* patch_offsets, int64_t total_patches,
-                            const int32_t* patch_desc, const float* weights, float* dst, int dst_stride, int accumulate,
-                            int t_begin, int t_end, void* stream);
+/* Tiled pair-weight tables of the specular prefilter (csrc/gs_splitsum_tiles.hip; replaces calling SpecularCubemapFwd/BwdKernel,
+ * rfstudio/graphics/_mesh/_splitsum/c_src/cubemap.cu:246-350, with weights recomputed every step).  The pair weights
+ * w(o,i) = g(o,i) * pixel_area(i) / 4 depend on (R, roughness, cutoff) only.  Units: a TILE = nb BLOCKS of 8x8 output texels of one
+ * face in rows of bw blocks (tiles[n][4] = {face, x0, y0, 0}; block b covers x0 + 8 (b % bw) .., y0 + 8 (b / bw) ..); per
+ * (tile, source face, block) -- "slot" (tile * 6 + face) * nb + b -- a list of ROWS, each one weight per lane (= output texel of
+ * the block, lane = (y & 7) * 8 + (x & 7)) for the source texel anchor_lane + (dx, dy), anchor = min corner of the lane's lobe box
+ * on that face (gs_specular_bounds), descriptor = (dy * pitch + dx) * 16 = the row's byte offset in the staged source rectangle.
+ * Row lists are padded to multiples of 8 rows (zero weights); weights are stored in row pairs, [row / 2][lane][2].
+ *   gs_specular_tiles_count : row_counts[n_tiles*6*nb] (un-padded), extents[n_tiles*6*nb][4] = {xmin, xmax, ymin, ymax} of the source
+ *                             texels a slot's rows can address, *pairs += number of (output, source) pairs.  backward != 0: the
+ *                             TRANSPOSED operator as a gather -- lane = source texel, partners = outputs inside the lane's own box
+ *                             grown by `margin` texels (margin >= R: every texel of every face) whose box contains the lane's texel:
+ *                             the exact adjoint of the forward.
+ *   gs_specular_tiles_fill  : desc[rows], weights[rows * 64] (caller zero-fills both; row_begin[slot] = exclusive sum of the padded
+ *                             counts; segments as below): g(o,i), the mirror-invariant factor of the weight.
+ *   gs_specular_tiles_check : out2[0] = texels whose direction-table entry is not the exact sign-flipped image under the cube's
+ *                             seven reflections, out2[1] = lobe boxes that are not the reflected box of the mirrored texel.  Both 0
+ *                             <=> tables built for the tiles of ONE octant may be applied with n_mirrors = 8.
+ *   gs_specular_tiles_apply : forward  dst[o] = sum_i g(o,i) src[i] scale[i] / sum_i g(o,i) scale[i]      (src = cubemap level [6,R,R,3],
+ *                                      scale[6 R^2] = pixel_area / 4)
+ *                             backward dst[i] = out_scale[i] sum_o g(o,i) src[o] scale[o]                  (src = d loss / d level,
+ *                                      scale = 1 / sum of the pair weights of o, out_scale = pixel_area / 4)
+ *                             for the tiles [tile_begin, tile_end) of `tiles` (and their 8 reflections when n_mirrors == 8; one rank's
+ *                             share when the prefilter is sharded).  One workgroup of 16 waves per (tile, reflection); 16 / nb waves
+ *                             share a block.  segments[n_tiles*6][4] = {x0, y0, rows, pitch} of the source rectangle staged in LDS
+ *                             per (tile, face) (pitch 0 = no rows), lds_bytes = max rows * pitch * 16. */
+int gs_specular_tiles_count(int R, float roughness, float costheta_cutoff, int backward, int margin, int bw, int nb, const float* bounds,
+                            const float* dir_table, const int32_t* tiles, int n_tiles, int32_t* row_counts, int32_t* extents,
+                            uint64_t* pairs, void* stream);
+int gs_specular_tiles_fill(int R, float roughness, float costheta_cutoff, int backward, int margin, int bw, int nb, const float* bounds,
+                           const float* dir_table, const int32_t* tiles, int n_tiles, const int64_t* row_begin,
+                           const int32_t* segments, int32_t* desc, float* weights, void* stream);
+int gs_specular_tiles_check(int R, const float* bounds, const float* dir_table, uint64_t* out2, void* stream);
+int gs_specular_tiles_apply(int R, int backward, int n_mirrors, int margin, int bw, int nb, const float* src, const float* scale,
+                            const float* out_scale, const float* bounds, const int32_t* tiles, const int32_t* segments,
+                            const int64_t* row_begin, const int32_t* row_counts, const int32_t* desc, const float* weights, float* dst,
+                            int tile_begin, int tile_end, size_t lds_bytes, void* stream);
 
 /* ------------------------------------------------------------------ M1: MGAdapter (mesh -> Gaussians) */
 /* rfstudio/model/geosplat.py:378-472 (MGAdapter.make, default ratios): every face -> 6 flat Gaussians (two rings

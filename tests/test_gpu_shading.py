@@ -104,21 +104,71 @@ def test_as_splitsum_fwd_bwd(cuda):
         assert torch.equal(a, b)
 
 
-def test_prefilter_cached_weights_equal_direct(cuda):
-    """The streamed pair-weight tables reproduce the direct lobe evaluation (same kernel code fills them)."""
+@pytest.mark.parametrize("symmetry", ["1", "0"])
+def test_prefilter_tiled_tables_equal_direct(cuda, symmetry, monkeypatch):
+    """The tiled pair-weight tables (csrc/gs_splitsum_tiles.hip: lane = output texel, sources staged in LDS, one table row shared
+    by the eight reflections of a block) reproduce the direct lobe evaluation of cubemap.cu:246-350 (gs_specular_cubemap_fwd /
+    _bwd: every weight recomputed in the kernel) -- forward and the exact-adjoint backward, with the shared-octant tables
+    (symmetry=1) and with tables built for every texel (symmetry=0: what a level that fails the mirror check runs)."""
     import geosplatting_amd as gs
+    from geosplatting_amd import splitsum as ss
+    monkeypatch.setenv("GEOSPLAT_PREFILTER_SYMMETRY", symmetry)
+    ss._tiles_cache.clear()
     g = torch.Generator().manual_seed(4)
-    for R, rough in ((64, 0.08), (32, 0.29), (16, 1.0)):
-        c = torch.rand(6, R, R, 3, generator=g).to(cuda)
-        v = (torch.rand(6, R, R, 3, generator=g) - 0.5).to(cuda)
-        outs, grads = [], []
-        for cached in (False, True):
-            x = c.clone().requires_grad_(True)
-            y = gs.specular_cubemap(x, rough, cached=cached)
-            y.backward(v)
-            outs.append(y.detach()); grads.append(x.grad)
-        assert float((outs[0] - outs[1]).abs().max()) <= 2e-6 * float(outs[0].abs().max())
-        assert float((grads[0] - grads[1]).abs().max()) <= 2e-6 * float(grads[0].abs().max())
+    try:
+        for R, rough in ((64, 0.08), (64, 0.395), (128, 0.29), (256, 0.185), (96, 0.2), (32, 0.29), (32, 0.5), (16, 1.0), (16, 0.3)):
+            c = (torch.rand(6, R, R, 3, generator=g) + 0.05).to(cuda)
+            v = (torch.rand(6, R, R, 3, generator=g) - 0.5).to(cuda)
+            outs, grads = [], []
+            for cached in (False, True):
+                x = c.clone().requires_grad_(True)
+                y = gs.specular_cubemap(x, rough, cached=cached)
+                y.backward(v)
+                outs.append(y.detach()); grads.append(x.grad)
+            e = ss.specular_tiles(R, rough, 0.99, cuda)
+            assert e is not None
+            bw, nb = e["bw"], e["nb"]
+            tw, th = 8 * bw, 8 * (nb // bw)
+            if R in (64, 128, 256):
+                assert e["symmetry_check"] == (0, 0), (R, e["symmetry_check"])     # powers of two: exact mirror images
+            can = e["symmetry_check"] == (0, 0) and (R // 2) % tw == 0 and (R // 2) % th == 0
+            assert e["n_mirrors"] == (8 if (symmetry == "1" and can) else 1), (R, e["n_mirrors"], e["symmetry_check"])
+            assert e["fwd"]["pairs"] == e["bwd"]["pairs"] > 0
+            dens = e["fwd"]["pairs"] / (64.0 * e["fwd"]["kept_rows"])
+            print(f"\n  R={R} rough={rough}: mirrors {e['n_mirrors']} (check {e['symmetry_check']}), tiles {e['n_tiles']} of {tw}x{th}, rows {e['fwd']['rows']} "
+                  f"(kept {e['fwd']['kept_rows']}), pairs {e['fwd']['pairs']}, lanes with a partner {dens:.2f}, LDS {e['fwd']['lds_bytes']} / {e['bwd']['lds_bytes']} B")
+            assert dens > 0.15                     # (0.2 for a 3-texel lobe under a 64-lane row; 0.7-0.9 for the pyramid levels)
+            # an output whose lobe holds no texel at all (R = 16 has ONE 16x16 culling tile per face: a narrow lobe can be culled
+            # altogether, tests/test_oracle_cpu.py) is 0 / 0 in the reference and in both paths here: same texels, NaN in both
+            nan = torch.isnan(outs[0])
+            assert torch.equal(nan, torch.isnan(outs[1])), (R, rough)
+            ef = float((outs[0] - outs[1])[~nan].abs().max()) / float(outs[0][~nan].abs().max())
+            eb = float((grads[0] - grads[1]).abs().max()) / float(grads[0].abs().max())
+            assert ef <= 1e-5 and eb <= 1e-5, (R, rough, ef, eb)       # summation order (64-lane tree vs one accumulator per texel)
+    finally:
+        ss._tiles_cache.clear()
+
+
+def test_prefilter_tile_shares_partition_the_level(cuda):
+    """Sharded S5: the shares [shard_tiles] of a level's tile list, applied into zero-filled levels and summed, give the whole
+    level bit for bit (what G ranks + one all-reduce compute), forward and backward."""
+    from geosplatting_amd import splitsum as ss
+    g = torch.Generator().manual_seed(6)
+    R, rough = 128, 0.29
+    c = (torch.rand(6, R, R, 3, generator=g) + 0.05).to(cuda)
+    e = ss.specular_tiles(R, rough, 0.99, cuda)
+    for direction in ("fwd", "bwd"):
+        full = torch.empty(6, R, R, 3, device=cuda)
+        ss._tiles_apply(e, direction, c, full)
+        for world in (2, 3, 8):
+            acc = torch.zeros(6, R, R, 3, device=cuda)
+            for r in range(world):
+                part = torch.zeros(6, R, R, 3, device=cuda)
+                t0, t1 = ss.shard_tiles(e["n_tiles"], r, world)
+                ss._tiles_apply(e, direction, c, part, t0, t1, world)
+                assert int((part != 0).any(-1).sum()) == (t1 - t0) * e["tile_texels"] * e["n_mirrors"]     # a share writes its own texels only
+                acc += part
+            assert torch.equal(acc, full), (direction, world)
 
 
 def test_splat_end_to_end(cuda):

@@ -110,20 +110,20 @@ def test_stage1_flat_gradient_allreduce(tmp_path):
         assert torch.equal(a, b) and torch.allclose(a, w, atol=1e-6)
 
 
-def test_prefilter_texel_shards_partition_every_level():
-    """host logic of the sharded split-sum prefilter: equal contiguous shares that tile [0, 6 R^2) for every level"""
-    from geosplatting_amd import _lib
-    from geosplatting_amd.splitsum import can_shard_prefilter, shard_texels
-    for world in (2, 3, 4, 6, 8):
-        for R in (512, 256, 128, 64, 32, 16):
-            n = 6 * R * R
-            edges = [shard_texels(n, r, world) for r in range(world)]
+def test_prefilter_tile_shards_partition_every_level():
+    """host logic of the sharded split-sum prefilter: contiguous shares that tile [0, n_tiles) with sizes differing by at most one,
+    equal to a round-robin deal of the longest-first tile order"""
+    from geosplatting_amd.splitsum import can_shard_prefilter, shard_tiles, tiles_eligible
+    for world in (1, 2, 3, 4, 6, 8):
+        for n in (12, 48, 96, 192, 384, 768, 1536, 6144, 7):
+            edges = [shard_tiles(n, r, world) for r in range(world)]
             assert edges[0][0] == 0 and edges[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
-            assert len({b - a for a, b in edges}) == 1
-    assert can_shard_prefilter(512, 8) and not can_shard_prefilter(512, 1) and not can_shard_prefilter(512, 5)
-    with pytest.raises(_lib.GeoSplatHipError):
-        shard_texels(6 * 16 * 16, 0, 5)
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
+            assert sizes == [len(range(r, n, world)) for r in range(world)]
+    assert can_shard_prefilter(512, 8) and not can_shard_prefilter(512, 1) and can_shard_prefilter(512, 5)
+    assert tiles_eligible(64) and tiles_eligible(96) and tiles_eligible(16) and not tiles_eligible(100) and not tiles_eligible(8)
 
 
 def test_stage_handoff_files(tmp_path):

@@ -126,6 +126,9 @@ def file_sha16(path):
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
+LAUNCHED_AS = {"raster_fwd_kernel": "raster_fwd_window_kernel<3>", "raster_bwd_kernel": "raster_bwd_lanes2_kernel<3>"}
+
+
 def committed_profile(name, kernel_source):
     """A committed profile summary (profiles/<name>) is only quoted while the kernel source it was measured on is unchanged:
     the file records the sha256[:16] of that source."""
@@ -139,6 +142,44 @@ def committed_profile(name, kernel_source):
         return j
     except Exception:
         return None
+
+
+def prefilter_report(cubemap, iters):
+    """S5 timed alone (forward and explicit backward of the whole pyramid, HIP events on the launch stream) and the bytes it moves:
+    the tiled pair-weight tables are read once per direction and step -- every row by the eight mirror workgroups of its tile
+    (L2 side), once from HBM."""
+    import geosplatting_amd as gs
+    from geosplatting_amd import splitsum as ss
+    dev = cubemap.device
+    with torch.no_grad():
+        env = gs.as_splitsum(cubemap)
+    gb = torch.rand_like(env.base); gl = [torch.rand_like(l) for l in env.levels]
+    out = {}
+    for name, fn in (("fwd_ms", lambda: gs.as_splitsum(cubemap)), ("bwd_ms", lambda: ss.as_splitsum_backward(gb, gl))):
+        with torch.no_grad():
+            fn(); torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+        out[name] = e0.elapsed_time(e1) / iters
+    n = len(env.levels)
+    rows = l2 = resident = pairs = 0
+    for lvl, rough in zip(env.levels, ss._level_roughness(n, env.min_roughness, env.max_roughness)):
+        e = ss.specular_tiles(int(lvl.shape[1]), rough, 0.99, dev)
+        if e is None:
+            continue
+        for d in ("fwd", "bwd"):
+            rows += e[d]["rows"]
+            l2 += e[d]["rows"] * 260 * e["n_mirrors"]                    # 64 weights + one descriptor per row, per mirror workgroup
+            resident += e[d]["weights"].numel() * 4 + e[d]["desc"].numel() * 4
+            pairs += e[d]["pairs"] * e["n_mirrors"]
+    pyramid = sum(l.numel() * 4 for l in env.levels) + env.base.numel() * 4
+    out.update({"table_bytes_resident": resident, "table_bytes_from_hbm_per_step": rows * 260, "table_bytes_through_l2_per_step": l2,
+                "pairs_per_step": pairs, "pyramid_bytes": pyramid,
+                "note": "round 2 streamed 11.8 GB of per-texel weight tables per step (13 GB resident)"})
+    return out
 
 
 def cpu_baseline_cfg1():
@@ -274,7 +315,7 @@ def main():
     # the warm-up); an overflow in any of them would make the number invalid -- checked here, outside the timed region
     cap_ok = graphed.check() if graphed is not None else step.poll_capacity(wait=True)
     capacity = {"mode": "device-side counts, no host synchronisation inside a step" if step._i_cap is not None else "exact (one read-back per view)",
-                "n_isects_cap": step._i_cap, "overflow_in_timed_steps": (not cap_ok),
+                "n_isects_cap": step._i_cap, "overflow_in_timed_steps": (not cap_ok), "truncated_steps": step.truncated_steps,
                 "hip_graph": graphed is not None}
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -322,8 +363,9 @@ def main():
         dom_flops = FLOPS_FWD_PER_PAIR if dom == "raster_fwd_kernel" else FLOPS_BWD_PER_PAIR
         dom_tf = None if not pairs_valid else pairs_valid * dom_flops / (kt[dom] * 1e-3) / 1e12
         # committed counter summaries, quoted only while gs_raster.hip is the source they were measured on
-        stats = committed_profile("r02_raster_stats.json", "gs_raster.hip")
-        pmc = committed_profile("r02_pmc_traffic.json", "gs_raster.hip")
+        stats = committed_profile("r03_raster_stats.json", "gs_raster.hip") or committed_profile("r02_raster_stats.json", "gs_raster.hip")
+        pmc = committed_profile("r03_pmc_traffic.json", "gs_raster.hip") or committed_profile("r02_pmc_traffic.json", "gs_raster.hip")
+        engine = committed_profile("r03_engine_kernel_ms.json", "gs_raster.hip")      # averages under the three-stream overlap
         lane_util = None
         if stats and args.level == 7 and args.res == 800:
             key = "fwd" if dom == "raster_fwd_kernel" else "bwd"
@@ -347,7 +389,7 @@ def main():
                                    + f", prefilter fwd+bwd {'in' if not args.no_prefilter else 'EXCLUDED from'} every step",
                        "N": N, "V": V, "I": I, "P": P, "views_per_step_total": views_total,
                        "parallelism": f"dp{world} (views sharded, prefilter sharded, flat RCCL all-reduce of per-Gaussian grads)"},
-            "roofline": {"bound": "valu", "kernel": dom, "launched_as": {"raster_fwd_kernel": "raster_fwd_lanes_kernel<3>", "raster_bwd_kernel": "raster_bwd_lanes2_kernel<3>"}[dom], "achieved": dom_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "valu", "kernel": dom, "launched_as": LAUNCHED_AS[dom], "achieved": dom_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": None if dom_tf is None else dom_tf / VALU_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "pairs_valid": pairs_valid, "flops_per_pair": {"fwd": FLOPS_FWD_PER_PAIR, "bwd": FLOPS_BWD_PER_PAIR},
@@ -355,14 +397,20 @@ def main():
                                                      "frac_of_157.3": None if valu_tf is None else valu_tf / VALU_PEAK_TFLOPS},
                          "lane_utilisation": lane_util,
                          "kernel_ms": kt,
+                         "kernel_ms_in_engine": None if not engine else engine.get("kernel_ms"),
+                         "frac_in_engine": None if not (engine and pairs_valid and engine.get("kernel_ms", {}).get(dom)) else
+                         pairs_valid * dom_flops / (engine["kernel_ms"][dom] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
                          "hbm": {"algorithmic_bytes": kbytes[dom], "achieved_GBs": hbm_achieved, "peak_GBs": HBM_PEAK_GBS,
                                  "frac": hbm_achieved / HBM_PEAK_GBS},
-                         "note": "kernels timed alone with HIP events on the launch stream (gs_raster_composite / gs_raster_bwd_acc: no "
-                                 "stream build, no memset); useful flops = composited (pixel, Gaussian) pairs x flops per pair"},
+                         "note": "`achieved` / `frac` / `kernel_ms`: kernels timed ALONE with HIP events on the launch stream (gs_raster_composite / "
+                                 "gs_raster_bwd_acc: no stream build, no memset); `kernel_ms_in_engine` / `frac_in_engine`: rocprofv3 averages of the "
+                                 "same kernels inside the three-stream step (profiles/r03_engine_kernel_ms.json, where they share the CUs with the "
+                                 "front and tail streams); useful flops = composited (pixel, Gaussian) pairs x flops per pair"},
             "view_roofline": {"algorithmic_bytes_per_view": view_bytes,
                               "achieved_GBs": view_bytes * views_per_s / world / 1e9,
                               "frac_of_8TBs": view_bytes * views_per_s / world / 1e9 / HBM_PEAK_GBS},
             "gpu_view_ms_without_prefilter": view_ms,
+            "prefilter": None if args.no_prefilter else prefilter_report(params.cubemap, max(3, args.kernel_iters // 2)),
             "capacity_protocol": capacity,
         }
         if cb is not None:

@@ -32,7 +32,7 @@ SYMBOLS = [
     "gs_last_error", "gs_version", "gs_project_ws_bytes", "gs_project_fwd", "gs_project_fwd_vis", "gs_isect_emit", "gs_sort_ws_bytes",
     "gs_isect_sort", "gs_isect_bin_ws_bytes", "gs_isect_bin", "gs_isect_offsets", "gs_raster_ws_bytes", "gs_raster_fwd", "gs_raster_prepare", "gs_raster_prepare_vis", "gs_raster_composite", "gs_raster_grad_stride", "gs_raster_bwd", "gs_raster_bwd_acc", "gs_selftest_rcp", "gs_selftest_exp", "gs_isect_bin_cap", "gs_isect_offsets_cap", "gs_raster_prepare_vis_cap", "gs_raster_composite_cap", "gs_raster_bwd_cap", "gs_raster_bwd_acc_cap", "gs_project_bwd_cap", "gs_project_bwd", "gs_shade_fwd",
     "gs_shade_bwd_ws_bytes", "gs_shade_bwd", "gs_tonemap_fwd", "gs_tonemap_bwd", "gs_tonemap_fwd3", "gs_tonemap_bwd3", "gs_cubemap_mip_fwd", "gs_cube_sample_linear",
-    "gs_cubemap_mip_bwd", "gs_diffuse_cubemap_fwd", "gs_diffuse_cubemap_bwd", "gs_specular_bounds", "gs_cube_dir_table",
+    "gs_cubemap_mip_bwd", "gs_diffuse_cubemap_fwd", "gs_diffuse_cubemap_bwd", "gs_specular_bounds", "gs_specular_bounds_ws_bytes", "gs_specular_bounds_fast", "gs_cube_dir_table",
     "gs_specular_cubemap_fwd", "gs_specular_cubemap_bwd", "gs_specular_tiles_count", "gs_specular_tiles_fill",
     "gs_specular_tiles_check", "gs_specular_tiles_apply", "gs_mgadapter_fwd", "gs_mgadapter_bwd", "gs_vertex_normals_fwd",
     "gs_vertex_normals_bwd", "gs_photo_loss_ws_bytes", "gs_photo_loss", "gs_hashgrid_fwd", "gs_hashgrid_bwd_ws_bytes", "gs_hashgrid_bwd", "gs_hashgrid_bwd_fixed_ws_bytes", "gs_hashgrid_bwd_fixed", "gs_mlp_wgrad_ws_bytes", "gs_mlp_wgrad",
@@ -75,6 +75,8 @@ def lib() -> C.CDLL:
         l.gs_flexicubes_ws_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
         l.gs_photo_loss_ws_bytes.restype = C.c_size_t
         l.gs_photo_loss_ws_bytes.argtypes = [C.c_int, C.c_int]
+        l.gs_specular_bounds_ws_bytes.restype = C.c_size_t
+        l.gs_specular_bounds_ws_bytes.argtypes = [C.c_int]
         l.gs_raster_ws_bytes.restype = C.c_size_t
         l.gs_raster_ws_bytes.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib = l

@@ -230,6 +230,125 @@ extern "C" int gs_specular_bounds(int R, float costheta_cutoff, float* bounds, v
     return GS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same boxes, two orders of magnitude faster (223 ms -> ~2 ms for the six levels of a 512^2 pyramid).  specular_bounds_kernel
+// above is shaped like the reference's SpecularBoundsKernel (cubemap.cu:181-244): every texel re-derives the four normalised
+// corner directions of every 16x16 tile of every face (4 x 6144 normalisations per texel at R = 512) before it tests the tile.
+//  * bounds_tile_aabb_kernel computes the corner-direction box {mn[3], mx[3]} of every tile ONCE -- the same fminf / fmaxf of the
+//    same four cube_to_dir values -- and of every GROUP of 4x4 tiles (component-wise min / max of its tiles' boxes);
+//  * specular_bounds_fast_kernel evaluates the reference's tile test `sum_k max(mn_k V_k, mx_k V_k) >= cutoff` from those boxes
+//    in the reference's operation order, so every tile decision is bit-identical; a group whose own test fails is skipped as a
+//    whole: its box contains its tiles' boxes, each product and each sum is monotone under rounding, so a failing group test
+//    implies that every tile test in it fails;
+//  * the texel test of a surviving tile reads the cached direction table (bit-identical to cube_to_dir, dir_table_kernel).
+__global__ void __launch_bounds__(256)
+bounds_tile_aabb_kernel(int R, int nt, int ng, float* __restrict__ tile_box /*[6][nt][nt][6]*/, float* __restrict__ group_box /*[6][ng][ng][6]*/)
+{
+    const int TILE = 16;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_tiles = 6 * nt * nt, n_groups = 6 * ng * ng;
+    if (i < n_tiles) {
+        const int tx = i % nt, ty = (i / nt) % nt, s = i / (nt * nt);
+        const int tsx = tx * TILE, tsy = ty * TILE;
+        const int tex = min((tx + 1) * TILE, R), tey = min((ty + 1) * TILE, R);
+        float L0[3], L1[3], L2[3], L3[3];
+        cube_to_dir(tsx, tsy, s, R, L0); cube_to_dir(tex, tsy, s, R, L1);
+        cube_to_dir(tsx, tey, s, R, L2); cube_to_dir(tex, tey, s, R, L3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            tile_box[(size_t)i * 6 + k] = fminf(fminf(L0[k], L1[k]), fminf(L2[k], L3[k]));
+            tile_box[(size_t)i * 6 + 3 + k] = fmaxf(fmaxf(L0[k], L1[k]), fmaxf(L2[k], L3[k]));
+        }
+    }
+    // groups of 4x4 tiles: recomputed from the corner directions (no dependency on the tile entries written above)
+    if (i < n_groups) {
+        const int gx = i % ng, gy = (i / ng) % ng, s = i / (ng * ng);
+        float mn[3] = { 3.0f, 3.0f, 3.0f }, mx[3] = { -3.0f, -3.0f, -3.0f };
+        for (int ty = gy * 4; ty < min(gy * 4 + 4, nt); ++ty)
+            for (int tx = gx * 4; tx < min(gx * 4 + 4, nt); ++tx) {
+                const int tsx = tx * TILE, tsy = ty * TILE;
+                const int tex = min((tx + 1) * TILE, R), tey = min((ty + 1) * TILE, R);
+                float L0[3], L1[3], L2[3], L3[3];
+                cube_to_dir(tsx, tsy, s, R, L0); cube_to_dir(tex, tsy, s, R, L1);
+                cube_to_dir(tsx, tey, s, R, L2); cube_to_dir(tex, tey, s, R, L3);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    mn[k] = fminf(mn[k], fminf(fminf(L0[k], L1[k]), fminf(L2[k], L3[k])));
+                    mx[k] = fmaxf(mx[k], fmaxf(fmaxf(L0[k], L1[k]), fmaxf(L2[k], L3[k])));
+                }
+            }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { group_box[(size_t)i * 6 + k] = mn[k]; group_box[(size_t)i * 6 + 3 + k] = mx[k]; }
+    }
+}
+
+__device__ __forceinline__ float box_maxdp(const float* __restrict__ box, const float* V)
+{
+    float maxdp = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) maxdp += fmaxf(box[k] * V[k], box[3 + k] * V[k]);
+    return maxdp;
+}
+
+__global__ void __launch_bounds__(256)
+specular_bounds_fast_kernel(int R, int nt, int ng, float cutoff, const float4* __restrict__ table, const float* __restrict__ tile_box,
+                            const float* __restrict__ group_box, float* __restrict__ bounds)
+{
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= 6 * R * R) return;
+    const float4 own = table[o];
+    const float VNR[3] = { own.x, own.y, own.z };
+    const int TILE = 16;
+    for (int s = 0; s < 6; ++s) {
+        int min_x = R - 1, max_x = 0, min_y = R - 1, max_y = 0;
+        for (int gy = 0; gy < ng; ++gy)
+            for (int gx = 0; gx < ng; ++gx) {
+                if (!(box_maxdp(group_box + (size_t)((s * ng + gy) * ng + gx) * 6, VNR) >= cutoff)) continue;
+                // the reference visits the tiles tx-major (cubemap.cu:198-199); the box is a min / max, so the order is free
+                for (int ty = gy * 4; ty < min(gy * 4 + 4, nt); ++ty)
+                    for (int tx = gx * 4; tx < min(gx * 4 + 4, nt); ++tx) {
+                        if (!(box_maxdp(tile_box + (size_t)((s * nt + ty) * nt + tx) * 6, VNR) >= cutoff)) continue;
+                        const int tsx = tx * TILE, tsy = ty * TILE;
+                        const int tex = min((tx + 1) * TILE, R), tey = min((ty + 1) * TILE, R);
+                        for (int y = tsy; y < tey; ++y)
+                            for (int x = tsx; x < tex; ++x) {
+                                const float4 q = table[((size_t)s * R + y) * R + x];
+                                const float L[3] = { q.x, q.y, q.z };
+                                if (dot3(L, VNR) >= cutoff) {
+                                    min_x = min(min_x, x); max_x = max(max_x, x);
+                                    min_y = min(min_y, y); max_y = max(max_y, y);
+                                }
+                            }
+                    }
+            }
+        float* b = bounds + (size_t)o * 24 + s * 4;
+        b[0] = (float)min_x; b[1] = (float)max_x; b[2] = (float)min_y; b[3] = (float)max_y;
+    }
+}
+
+extern "C" size_t gs_specular_bounds_ws_bytes(int R)
+{
+    if (R < 1) return 0;
+    const size_t nt = (size_t)(R + 15) / 16, ng = (nt + 3) / 4;
+    return (6 * nt * nt + 6 * ng * ng) * 6 * sizeof(float);
+}
+
+extern "C" int gs_specular_bounds_fast(int R, float costheta_cutoff, const float* dir_table, float* bounds, void* ws, size_t ws_bytes,
+                                       void* stream)
+{
+    GS_CHECK_ARG(R >= 1 && dir_table && bounds && ws, "bad arguments");
+    GS_CHECK_ARG(ws_bytes >= gs_specular_bounds_ws_bytes(R), "workspace too small (gs_specular_bounds_ws_bytes)");
+    const int nt = (R + 15) / 16, ng = (nt + 3) / 4;
+    float* tile_box = (float*)ws;
+    float* group_box = tile_box + (size_t)6 * nt * nt * 6;
+    hipLaunchKernelGGL(bounds_tile_aabb_kernel, dim3(gs_cdiv(6 * nt * nt, 256)), dim3(256), 0, (hipStream_t)stream, R, nt, ng, tile_box, group_box);
+    GS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(specular_bounds_fast_kernel, dim3(gs_cdiv(6 * R * R, 256)), dim3(256), 0, (hipStream_t)stream, R, nt, ng,
+                       costheta_cutoff, (const float4*)dir_table, tile_box, group_box, bounds);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
 // Per-texel table {dir.xyz, pixel_area}: depends on R only, cached by the host across steps.  It removes the
 // normalisation (3 correctly-rounded divisions + sqrt) and the four atanf of pixel_area from every (output,
 // input) pair of the lobe loops; values are bit-identical to calling cube_to_dir / pixel_area in place.

@@ -191,10 +191,10 @@ class RenderStep:
             self._status = torch.zeros(3, dtype=torch.int64, device=dev)
         side = self._side_stream
         if side is None:
-            side = self._side_stream = torch.cuda.Stream(device=dev)
+            side = self._side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("GEOSPLAT_SIDE_PRIO", "0")))
         tail = self._tail_stream
         if tail is None:
-            tail = self._tail_stream = torch.cuda.Stream(device=dev)
+            tail = self._tail_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("GEOSPLAT_TAIL_PRIO", "0")))
         side.wait_stream(main)                               # prefilter pyramid, activations, zeroed buckets
         tail.wait_stream(main)
 

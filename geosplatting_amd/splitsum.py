@@ -43,7 +43,13 @@ def specular_bounds(res: int, roughness: float, cutoff: float, device: torch.dev
     if key not in _bounds_cache:
         ct = ndf_cutoff(roughness, cutoff)
         b = torch.empty(6, res, res, 24, dtype=torch.float32, device=device)
-        L.check(L.lib().gs_specular_bounds(res, L.f32(ct), L.ptr(b), L.stream()), "gs_specular_bounds")
+        if os.environ.get("GEOSPLAT_BOUNDS", "fast") == "reference":     # the kernel shaped like SpecularBoundsKernel (0.2 s at 512^2)
+            L.check(L.lib().gs_specular_bounds(res, L.f32(ct), L.ptr(b), L.stream()), "gs_specular_bounds")
+        else:
+            nbytes = L.lib().gs_specular_bounds_ws_bytes(res)
+            ws = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+            L.check(L.lib().gs_specular_bounds_fast(res, L.f32(ct), L.ptr(dir_table(res, device)), L.ptr(b), L.ptr(ws), C.c_size_t(nbytes),
+                                                    L.stream()), "gs_specular_bounds_fast")
         _bounds_cache[key] = (ct, b)
     return _bounds_cache[key]
 

@@ -284,8 +284,13 @@ int gs_cube_sample_linear(int64_t n, const float* tex, int R, const float* dirs,
 int gs_cubemap_mip_bwd(int R, const float* v_out, float* v_in, int accumulate, void* stream);
 int gs_diffuse_cubemap_fwd(int R, const float* cubemap, float* out, void* stream);
 int gs_diffuse_cubemap_bwd(int R, const float* v_out, float* v_cubemap, int accumulate, void* stream);
-/* bounds[6,R,R,24] (float-encoded ints, layout of the reference). */
+/* bounds[6,R,R,24] (float-encoded ints, layout of the reference: per texel and face xmin, xmax, ymin, ymax of the lobe's texels).
+ * gs_specular_bounds is shaped like SpecularBoundsKernel (cubemap.cu:181-244: every texel re-derives the corner directions of every
+ * 16x16 tile); gs_specular_bounds_fast gives bit-identical boxes from per-tile / per-4x4-tile-group corner boxes computed once
+ * (ws: gs_specular_bounds_ws_bytes(R) bytes of device scratch) and the cached direction table -- ~100x faster, the one the host uses. */
 int gs_specular_bounds(int R, float costheta_cutoff, float* bounds, void* stream);
+size_t gs_specular_bounds_ws_bytes(int R);
+int gs_specular_bounds_fast(int R, float costheta_cutoff, const float* dir_table, float* bounds, void* ws, size_t ws_bytes, void* stream);
 /* table[6,R,R,4] = {unit direction xyz, pixel_area}: depends on R only -- compute once, reuse every step. */
 int gs_cube_dir_table(int R, float* table, void* stream);
 /* out[6,R,R,4] = (sum rgb*w, sum w) */

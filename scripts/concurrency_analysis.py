@@ -7,7 +7,7 @@ kt = [t for t in tabs if 'kernel_dispatch' in t][0]
 ks = [t for t in tabs if t.startswith('rocpd_info_kernel_symbol')][0]
 rows = list(c.execute(f"select s.kernel_name, d.start, d.end from {kt} d join {ks} s on d.kernel_id=s.id order by d.start"))
 short = lambda n: n.split('(')[0].replace('void ', '')[:40]
-ap = [i for i, r in enumerate(rows) if 'specular_apply' in r[0]]
+ap = [i for i, r in enumerate(rows) if ('tile_apply' in r[0] or 'specular_apply' in r[0])]
 rb = [i for i, r in enumerate(rows) if 'raster_bwd' in r[0]]
 groups = []                                               # runs of prefilter applies (one run = one direction of one step)
 for i in ap:

@@ -149,6 +149,27 @@ def test_prefilter_tiled_tables_equal_direct(cuda, symmetry, monkeypatch):
         ss._tiles_cache.clear()
 
 
+def test_specular_bounds_fast_equals_reference_shape(cuda):
+    """gs_specular_bounds_fast (corner boxes of tiles / 4x4 tile groups computed once, whole groups skipped, cached directions)
+    == gs_specular_bounds (the kernel shaped like SpecularBoundsKernel, cubemap.cu:181-244) for every texel, face and level --
+    and both equal the oracle's boxes."""
+    import ctypes as C
+    from geosplatting_amd import _lib as L
+    from geosplatting_amd import splitsum as ss
+    lib = L.lib()
+    for R, rough in ((16, 1.0), (32, 0.5), (64, 0.395), (64, 0.08), (128, 0.29), (96, 0.2), (256, 0.185)):
+        ct = ss.ndf_cutoff(rough)
+        a = torch.empty(6, R, R, 24, device=cuda); b = torch.full((6, R, R, 24), -7.0, device=cuda)
+        L.check(lib.gs_specular_bounds(R, L.f32(ct), L.ptr(a), L.stream()), "gs_specular_bounds")
+        n = lib.gs_specular_bounds_ws_bytes(R)
+        ws = torch.empty(int(n), dtype=torch.uint8, device=cuda)
+        L.check(lib.gs_specular_bounds_fast(R, L.f32(ct), L.ptr(ss.dir_table(R, cuda)), L.ptr(b), L.ptr(ws), C.c_size_t(n), L.stream()),
+                "gs_specular_bounds_fast")
+        assert torch.equal(a, b), (R, rough, int((a != b).sum()))
+        if R <= 64:
+            assert np.array_equal(a.cpu().numpy(), oracle.specular_bounds(R, ct)), (R, rough)
+
+
 def test_prefilter_tile_shares_partition_the_level(cuda):
     """Sharded S5: the shares [shard_tiles] of a level's tile list, applied into zero-filled levels and summed, give the whole
     level bit for bit (what G ranks + one all-reduce compute), forward and backward."""

@@ -7,7 +7,7 @@ behind it is two or three plain GEMMs and goes to the BLAS library through torch
 from __future__ import annotations
 
 import os
-from typing import List, Optional, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -182,6 +182,65 @@ class HashEncoding:
         return f
 
 
+# ----------------------------------------------------------------------------- 'vertex' sampling helpers (host-side glue, plain torch)
+def _unit_or_z(v: Tensor) -> Tensor:
+    """rfstudio.graphics.math.safe_normalize (:119-128): unit vectors, (0, 0, 1) where the length is below 1e-6."""
+    n = v.norm(dim=-1, keepdim=True)
+    z = torch.tensor([0.0, 0.0, 1.0], device=v.device, dtype=v.dtype)
+    return torch.where(n < 1e-6, z, v / n.clamp_min(1e-6))
+
+
+def vertex_patches(vertices: Tensor, faces: Tensor) -> Tuple[Tensor, Tensor]:
+    """GaussianField.get_patches (rfstudio/model/geosplat.py:520-557): per vertex the normal (normalised sum of the UNIT normals of
+    its faces -- unlike compute_vertex_normals, which weights by area) and a third of the area of its face fan projected on that
+    normal, `sum_f (n_f |A_f| . n_v) / 6` with |A_f| twice the face area, floored at 1e-10 / 6.  Differentiable (torch ops:
+    V Gaussians for the first 50 steps of a run -- nothing here is on the hot path)."""
+    F = faces.shape[0]
+    p = vertices[faces]                                                    # [F,3,3]
+    wn = torch.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0], dim=-1)           # area-weighted face normals
+    flat = faces.reshape(-1)
+    unit = _unit_or_z(wn)[:, None, :].expand(F, 3, 3).reshape(-1, 3)
+    normals = _unit_or_z(torch.zeros_like(vertices).index_add_(0, flat, unit))
+    proj = (wn[:, None, :] * normals[faces]).sum(-1).reshape(-1, 1)         # [3F,1]
+    areas = torch.zeros_like(vertices[:, :1]).index_add_(0, flat, proj)
+    return normals, areas.clamp_min(1e-10) / 6
+
+
+def rotation_between(a: Tensor, b: Tensor, eps: float = 1e-6, generator: Optional[torch.Generator] = None) -> Tensor:
+    """get_rotation_from_relative_vectors (rfstudio/graphics/math.py:159-188): the rotation [..,3,3] that turns `a` into `b`
+    (Rodrigues from v = a x b:  I + [v]x + [v]x^2 (1 - c) / (|v|^2 + eps)).  Where the two are opposite (c < -1 + eps) the
+    reference perturbs `a` by uniform noise of amplitude 0.005 and starts over; so does this (noise from `generator`)."""
+    a = a / a.norm(dim=-1, keepdim=True)
+    b = b / b.norm(dim=-1, keepdim=True)
+    c = (a * b).sum(-1)
+    bad = c < -1 + eps
+    if bool(bad.any()):
+        noise = (torch.rand(torch.broadcast_shapes(a.shape, b.shape), device=b.device, generator=generator) - 0.5) * 0.01
+        return rotation_between(a + torch.where(bad[..., None], noise, torch.zeros_like(noise)), b, eps, generator)
+    v = torch.cross(a.expand(*c.shape, 3), b.expand(*c.shape, 3), dim=-1)
+    z = torch.zeros_like(c)
+    K = torch.stack((z, -v[..., 2], v[..., 1], v[..., 2], z, -v[..., 0], -v[..., 1], v[..., 0], z), -1).reshape(*c.shape, 3, 3)
+    k = (1 - c) / ((v * v).sum(-1).sqrt() ** 2 + eps)
+    return torch.eye(3, device=b.device, dtype=b.dtype) + K + (K @ K) * k[..., None, None]
+
+
+def quaternions_from_rotations(R: Tensor) -> Tensor:
+    """rot2quat (rfstudio/graphics/math.py:246-278): wxyz from [..,3,3], taking the best-conditioned of the four candidate rows
+    (largest of 1 +- m00 +- m11 +- m22), denominators floored at 0.1."""
+    m = R.reshape(-1, 3, 3)
+    d0, d1, d2 = m[:, 0, 0], m[:, 1, 1], m[:, 2, 2]
+    four = torch.stack((1 + d0 + d1 + d2, 1 + d0 - d1 - d2, 1 - d0 + d1 - d2, 1 - d0 - d1 + d2), -1)
+    mag = four.clamp_min(0).sqrt()
+    pick = mag.argmax(-1)
+    s_yz, s_zx, s_xy = m[:, 2, 1] - m[:, 1, 2], m[:, 0, 2] - m[:, 2, 0], m[:, 1, 0] - m[:, 0, 1]
+    a_xy, a_zx, a_yz = m[:, 1, 0] + m[:, 0, 1], m[:, 0, 2] + m[:, 2, 0], m[:, 1, 2] + m[:, 2, 1]
+    sq = mag * mag
+    rows = torch.stack((torch.stack((sq[:, 0], s_yz, s_zx, s_xy), -1), torch.stack((s_yz, sq[:, 1], a_xy, a_zx), -1),
+                        torch.stack((s_zx, a_xy, sq[:, 2], a_yz), -1), torch.stack((s_xy, a_zx, a_yz, sq[:, 3]), -1)), 1)   # [n,4,4]
+    q = rows[torch.arange(m.shape[0], device=m.device), pick] / (2 * mag.gather(1, pick[:, None]).clamp_min(0.1))
+    return q.reshape(*R.shape[:-2], 4)
+
+
 class GaussianField:
     """Mirror of rfstudio's GaussianField (rfstudio/model/geosplat.py:482-520) with its three default encoders and of
     `get_gaussians_from_face` (:620-672, the MGAdapter branch used by GeoSplatter): mesh -> Gaussians, with kd / ks
@@ -196,6 +255,32 @@ class GaussianField:
 
     def parameters(self) -> List[Tensor]:
         return self.kd_enc.parameters() + self.ks_enc.parameters() + self.z_enc.parameters()
+
+    def get_gaussians_from_vertex(self, vertices: Tensor, faces: Tensor, kd_perturb_std: float = 0.0, ks_perturb_std: float = 0.0, *,
+                                  scale: float, initial_guess: Tensor, generator: Optional[torch.Generator] = None):
+        """GaussianField.get_gaussians_from_vertex (rfstudio/model/geosplat.py:559-620), the sampling of the first
+        `vertex_sample_warmup` steps: ONE flat Gaussian per mesh vertex, facing the vertex normal, its two in-plane log-scales
+        0.5 log(patch area / 2.5) (the third log 1e-10), pushed under the surface by sigmoid(z field) times that scale.  Returns
+        (SplatSet, RenderableAttrs)."""
+        from .shading import RenderableAttrs
+        from .splats import SplatSet
+        normals, areas = vertex_patches(vertices, faces)
+        half_log = (areas * (1 / 2.5)).log() * 0.5                              # [V,1]
+        x = (vertices / scale).clamp(-1, 1)
+        kd_jitter = ks_jitter = None
+        if kd_perturb_std > 0:
+            kd_jitter = self.kd_enc((x + torch.randn(x.shape, device=x.device, generator=generator) * kd_perturb_std).clamp(-1, 1))
+        if ks_perturb_std > 0:
+            ks_jitter = (self.ks_enc((x + torch.randn(x.shape, device=x.device, generator=generator) * ks_perturb_std).clamp(-1, 1)) + initial_guess).sigmoid()
+        attrs = RenderableAttrs(kd=self.kd_enc(x), ks=(self.ks_enc(x) + initial_guess).sigmoid(), normals=normals,
+                                kd_jitter=kd_jitter, ks_jitter=ks_jitter)
+        depth = half_log.detach().exp() * self.z_enc(x.detach()).sigmoid()        # [V,1]
+        z_axis = torch.tensor([0.0, 0.0, 1.0], device=vertices.device, dtype=vertices.dtype)
+        quats = quaternions_from_rotations(rotation_between(z_axis, normals.detach(), generator=generator))
+        scales = torch.cat((half_log, half_log, torch.full_like(half_log, 1e-10).log()), -1)
+        V = vertices.shape[0]
+        opac = torch.logit(0.99 * torch.ones(V, 1, device=vertices.device))
+        return SplatSet(vertices - normals * depth, scales, quats, opac, torch.empty_like(normals)), attrs
 
     def get_gaussians_from_face(self, vertices: Tensor, faces: Tensor, kd_perturb_std: float = 0.0,
                                 ks_perturb_std: float = 0.0, *, scale: float, initial_guess: Tensor,

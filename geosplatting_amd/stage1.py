@@ -19,6 +19,7 @@ branches and `normal_grad_weight` of render_report (:881-922: extra un-shaded re
 from __future__ import annotations
 
 import os
+from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -81,6 +82,7 @@ class Stage1Model:
         self.ks_grad_weight = 0.0; self.ks_regualr_perturb_std = 0.0
         self.normal_grad_weight = 0.0
         self.smooth_type = "jitter"                              # 'jitter' | 'grad' | 'tv'  (geosplat.py:697)
+        self.sample_method = "face"                              # 'face' | 'vertex': set by the trainer's schedule (GeoSplatSchedule)
         self.background_color = torch.ones(3, device=dev)        # get_background_color() of a 'white' model
         self.last_num_gaussians = 0
         # random streams owned by the model: the kd / ks jitter must be IDENTICAL on every rank (replicas extract and perturb
@@ -200,16 +202,24 @@ class Stage1Model:
         white = self.cubemap.mean(-1, keepdim=True)
         return as_splitsum(self.cubemap), (self.cubemap - white).abs().mean()
 
-    def get_gsplat(self):
-        """:787-831 with sampling='face', smooth_type='jitter' -> (mesh, splats, attrs, regularisation)"""
+    def get_gsplat(self, sampling: Optional[str] = None):
+        """:787-831 -> (mesh, splats, attrs, regularisation).  sampling 'face' (six Gaussians per face through the MGAdapter) or
+        'vertex' (one per vertex: what the trainer selects for its first `vertex_sample_warmup` steps); default: self.sample_method."""
+        sampling = self.sample_method if sampling is None else sampling
+        if sampling not in ("face", "vertex"):
+            raise ValueError(sampling)
         (v, f), reg = self.get_geometry()
-        self.last_num_gaussians = f.shape[0] * 6
+        self.last_num_gaussians = f.shape[0] * 6 if sampling == "face" else v.shape[0]
         # the jittered encoder evaluations and their L1 terms exist for smooth_type == 'jitter' only (:800-801): under 'grad' /
         # 'tv' the perturbation stds are zeroed, nothing is drawn from the jitter generator and no jitter term enters the loss
         kd_std = self.kd_regualr_perturb_std if self.smooth_type == "jitter" else 0.0
         ks_std = self.ks_regualr_perturb_std if self.smooth_type == "jitter" else 0.0
-        splats, attrs, _ = self.field.get_gaussians_from_face(v, f, kd_std, ks_std, scale=self.scale,
-                                                              initial_guess=self.initial_guess_bias, generator=self._jitter_gen)
+        if sampling == "face":
+            splats, attrs, _ = self.field.get_gaussians_from_face(v, f, kd_std, ks_std, scale=self.scale,
+                                                                  initial_guess=self.initial_guess_bias, generator=self._jitter_gen)
+        else:
+            splats, attrs = self.field.get_gaussians_from_vertex(v, f, kd_std, ks_std, scale=self.scale,
+                                                                 initial_guess=self.initial_guess_bias, generator=self._jitter_gen)
         if kd_std > 0 and self.kd_grad_weight > 0:
             reg = reg + self.kd_grad_weight * (attrs.kd_jitter - attrs.kd).abs().mean()
         if ks_std > 0 and self.ks_grad_weight > 0:
@@ -258,6 +268,62 @@ class Stage1Model:
             self._last_smoothing = self.smoothing_regularization(splats, attrs, cameras, gt_rgba, batch_size or len(cameras))
             reg = reg + self._last_smoothing                 # per-view terms (already / batch_size): NOT replicated across ranks
         return images, splats.means.shape[0], reg + light_reg * self.light_weight
+
+
+@dataclass
+class GeoSplatSchedule:
+    """The per-step schedule of the reference's stage-1 trainer (GeoSplatTrainer.before_update / after_update / the gradient hooks
+    of setup, rfstudio/trainer/geosplat_trainer.py:20-62,66-69,209-266) as plain host code: which sampling the model uses, the
+    linear ramps of its regularisation weights, the x64 scaling of the environment-map gradient and the floor of the cubemap."""
+    vertex_sample_warmup: int = 50
+    light_reg_begin: float = 2e-3
+    light_reg_end: float = 2e-3
+    light_reg_decay: int = 500
+    sdf_reg_begin: float = 0.2
+    sdf_reg_end: float = 0.12
+    sdf_reg_decay: int = 500
+    kd_grad_reg_begin: float = 0.0
+    kd_grad_reg_end: float = 0.03
+    kd_grad_reg_decay: int = 500
+    kd_regualr_perturb_std: float = 0.01
+    ks_grad_reg_begin: float = 0.0
+    ks_grad_reg_end: float = 0.001
+    ks_grad_reg_decay: int = 500
+    ks_regualr_perturb_std: float = 0.01
+    normal_grad_reg_begin: float = 0.0
+    normal_grad_reg_end: float = 0.5
+    normal_grad_reg_decay: int = 0
+    light_gradient_scale: float = 64.0
+    cubemap_floor: float = 1e-2
+
+    @staticmethod
+    def _ramp(begin: float, end: float, t: float) -> float:
+        return begin - (begin - end) * min(1.0, t)
+
+    def before_update(self, model, curr_step: int) -> None:
+        model.sample_method = "vertex" if (self.vertex_sample_warmup > 0 and curr_step < self.vertex_sample_warmup) else "face"
+        model.light_weight = self._ramp(self.light_reg_begin, self.light_reg_end, curr_step / self.light_reg_decay)
+        if self.sdf_reg_decay > 0:
+            model.sdf_weight = self._ramp(self.sdf_reg_begin, self.sdf_reg_end, curr_step / self.sdf_reg_decay)
+        if self.kd_grad_reg_decay > 0:
+            model.kd_grad_weight = self._ramp(self.kd_grad_reg_begin, self.kd_grad_reg_end, curr_step / self.kd_grad_reg_decay)
+            model.kd_regualr_perturb_std = self.kd_regualr_perturb_std
+        if self.ks_grad_reg_decay > 0:
+            model.ks_grad_weight = self._ramp(self.ks_grad_reg_begin, self.ks_grad_reg_end, curr_step / self.ks_grad_reg_decay)
+            model.ks_regualr_perturb_std = self.ks_regualr_perturb_std
+        if self.normal_grad_reg_decay > 0:
+            model.normal_grad_weight = self._ramp(self.normal_grad_reg_begin, self.normal_grad_reg_end,
+                                                  max(curr_step - 200, 0) / self.normal_grad_reg_decay)
+
+    def scale_light_gradient(self, model) -> None:
+        """setup's `model.cubemap.register_hook(lambda grad: grad * 64)`, applied to the finished gradient (the fused step writes
+        .grad directly, so a tensor hook would not see it)"""
+        if model.cubemap.grad is not None:
+            model.cubemap.grad.mul_(self.light_gradient_scale)
+
+    def after_update(self, model, curr_step: int) -> None:
+        with torch.no_grad():
+            model.cubemap.clamp_min_(self.cubemap_floor)
 
 
 def train_step_fused(model: Stage1Model, cameras: Sequence[Camera], gt_rgba: Sequence[Tensor], *, gt_is_srgb: bool = True,

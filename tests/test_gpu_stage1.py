@@ -177,3 +177,47 @@ def test_smoothing_branches(cuda):
         smooth.backward()
         assert float(m.field.kd_enc.hash_table.grad.abs().sum()) > 0 and float(m.field.ks_enc.hash_table.grad.abs().sum()) > 0
         assert float(m.sdf_params.grad.abs().sum()) > 0
+
+
+def test_scheduled_run_starts_with_vertex_sampling():
+    """The reference's schedule (GeoSplatTrainer.before_update / after_update, rfstudio/trainer/geosplat_trainer.py:209-266) on the
+    HIP path: the first `vertex_sample_warmup` steps render ONE Gaussian per mesh vertex (GaussianField.get_gaussians_from_vertex,
+    rfstudio/model/geosplat.py:559-620), then the MGAdapter's six per face; the fused step and the autograd step agree in both
+    samplings, every parameter receives a finite gradient, the environment gradient is scaled by 64 and the cubemap floored."""
+    from geosplatting_amd.stage1 import GeoSplatSchedule, train_step, train_step_fused
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    cams, gts, grid = _scene(dev)
+    model = _model(dev, grid)
+    sch = GeoSplatSchedule(vertex_sample_warmup=2)
+    opt = torch.optim.Adam(model.parameters(), lr=3e-3)
+    g_b = torch.Generator().manual_seed(4)
+    bgs = [torch.rand(HW, HW, 3, generator=g_b).to(dev) for _ in range(N_VIEWS)]
+    counts = []
+    for it in range(4):
+        sch.before_update(model, it)
+        assert model.sample_method == ("vertex" if it < 2 else "face")
+        assert abs(model.sdf_weight - (0.2 - 0.08 * it / 500)) < 1e-9 and model.kd_regualr_perturb_std == 0.01
+        model.kd_regualr_perturb_std = model.ks_regualr_perturb_std = 0.0           # (the jitter is a random draw: off for the comparison)
+        (v, f), splats, attrs, _ = model.get_gsplat()
+        assert splats.means.shape[0] == (v.shape[0] if it < 2 else 6 * f.shape[0]) == model.last_num_gaussians
+        assert torch.allclose(attrs.normals.norm(dim=-1), torch.ones_like(attrs.normals[:, 0]), atol=1e-5)
+        ref = {}
+        rng = model._jitter_gen.get_state().clone()          # a vertex normal exactly opposite to +z takes rotation_between's random restart
+        for name, fn in (("autograd", train_step), ("fused", train_step_fused)):
+            model._jitter_gen.set_state(rng)
+            out = fn(model, cams, gts, gt_is_srgb=False, train_bg=bgs)
+            ref[name] = {k: p.grad.detach().clone() for k, p in model.named_parameters().items()}
+            assert int(out["#gaussians"]) == model.last_num_gaussians
+        for k, w in ref["autograd"].items():
+            assert torch.isfinite(w).all(), k
+            err = (ref["fused"][k] - w).abs().max().item() / (w.abs().max().item() + 1e-30)
+            assert err < 1e-3, (it, k, err)                   # order of the float atomics (few, large Gaussians in vertex mode)
+        counts.append(model.last_num_gaussians)
+        before = model.cubemap.grad.clone()
+        sch.scale_light_gradient(model)
+        assert torch.equal(model.cubemap.grad, before * 64)
+        opt.step()
+        sch.after_update(model, it)
+        assert float(model.cubemap.min()) >= 1e-2
+    assert counts[2] > 3 * counts[0]                                                # six per face >> one per vertex

@@ -88,6 +88,49 @@ def test_canonical_exp_accuracy():
     assert oracle.exp_neg_check(0.0, 0.0) == (0.0, 0x3f800000)     # exp(-0) == 1 exactly; checksum of one item = its bits
 
 
+def test_golden_vertex_sampling_and_schedule():
+    """'vertex' sampling of the stage-1 loop and the trainer's schedule against the reference's own code (scripts/make_golden_vertex.py:
+    GaussianField.get_patches / get_gaussians_from_vertex, get_rotation_from_relative_vectors, GeoSplatTrainer.before_update)."""
+    from types import SimpleNamespace
+    from geosplatting_amd import field as F
+    from geosplatting_amd.stage1 import GeoSplatSchedule
+    g = gold("ref_vertex.npz")
+    v, f = torch.tensor(g["vertices"]), torch.tensor(g["faces"])
+    n, a = F.vertex_patches(v, f)
+    assert np.allclose(n.numpy(), g["patch_normals"], atol=1e-6) and np.allclose(a.numpy(), g["patch_areas"], rtol=1e-5, atol=1e-9)
+    R = F.rotation_between(torch.tensor([0.0, 0.0, 1.0]), torch.tensor(g["rel_b"]))
+    assert np.allclose(R.numpy(), g["rel_rot"], atol=2e-6)
+    # a vector opposite to `a` takes the perturbed restart (the formula's `+ eps` makes that result approximate in the reference
+    # too: the image of a is within ~0.2 of b, finite, and the regular row is untouched)
+    opp = F.rotation_between(torch.tensor([0.0, 0.0, 1.0]), torch.tensor([[0.0, 0.0, -1.0], [0.6, 0.0, 0.8]]), generator=torch.Generator().manual_seed(1))
+    img = (opp @ torch.tensor([0.0, 0.0, 1.0])).numpy()
+    assert np.isfinite(opp.numpy()).all() and img[0, 2] < -0.8 and np.allclose(img[1], [0.6, 0.0, 0.8], atol=1e-5)
+    # the whole sampling with the golden's stand-in encoders (the hash encoders themselves are pinned by ref_hashgrid.npz)
+    Wkd, Wks, Wz = (torch.tensor(g[k]) for k in ("Wkd", "Wks", "Wz"))
+    fld = SimpleNamespace(kd_enc=lambda x: torch.sigmoid(x @ Wkd), ks_enc=lambda x: x @ Wks, z_enc=lambda x: x @ Wz)
+    sp, attrs = F.GaussianField.get_gaussians_from_vertex(fld, v, f, scale=float(g["scale"]), initial_guess=torch.tensor(g["guess"]))
+    for name, got in (("means", sp.means), ("scales", sp.scales), ("quats", sp.quats), ("opacities", sp.opacities), ("kd", attrs.kd),
+                      ("ks", attrs.ks), ("normals", attrs.normals)):
+        assert np.allclose(got.numpy(), g[name], atol=2e-6, rtol=1e-5), name
+    # schedule
+    sch = GeoSplatSchedule()
+    d = g["sched_defaults"]
+    assert [sch.vertex_sample_warmup, sch.light_reg_begin, sch.light_reg_end, sch.light_reg_decay, sch.sdf_reg_begin, sch.sdf_reg_end,
+            sch.sdf_reg_decay, sch.kd_grad_reg_begin, sch.kd_grad_reg_end, sch.kd_grad_reg_decay, sch.ks_grad_reg_begin, sch.ks_grad_reg_end,
+            sch.ks_grad_reg_decay, sch.kd_regualr_perturb_std, sch.ks_regualr_perturb_std] == list(d)
+    model = SimpleNamespace(sample_method="face", light_weight=0.0, sdf_weight=0.0, kd_grad_weight=0.0, kd_regualr_perturb_std=0.0,
+                            ks_grad_weight=0.0, ks_regualr_perturb_std=0.0, normal_grad_weight=0.0)
+    keys = [str(k) for k in g["sched_keys"]]
+    for step, row in zip(g["sched_steps"], g["sched_values"]):
+        sch.before_update(model, int(step))
+        got = [1.0 if model.sample_method == "vertex" else 0.0] + [float(getattr(model, k)) for k in keys[1:]]
+        assert np.allclose(got, row, rtol=1e-12, atol=0), (int(step), got, list(row))
+    cm = SimpleNamespace(cubemap=torch.tensor([[-1.0, 0.005, 0.5]]))
+    cm.cubemap.grad = torch.ones(1, 3)
+    sch.scale_light_gradient(cm); sch.after_update(cm, 10)
+    assert torch.equal(cm.cubemap.grad, torch.full((1, 3), 64.0)) and torch.equal(cm.cubemap, torch.tensor([[0.01, 0.01, 0.5]]))
+
+
 def test_tonemap_none_scales_alpha_too():
     """tone_type='none' is `render_rgba * exposure` (rfstudio/model/geosplat.py:123-124): alpha is scaled with the colours and
     the exposure gradient carries the alpha term"""

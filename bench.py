@@ -108,17 +108,33 @@ def time_dominant_kernels(scene_state, iters):
 
 def time_view_without_prefilter(params, cam, up, iters):
     """GPU time of ONE view fwd+bwd with the pyramid held fixed (shade + project + bin + sort + composite + tone map and the
-    whole backward): the same work the cpu_baseline sample times, so the two are comparable."""
+    whole backward): the same work the cpu_baseline sample times, so the two are comparable.  Measured twice: launched eagerly
+    (~45 launches from Python: host-bound on a slow host core) and as ONE HIP graph replay (engine.RenderStep.capture, possible
+    because the capacity protocol leaves no host synchronisation in a step) -- the BASELINE config 4 case, one view per GPU."""
     from geosplatting_amd.engine import RenderStep
     step = RenderStep(params, prefilter=False)
+    fn = lambda: step([cam], lambda i, img: up, all_reduce=False)
+
+    def clock(f):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            f()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
     for _ in range(2):
-        step([cam], lambda i, img: up, all_reduce=False)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        step([cam], lambda i, img: up, all_reduce=False)
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / iters * 1e3
+        fn()
+    out = {"eager_ms": clock(fn), "graph_ms": None}
+    try:
+        if step.poll_capacity(wait=True) and step._i_cap is not None:
+            replay = step.capture([cam], lambda i, img: up)
+            replay(); replay()
+            out["graph_ms"] = clock(replay)
+            if not replay.check():
+                out["graph_ms"] = None
+    except Exception as e:                                   # the diagnostic must never take the bench line down
+        out["graph_error"] = repr(e)[:200]
+    return out
 
 
 def file_sha16(path):
@@ -342,7 +358,9 @@ def main():
                   colors=colors[meta["gaussian_ids"]].contiguous(), offsets=meta["isect_offsets"].reshape(-1).contiguous(),
                   flatten_ids=meta["flatten_ids"], V=V, I=I, res=args.res)
         kt = time_dominant_kernels(st, args.kernel_iters)
-        view_ms = time_view_without_prefilter(params, cam, ups[0], max(3, args.kernel_iters // 2))
+        view_detail = time_view_without_prefilter(params, cam, ups[0], max(3, args.kernel_iters // 2))
+        view_detail["note"] = "one view fwd+bwd, pyramid fixed; the headline figure is the HIP-graph replay when it could be captured, else the eager launch"
+        view_ms = view_detail["graph_ms"] if view_detail.get("graph_ms") else view_detail["eager_ms"]
         comp = {k: v for k, v in kt.items() if k.startswith("raster_") and "prepare" not in k}
         dom = max(comp, key=comp.get)
         # algorithmic bytes of the compositor launches:
@@ -410,6 +428,7 @@ def main():
                               "achieved_GBs": view_bytes * views_per_s / world / 1e9,
                               "frac_of_8TBs": view_bytes * views_per_s / world / 1e9 / HBM_PEAK_GBS},
             "gpu_view_ms_without_prefilter": view_ms,
+            "gpu_view_ms_detail": view_detail,
             "prefilter": None if args.no_prefilter else prefilter_report(params.cubemap, max(3, args.kernel_iters // 2)),
             "capacity_protocol": capacity,
         }

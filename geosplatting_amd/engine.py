@@ -181,25 +181,30 @@ class RenderStep:
         normals, kd, ks = p.normals.detach(), p.kd.detach(), p.ks.detach()
         images = []
 
-        # Two HIP streams per step.  The side stream runs the memory/latency-bound front of every view (shading,
-        # projection, intersection emit, radix sort, tile offsets: ~0.8 ms), the main stream the VALU-bound compositor
-        # forward/backward and the gradient kernels (~2.8 ms): issued one to two views ahead, the front of view i+1
-        # overlaps the compositor of view i on the CUs instead of queueing behind it, and the host's wait for the
-        # (V, I) counts of a view never stalls the main stream.
+        # HIP streams of a step.  The FRONT streams run the memory / latency-bound front of every view (shading, projection,
+        # intersection emit, radix passes, tile offsets, record stream: ~0.75 ms of ~22 short kernels, none of which fills the
+        # chip), the main stream the VALU-bound compositor forward / backward (~0.9 ms), a tail stream the gradient kernels.
+        # Fronts of consecutive views ALTERNATE between two streams: one front stream was the step's critical path (1.3 ms per
+        # view under contention against 0.98 ms of compositor work); with two, 496 -> 525 views/s (three: 502).  In capacity mode
+        # nothing makes the host wait, so the fronts run as far ahead of the compositor as their inputs allow.
         main = torch.cuda.current_stream(dev)
         if self._use_capacity and self._status is None:      # zero-filled on the main stream BEFORE the side stream forks from it
             self._status = torch.zeros(3, dtype=torch.int64, device=dev)
-        side = self._side_stream
-        if side is None:
-            side = self._side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("GEOSPLAT_SIDE_PRIO", "0")))
+        if self._side_stream is None:
+            # GEOSPLAT_FRONT_STREAMS=2: the fronts of consecutive views alternate between two streams (see start_view)
+            self._side_stream = [torch.cuda.Stream(device=dev, priority=int(os.environ.get("GEOSPLAT_SIDE_PRIO", "0")))
+                                 for _ in range(max(1, int(os.environ.get("GEOSPLAT_FRONT_STREAMS", "2"))))]
+        sides = self._side_stream
         tail = self._tail_stream
         if tail is None:
             tail = self._tail_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("GEOSPLAT_TAIL_PRIO", "0")))
-        side.wait_stream(main)                               # prefilter pyramid, activations, zeroed buckets
+        for sd in sides:
+            sd.wait_stream(main)                             # prefilter pyramid, activations, zeroed buckets
         tail.wait_stream(main)
 
-        def start_view(cam):                                 # S1-S3 + A1; (V, I) travel to the host asynchronously
+        def start_view(cam, j):                              # S1-S3 + A1; (V, I) travel to the host asynchronously
             vm, K, cam_pos = self._camera_tensors(cam)
+            side = sides[j % len(sides)]
             with torch.cuda.stream(side):
                 col = torch.empty(N, 3, dtype=f32, device=dev)
                 L.check(lib.gs_shade_fwd(N, L.ptr(means), L.ptr(normals), L.ptr(kd), L.ptr(ks), L.ptr(cam_pos),
@@ -207,7 +212,7 @@ class RenderStep:
                                          st()), "gs_shade_fwd")
                 pr = _project_stage(means, quats, scales_act, opac_act, col, vm, K, cam.width, cam.height, 16, 0.3, 0.01,
                                     1e10, 0.0)
-            return pr, col
+            return pr, col, side
 
         # Capacity protocol (include/geosplat_hip.h): once the engine has seen the intersection counts of a step, the later
         # steps size every per-view buffer by (N, I_cap) and leave (V, I) on the device -- no read-back, no host wait inside
@@ -217,7 +222,7 @@ class RenderStep:
         seen = []                                            # (pinned counts, event) of this step's views
 
         def bin_view(item):                                  # A2-A4 on the side stream (exact mode: host waits for that view's counts)
-            pr, col = item
+            pr, col, side = item
             with torch.cuda.stream(side):
                 if i_cap is not None:
                     seen.append((pr.host_counts, pr.event))       # read a step later by poll_capacity (never waited for here)
@@ -237,7 +242,7 @@ class RenderStep:
             return state, V, I, D, whs, ev, col
 
         n_views = len(cameras)
-        proj = [start_view(cameras[j]) for j in range(min(2, n_views))]      # prologue: A(0), A(1), B1(0)
+        proj = [start_view(cameras[j], j) for j in range(min(2, n_views))]   # prologue: A(0), A(1), B1(0)
         binned = bin_view(proj.pop(0)) if n_views else None
         for i, cam in enumerate(cameras):
             vm, K, cam_pos = self._camera_tensors(cam)
@@ -250,7 +255,7 @@ class RenderStep:
                 render, alphas, s, V, I = _composite_stage(state, V, I, D, whs, None)
             # keep the side stream two views ahead: A(i+2), then B1(i+1)
             if i + 2 < n_views:
-                proj.append(start_view(cameras[i + 2]))
+                proj.append(start_view(cameras[i + 2], i + 2))
             binned = bin_view(proj.pop(0)) if i + 1 < n_views else None
             img = torch.empty(H, W, 4, dtype=f32, device=dev)
             P = W * H

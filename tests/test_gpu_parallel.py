@@ -163,6 +163,26 @@ def test_step_captured_in_hip_graph():
     _same(ref, got)
 
 
+def test_views_segment_captured_in_hip_graph():
+    """RenderStep.capture_views: the views of a step (shading ... compositor ... per-view backward) as ONE HIP graph with the
+    prefilter forward / backward and every collective outside of it -- the shape one view per GPU needs (BASELINE config 4).
+    Same images and gradients as the eager step, also after the environment map changed under the graph's feet."""
+    step, run = _engine(torch.device("cuda", 0))
+    run()
+    assert step.poll_capacity(wait=True) and step._i_cap is not None
+    graphed = step.capture_views(step_cams, step_up, all_reduce=False, keep_images=True)
+    for scale in (1.0, 1.7):
+        with torch.no_grad():
+            step.p.cubemap.mul_(scale)                                # the prefilter is NOT in the graph: it must follow the parameter
+        ref = run()
+        for _ in range(2):
+            grads, images = graphed()
+        assert graphed.check()
+        got = ({n: v.detach().cpu().clone() for n, v in grads.items()}, [im.detach().cpu().clone() for im in images])
+        _same(ref, got)
+    assert float(ref[0]["cubemap"].abs().sum()) > 0
+
+
 def test_capacity_follows_changing_views():
     """Thirty steps over changing camera subsets and resolutions' worth of intersection counts: the capacity only ever grows to
     1.25 x the largest count seen, every step is either complete or reported (and then repeated), the pool of pinned count

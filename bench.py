@@ -390,8 +390,10 @@ def main():
         dom_flops = FLOPS_FWD_PER_PAIR if dom == "raster_fwd_kernel" else FLOPS_BWD_PER_PAIR
         dom_tf = None if not pairs_valid else pairs_valid * dom_flops / (kt[dom] * 1e-3) / 1e12
         # committed counter summaries, quoted only while gs_raster.hip is the source they were measured on
-        stats = committed_profile("r03_raster_stats.json", "gs_raster.hip") or committed_profile("r02_raster_stats.json", "gs_raster.hip")
-        pmc = committed_profile("r03_pmc_traffic.json", "gs_raster.hip") or committed_profile("r02_pmc_traffic.json", "gs_raster.hip")
+        stats_name = "r03_raster_stats.json" if committed_profile("r03_raster_stats.json", "gs_raster.hip") else "r02_raster_stats.json"
+        pmc_name = "r03_pmc_traffic.json" if committed_profile("r03_pmc_traffic.json", "gs_raster.hip") else "r02_pmc_traffic.json"
+        stats = committed_profile(stats_name, "gs_raster.hip")
+        pmc = committed_profile(pmc_name, "gs_raster.hip")
         engine = committed_profile("r03_engine_kernel_ms.json", "gs_raster.hip")      # averages under the three-stream overlap
         lane_util = None
         if stats and args.level == 7 and args.res == 800:
@@ -399,11 +401,11 @@ def main():
             cpt = int(stats.get("candidates_per_trip", 1))
             lane_util = {"valid_pairs": stats[key]["valid_pairs"], "trips": stats[key]["trips"], "candidates_per_lane_and_trip": cpt,
                          "frac_of_candidate_slots_used": stats[key]["valid_pairs"] / max(1, stats[key]["trips"] * 64 * cpt),
-                         "source": "profiles/r02_raster_stats.json (scripts/raster_stats.py, -DGS_RASTER_STATS build of the same source)"}
+                         "source": f"profiles/{stats_name} (scripts/raster_stats.py, -DGS_RASTER_STATS build of the same source)"}
         traffic = traffic_src = None
         if pmc and args.level == 7 and args.res == 800 and dom in pmc.get("kernels", {}):
             traffic = pmc["kernels"][dom]["hbm_bytes"]
-            traffic_src = ("profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes per launch, "
+            traffic_src = (f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes per launch, "
                            f"measured at commit {pmc.get('commit', '?')} on this kernel source)")
         result = {
             "metric": "fwd+bwd views/sec at 2M Gaussians, 800x800",

@@ -451,6 +451,36 @@ isect_offsets_kernel(GsCount nc, const int64_t* __restrict__ ids, int n_tiles, i
         for (int t = cur + 1; t < n_tiles; ++t) offsets[t] = (int32_t)n;
 }
 
+// the same from int32 tile ids (gs_isect_bin_tiles_cap)
+__global__ void __launch_bounds__(256)
+isect_offsets_tiles_kernel(GsCount nc, const int32_t* __restrict__ tiles, int n_tiles, int32_t* __restrict__ offsets)
+{
+    const int64_t n = gs_count(nc);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n == 0 && i == 0)
+        for (int t = 0; t < n_tiles; ++t) offsets[t] = 0;
+    if (i >= n) return;
+    const int cur = tiles[i];
+    if (i == 0) {
+        for (int t = 0; t <= cur && t < n_tiles; ++t) offsets[t] = 0;
+    } else {
+        const int prev = tiles[i - 1];
+        for (int t = prev + 1; t <= cur && t < n_tiles; ++t) offsets[t] = (int32_t)i;
+    }
+    if (i == n - 1)
+        for (int t = cur + 1; t < n_tiles; ++t) offsets[t] = (int32_t)n;
+}
+
+extern "C" int gs_isect_offsets_tiles_cap(int64_t n_isects_cap, const int64_t* counts_dev, const int32_t* tile_ids_sorted, int n_tiles,
+                                          int32_t* offsets, void* stream)
+{
+    GS_CHECK_ARG(n_isects_cap > 0 && n_tiles > 0 && counts_dev != nullptr && tile_ids_sorted != nullptr, "bad arguments");
+    hipLaunchKernelGGL(isect_offsets_tiles_kernel, dim3(gs_cdiv(n_isects_cap, 256)), dim3(256), 0, (hipStream_t)stream,
+                       GsCount{ n_isects_cap, (const long long*)counts_dev + 1 }, tile_ids_sorted, n_tiles, offsets);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
 extern "C" int gs_isect_offsets(int64_t n_isects, const int64_t* isect_ids_sorted, int n_tiles, int32_t* offsets,
                                 void* stream)
 {

@@ -71,6 +71,14 @@ struct XDigit {                                                    // digit of .
     int shift; unsigned mask;
     __device__ __forceinline__ unsigned operator()(const uint2& it) const { return (it.x >> shift) & mask; }
 };
+struct FinalTiles {                                                // last tile pass without the 64-bit keys: (tile id, flatten id) as two int32 arrays
+    int32_t* tile_ids; int32_t* flatten_ids;
+    __device__ __forceinline__ void store(int64_t i, const uint2& it) const
+    {
+        flatten_ids[i] = (int32_t)it.y;
+        tile_ids[i] = (int32_t)it.x;
+    }
+};
 struct FinalOut {                                                  // last tile pass: the two sorted meta arrays
     u64* isect_ids; int32_t* flatten_ids; const float* depths;
     __device__ __forceinline__ void store(int64_t i, const uint2& it) const
@@ -636,7 +644,7 @@ __global__ void capacity_check_kernel(const long long* __restrict__ counts, long
 
 static int isect_bin_impl(int V, const float* means2d, const int32_t* radii, const float* depths, int64_t n_isects,
                           const long long* counts_dev, int tile_size, int tile_w, int tile_h, int64_t* isect_ids_sorted,
-                          int32_t* flatten_ids_sorted, void* ws, size_t ws_bytes, void* stream);
+                          int32_t* flatten_ids_sorted, void* ws, size_t ws_bytes, void* stream, int32_t* tile_ids_sorted);
 
 extern "C" int gs_isect_bin(int V, const float* means2d, const int32_t* radii, const float* depths,
                             const int32_t* tiles_per_gauss, int64_t n_isects, int tile_size, int tile_w, int tile_h,
@@ -644,7 +652,7 @@ extern "C" int gs_isect_bin(int V, const float* means2d, const int32_t* radii, c
 {
     (void)tiles_per_gauss;                                  // the counts are re-derived from the rectangles (same arithmetic as gs_project_fwd)
     return isect_bin_impl(V, means2d, radii, depths, n_isects, nullptr, tile_size, tile_w, tile_h, isect_ids_sorted, flatten_ids_sorted,
-                          ws, ws_bytes, stream);
+                          ws, ws_bytes, stream, nullptr);
 }
 
 extern "C" int gs_isect_bin_cap(int V_cap, const float* means2d, const int32_t* radii, const float* depths, const int64_t* counts_dev,
@@ -656,12 +664,27 @@ extern "C" int gs_isect_bin_cap(int V_cap, const float* means2d, const int32_t* 
                        (long long)n_isects_cap, (long long*)status_dev);
     GS_CHECK_LAUNCH();
     return isect_bin_impl(V_cap, means2d, radii, depths, n_isects_cap, (const long long*)counts_dev, tile_size, tile_w, tile_h,
-                          isect_ids_sorted, flatten_ids_sorted, ws, ws_bytes, stream);
+                          isect_ids_sorted, flatten_ids_sorted, ws, ws_bytes, stream, nullptr);
+}
+
+// The same without the 64-bit `isect_ids`: a caller that only composites (the step engine: `meta` is never returned) needs the sorted
+// flatten ids and the tile offsets; the last pass then writes 8 bytes per intersection instead of 12 and does not gather the depths
+// (gs_isect_offsets_tiles_cap takes the int32 tile ids).
+extern "C" int gs_isect_bin_tiles_cap(int V_cap, const float* means2d, const int32_t* radii, const float* depths, const int64_t* counts_dev,
+                                      int64_t n_isects_cap, int tile_size, int tile_w, int tile_h, int32_t* tile_ids_sorted,
+                                      int32_t* flatten_ids_sorted, void* ws, size_t ws_bytes, int64_t* status_dev, void* stream)
+{
+    GS_CHECK_ARG(counts_dev != nullptr && status_dev != nullptr && tile_ids_sorted != nullptr, "counts_dev / status_dev / tile_ids_sorted must not be NULL");
+    hipLaunchKernelGGL(capacity_check_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const long long*)counts_dev, (long long)V_cap,
+                       (long long)n_isects_cap, (long long*)status_dev);
+    GS_CHECK_LAUNCH();
+    return isect_bin_impl(V_cap, means2d, radii, depths, n_isects_cap, (const long long*)counts_dev, tile_size, tile_w, tile_h,
+                          nullptr, flatten_ids_sorted, ws, ws_bytes, stream, tile_ids_sorted);
 }
 
 static int isect_bin_impl(int V, const float* means2d, const int32_t* radii, const float* depths, int64_t n_isects,
                           const long long* counts_dev, int tile_size, int tile_w, int tile_h, int64_t* isect_ids_sorted,
-                          int32_t* flatten_ids_sorted, void* ws, size_t ws_bytes, void* stream)
+                          int32_t* flatten_ids_sorted, void* ws, size_t ws_bytes, void* stream, int32_t* tile_ids_sorted)
 {
     const GsCount vc{ (long long)V, counts_dev }, ic{ (long long)n_isects, counts_dev ? counts_dev + 1 : nullptr };
     GS_CHECK_ARG(V >= 0 && n_isects >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0, "bad sizes");
@@ -742,7 +765,10 @@ static int isect_bin_impl(int V, const float* means2d, const int32_t* radii, con
             else
                 rc = onesweep_pass<uint2>(n_isects, U2In{ src }, XDigit{ shift, (1u << nbits) - 1u }, U2Out{ dst }, nbits, tickets + 4 + pass, st,
                                           thist + pass * 256, s);
-        } else if (pass == npass - 1)
+        } else if (pass == npass - 1 && tile_ids_sorted != nullptr)
+            rc = radix_pass<uint2>(ic, U2In{ src }, XDigit{ shift, (1u << nbits) - 1u },
+                                   FinalTiles{ tile_ids_sorted, flatten_ids_sorted }, nbits, table, s);
+        else if (pass == npass - 1)
             rc = radix_pass<uint2>(ic, U2In{ src }, XDigit{ shift, (1u << nbits) - 1u },
                                    FinalOut{ (u64*)isect_ids_sorted, flatten_ids_sorted, depths }, nbits, table, s);
         else

@@ -228,7 +228,7 @@ class RenderStep:
             with torch.cuda.stream(side):
                 if i_cap is not None:
                     seen.append((pr.host_counts, pr.event))       # read a step later by poll_capacity (never waited for here)
-                    state, V, I, D, whs = _bin_stage_cap(pr, i_cap, self._status)
+                    state, V, I, D, whs = _bin_stage_cap(pr, i_cap, self._status, want_ids=False)   # no `meta` here: int32 tile ids do
                     state = _prepare_stage_cap(state, V, I, D, whs)
                 else:
                     state, V, I, D, whs = _bin_stage(pr)

@@ -152,7 +152,7 @@ def _composite_stage(state, V: int, I: int, D: int, whs, background: Optional[Te
 
 
 # ---- capacity protocol (include/geosplat_hip.h): the same three stages without the (V, I) read-back --------------------------
-def _bin_stage_cap(pr: _Projected, I_cap: int, status: Tensor):
+def _bin_stage_cap(pr: _Projected, I_cap: int, status: Tensor, want_ids: bool = True):
     """A2-A4 with the counts left on the device: buffers, workspaces and grids are sized by (N, I_cap), the kernels read
     (V, I) from pr's device counts; an overflow is reported in `status` (int64[3], sticky), never written out of bounds."""
     lib = L.lib()
@@ -162,14 +162,23 @@ def _bin_stage_cap(pr: _Projected, I_cap: int, status: Tensor):
     N = means2d.shape[0]
     tw, th = (W + tile_size - 1) // tile_size, (H + tile_size - 1) // tile_size
     st = L.stream()
-    ids_s = torch.empty(I_cap, dtype=torch.int64, device=dev); flat_s = torch.empty(I_cap, dtype=torch.int32, device=dev)
+    flat_s = torch.empty(I_cap, dtype=torch.int32, device=dev)
     bin_bytes = lib.gs_isect_bin_ws_bytes(N, L.i64(I_cap), tw, th)
     bin_ws = torch.empty(max(bin_bytes, 1), dtype=torch.uint8, device=dev)
-    L.check(lib.gs_isect_bin_cap(N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(counts), L.i64(I_cap), tile_size, tw, th,
-                                 L.ptr(ids_s), L.ptr(flat_s), L.ptr(bin_ws), C.c_size_t(bin_bytes), L.ptr(status), st),
-            "gs_isect_bin_cap")
     offsets = torch.empty(th * tw, dtype=torch.int32, device=dev)
-    L.check(lib.gs_isect_offsets_cap(L.i64(I_cap), L.ptr(counts), L.ptr(ids_s), tw * th, L.ptr(offsets), st), "gs_isect_offsets_cap")
+    if want_ids:
+        ids_s = torch.empty(I_cap, dtype=torch.int64, device=dev)
+        L.check(lib.gs_isect_bin_cap(N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(counts), L.i64(I_cap), tile_size, tw, th,
+                                     L.ptr(ids_s), L.ptr(flat_s), L.ptr(bin_ws), C.c_size_t(bin_bytes), L.ptr(status), st),
+                "gs_isect_bin_cap")
+        L.check(lib.gs_isect_offsets_cap(L.i64(I_cap), L.ptr(counts), L.ptr(ids_s), tw * th, L.ptr(offsets), st), "gs_isect_offsets_cap")
+    else:                      # the caller only composites: int32 tile ids instead of the 64-bit keys (the `isect_ids` entry holds them)
+        ids_s = torch.empty(I_cap, dtype=torch.int32, device=dev)
+        L.check(lib.gs_isect_bin_tiles_cap(N, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(counts), L.i64(I_cap), tile_size, tw, th,
+                                           L.ptr(ids_s), L.ptr(flat_s), L.ptr(bin_ws), C.c_size_t(bin_bytes), L.ptr(status), st),
+                "gs_isect_bin_tiles_cap")
+        L.check(lib.gs_isect_offsets_tiles_cap(L.i64(I_cap), L.ptr(counts), L.ptr(ids_s), tw * th, L.ptr(offsets), st),
+                "gs_isect_offsets_tiles_cap")
     state = dict(gaussian_ids_i32=gids, radii=radii, means2d=means2d, depths=depths, conics=conics, compensations=comps,
                  opacities=opac_p, colors=colors_p, tiles_per_gauss=tpg, isect_ids=ids_s, flatten_ids=flat_s,
                  isect_offsets=offsets, counts=counts, vis_records=pr.vis)

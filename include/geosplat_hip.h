@@ -178,6 +178,14 @@ int gs_isect_bin_cap(int V_cap, const float* means2d, const int32_t* radii, cons
                      int32_t* flatten_ids_sorted, void* ws, size_t ws_bytes, int64_t* status_dev, void* stream);
 int gs_isect_offsets_cap(int64_t n_isects_cap, const int64_t* counts_dev, const int64_t* isect_ids_sorted, int n_tiles,
                          int32_t* offsets, void* stream);
+/* The pair for a caller that only composites (the step engine never returns `meta`): the binning without the 64-bit isect_ids -- the
+ * last pass writes int32 tile ids instead (8 bytes per intersection instead of 12, no depth gather) -- and the tile offsets from
+ * those.  flatten_ids_sorted / offsets are bit-identical to gs_isect_bin_cap + gs_isect_offsets_cap. */
+int gs_isect_bin_tiles_cap(int V_cap, const float* means2d, const int32_t* radii, const float* depths, const int64_t* counts_dev,
+                           int64_t n_isects_cap, int tile_size, int tile_w, int tile_h, int32_t* tile_ids_sorted,
+                           int32_t* flatten_ids_sorted, void* ws, size_t ws_bytes, int64_t* status_dev, void* stream);
+int gs_isect_offsets_tiles_cap(int64_t n_isects_cap, const int64_t* counts_dev, const int32_t* tile_ids_sorted, int n_tiles,
+                               int32_t* offsets, void* stream);
 int gs_raster_prepare_vis_cap(int W, int H, int tile_size, int D, int V_cap, const float* vis_records, int64_t n_isects_cap,
                               const int64_t* counts_dev, const int32_t* offsets, const int32_t* flatten_ids, void* ws,
                               size_t ws_bytes, void* stream);

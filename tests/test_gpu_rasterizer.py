@@ -270,6 +270,31 @@ def test_binning_variants_bit_identical(cuda, monkeypatch):
     assert np.array_equal(out["depth_major"][2]["flatten_ids"].cpu().numpy(), ref["flatten_ids"])
 
 
+def test_binning_without_isect_ids_bit_identical(cuda):
+    """gs_isect_bin_tiles_cap + gs_isect_offsets_tiles_cap (what the step engine runs: int32 tile ids instead of the 64-bit keys, no
+    depth gather in the last pass) == gs_isect_bin_cap + gs_isect_offsets_cap: same sorted flatten ids, same tile offsets, and the
+    tile ids are the high halves of the keys."""
+    import importlib
+    R = importlib.import_module("geosplatting_amd.rasterization")      # (the package attribute of that name is the function)
+    sp, cam = random_case(20000, 320, view=2, seed=11)
+    means, quats, scales, opac = activated(sp)
+    t = lambda a: torch.tensor(a, device=cuda)
+    out = {}
+    for want_ids in (True, False):
+        pr = R._project_stage(t(means), t(quats), t(scales), t(opac), t(sp.colors.numpy()), cam.view_matrix.to(cuda), cam.intrinsic_matrix.to(cuda),
+                              320, 320, 16, 0.3, 0.01, 1e10, 0.0)
+        pr.event.synchronize()
+        V, I = (int(x) for x in pr.host_counts.tolist())
+        status = torch.zeros(3, dtype=torch.int64, device=cuda)
+        state, *_ = R._bin_stage_cap(pr, I + 1000, status, want_ids=want_ids)
+        torch.cuda.synchronize()
+        assert int(status[0]) == 0
+        out[want_ids] = (state["isect_ids"][:I].clone(), state["flatten_ids"][:I].clone(), state["isect_offsets"].clone())
+    assert I > 50000
+    assert torch.equal(out[True][1], out[False][1]) and torch.equal(out[True][2], out[False][2])
+    assert out[False][0].dtype == torch.int32 and torch.equal((out[True][0] >> 32).int(), out[False][0])
+
+
 def test_onesweep_passes_bit_identical(cuda):
     """the one-kernel look-back radix passes (GEOSPLAT_RADIX=onesweep, off by default: slower here) give the same order; the switch is
     read once per process, so the comparison runs in a child process"""

@@ -310,26 +310,17 @@ specular_bounds_fast_kernel(int R, int nt, int ng, float cutoff, const float4* _
                         if (!(box_maxdp(tile_box + (size_t)((s * nt + ty) * nt + tx) * 6, VNR) >= cutoff)) continue;
                         const int tsx = tx * TILE, tsy = ty * TILE;
                         const int tex = min((tx + 1) * TILE, R), tey = min((ty + 1) * TILE, R);
-                        // per row only the first hit from the left and the first from the right matter for a min / max box (no
-                        // assumption about the shape of the lobe): a row inside the lobe costs 2 tests instead of 16
-                        for (int y = tsy; y < tey; ++y) {
-                            const float4* row = table + ((size_t)s * R + y) * R;
-                            int xl = tsx;
-                            for (; xl < tex; ++xl) {
-                                const float4 q = row[xl];
+                        // (first-hit scans from both ends of a row were measured: 47.6 instead of 31.9 ms for the six levels -- the
+                        // lanes of a wave then leave their loops at different times)
+                        for (int y = tsy; y < tey; ++y)
+                            for (int x = tsx; x < tex; ++x) {
+                                const float4 q = table[((size_t)s * R + y) * R + x];
                                 const float L[3] = { q.x, q.y, q.z };
-                                if (dot3(L, VNR) >= cutoff) break;
+                                if (dot3(L, VNR) >= cutoff) {
+                                    min_x = min(min_x, x); max_x = max(max_x, x);
+                                    min_y = min(min_y, y); max_y = max(max_y, y);
+                                }
                             }
-                            if (xl == tex) continue;
-                            int xr = tex - 1;
-                            for (; xr > xl; --xr) {
-                                const float4 q = row[xr];
-                                const float L[3] = { q.x, q.y, q.z };
-                                if (dot3(L, VNR) >= cutoff) break;
-                            }
-                            min_x = min(min_x, xl); max_x = max(max_x, xr);
-                            min_y = min(min_y, y); max_y = max(max_y, y);
-                        }
                     }
             }
         float* b = bounds + (size_t)o * 24 + s * 4;

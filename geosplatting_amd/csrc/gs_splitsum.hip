@@ -290,41 +290,69 @@ __device__ __forceinline__ float box_maxdp(const float* __restrict__ box, const 
     return maxdp;
 }
 
+// One WAVE per output texel (VNR is wave-uniform): lanes test 64 groups, then the <= 16 tiles of a surviving group, then 64 texels
+// of a surviving tile per step -- uniform control flow, coalesced table reads -- and keep per-lane min / max that meet in one
+// cross-lane reduction per face.  (One THREAD per texel, the reference's shape, diverged: 32 ms for the six levels.)
+__device__ __forceinline__ int bounds_wave_min(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int bounds_wave_max(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
 __global__ void __launch_bounds__(256)
 specular_bounds_fast_kernel(int R, int nt, int ng, float cutoff, const float4* __restrict__ table, const float* __restrict__ tile_box,
                             const float* __restrict__ group_box, float* __restrict__ bounds)
 {
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int o = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (o >= 6 * R * R) return;
     const float4 own = table[o];
     const float VNR[3] = { own.x, own.y, own.z };
     const int TILE = 16;
     for (int s = 0; s < 6; ++s) {
         int min_x = R - 1, max_x = 0, min_y = R - 1, max_y = 0;
-        for (int gy = 0; gy < ng; ++gy)
-            for (int gx = 0; gx < ng; ++gx) {
-                if (!(box_maxdp(group_box + (size_t)((s * ng + gy) * ng + gx) * 6, VNR) >= cutoff)) continue;
-                // the reference visits the tiles tx-major (cubemap.cu:198-199); the box is a min / max, so the order is free
-                for (int ty = gy * 4; ty < min(gy * 4 + 4, nt); ++ty)
-                    for (int tx = gx * 4; tx < min(gx * 4 + 4, nt); ++tx) {
-                        if (!(box_maxdp(tile_box + (size_t)((s * nt + ty) * nt + tx) * 6, VNR) >= cutoff)) continue;
-                        const int tsx = tx * TILE, tsy = ty * TILE;
-                        const int tex = min((tx + 1) * TILE, R), tey = min((ty + 1) * TILE, R);
-                        // (first-hit scans from both ends of a row were measured: 47.6 instead of 31.9 ms for the six levels -- the
-                        // lanes of a wave then leave their loops at different times)
-                        for (int y = tsy; y < tey; ++y)
-                            for (int x = tsx; x < tex; ++x) {
-                                const float4 q = table[((size_t)s * R + y) * R + x];
-                                const float L[3] = { q.x, q.y, q.z };
-                                if (dot3(L, VNR) >= cutoff) {
-                                    min_x = min(min_x, x); max_x = max(max_x, x);
-                                    min_y = min(min_y, y); max_y = max(max_y, y);
-                                }
+        for (int g0 = 0; g0 < ng * ng; g0 += 64) {
+            const int g = g0 + lane;
+            const bool gpass = g < ng * ng && box_maxdp(group_box + (size_t)(s * ng * ng + g) * 6, VNR) >= cutoff;
+            unsigned long long gmask = __ballot(gpass);
+            while (gmask != 0ull) {
+                const int gi = g0 + __builtin_ctzll(gmask);
+                gmask &= gmask - 1ull;
+                const int gx = gi % ng, gy = gi / ng;
+                const int tx = gx * 4 + (lane & 3), ty = gy * 4 + ((lane >> 2) & 3);
+                const bool tpass = lane < 16 && tx < nt && ty < nt &&
+                                   box_maxdp(tile_box + (size_t)((s * nt + ty) * nt + tx) * 6, VNR) >= cutoff;
+                unsigned long long tmask = __ballot(tpass);
+                while (tmask != 0ull) {
+                    const int tl = __builtin_ctzll(tmask);
+                    tmask &= tmask - 1ull;
+                    const int tsx = (gx * 4 + (tl & 3)) * TILE, tsy = (gy * 4 + (tl >> 2)) * TILE;
+                    const int tex = min(tsx + TILE, R), tey = min(tsy + TILE, R);
+                    const int x = tsx + (lane & 15);
+                    for (int y = tsy + (lane >> 4); y < tey; y += 4) {
+                        if (x < tex) {
+                            const float4 q = table[((size_t)s * R + y) * R + x];
+                            const float L[3] = { q.x, q.y, q.z };
+                            if (dot3(L, VNR) >= cutoff) {
+                                min_x = min(min_x, x); max_x = max(max_x, x);
+                                min_y = min(min_y, y); max_y = max(max_y, y);
                             }
+                        }
                     }
+                }
             }
-        float* b = bounds + (size_t)o * 24 + s * 4;
-        b[0] = (float)min_x; b[1] = (float)max_x; b[2] = (float)min_y; b[3] = (float)max_y;
+        }
+        min_x = bounds_wave_min(min_x); max_x = bounds_wave_max(max_x);
+        min_y = bounds_wave_min(min_y); max_y = bounds_wave_max(max_y);
+        if (lane == 0)
+            *reinterpret_cast<float4*>(bounds + (size_t)o * 24 + s * 4) = make_float4((float)min_x, (float)max_x, (float)min_y, (float)max_y);
     }
 }
 
@@ -345,7 +373,7 @@ extern "C" int gs_specular_bounds_fast(int R, float costheta_cutoff, const float
     float* group_box = tile_box + (size_t)6 * nt * nt * 6;
     hipLaunchKernelGGL(bounds_tile_aabb_kernel, dim3(gs_cdiv(6 * nt * nt, 256)), dim3(256), 0, (hipStream_t)stream, R, nt, ng, tile_box, group_box);
     GS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(specular_bounds_fast_kernel, dim3(gs_cdiv(6 * R * R, 256)), dim3(256), 0, (hipStream_t)stream, R, nt, ng,
+    hipLaunchKernelGGL(specular_bounds_fast_kernel, dim3(gs_cdiv(6 * R * R, 4)), dim3(256), 0, (hipStream_t)stream, R, nt, ng,
                        costheta_cutoff, (const float4*)dir_table, tile_box, group_box, bounds);
     GS_CHECK_LAUNCH();
     return GS_OK;

@@ -377,6 +377,11 @@ tile_apply_kernel(int R, int E, int bw, int nb, int K, const float* __restrict__
 #else
 #define GS_TILE_WLOAD(P) (SHARED_ROWS ? *(P) : __builtin_nontemporal_load(P))
 #endif
+#ifdef GS_TILE_EXP_NODESC
+#define GS_TILE_DLOAD(D0, D1, KK) do { D0 = make_int4((KK) * 16, (KK) * 16 + 16, (KK) * 16 + 32, (KK) * 16 + 48); D1 = make_int4((KK) * 16 + 64, (KK) * 16 + 80, (KK) * 16 + 96, (KK) * 16 + 112); } while (0)
+#else
+#define GS_TILE_DLOAD(D0, D1, KK) do { D0 = dp[(KK) >> 2]; D1 = dp[((KK) >> 2) + 1]; } while (0)
+#endif
 #define GS_CHUNK_ROW(J) ((min((J), nj - 1) * K + part) * 8)
 #define GS_ROWS_LOAD(W, J)                                                                                          \
             do {                                                                                                    \
@@ -385,7 +390,7 @@ tile_apply_kernel(int R, int E, int bw, int nb, int K, const float* __restrict__
                     W[u] = GS_TILE_WLOAD(wp2 + (size_t)((kk >> 1) + u) * 64);                                       \
             } while (0)
 #define GS_DESC_LOAD(D0, D1, J)                                                                                     \
-            do { const int kk = GS_CHUNK_ROW(J); D0 = dp[kk >> 2]; D1 = dp[(kk >> 2) + 1]; } while (0)
+            do { const int kk = GS_CHUNK_ROW(J); GS_TILE_DLOAD(D0, D1, kk); } while (0)
             // acc += w * v for one row as TWO packed FMAs.  The weight of an even row is the low half of its register pair, that of
             // an odd row the high half; `op_sel` broadcasts either half to both result lanes (the compiler only knows the
             // low-half form and copies every odd-row weight into a fresh even register first: 8 v_mov per chunk and a full
@@ -451,6 +456,7 @@ tile_apply_kernel(int R, int E, int bw, int nb, int K, const float* __restrict__
 #undef GS_STEP
 #undef GS_DESC_LOAD
 #undef GS_CHUNK_ROW
+#undef GS_TILE_DLOAD
 #undef GS_TILE_WLOAD
 #undef GS_ROWS_LOAD
 #undef GS_ROWS_USE

@@ -83,12 +83,20 @@ def tile_geometry(res: int) -> Tuple[int, int]:
     """(bw, nb): blocks per tile row, blocks per tile, for the 16 waves of a workgroup.  Large tiles where the lobes are small
     against the face (the staged rectangle grows by the lobe diameter once per tile), one 8x8 block split over all 16 waves
     where a lobe covers most of a face and the level has few texels."""
+    override = os.environ.get("GEOSPLAT_TILE_GEOMETRY")       # experiments: "512:4,16;256:2,4" = res:bw,nb;...
+    if override:
+        for item in override.split(";"):
+            r, g = item.split(":")
+            if int(r) == res:
+                bw, nb = (int(v) for v in g.split(","))
+                return bw, nb
+    # measured per level with scripts/prefilter_bench.py (GEOSPLAT_TILE_GEOMETRY sweeps, profiles/r03_prefilter_geometry.txt)
     if res >= 512:
-        return 4, 16          # 32 x 32 texels, one wave per block
-    if res >= 256:
-        return 4, 8           # 32 x 16, two waves per block
+        return 4, 16          # 32 x 32 texels, one wave per block (32x16: 217 us instead of 161; 16x16: 273)
     if res >= 128:
-        return 2, 4           # 16 x 16, four waves per block
+        return 2, 4           # 16 x 16, four waves per block (256^2: 32x16 307 us, 32x32 369; 128^2: 32x16 180, 32x32 331)
+    if res >= 64:
+        return 1, 2           # 8 x 16, eight waves per block (8x8: 54 us instead of 47; 16x16: 76)
     return 1, 1               # 8 x 8, sixteen waves on the block
 _tiles_cache: Dict[Tuple[int, float, float, int], Optional[Dict]] = {}
 

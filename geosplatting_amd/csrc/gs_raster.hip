@@ -19,6 +19,7 @@
 //     across the wave with DPP row operations and ONE lane issues the fp32 atomics.
 // Both kernels are FP32-VALU / transcendental bound (one v_exp_f32 per evaluated pair), not HBM bound.
 #include "gs_common.h"
+#include "gs_tone.h"
 #include <stdlib.h>
 
 #pragma clang fp contract(off)   // sigma / compositing are spelled with explicit fmaf (bit-exact vs oracle)
@@ -953,6 +954,15 @@ raster_fwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
 // everywhere B becomes A and a new B is built from the next 64 culled records.  The CPU simulation of the schedule (DESIGN.md
 // section 4) gives 40 % slot utilisation against 26 %.  Per-pixel order is unchanged (A before B, ascending inside), so the
 // image stays bit-identical.  The record ring holds 192 slots (A + B + one raw batch of survivors) = 8 448 B per wave.
+// S4 applied inside the compositor (gs_raster_composite_tone* / gs_raster_bwd_tone*): the engine's main stream is the step's
+// critical path, and between the two compositor kernels of a view it ran two tiny dependent launches (tone map forward, tone map
+// backward) that each waited 20-80 us for a slot on a GPU the other streams keep full (profiles/r03_concurrency_one_step.txt).
+// Forward: the epilogue also writes image[p] = tone(render * exposure | alpha).  Backward: the prologue reads the image cotangent
+// and forms v_render / v_alpha itself (the arithmetic of tonemap_bwd3_kernel), one atomic per wave for the exposure gradient.
+// D == 3 and no background only (what RenderableAttrs.splat passes).
+struct ToneFwd { int mode; const float* exposure; float4* image; };
+struct ToneBwd { int mode; const float* exposure; const float* render; const float4* v_image; float* v_exposure; };
+
 static constexpr int GS_WIN_Q = 192;
 static constexpr int GS_WIN_Q_BYTES = GS_WIN_Q * (16 + 16 + 8 + 4);
 
@@ -978,7 +988,7 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
                          const float4* __restrict__ rec0, const float4* __restrict__ rec1, const float4* __restrict__ rec2,
                          const float* __restrict__ colors, const float* __restrict__ background, GsCount ic,
                          const int32_t* __restrict__ offsets,
-                         float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids)
+                         float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids, ToneFwd tone)
 {
     const int n_isects = (int)gs_count(ic);
     extern __shared__ __align__(16) unsigned char gs_lds_raw[];
@@ -1132,6 +1142,12 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
 #pragma unroll
         for (int k = 0; k < CD; ++k)
             if (k < D) render[pid * D + k] = background ? fmaf(T, background[k], pix[k]) : pix[k];
+        if (CD == 3 && tone.image) {                              // D == 3, background == nullptr (checked on the host)
+#pragma clang fp contract(off)
+            const float e = tone.exposure[0], a = 1.0f - T;
+            tone.image[pid] = make_float4(tone_fwd(tone.mode, pix[0] * e), tone_fwd(tone.mode, pix[1] * e), tone_fwd(tone.mode, pix[2] * e),
+                                          tone.mode == GS_TONE_NONE ? a * e : a);
+        }
     }
 }
 
@@ -1361,7 +1377,7 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
                          const float* __restrict__ background, GsCount ic, const int32_t* __restrict__ offsets,
                          const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
                          const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-                         float* __restrict__ v_packed, int rec_stride)
+                         float* __restrict__ v_packed, int rec_stride, ToneBwd tone)
 {
     const int n_isects = (int)gs_count(ic);
     static_assert(CD <= 3, "colours come from the record stream (D <= 3)");
@@ -1389,6 +1405,7 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
     const int start = offsets[tile];
     const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
     GS_TL_BEGIN(end - start);
+    // (an empty tile has render = 0 and alpha = 0 without a background: its pixels add nothing to the exposure gradient either)
     if (end <= start) { GS_TL_END(); return; }
 
     unsigned char* wbase = gs_lds_raw + (size_t)wave * LD::WAVE_BYTES;
@@ -1399,18 +1416,34 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
     float2* pairbuf = (float2*)(wbase + LD::OFF_PAIR);
     float* stage = (float*)(wbase + LD::OFF_PAIR);              // aliases pairbuf (separated by wave syncs)
 
-    float T_final = 1.0f, v_a = 0.0f;
+    float T_final = 1.0f, v_a = 0.0f, v_exp = 0.0f;
     int bin_final = -1;
     float v_rc[CD];
 #pragma unroll
     for (int k = 0; k < CD; ++k) v_rc[k] = 0.0f;
     if (inside) {
         const size_t pid = (size_t)pyi * W + pxi;
-        T_final = 1.0f - alphas[pid];
+        const float a_out = alphas[pid];
+        T_final = 1.0f - a_out;
         bin_final = last_ids[pid];
-        v_a = v_alphas[pid];
+        if (CD == 3 && tone.v_image) {                            // S4 backward here (tonemap_bwd3_kernel's arithmetic, same order)
+#pragma clang fp contract(off)
+            const float e = tone.exposure[0];
+            const float r = tone.render[3 * pid], gch = tone.render[3 * pid + 1], bl = tone.render[3 * pid + 2];
+            const float4 g = tone.v_image[pid];
+            const float gx = g.x * tone_grad(tone.mode, r * e), gy = g.y * tone_grad(tone.mode, gch * e), gz = g.z * tone_grad(tone.mode, bl * e);
+            v_rc[0] = gx * e; v_rc[1] = gy * e; v_rc[2] = gz * e;
+            v_a = tone.mode == GS_TONE_NONE ? g.w * e : g.w;
+            v_exp = gx * r + gy * gch + gz * bl + (tone.mode == GS_TONE_NONE ? g.w * a_out : 0.0f);
+        } else {
+            v_a = v_alphas[pid];
 #pragma unroll
-        for (int k = 0; k < CD; ++k) if (k < D) v_rc[k] = v_render[pid * D + k];
+            for (int k = 0; k < CD; ++k) if (k < D) v_rc[k] = v_render[pid * D + k];
+        }
+    }
+    if (CD == 3 && tone.v_image) {                                // one exposure-gradient atomic per quadrant wave
+        v_exp = gs_wave_sum(v_exp);
+        if (lane == 0 && v_exp != 0.0f) gs_atomic_add(tone.v_exposure, v_exp);
     }
     float bg_dot = 0.0f;
     if (background) {
@@ -1702,6 +1735,12 @@ struct CountsScope {
     ~CountsScope() { t_counts_dev = nullptr; }
 };
 static GsCount isect_count(int64_t n) { return GsCount{ (long long)n, t_counts_dev ? t_counts_dev + 1 : nullptr }; }
+// The same mechanism for the tone-mapping variants: while a gs_raster_*_tone* entry point is on the stack the launches below hand
+// its ToneFwd / ToneBwd to the kernels (zero = plain compositor).
+static thread_local ToneFwd t_tone_fwd = { 0, nullptr, nullptr };
+static thread_local ToneBwd t_tone_bwd = { 0, nullptr, nullptr, nullptr, nullptr };
+struct ToneFwdScope { explicit ToneFwdScope(const ToneFwd& t) { t_tone_fwd = t; } ~ToneFwdScope() { t_tone_fwd = ToneFwd{ 0, nullptr, nullptr }; } };
+struct ToneBwdScope { explicit ToneBwdScope(const ToneBwd& t) { t_tone_bwd = t; } ~ToneBwdScope() { t_tone_bwd = ToneBwd{ 0, nullptr, nullptr, nullptr, nullptr }; } };
 
 template <int CD>
 static int launch_fwd(int W, int H, int D, const RasterWs& ws, const float* colors, const float* background,
@@ -1709,12 +1748,16 @@ static int launch_fwd(int W, int H, int D, const RasterWs& ws, const float* colo
                       hipStream_t s)
 {
     const int tile_w = (W + GS_TILE - 1) / GS_TILE, tile_h = (H + GS_TILE - 1) / GS_TILE;
+    if (t_tone_fwd.image && !(gs_raster_lanes() == 1 && CD == 3 && D == 3 && background == nullptr)) {
+        gs_set_error("gs_raster_composite_tone: needs D == 3, no background and the default compositor kernels (GEOSPLAT_RASTER_LANES=1)");
+        return GS_EINVAL;
+    }
     if (gs_raster_lanes() == 1) {                             // default: sliding window of two dense batches
         size_t lds = 4 * (size_t)GS_WIN_Q_BYTES;
         if (lds < gs_raster_lds_pad()) lds = gs_raster_lds_pad();
         hipLaunchKernelGGL(raster_fwd_window_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
                            ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, isect_count(n_isects), offsets, render, alphas,
-                           last_ids);
+                           last_ids, t_tone_fwd);
         GS_CHECK_LAUNCH();
         return GS_OK;
     }
@@ -1832,13 +1875,17 @@ static int launch_bwd(int W, int H, int D, const RasterWs& ws, const float* colo
                       const float* v_render, const float* v_alphas, float* v_packed, int rec_stride, hipStream_t s)
 {
     const int tile_w = (W + GS_TILE - 1) / GS_TILE, tile_h = (H + GS_TILE - 1) / GS_TILE;
+    if (t_tone_bwd.v_image && !((gs_raster_lanes() == 1 || gs_raster_lanes() == 3) && CD == 3 && D == 3 && background == nullptr)) {
+        gs_set_error("gs_raster_bwd_tone: needs D == 3, no background and the default compositor kernels (GEOSPLAT_RASTER_LANES=1)");
+        return GS_EINVAL;
+    }
     if constexpr (CD <= 3) {                                  // colours travel in the record stream only for D <= 3
         if ((gs_raster_lanes() == 1 || gs_raster_lanes() == 3)) {
             size_t lds = 4 * (size_t)Lanes2Lds<CD>::WAVE_BYTES;
             if (lds < gs_raster_lds_pad()) lds = gs_raster_lds_pad();
             hipLaunchKernelGGL(raster_bwd_lanes2_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
                                ws.order, ws.rec0, ws.rec1, ws.rec2, background, isect_count(n_isects), offsets, alphas, last_ids,
-                               v_render, v_alphas, v_packed, rec_stride);
+                               v_render, v_alphas, v_packed, rec_stride, t_tone_bwd);
             GS_CHECK_LAUNCH();
             return GS_OK;
         }
@@ -1957,6 +2004,34 @@ extern "C" int gs_raster_bwd_acc_cap(int W, int H, int tile_size, int D, int V_c
     CountsScope sc(counts_dev);
     return gs_raster_bwd_acc(W, H, tile_size, D, V_cap, colors, background, n_isects_cap, offsets, alphas, last_ids, v_render, v_alphas,
                              v_packed, ws, ws_bytes, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Compositor with S4 inside (see ToneFwd / ToneBwd).  The plain outputs (render, alphas, last_ids) are written as well: the backward
+// needs them.  n_isects / V are exact counts, or capacities when counts_dev != NULL (capacity protocol, as the *_cap entry points).
+extern "C" int gs_raster_composite_tone(int W, int H, int tile_size, int V, const float* colors, int64_t n_isects,
+                                        const int64_t* counts_dev, const int32_t* offsets, float* render, float* alphas,
+                                        int32_t* last_ids, int tone_mode, const float* exposure, float* image, const void* ws,
+                                        size_t ws_bytes, void* stream)
+{
+    GS_CHECK_ARG(tone_mode >= 0 && tone_mode <= 2 && exposure != nullptr && image != nullptr, "bad tone mode / exposure / image");
+    CountsScope sc(counts_dev);
+    ToneFwdScope ts(ToneFwd{ tone_mode, exposure, (float4*)image });
+    return gs_raster_composite(W, H, tile_size, 3, V, colors, nullptr, n_isects, offsets, render, alphas, last_ids, ws, ws_bytes, stream);
+}
+
+// v_packed is ACCUMULATED into (as gs_raster_bwd_acc), v_exposure too (one atomic per quadrant wave).
+extern "C" int gs_raster_bwd_tone_acc(int W, int H, int tile_size, int V, const float* colors, int64_t n_isects,
+                                      const int64_t* counts_dev, const int32_t* offsets, const float* render, const float* alphas,
+                                      const int32_t* last_ids, int tone_mode, const float* exposure, const float* v_image,
+                                      float* v_packed, float* v_exposure, const void* ws, size_t ws_bytes, void* stream)
+{
+    GS_CHECK_ARG(tone_mode >= 0 && tone_mode <= 2 && exposure != nullptr && v_image != nullptr && render != nullptr && v_exposure != nullptr,
+                 "bad tone mode / exposure / v_image / render / v_exposure");
+    CountsScope sc(counts_dev);
+    ToneBwdScope ts(ToneBwd{ tone_mode, exposure, render, (const float4*)v_image, v_exposure });
+    return gs_raster_bwd_acc(W, H, tile_size, 3, V, colors, nullptr, n_isects, offsets, alphas, last_ids, nullptr, nullptr, v_packed, ws,
+                             ws_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -510,28 +510,7 @@ extern "C" int gs_shade_bwd(int N, const float* means, const float* normals, con
 
 // ---------------------------------------------------------------------------------------------------
 // S4 tone mapping
-__device__ __forceinline__ float tone_fwd(int mode, float rgb)
-{
-    if (mode == GS_TONE_NAIVE) {
-        const float x = 1.0f - rgb, bx = 100.0f * x;
-        const float sp = bx > 20.0f ? x : log1pf(expf(bx)) / 100.0f;
-        return 1.0f - sp;
-    }
-    if (mode == GS_TONE_ACES) return (rgb * (2.51f * rgb + 0.03f)) / (rgb * (2.43f * rgb + 0.59f) + 0.14f);
-    return rgb;
-}
-__device__ __forceinline__ float tone_grad(int mode, float rgb)
-{
-    if (mode == GS_TONE_NAIVE) {
-        const float bx = 100.0f * (1.0f - rgb);
-        return bx > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-bx));
-    }
-    if (mode == GS_TONE_ACES) {
-        const float num = rgb * (2.51f * rgb + 0.03f), den = rgb * (2.43f * rgb + 0.59f) + 0.14f;
-        return ((5.02f * rgb + 0.03f) * den - num * (4.86f * rgb + 0.59f)) / (den * den);
-    }
-    return 1.0f;
-}
+#include "gs_tone.h"
 
 __global__ void __launch_bounds__(256)
 tonemap_fwd_kernel(int64_t P, int mode, const float4* __restrict__ rgba, const float* __restrict__ exposure,

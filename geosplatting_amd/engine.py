@@ -244,6 +244,9 @@ class RenderStep:
             return state, V, I, D, whs, ev, col
 
         n_views = len(cameras)
+        front_first = os.environ.get("GEOSPLAT_ENQUEUE", "main_first") == "front_first"
+        # S4 inside the compositor kernels (default; needs the default kernel pair): GEOSPLAT_FUSED_TONE=0 keeps the two tone-map launches
+        fused_tone = os.environ.get("GEOSPLAT_FUSED_TONE", "1") != "0" and os.environ.get("GEOSPLAT_RASTER_LANES", "1") == "1"
         proj = [start_view(cameras[j], j) for j in range(min(2, n_views))]   # prologue: A(0), A(1), B1(0)
         binned = bin_view(proj.pop(0)) if n_views else None
         for i, cam in enumerate(cameras):
@@ -251,32 +254,61 @@ class RenderStep:
             W, H = cam.width, cam.height
             state, V, I, D, whs, ev, colors = binned
             main.wait_event(ev)
-            if i_cap is not None:
+            P = W * H
+            if fused_tone:
+                # compositor with S4 in its epilogue: `img` comes out of the same launch (gs_raster_composite_tone)
+                render = torch.empty(H, W, 3, dtype=f32, device=dev); alphas = torch.empty(H, W, dtype=f32, device=dev)
+                last_ids = torch.empty(H, W, dtype=torch.int32, device=dev)
+                img = torch.empty(H, W, 4, dtype=f32, device=dev)
+                rws0 = state["raster_ws"]
+                L.check(lib.gs_raster_composite_tone(W, H, 16, V, L.ptr(state["colors"]), L.i64(I),
+                                                     L.ptr(state["counts"]) if i_cap is not None else None,
+                                                     L.ptr(state["isect_offsets"]), L.ptr(render), L.ptr(alphas), L.ptr(last_ids), tone,
+                                                     L.ptr(exposure), L.ptr(img), L.ptr(rws0), C.c_size_t(rws0.numel()), st()),
+                        "gs_raster_composite_tone")
+                s = dict(state, last_ids=last_ids)
+            elif i_cap is not None:
                 render, alphas, s = _composite_stage_cap(state, V, I, D, whs, None)
             else:
                 render, alphas, s, V, I = _composite_stage(state, V, I, D, whs, None)
-            # keep the side stream two views ahead: A(i+2), then B1(i+1)
-            if i + 2 < n_views:
-                proj.append(start_view(cameras[i + 2], i + 2))
-            binned = bin_view(proj.pop(0)) if i + 1 < n_views else None
-            img = torch.empty(H, W, 4, dtype=f32, device=dev)
-            P = W * H
-            L.check(lib.gs_tonemap_fwd3(L.i64(P), tone, L.ptr(render), L.ptr(alphas), L.ptr(exposure), L.ptr(img), st()), "gs_tonemap_fwd3")
+            # keep the side streams two views ahead: A(i+2), then B1(i+1).  Their ~35 launches cost the host 0.2-0.3 ms: issued
+            # HERE (GEOSPLAT_ENQUEUE=front_first, the round-2 order) the compositor forward of this view has finished before the
+            # host reaches its backward -- the main stream, the step's critical path, idled 0.13-0.28 ms per view
+            # (profiles/r03_concurrency_one_step.txt).  Default: the rest of this view's main-stream chain first, the fronts after it.
+            if front_first:
+                if i + 2 < n_views:
+                    proj.append(start_view(cameras[i + 2], i + 2))
+                binned = bin_view(proj.pop(0)) if i + 1 < n_views else None
+            if not fused_tone:
+                img = torch.empty(H, W, 4, dtype=f32, device=dev)
+                L.check(lib.gs_tonemap_fwd3(L.i64(P), tone, L.ptr(render), L.ptr(alphas), L.ptr(exposure), L.ptr(img), st()), "gs_tonemap_fwd3")
             v_img = upstream(i, img).contiguous()
-            v_render = torch.empty(H, W, 3, dtype=f32, device=dev); v_alpha = torch.empty(H, W, dtype=f32, device=dev)
-            L.check(lib.gs_tonemap_bwd3(L.i64(P), tone, L.ptr(render), L.ptr(alphas), L.ptr(exposure), L.ptr(v_img), L.ptr(v_render),
-                                        L.ptr(v_alpha), L.ptr(b["exposure"]), 1, st()), "gs_tonemap_bwd3")
             v_packed = s["v_packed"]
             rws = s["raster_ws"]
-            if i_cap is not None:
-                L.check(lib.gs_raster_bwd_acc_cap(W, H, 16, 3, V, L.ptr(s["colors"]), None, L.i64(I), L.ptr(s["counts"]),
-                                              L.ptr(s["isect_offsets"]), L.ptr(alphas), L.ptr(s["last_ids"]), L.ptr(v_render),
-                                              L.ptr(v_alpha), L.ptr(v_packed), L.ptr(rws), C.c_size_t(rws.numel()), st()),
-                        "gs_raster_bwd_acc_cap")
+            if fused_tone:
+                # ... and S4 backward in the prologue of the compositor backward (gs_raster_bwd_tone_acc)
+                L.check(lib.gs_raster_bwd_tone_acc(W, H, 16, V, L.ptr(s["colors"]), L.i64(I),
+                                                   L.ptr(s["counts"]) if i_cap is not None else None, L.ptr(s["isect_offsets"]),
+                                                   L.ptr(render), L.ptr(alphas), L.ptr(s["last_ids"]), tone, L.ptr(exposure), L.ptr(v_img),
+                                                   L.ptr(v_packed), L.ptr(b["exposure"]), L.ptr(rws), C.c_size_t(rws.numel()), st()),
+                        "gs_raster_bwd_tone_acc")
             else:
-                L.check(lib.gs_raster_bwd_acc(W, H, 16, 3, V, L.ptr(s["colors"]), None, L.i64(I), L.ptr(s["isect_offsets"]),
-                                          L.ptr(alphas), L.ptr(s["last_ids"]), L.ptr(v_render), L.ptr(v_alpha), L.ptr(v_packed),
-                                          L.ptr(rws), C.c_size_t(rws.numel()), st()), "gs_raster_bwd_acc")
+                v_render = torch.empty(H, W, 3, dtype=f32, device=dev); v_alpha = torch.empty(H, W, dtype=f32, device=dev)
+                L.check(lib.gs_tonemap_bwd3(L.i64(P), tone, L.ptr(render), L.ptr(alphas), L.ptr(exposure), L.ptr(v_img), L.ptr(v_render),
+                                            L.ptr(v_alpha), L.ptr(b["exposure"]), 1, st()), "gs_tonemap_bwd3")
+                if i_cap is not None:
+                    L.check(lib.gs_raster_bwd_acc_cap(W, H, 16, 3, V, L.ptr(s["colors"]), None, L.i64(I), L.ptr(s["counts"]),
+                                                      L.ptr(s["isect_offsets"]), L.ptr(alphas), L.ptr(s["last_ids"]), L.ptr(v_render),
+                                                      L.ptr(v_alpha), L.ptr(v_packed), L.ptr(rws), C.c_size_t(rws.numel()), st()),
+                            "gs_raster_bwd_acc_cap")
+                else:
+                    L.check(lib.gs_raster_bwd_acc(W, H, 16, 3, V, L.ptr(s["colors"]), None, L.i64(I), L.ptr(s["isect_offsets"]),
+                                                  L.ptr(alphas), L.ptr(s["last_ids"]), L.ptr(v_render), L.ptr(v_alpha), L.ptr(v_packed),
+                                                  L.ptr(rws), C.c_size_t(rws.numel()), st()), "gs_raster_bwd_acc")
+            if not front_first:
+                if i + 2 < n_views:
+                    proj.append(start_view(cameras[i + 2], i + 2))
+                binned = bin_view(proj.pop(0)) if i + 1 < n_views else None
             # gradient tail of the view (A7 + S1-S3 backward: HBM / atomic-rate bound) on a third stream, so that it
             # overlaps the VALU-bound compositor of the next view; the tail kernels of successive views stay in order
             # on that stream (they accumulate into the same gradient buffers)

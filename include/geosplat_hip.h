@@ -202,6 +202,20 @@ int gs_raster_bwd_acc_cap(int W, int H, int tile_size, int D, int V_cap, const f
                           int64_t n_isects_cap, const int64_t* counts_dev, const int32_t* offsets, const float* alphas,
                           const int32_t* last_ids, const float* v_render, const float* v_alphas, float* v_packed, const void* ws,
                           size_t ws_bytes, void* stream);
+/* The compositor with S4 (tone mapping, rfstudio/model/geosplat.py:123-133) inside, D = 3 and no background -- what
+ * RenderableAttrs.splat runs between `rasterization` and the loss (rfstudio/model/geosplat.py:108-133): the forward also writes
+ * image[P,4] = tonemap(render * exposure | alpha) (= gs_tonemap_fwd3 on its outputs, bit-identical), the backward takes the image
+ * cotangent v_image[P,4] instead of v_render / v_alphas (= gs_tonemap_bwd3 + gs_raster_bwd_acc) and ADDS the exposure gradient to
+ * the device scalar v_exposure.  Two dependent launches fewer per view on the step's critical stream.  counts_dev == NULL: V and
+ * n_isects are exact; otherwise they are capacities and {V, I} are read on the device (capacity protocol). */
+int gs_raster_composite_tone(int W, int H, int tile_size, int V, const float* colors, int64_t n_isects,
+                             const int64_t* counts_dev, const int32_t* offsets, float* render, float* alphas,
+                             int32_t* last_ids, int tone_mode, const float* exposure /*device scalar*/, float* image,
+                             const void* ws, size_t ws_bytes, void* stream);
+int gs_raster_bwd_tone_acc(int W, int H, int tile_size, int V, const float* colors, int64_t n_isects,
+                           const int64_t* counts_dev, const int32_t* offsets, const float* render, const float* alphas,
+                           const int32_t* last_ids, int tone_mode, const float* exposure, const float* v_image,
+                           float* v_packed, float* v_exposure, const void* ws, size_t ws_bytes, void* stream);
 int gs_project_bwd_cap(int N, const int64_t* counts_dev, int D, const float* means, const float* quats, const float* scales,
                        const float* opacities, const float* viewmat, const float* K, int W, int H, float eps2d,
                        const int32_t* gaussian_ids, const float* conics, const float* compensations, const float* v_packed,

@@ -41,3 +41,35 @@ for k in sorted(depth_time):
 print("  alone on the GPU:")
 for n, v in alone.most_common(14):
     print(f"    {v / 1e3:8.1f} us  {n}")
+# the compositor (main stream) is the step's critical path: where does it start, how long are its kernels inside the step, and what
+# lies between them (tone map + loss glue, waiting for the next view's front)?
+print("  main-stream timeline (ms from the step's first kernel): kernel, start, duration, gap since the previous compositor kernel")
+prev_end = None
+for n, s, e in seg:
+    if 'raster_fwd' in n or 'raster_bwd' in n:
+        gap = (s - prev_end) / 1e6 if prev_end is not None else float('nan')
+        print(f"    {short(n):36s} {(s - t0) / 1e6:7.3f} {(e - s) / 1e6:6.3f}   gap {gap:6.3f}")
+        prev_end = e
+print(f"    last compositor kernel ends at {(prev_end - t0) / 1e6:.3f} ms; step ends at {wall / 1e6:.3f} ms")
+for pat in ('tile_apply', 'shade_bwd', 'project_bwd', 'project_fwd', 'shade_fwd', 'build_stream'):
+    xs = [(s - t0, e - t0) for n, s, e in seg if pat in n]
+    if xs:
+        print(f"    {pat:14s} starts (ms): " + " ".join(f"{a / 1e6:.2f}" for a, _ in xs[:20]))
+# everything the compositor's own stream runs around the first three views (what sits between a forward and its backward)
+try:
+    cols = [r[1] for r in c.execute(f"pragma table_info({kt})")]
+    key = 'stream_id' if 'stream_id' in cols else ('queue_id' if 'queue_id' in cols else None)
+    if key:
+        full = list(c.execute(f"select s.kernel_name, d.start, d.end, d.{key} from {kt} d join {ks} s on d.kernel_id=s.id where d.start >= {t0} and d.start <= {t1} order by d.start"))
+        main_id = next(r[3] for r in full if 'raster_fwd' in r[0])
+        print(f"  kernels of the compositor's stream ({key} {main_id}), first three views: start, duration (ms)")
+        seen_bwd = 0
+        for n, s_, e_, q_ in full:
+            if q_ != main_id:
+                continue
+            print(f"    {(s_ - t0) / 1e6:7.3f} {(e_ - s_) / 1e6:6.3f}  {short(n)}")
+            seen_bwd += 'raster_bwd' in n
+            if seen_bwd == 3:
+                break
+except Exception as ex:
+    print("  (no per-stream listing:", ex, ")")

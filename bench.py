@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--settle-seconds", type=float, default=1.0,
+                    help="untimed steps for this long BEFORE the W warm-up steps: a GPU that has idled starts a process at low clocks "
+                         "(the first bench run on a fresh box read 10 %% below every later one); part of initialisation, like the table build")
     ap.add_argument("--level", type=int, default=7, help="icosphere level: 7 -> 1 966 080 Gaussians, 6 -> 491 520")
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--views", type=int, default=8, help="views per step per GPU (reference batch_size = 8)")
@@ -306,6 +309,17 @@ def main():
     def one_step():
         step(cams, lambda i, img: ups[i], all_reduce=(world > 1))
 
+    n_settle = 0
+    if args.settle_seconds > 0 and len(cams) > 0:          # clocks / allocator / capacity settle; identical on every rank (fixed step count)
+        t_s = time.perf_counter()
+        one_step(); torch.cuda.synchronize()
+        per = max(time.perf_counter() - t_s, 1e-3)
+        n_settle = int(min(200, max(0, args.settle_seconds / per)))
+        if world > 1:
+            t_n = torch.tensor([n_settle], device=dev); dist.all_reduce(t_n, op=dist.ReduceOp.MAX); n_settle = int(t_n.item())
+        for _ in range(n_settle):
+            one_step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         one_step()
     graphed = None
@@ -341,6 +355,7 @@ def main():
     cap_ok = graphed.check() if graphed is not None else step.poll_capacity(wait=True)
     capacity = {"mode": "device-side counts, no host synchronisation inside a step" if step._i_cap is not None else "exact (one read-back per view)",
                 "n_isects_cap": step._i_cap, "overflow_in_timed_steps": (not cap_ok), "truncated_steps": step.truncated_steps,
+                "untimed_settle_steps_before_warmup": n_settle,
                 "hip_graph": ({1: "whole step", 2: "views segment (prefilter and collectives eager)"}[args.graph] if graphed is not None else False)}
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:

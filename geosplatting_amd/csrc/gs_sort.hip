@@ -26,7 +26,9 @@
 
 #define RS_THREADS 256
 #define RS_WAVES 4
+#ifndef RS_ITEMS
 #define RS_ITEMS 16                       // per thread
+#endif
 #define RS_TILE (RS_THREADS * RS_ITEMS)   // 4096 items per block
 #define RS_WCHUNK (64 * RS_ITEMS)         // 1024 items per wave
 

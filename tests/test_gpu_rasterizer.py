@@ -108,6 +108,22 @@ def test_partial_visibility_and_ragged_image(cuda):
     assert 0 < len(ref["gaussian_ids"]) < 4000
 
 
+def test_many_tiles_and_screen_filling_gaussians(cuda):
+    """1920x1080 = 120 x 68 = 8 160 tiles (13 tile bits: more than two 6-bit tile passes), with a few Gaussians scaled up until
+    their rectangles cover most of the screen (maximum-size tile rectangles, lists that hold the same Gaussian in thousands of tiles)."""
+    from geosplatting_amd.cameras import Camera, lookat_c2w
+    import geosplatting_amd.synthetic as syn
+    sp = syn.random_splats(3000, seed=12)
+    c2w = lookat_c2w(torch.tensor([0.0, 0.3, 3.0]), torch.tensor([0.0, 0.0, 0.0]), torch.tensor([0.0, 1.0, 0.0]))
+    cam = Camera(c2w, 1500.0, 1500.0, 960.0, 540.0, 1920, 1080)
+    means, quats, scales, opac = activated(sp)
+    scales = scales.copy(); opac = np.clip(opac * 4, 0, 0.9).astype(np.float32)
+    scales[:6] *= 40.0                                            # six screen-filling splats
+    opac[:6] = 0.05
+    ref, meta = _run_case(cuda, means, quats, scales, opac, sp.colors.numpy(), cam)
+    assert int(ref["tiles_per_gauss"].max()) > 2000 and len(ref["flatten_ids"]) > 20000
+
+
 def test_background_and_channels(cuda):
     """D=5 channels (generic path) with a background colour."""
     sp, cam = random_case(3000, 96)

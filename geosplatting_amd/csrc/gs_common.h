@@ -41,6 +41,31 @@ __device__ __forceinline__ long long gs_count(const GsCount& c)
     return v < 0 ? 0 : (v < c.n ? v : c.n);
 }
 
+// Zero device memory with a KERNEL, not hipMemsetAsync, on every path that may be captured into a HIP graph.  Observed on ROCm 7.2
+// (scripts/debug_graph_sync4.py): when the replay of a captured step was launched behind an eager kernel that had already finished,
+// the memset NODE that clears the chained-scan state of project_fwd_kernel was no longer ordered in front of that kernel -- its blocks
+// then spun on look-back flags that were wiped under them (5-20 s per replay, memory faults later).  Kernel nodes keep their order.
+static __global__ void __launch_bounds__(256) gs_zero_kernel(uint32_t* __restrict__ p, size_t n_words)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static __global__ void __launch_bounds__(256) gs_zero16_kernel(uint4* __restrict__ p, size_t n_quads)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_quads; i += (size_t)gridDim.x * blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+static inline hipError_t gs_zero_async(void* p, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0) return hipSuccess;
+    if ((bytes & 3) != 0 || (((uintptr_t)p) & 3) != 0) return hipMemsetAsync(p, 0, bytes, s);     // (no such caller on a graph path)
+    const bool wide = (bytes & 15) == 0 && (((uintptr_t)p) & 15) == 0;
+    const size_t n = wide ? bytes / 16 : bytes / 4;
+    const size_t want = (n + 255) / 256;
+    const int blocks = (int)(want < 4096 ? want : 4096);
+    if (wide) hipLaunchKernelGGL(gs_zero16_kernel, dim3(blocks), dim3(256), 0, s, (uint4*)p, n);
+    else hipLaunchKernelGGL(gs_zero_kernel, dim3(blocks), dim3(256), 0, s, (uint32_t*)p, n);
+    return hipGetLastError();
+}
+
 // ---- wave64 cross-lane helpers -------------------------------------------------------------------
 __device__ __forceinline__ float gs_readlane(float v, int lane)
 {

@@ -766,11 +766,11 @@ extern "C" int gs_flexicubes_bwd(int R0, int R1, int R2, const float* vertices, 
     hipStream_t s = (hipStream_t)stream;
     const FcParams prm = {weight_scale, sdf_eps};
     GS_CHECK_HIP(hipMemcpyAsync(g_vd_scratch, v_out_vertices, sizeof(float) * 3 * (size_t)Q, hipMemcpyDeviceToDevice, s));
-    GS_CHECK_HIP(hipMemsetAsync(g_vertices, 0, sizeof(float) * 3 * (size_t)g.Vg, s));
-    GS_CHECK_HIP(hipMemsetAsync(g_sdf, 0, sizeof(float) * (size_t)g.Vg, s));
-    if (g_alpha) GS_CHECK_HIP(hipMemsetAsync(g_alpha, 0, sizeof(float) * 8 * (size_t)g.C, s));
-    if (g_beta) GS_CHECK_HIP(hipMemsetAsync(g_beta, 0, sizeof(float) * 12 * (size_t)g.C, s));
-    if (g_gamma) GS_CHECK_HIP(hipMemsetAsync(g_gamma, 0, sizeof(float) * (size_t)g.C, s));
+    GS_CHECK_HIP(gs_zero_async(g_vertices, sizeof(float) * 3 * (size_t)g.Vg, s));
+    GS_CHECK_HIP(gs_zero_async(g_sdf, sizeof(float) * (size_t)g.Vg, s));
+    if (g_alpha) GS_CHECK_HIP(gs_zero_async(g_alpha, sizeof(float) * 8 * (size_t)g.C, s));
+    if (g_beta) GS_CHECK_HIP(gs_zero_async(g_beta, sizeof(float) * 12 * (size_t)g.C, s));
+    if (g_gamma) GS_CHECK_HIP(gs_zero_async(g_gamma, sizeof(float) * (size_t)g.C, s));
     if (num_quads > 0)
         hipLaunchKernelGGL(fc_quad_bwd_kernel, dim3(gs_cdiv(3 * (int64_t)g.Vg, 256)), dim3(256), 0, s, g, prm, sdf, gamma, w.case8,
                            w.vd_base, w.quad_id, (int)Q, out_vertices, v_out_vertices, g_vd_scratch, g_gamma);
@@ -803,7 +803,7 @@ extern "C" int gs_flexicubes_entropy_bwd(int R0, int R1, int R2, const float* sd
     const FcWs w = fc_ws(g, (void*)ws);
     GS_CHECK_ARG(ws_bytes >= w.bytes, "workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    if (!accumulate) GS_CHECK_HIP(hipMemsetAsync(g_sdf, 0, sizeof(float) * (size_t)g.Vg, s));
+    if (!accumulate) GS_CHECK_HIP(gs_zero_async(g_sdf, sizeof(float) * (size_t)g.Vg, s));
     hipLaunchKernelGGL(fc_entropy_bwd_kernel, dim3(w.nb_ent), dim3(256), 0, s, g, sdf, w.hdr, v_out, g_sdf);
     GS_CHECK_LAUNCH();
     return GS_OK;

@@ -369,12 +369,12 @@ extern "C" int gs_hashgrid_bwd(int N, int L, int F, int log2_T, const float* sca
     for (int l = 0; l < GS_HG_MAX_LEVELS; ++l) lv.scaling[l] = l < L ? scalings_host[l] : 0.0f;
     const bool slabs = ws != nullptr && ws_bytes >= gs_hashgrid_bwd_ws_bytes(N, L, F);
     if (N == 0) {
-        if (!accumulate) GS_CHECK_HIP(hipMemsetAsync(v_table, 0, sizeof(float) * n, s));
+        if (!accumulate) GS_CHECK_HIP(gs_zero_async(v_table, sizeof(float) * n, s));
         return GS_OK;
     }
     if (!slabs) {
         // fallback without workspace: per-point kernel with memory-side atomics (4-5x slower at 2 M points)
-        if (!accumulate) GS_CHECK_HIP(hipMemsetAsync(v_table, 0, sizeof(float) * n, s));
+        if (!accumulate) GS_CHECK_HIP(gs_zero_async(v_table, sizeof(float) * n, s));
         hipLaunchKernelGGL(hashgrid_bwd_kernel<2>, dim3(gs_cdiv(N, 256)), dim3(256), 0, s, N, L, (unsigned)log2_T, lv, x, table,
                            v_out, table_grad_scale, v_table, v_x);
         GS_CHECK_LAUNCH();
@@ -387,7 +387,7 @@ extern "C" int gs_hashgrid_bwd(int N, int L, int F, int log2_T, const float* sca
     const int slabs_per_level = (int)(T / (unsigned)rows);
     int parts = 1;
     while (L * slabs_per_level * parts < 192 && parts < 64) parts *= 2;    // small tables: split the points to fill the CUs
-    if (parts > 1 && !accumulate) GS_CHECK_HIP(hipMemsetAsync(v_table, 0, sizeof(float) * n, s));
+    if (parts > 1 && !accumulate) GS_CHECK_HIP(gs_zero_async(v_table, sizeof(float) * n, s));
     const size_t lds = sizeof(float) * 2 * (size_t)rows;
     GS_CHECK_HIP(hipFuncSetAttribute((const void*)hashgrid_bwd_slab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(hashgrid_bwd_slab_kernel, dim3(L * slabs_per_level * parts), dim3(1024), lds, s, N, L, (unsigned)log2_T, lv,
@@ -598,7 +598,7 @@ extern "C" int gs_hashgrid_bwd_fixed(int N, int L, int F, int log2_T, const floa
     HgLevels lv;
     for (int l = 0; l < GS_HG_MAX_LEVELS; ++l) lv.scaling[l] = l < L ? scalings_host[l] : 0.0f;
     if (N == 0) {
-        if (!accumulate) GS_CHECK_HIP(hipMemsetAsync(v_table, 0, sizeof(float) * n, s));
+        if (!accumulate) GS_CHECK_HIP(gs_zero_async(v_table, sizeof(float) * n, s));
         return GS_OK;
     }
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -608,7 +608,7 @@ extern "C" int gs_hashgrid_bwd_fixed(int N, int L, int F, int log2_T, const floa
     unsigned* gmax = (unsigned*)((char*)q_counts + al(sizeof(int) * L * slabs));
     int* queues = (int*)((char*)gmax + 256);
     hipLaunchKernelGGL(hashgrid_transpose_kernel, dim3(gs_cdiv((int64_t)N * L, 256)), dim3(256), 0, s, N, L * F, v_out, v_lm);
-    GS_CHECK_HIP(hipMemsetAsync(q_counts, 0, al(sizeof(int) * L * slabs) + 256, s));            // counters and maxima
+    GS_CHECK_HIP(gs_zero_async(q_counts, al(sizeof(int) * L * slabs) + 256, s));            // counters and maxima
     hipLaunchKernelGGL(hashgrid_level_max_kernel, dim3(min(64, gs_cdiv(2 * (int64_t)N, 4096)), L), dim3(1024), 0, s, N, v_lm, gmax);
     int rows_shift = 0;
     while ((1 << rows_shift) < HG_FX_ROWS) ++rows_shift;
@@ -716,7 +716,7 @@ extern "C" int gs_mlp_wgrad(int64_t N, int O, int I, const float* dY, const floa
     GS_CHECK_ARG(ws_bytes >= gs_mlp_wgrad_ws_bytes(N), "workspace too small");
     hipStream_t s = (hipStream_t)stream;
     if (N == 0) {
-        if (!accumulate) GS_CHECK_HIP(hipMemsetAsync(dW, 0, sizeof(float) * O * I, s));
+        if (!accumulate) GS_CHECK_HIP(gs_zero_async(dW, sizeof(float) * O * I, s));
         return GS_OK;
     }
     const int nb = wgrad_blocks(N);

@@ -323,8 +323,8 @@ extern "C" int gs_mgadapter_bwd(int F, int V, const float* vertices, const int64
 {
     GS_CHECK_ARG(F >= 0 && V >= 0, "bad sizes");
     hipStream_t s = (hipStream_t)stream;
-    GS_CHECK_HIP(hipMemsetAsync(v_vertices, 0, sizeof(float) * 3 * (size_t)V, s));
-    GS_CHECK_HIP(hipMemsetAsync(v_vnormals, 0, sizeof(float) * 3 * (size_t)V, s));
+    GS_CHECK_HIP(gs_zero_async(v_vertices, sizeof(float) * 3 * (size_t)V, s));
+    GS_CHECK_HIP(gs_zero_async(v_vnormals, sizeof(float) * 3 * (size_t)V, s));
     if (F == 0) return GS_OK;
     hipLaunchKernelGGL(mgadapter_bwd_kernel, dim3(gs_cdiv(F, 256)), dim3(256), 0, s, F, vertices, faces, vnormals, v_means,
                        v_scales, v_quats, v_normals, v_vertices, v_vnormals);
@@ -338,7 +338,7 @@ extern "C" int gs_vertex_normals_fwd(int F, int V, const float* vertices, const 
     GS_CHECK_ARG(F >= 0 && V >= 0, "bad sizes");
     hipStream_t s = (hipStream_t)stream;
     if (V == 0) return GS_OK;
-    GS_CHECK_HIP(hipMemsetAsync(raw, 0, sizeof(float) * 3 * (size_t)V, s));
+    GS_CHECK_HIP(gs_zero_async(raw, sizeof(float) * 3 * (size_t)V, s));
     if (F > 0) hipLaunchKernelGGL(vnormal_scatter_kernel, dim3(gs_cdiv(F, 256)), dim3(256), 0, s, F, vertices, faces, raw);
     hipLaunchKernelGGL(vnormal_normalize_kernel, dim3(gs_cdiv(V, 256)), dim3(256), 0, s, V, raw, vnormals);
     GS_CHECK_LAUNCH();
@@ -352,7 +352,7 @@ extern "C" int gs_vertex_normals_bwd(int F, int V, const float* vertices, const 
     GS_CHECK_ARG(F >= 0 && V >= 0, "bad sizes");
     hipStream_t s = (hipStream_t)stream;
     if (V == 0) return GS_OK;
-    if (!accumulate) GS_CHECK_HIP(hipMemsetAsync(v_vertices, 0, sizeof(float) * 3 * (size_t)V, s));
+    if (!accumulate) GS_CHECK_HIP(gs_zero_async(v_vertices, sizeof(float) * 3 * (size_t)V, s));
     hipLaunchKernelGGL(vnormal_bwd_vertex_kernel, dim3(gs_cdiv(V, 256)), dim3(256), 0, s, V, raw, v_vnormals, v_raw);
     if (F > 0) hipLaunchKernelGGL(vnormal_bwd_face_kernel, dim3(gs_cdiv(F, 256)), dim3(256), 0, s, F, vertices, faces, v_raw, v_vertices);
     GS_CHECK_LAUNCH();

@@ -167,7 +167,7 @@ __device__ __forceinline__ void tile_range_exact(float mx, float my, int radius,
 //  every kernel here is HBM-bound, the lost FMAs are free)
 
 // ---------------------------------------------------------------------------------------------------
-// Chained-scan state (one per launch, zeroed by hipMemsetAsync before the launch):
+// Chained-scan state (one per launch, zeroed by gs_zero_async -- a kernel, see gs_common.h -- before the launch):
 //   word 0      : ticket counter (chunk ids are handed out in ARRIVAL order -> look-back cannot deadlock)
 //   word 1      : error flag (spin timeout)
 //   then 4 arrays of n_chunks u64, each word written exactly once: bit 63 = valid, bits 62..0 = value
@@ -377,8 +377,8 @@ extern "C" int gs_project_fwd_vis(int N, const float* means, const float* quats,
     GS_CHECK_ARG((colors == nullptr) == (colors_packed == nullptr), "colors and colors_packed go together");
     if (ws_bytes < gs_project_ws_bytes(N)) { gs_set_error("gs_project_fwd: workspace too small"); return GS_ENOSPC; }
     hipStream_t s = (hipStream_t)stream;
-    GS_CHECK_HIP(hipMemsetAsync(ws, 0, gs_project_ws_bytes(N), s));
-    GS_CHECK_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(int64_t), s));
+    GS_CHECK_HIP(gs_zero_async(ws, gs_project_ws_bytes(N), s));
+    GS_CHECK_HIP(gs_zero_async(counts, 2 * sizeof(int64_t), s));
     if (N == 0) return GS_OK;
     const int n_chunks = (N + GS_PROJ_BLOCK - 1) / GS_PROJ_BLOCK;
     const int tile_w = (W + tile_size - 1) / tile_size, tile_h = (H + tile_size - 1) / tile_size;
@@ -487,7 +487,7 @@ extern "C" int gs_isect_offsets(int64_t n_isects, const int64_t* isect_ids_sorte
     GS_CHECK_ARG(n_isects >= 0 && n_tiles > 0, "bad sizes");
     hipStream_t s = (hipStream_t)stream;
     if (n_isects == 0) {
-        GS_CHECK_HIP(hipMemsetAsync(offsets, 0, sizeof(int32_t) * (size_t)n_tiles, s));
+        GS_CHECK_HIP(gs_zero_async(offsets, sizeof(int32_t) * (size_t)n_tiles, s));
         return GS_OK;
     }
     hipLaunchKernelGGL(isect_offsets_kernel, dim3(gs_cdiv(n_isects, 256)), dim3(256), 0, s, GsCount{ n_isects, nullptr },

@@ -1949,7 +1949,7 @@ static int raster_bwd_impl(int W, int H, int tile_size, int D, int V, const floa
     if (ws_bytes < gs_raster_ws_bytes(n_isects, V, W, H, tile_size)) { gs_set_error("gs_raster_bwd: workspace too small"); return GS_ENOSPC; }
     hipStream_t s = (hipStream_t)stream;
     const int rec_stride = gs_raster_grad_stride(D);
-    if (V > 0 && zero) GS_CHECK_HIP(hipMemsetAsync(v_packed, 0, sizeof(float) * (size_t)rec_stride * (size_t)V, s));
+    if (V > 0 && zero) GS_CHECK_HIP(gs_zero_async(v_packed, sizeof(float) * (size_t)rec_stride * (size_t)V, s));
     if (n_isects == 0 || V == 0) return GS_OK;
     const int tiles = ((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
     const RasterWs r = carve((void*)ws, n_isects, V, tiles);
@@ -2053,7 +2053,7 @@ extern "C" int gs_selftest_rcp(uint32_t lo_bits, uint32_t hi_bits, uint64_t* mis
 {
     GS_CHECK_ARG(mismatches_dev != nullptr && hi_bits >= lo_bits, "bad range");
     hipStream_t s = (hipStream_t)stream;
-    GS_CHECK_HIP(hipMemsetAsync(mismatches_dev, 0, sizeof(uint64_t), s));
+    GS_CHECK_HIP(gs_zero_async(mismatches_dev, sizeof(uint64_t), s));
     hipLaunchKernelGGL(selftest_rcp_kernel, dim3(4096), dim3(256), 0, s, lo_bits, hi_bits, (unsigned long long*)mismatches_dev);
     GS_CHECK_LAUNCH();
     return GS_OK;
@@ -2084,7 +2084,7 @@ extern "C" int gs_selftest_exp(uint32_t lo_bits, uint32_t hi_bits, uint64_t* out
 {
     GS_CHECK_ARG(out_dev != nullptr && hi_bits >= lo_bits, "bad range");
     hipStream_t s = (hipStream_t)stream;
-    GS_CHECK_HIP(hipMemsetAsync(out_dev, 0, 2 * sizeof(uint64_t), s));
+    GS_CHECK_HIP(gs_zero_async(out_dev, 2 * sizeof(uint64_t), s));
     hipLaunchKernelGGL(selftest_exp_kernel, dim3(4096), dim3(256), 0, s, lo_bits, hi_bits, (unsigned long long*)out_dev);
     GS_CHECK_LAUNCH();
     return GS_OK;

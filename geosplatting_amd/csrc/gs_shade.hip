@@ -481,7 +481,7 @@ extern "C" int gs_shade_bwd(int N, const float* means, const float* normals, con
     const int max_blocks = used > 0 ? 256 * per_cu : 2048;
     if (blocks > max_blocks) blocks = max_blocks;
     if (use_priv) {
-        GS_CHECK_HIP(hipMemsetAsync(ws, 0, priv_floats * sizeof(float) * GS_XCD_COPIES, s));
+        GS_CHECK_HIP(gs_zero_async(ws, priv_floats * sizeof(float) * GS_XCD_COPIES, s));
 #define GS_SHADE_LAUNCH(P, B)                                                                                                   \
         do {                                                                                                                    \
             GS_CHECK_HIP(hipFuncSetAttribute((const void*)shade_bwd_kernel<P, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
@@ -595,7 +595,7 @@ extern "C" int gs_tonemap_bwd3(int64_t P, int mode, const float* render, const f
 {
     GS_CHECK_ARG(P >= 0 && mode >= 0 && mode <= 2, "bad P or mode");
     hipStream_t s = (hipStream_t)stream;
-    if (!accumulate) GS_CHECK_HIP(hipMemsetAsync(v_exposure, 0, sizeof(float), s));
+    if (!accumulate) GS_CHECK_HIP(gs_zero_async(v_exposure, sizeof(float), s));
     if (P == 0) return GS_OK;
     const int blocks = (int)((P + 255) / 256 < 1024 ? (P + 255) / 256 : 1024);
     hipLaunchKernelGGL(tonemap_bwd3_kernel, dim3(blocks), dim3(256), 0, s, P, mode, render, alphas, exposure, (const float4*)v_out,
@@ -620,7 +620,7 @@ extern "C" int gs_tonemap_bwd(int64_t P, int mode, const float* rgba, const floa
 {
     GS_CHECK_ARG(P >= 0 && mode >= 0 && mode <= 2, "bad P or mode");
     hipStream_t s = (hipStream_t)stream;
-    if (!accumulate) GS_CHECK_HIP(hipMemsetAsync(v_exposure, 0, sizeof(float), s));
+    if (!accumulate) GS_CHECK_HIP(gs_zero_async(v_exposure, sizeof(float), s));
     if (P == 0) return GS_OK;
     const int blocks = (int)((P + 255) / 256 < 1024 ? (P + 255) / 256 : 1024);
     hipLaunchKernelGGL(tonemap_bwd_kernel, dim3(blocks), dim3(256), 0, s, P, mode, (const float4*)rgba, exposure,

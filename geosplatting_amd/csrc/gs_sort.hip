@@ -720,7 +720,7 @@ static int isect_bin_impl(int V, const float* means2d, const int32_t* radii, con
     unsigned* dstatus = tickets + 8; unsigned* tstatus = dstatus + 4 * bv * 256;
     int rc = GS_OK;
     if (onesweep) {
-        GS_CHECK_HIP(hipMemsetAsync(os, 0, onesweep_bytes(V, n_isects), s));
+        GS_CHECK_HIP(gs_zero_async(os, onesweep_bytes(V, n_isects), s));
         hipLaunchKernelGGL(depth_hist4_kernel, dim3(gs_cdiv(V, 256 * 8) < 1024 ? gs_cdiv(V, 256 * 8) : 1024), dim3(256), 0, s, V, depths, dhist);
         GS_CHECK_LAUNCH();
         // 1. depth order of the Gaussians: four stable 8-bit passes over (depth bits, index), one launch each

@@ -244,7 +244,7 @@ tile_symmetry_check_kernel(int R, const float* __restrict__ bounds, const float4
 extern "C" int gs_specular_tiles_check(int R, const float* bounds, const float* dir_table, uint64_t* out2, void* stream)
 {
     GS_CHECK_ARG(R >= 1 && bounds && dir_table && out2, "bad arguments");
-    GS_CHECK_HIP(hipMemsetAsync(out2, 0, 2 * sizeof(uint64_t), (hipStream_t)stream));
+    GS_CHECK_HIP(gs_zero_async(out2, 2 * sizeof(uint64_t), (hipStream_t)stream));
     hipLaunchKernelGGL(tile_symmetry_check_kernel, dim3(gs_cdiv(6 * R * R, 256)), dim3(256), 0, (hipStream_t)stream, R, bounds,
                        (const float4*)dir_table, (unsigned long long*)out2);
     GS_CHECK_LAUNCH();

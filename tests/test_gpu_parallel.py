@@ -183,6 +183,33 @@ def test_views_segment_captured_in_hip_graph():
     assert float(ref[0]["cubemap"].abs().sum()) > 0
 
 
+def test_graph_replay_behind_a_finished_eager_kernel():
+    """Regression: a replay of the captured views launched on an idle device behind a short eager kernel (what a host-synchronous
+    collective in front of the replay produces) took 1-20 s and later faulted -- the chained-scan state of the projection was cleared
+    by a hipMemsetAsync NODE that the runtime no longer ordered in front of the kernel.  Every clear on a capturable path is a
+    kernel now (gs_zero_async); the replay must take its normal time and give the same results."""
+    import time
+    dev = torch.device("cuda", 0)
+    step, run = _engine(dev)
+    run()
+    assert step.poll_capacity(wait=True) and step._i_cap is not None
+    graphed = step.capture_views(step_cams, step_up, all_reduce=False, keep_images=True)
+    ref = run()
+    graphed(); torch.cuda.synchronize()
+    one = torch.zeros(1024, device=dev)
+    times = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        one.add_(1.0); time.sleep(0.01)                               # the eager kernel has long finished when the graph is launched
+        t0 = time.perf_counter()
+        grads, images = graphed()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    assert graphed.check()
+    assert max(times) < 0.25, times                                   # (normal: a few milliseconds; the bug: > 1 s at this size)
+    _same(ref, ({n: v.detach().cpu().clone() for n, v in grads.items()}, [im.detach().cpu().clone() for im in images]))
+
+
 def test_capacity_follows_changing_views():
     """Thirty steps over changing camera subsets and resolutions' worth of intersection counts: the capacity only ever grows to
     1.25 x the largest count seen, every step is either complete or reported (and then repeated), the pool of pinned count

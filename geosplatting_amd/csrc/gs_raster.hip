@@ -630,6 +630,19 @@ __device__ __forceinline__ int gs_pop_lowest(unsigned long long& list)
     return (int)min(flo, fhi + 32u);
 }
 
+// sigma(dx, dy) = fma(ha dx, dx, fma(hc dy, dy, (cb dx) dy)) for ONE record from d = {dx, dy}, p = {ha dx, cb dx}.  The four scalar
+// operations are inline assembly only so that the SLP vectoriser does not pair them with the other candidate's (it did, at the price
+// of eight v_mov per trip to line the operands up); v_mul_f32 / v_fma_f32 are the instructions the compiler emits for the same C.
+__device__ __forceinline__ float gs_sigma_xy(v2f d, v2f p, float hc)
+{
+    float t1, q, r, sg;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(t1) : "v"(hc), "v"(d.y));
+    asm("v_mul_f32 %0, %1, %2" : "=v"(q) : "v"(p.y), "v"(d.y));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(t1), "v"(d.y), "v"(q));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(sg) : "v"(p.x), "v"(d.x), "v"(r));
+    return sg;
+}
+
 // gs_exp_neg for two candidates at once, for callers that discard results below 1/255: without the flush to zero below 2^-125
 // and the upper clamp (sigma < 0 is rejected by the caller), which changes no result that survives the alpha >= 1/255 test --
 // those have y >= -8.  The lower clamp stays: it turns an infinite or NaN y into -126 instead of a NaN that fminf would drop.
@@ -999,6 +1012,7 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
     const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
     const bool inside = pxi < W && pyi < H;
     const float px = (float)pxi + 0.5f, py = (float)pyi + 0.5f;
+    const v2f pxy = v2f{px, py};
     LaneQueue q;
     {
         unsigned char* base = gs_lds_raw + (size_t)wave * GS_WIN_Q_BYTES;
@@ -1089,9 +1103,12 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
             v2f alpha; bool ok[2];
             {
 #pragma clang fp contract(off)
-                const v2f dx = v2f{ca[0].x, ca[1].x} - px, dy = v2f{ca[0].y, ca[1].y} - py;
-                const v2f t0 = v2f{ca[0].z, ca[1].z} * dx, t1 = v2f{cb[0].x, cb[1].x} * dy, t2 = v2f{ca[0].w, ca[1].w} * dx;
-                const v2f sigma = __builtin_elementwise_fma(t0, dx, __builtin_elementwise_fma(t1, dy, t2 * dy));
+                // (packed over (x, y) of one record, see the backward walk: same operations in the same order)
+                const v2f d0 = v2f{ca[0].x, ca[0].y} - pxy, d1 = v2f{ca[1].x, ca[1].y} - pxy;
+                const v2f p0 = v2f{ca[0].z, ca[0].w} * v2f{d0.x, d0.x}, p1 = v2f{ca[1].z, ca[1].w} * v2f{d1.x, d1.x};
+                v2f sigma;
+                sigma.x = gs_sigma_xy(d0, p0, cb[0].x);
+                sigma.y = gs_sigma_xy(d1, p1, cb[1].x);
                 alpha = __builtin_elementwise_min(v2f{cb[0].y, cb[1].y} * gs_exp_neg_live2(sigma), (v2f)(0.999f));
                 ok[0] = has[0] && sigma.x >= 0.0f && alpha.x >= GS_ALPHA_MIN;
                 ok[1] = has[1] && sigma.y >= 0.0f && alpha.y >= GS_ALPHA_MIN;
@@ -1401,6 +1418,7 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
     const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
     const bool inside = pxi < W && pyi < H;
     const float px = (float)pxi + 0.5f, py = (float)pyi + 0.5f;
+    const v2f pxy = v2f{px, py};
 
     const int start = offsets[tile];
     const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
@@ -1553,9 +1571,13 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
             v2f sigma, ov, alpha, ra;
             {
 #pragma clang fp contract(off)
-                const v2f dx = v2f{a0.x, a1.x} - px, dy = v2f{a0.y, a1.y} - py;
-                const v2f t0 = v2f{a0.z, a1.z} * dx, t1 = v2f{b0.x, b1.x} * dy, t2 = v2f{a0.w, a1.w} * dx;
-                sigma = __builtin_elementwise_fma(t0, dx, __builtin_elementwise_fma(t1, dy, t2 * dy));
+                // sigma per candidate, packed over (x, y) of ONE record -- the operands arrive that way from the 16-byte LDS read; packing
+                // over the two candidates cost nine v_mov per trip to pair their fields up.  Same operations, same order:
+                // sigma = fma(ha dx, dx, fma(hc dy, dy, (cb dx) dy)).
+                const v2f d0 = v2f{a0.x, a0.y} - pxy, d1 = v2f{a1.x, a1.y} - pxy;                 // {dx, dy}
+                const v2f p0 = v2f{a0.z, a0.w} * v2f{d0.x, d0.x}, p1 = v2f{a1.z, a1.w} * v2f{d1.x, d1.x};   // {ha dx, cb dx}
+                sigma.x = gs_sigma_xy(d0, p0, b0.x);
+                sigma.y = gs_sigma_xy(d1, p1, b1.x);
                 ov = v2f{b0.y, b1.y} * gs_exp_neg_live2(sigma);
                 alpha = __builtin_elementwise_min(ov, (v2f)(0.999f));
                 ra = gs_rcp_exact2((v2f)(1.0f) - alpha);

@@ -12,6 +12,7 @@ Order of work per step (all on the current HIP stream, kernels in libgeosplat_hi
 """
 from __future__ import annotations
 
+import collections
 import os
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Sequence
@@ -74,6 +75,9 @@ class RenderStep:
         self._pre_group = None
         self.truncated_steps = 0           # steps whose overflow word was seen set (each was composited from a truncated list)
         self._overflow_unreported = False  # an overflow seen by the poll inside __call__ that no caller has been told about yet
+        n_fly = int(os.environ.get("GEOSPLAT_STEPS_IN_FLIGHT", "2"))
+        self._max_in_flight = max(1, n_fly)
+        self._in_flight = collections.deque() if n_fly > 0 else None     # end-of-step events of the steps the GPU has not finished (None: unbounded)
 
     def _prefilter_group(self):
         """A second communicator for the prefilter exchange (25 MB all-reduce + two rounds of small all-gathers), so that it
@@ -530,6 +534,22 @@ class RenderStep:
         step.graph = graph
         return step
 
+    def _throttle(self) -> None:
+        """Bound how far the host runs ahead of the GPU.  The step has no host synchronisation, the host enqueues it in 3-5 ms
+        against 15 ms on the GPU, and HIP queues without limit: after 400 steps the host was 200 steps ahead and the caching
+        allocator -- whose blocks are only reusable once the streams they were recorded on have passed them -- held 186 GiB for
+        a step whose live memory is 3.8 GiB (scripts/soak.py).  At most GEOSPLAT_STEPS_IN_FLIGHT (default 2) steps are enqueued
+        beyond the one the GPU is working on; the wait polls the event (no blocking call: the step stays clean under
+        torch.cuda.set_sync_debug_mode) and never leaves the GPU idle, since one whole step is still queued behind it."""
+        if self._in_flight is None:
+            return
+        import time
+        while len(self._in_flight) >= self._max_in_flight:
+            ev = self._in_flight[0]
+            while not ev.query():
+                time.sleep(5e-5)
+            self._in_flight.popleft()
+
     def poll_capacity(self, wait: bool = False, _internal: bool = False) -> bool:
         """Host side of the capacity protocol; never blocks unless `wait`.  Looks at what the earlier steps left in pinned memory:
         the per-view (V, I) counts set / raise the intersection capacity (1.25 x the largest count seen, rounded up to 64 Ki),
@@ -585,7 +605,12 @@ class RenderStep:
         if self.fused and self.mode == "pbr":
             self.poll_capacity(_internal=True)               # non-blocking: counts / overflow word of the earlier steps (an overflow
                                                              # seen here is kept for the caller's next poll_capacity())
-            return self._step_fused(cameras, upstream, all_reduce, keep_images)
+            self._throttle()
+            out = self._step_fused(cameras, upstream, all_reduce, keep_images)
+            if self._in_flight is not None:
+                ev = torch.cuda.Event(); ev.record()
+                self._in_flight.append(ev)
+            return out
         p = self.p
         leaves = {k: v.detach().requires_grad_(True) for k, v in p.named().items()}
         if self.prefilter:

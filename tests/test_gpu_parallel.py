@@ -210,6 +210,25 @@ def test_graph_replay_behind_a_finished_eager_kernel():
     _same(ref, ({n: v.detach().cpu().clone() for n, v in grads.items()}, [im.detach().cpu().clone() for im in images]))
 
 
+def test_host_lead_is_bounded():
+    """The step never synchronises, so nothing but the engine keeps the host from running hundreds of steps ahead of the GPU -- and the
+    caching allocator from holding the buffers of all of them (186 GiB after 400 bench steps before the bound existed).  At most
+    GEOSPLAT_STEPS_IN_FLIGHT (2) unfinished steps are outstanding, and the reserved memory stops growing."""
+    dev = torch.device("cuda", 0)
+    step, run = _engine(dev)
+    for _ in range(6):
+        run()
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_reserved(dev)
+    for _ in range(60):
+        step(step_cams, step_up, all_reduce=False)
+        assert len(step._in_flight) <= step._max_in_flight == 2
+    grown = torch.cuda.memory_reserved(dev) - base
+    torch.cuda.synchronize()
+    assert step.poll_capacity(wait=True)
+    assert grown <= 0.5 * base + (64 << 20), (grown, base)
+
+
 def test_capacity_follows_changing_views():
     """Thirty steps over changing camera subsets and resolutions' worth of intersection counts: the capacity only ever grows to
     1.25 x the largest count seen, every step is either complete or reported (and then repeated), the pool of pinned count

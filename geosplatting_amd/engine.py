@@ -75,7 +75,7 @@ class RenderStep:
         self._pre_group = None
         self.truncated_steps = 0           # steps whose overflow word was seen set (each was composited from a truncated list)
         self._overflow_unreported = False  # an overflow seen by the poll inside __call__ that no caller has been told about yet
-        n_fly = int(os.environ.get("GEOSPLAT_STEPS_IN_FLIGHT", "2"))
+        n_fly = int(os.environ.get("GEOSPLAT_STEPS_IN_FLIGHT", "3"))
         self._max_in_flight = max(1, n_fly)
         self._in_flight = collections.deque() if n_fly > 0 else None     # end-of-step events of the steps the GPU has not finished (None: unbounded)
 
@@ -538,7 +538,7 @@ class RenderStep:
         """Bound how far the host runs ahead of the GPU.  The step has no host synchronisation, the host enqueues it in 3-5 ms
         against 15 ms on the GPU, and HIP queues without limit: after 400 steps the host was 200 steps ahead and the caching
         allocator -- whose blocks are only reusable once the streams they were recorded on have passed them -- held 186 GiB for
-        a step whose live memory is 3.8 GiB (scripts/soak.py).  At most GEOSPLAT_STEPS_IN_FLIGHT (default 2) steps are enqueued
+        a step whose live memory is 3.8 GiB (scripts/soak.py).  At most GEOSPLAT_STEPS_IN_FLIGHT (default 3) steps are enqueued
         beyond the one the GPU is working on; the wait polls the event (no blocking call: the step stays clean under
         torch.cuda.set_sync_debug_mode) and never leaves the GPU idle, since one whole step is still queued behind it."""
         if self._in_flight is None:

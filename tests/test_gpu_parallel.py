@@ -213,7 +213,7 @@ def test_graph_replay_behind_a_finished_eager_kernel():
 def test_host_lead_is_bounded():
     """The step never synchronises, so nothing but the engine keeps the host from running hundreds of steps ahead of the GPU -- and the
     caching allocator from holding the buffers of all of them (186 GiB after 400 bench steps before the bound existed).  At most
-    GEOSPLAT_STEPS_IN_FLIGHT (2) unfinished steps are outstanding, and the reserved memory stops growing."""
+    GEOSPLAT_STEPS_IN_FLIGHT (3) unfinished steps are outstanding, and the reserved memory stops growing."""
     dev = torch.device("cuda", 0)
     step, run = _engine(dev)
     for _ in range(6):
@@ -222,7 +222,7 @@ def test_host_lead_is_bounded():
     base = torch.cuda.memory_reserved(dev)
     for _ in range(60):
         step(step_cams, step_up, all_reduce=False)
-        assert len(step._in_flight) <= step._max_in_flight == 2
+        assert len(step._in_flight) <= step._max_in_flight == 3
     grown = torch.cuda.memory_reserved(dev) - base
     torch.cuda.synchronize()
     assert step.poll_capacity(wait=True)

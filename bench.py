@@ -311,6 +311,8 @@ def main():
 
     n_settle = 0
     if args.settle_seconds > 0 and len(cams) > 0:          # clocks / allocator / capacity settle; identical on every rank (fixed step count)
+        one_step(); torch.cuda.synchronize()               # (the first step builds the prefilter tables and learns the capacity)
+        step.poll_capacity(wait=True)
         t_s = time.perf_counter()
         one_step(); torch.cuda.synchronize()
         per = max(time.perf_counter() - t_s, 1e-3)

@@ -11,10 +11,13 @@ Workload (BASELINE.json `metric`: "fwd+bwd views/sec at 2M Gaussians, 800x800"):
   tests/model/test_geosplat.py:28):
       split-sum prefilter forward (S5) -> 8 x [shade -> project/bin/sort/composite -> tone-map, then the backward of
       all of it] -> prefilter backward -> (N>1) one flat RCCL all-reduce of all parameter gradients.
-  value = views/sec = 8 * N / (max-over-ranks step time).  Weak scaling (default): every GPU renders its own 8 views.
-  --views-total V: STRONG scaling -- the reference batch of V views (8) is spread over the N GPUs, view i -> rank i mod N
-  (one view per GPU at N = 8, BASELINE.json config 4); value = V / step time.  With N > 1 the split-sum prefilter is sharded
-  over the ranks (geosplatting_amd/splitsum.py) in both modes.
+  DEFAULT = the north star's split (BASELINE.json north_star / config 4): STRONG scaling -- the reference batch of 8 views is
+  spread over the N GPUs, view i -> rank i mod N (one view per GPU at N = 8); value = 8 / (max-over-ranks step time); a rank with
+  at most two views replays them as one HIP graph, prefilter and collectives stay eager around it.  At N = 1 this is the same
+  workload as before (8 views on the one GPU).  --views-total V changes the batch; --weak restores weak scaling (every GPU
+  renders its own --views views, value = views * N / step time).  With N > 1 the split-sum prefilter is sharded over the ranks
+  (geosplatting_amd/splitsum.py) in both modes.  `scale_model` in the line is the prediction for N = 1, 2, 4, 8 from the
+  single-GPU measurements (view alone, prefilter alone, bytes per collective over xGMI) that a hardware curve is to be read against.
 """
 import argparse
 import ctypes as C
@@ -45,7 +48,8 @@ def parse():
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--views", type=int, default=8, help="views per step per GPU (reference batch_size = 8)")
     ap.add_argument("--views-total", type=int, default=0,
-                    help="strong scaling: this many views per step over ALL GPUs (view i -> rank i mod N); 0 = weak scaling")
+                    help="strong scaling (default): this many views per step over ALL GPUs (view i -> rank i mod N); 0 = --views (8)")
+    ap.add_argument("--weak", action="store_true", help="weak scaling instead: every GPU renders its own --views views per step")
     ap.add_argument("--cubemap-res", type=int, default=512)
     ap.add_argument("--no-prefilter", action="store_true", help="diagnostic only: keep the pyramid fixed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -201,6 +205,49 @@ def prefilter_report(cubemap, iters):
     return out
 
 
+XGMI_LINK_GBS = 153.0       # one xGMI link, one direction (MI355X: 7 links per GPU, fully connected 8-GPU node)
+
+
+def scale_model(view_ms, pre, n_gauss, cubemap_res, views_total, measured_1gpu_ms):
+    """Prediction of the STRONG-scaling step (views_total views over G GPUs, view i -> rank i mod G) from single-GPU measurements,
+    to be read beside the hardware curve: ceil(views/G) views at the time of one view alone (graph replay, pyramid fixed), the
+    tiled prefilter at 1/G, and the collectives of a step at the xGMI rate.  all-reduce of S bytes over G fully connected GPUs as
+    reduce-scatter + all-gather with every peer link in use: 2 (G-1)/G S / ((G-1) x 153 GB/s); on ONE link (a ring): x (G-1).
+    The per-Gaussian all-reduce overlaps the prefilter backward (engine._finish)."""
+    if view_ms is None:
+        return None
+    res, tiled = cubemap_res, []
+    while res >= 16:
+        tiled.append(res); res //= 2
+    pyramid = sum(6 * r * r * 3 * 4 for r in tiled if r >= 64)               # levels the tiled operator covers (splitsum.tiles_eligible)
+    texel = sum(6 * r * r * 3 * 4 for r in tiled) + 6 * 16 * 16 * 3 * 4        # base + every level: one flat buffer
+    per_gauss = 76 * n_gauss
+    pre_fwd = pre["fwd_ms"] if pre else 0.0
+    pre_bwd = pre["bwd_ms"] if pre else 0.0
+    coll = {"pyramid_allreduce_bytes": pyramid, "texel_grad_allreduce_bytes": texel, "per_gaussian_grad_allreduce_bytes": per_gauss,
+            "cubemap_grad_pieces_allreduce_bytes": pyramid, "exposure_allreduce_bytes": 4}
+    rows = []
+    for G in (1, 2, 4, 8):
+        vpr = -(-views_total // G)
+        if G == 1:
+            rows.append({"gpus": 1, "views_per_gpu": vpr, "step_ms": measured_1gpu_ms,
+                         "views_per_s": None if not measured_1gpu_ms else views_total / measured_1gpu_ms * 1e3,
+                         "basis": "measured (this run)" if measured_1gpu_ms else "not measured in this run"})
+            continue
+        t = lambda S: 2.0 * (G - 1) / G * S / ((G - 1) * XGMI_LINK_GBS * 1e9) * 1e3       # ms, every peer link in use
+        small = t(pyramid) + t(texel) + t(pyramid)
+        tail = max(pre_bwd / G, t(per_gauss))                                            # the 76 B x N all-reduce runs under the prefilter backward
+        step = vpr * view_ms + pre_fwd / G + small + tail
+        ring = vpr * view_ms + pre_fwd / G + (G - 1) * small + max(pre_bwd / G, (G - 1) * t(per_gauss))
+        rows.append({"gpus": G, "views_per_gpu": vpr, "view_ms": vpr * view_ms, "prefilter_ms": (pre_fwd + pre_bwd) / G,
+                     "collectives_ms_all_links": small + t(per_gauss), "collectives_ms_one_link_ring": (G - 1) * (small + t(per_gauss)),
+                     "step_ms": step, "views_per_s": views_total / step * 1e3,
+                     "step_ms_one_link_ring": ring, "views_per_s_one_link_ring": views_total / ring * 1e3})
+    return {"link_GBs": XGMI_LINK_GBS, "collectives": coll, "view_ms_alone": view_ms, "prefilter_fwd_ms": pre_fwd, "prefilter_bwd_ms": pre_bwd,
+            "rows": rows, "note": "prediction, not a measurement: latency of the five collectives (tens of microseconds each) and the host's "
+                                  "eager launches around the graph replay are not modelled"}
+
+
 def cpu_baseline_cfg1():
     """BASELINE.json configs[0]: 10k random Gaussians, 256x256, 4 orbit views, fwd+bwd on the CPU oracle (rasterizer only, as
     that config has no shading); median of 5 runs after one warm-up."""
@@ -297,8 +344,8 @@ def main():
     torch.manual_seed(1)
     scene = syn.sphere_scene(args.level, seed=1, cubemap_res=args.cubemap_res, device=dev)
     N = scene.splats.num
-    strong = args.views_total > 0
-    views_total = args.views_total if strong else args.views * world
+    strong = not args.weak
+    views_total = (args.views_total or args.views) if strong else args.views * world
     all_cams = syn.blender_cameras(num=views_total, width=args.res, height=args.res)
     cams = [all_cams[i] for i in range(rank, views_total, world)]                # view i -> rank i mod world
     params = params_from_scene(scene, dev)
@@ -359,6 +406,19 @@ def main():
                 "n_isects_cap": step._i_cap, "overflow_in_timed_steps": (not cap_ok), "truncated_steps": step.truncated_steps,
                 "untimed_settle_steps_before_warmup": n_settle,
                 "hip_graph": ({1: "whole step", 2: "views segment (prefilter and collectives eager)"}[args.graph] if graphed is not None else False)}
+    # the compositor launches INSIDE the step (they share the CUs with the front / tail streams there): HIP events on the stream they
+    # are launched on, three extra untimed steps; not available when the views are replayed from a graph
+    engine_ms = None
+    if graphed is None and len(cams) > 0 and world == 1:      # (single process only: extra steps would have to be agreed on by all ranks)
+        step.kernel_events = []
+        for _ in range(3):
+            one_step()
+        torch.cuda.synchronize()
+        acc = {}
+        for name, a, b in step.kernel_events:
+            acc.setdefault(name, []).append(a.elapsed_time(b))
+        step.kernel_events = None
+        engine_ms = {k: sum(v) / len(v) for k, v in acc.items()} or None
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -406,12 +466,13 @@ def main():
         valu_tf = None if not pairs_valid else pairs_valid * (FLOPS_FWD_PER_PAIR + FLOPS_BWD_PER_PAIR) / t_pair / 1e12
         dom_flops = FLOPS_FWD_PER_PAIR if dom == "raster_fwd_kernel" else FLOPS_BWD_PER_PAIR
         dom_tf = None if not pairs_valid else pairs_valid * dom_flops / (kt[dom] * 1e-3) / 1e12
+        dom_tf_engine = None if not (pairs_valid and engine_ms and engine_ms.get(dom)) else pairs_valid * dom_flops / (engine_ms[dom] * 1e-3) / 1e12
         # committed counter summaries, quoted only while gs_raster.hip is the source they were measured on
-        stats_name = "r03_raster_stats.json" if committed_profile("r03_raster_stats.json", "gs_raster.hip") else "r02_raster_stats.json"
-        pmc_name = "r03_pmc_traffic.json" if committed_profile("r03_pmc_traffic.json", "gs_raster.hip") else "r02_pmc_traffic.json"
+        first = lambda stem: next((f"r{r:02d}_{stem}" for r in (4, 3, 2) if committed_profile(f"r{r:02d}_{stem}", "gs_raster.hip")), f"r04_{stem}")
+        stats_name, pmc_name = first("raster_stats.json"), first("pmc_traffic.json")
         stats = committed_profile(stats_name, "gs_raster.hip")
         pmc = committed_profile(pmc_name, "gs_raster.hip")
-        engine = committed_profile("r03_engine_kernel_ms.json", "gs_raster.hip")      # averages under the three-stream overlap
+        engine = {"kernel_ms": engine_ms} if engine_ms else None                     # measured live, inside the step (see above)
         lane_util = None
         if stats and args.level == 7 and args.res == 800:
             key = "fwd" if dom == "raster_fwd_kernel" else "bwd"
@@ -424,6 +485,7 @@ def main():
             traffic = pmc["kernels"][dom]["hbm_bytes"]
             traffic_src = (f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes per launch, "
                            f"measured at commit {pmc.get('commit', '?')} on this kernel source)")
+        pre = None if args.no_prefilter else prefilter_report(params.cubemap, max(3, args.kernel_iters // 2))
         result = {
             "metric": "fwd+bwd views/sec at 2M Gaussians, 800x800",
             "value": views_per_s, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -435,8 +497,11 @@ def main():
                                    + f", prefilter fwd+bwd {'in' if not args.no_prefilter else 'EXCLUDED from'} every step",
                        "N": N, "V": V, "I": I, "P": P, "views_per_step_total": views_total,
                        "parallelism": f"dp{world} (views sharded, prefilter sharded, flat RCCL all-reduce of per-Gaussian grads)"},
-            "roofline": {"bound": "valu", "kernel": dom, "launched_as": LAUNCHED_AS[dom], "achieved": dom_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": None if dom_tf is None else dom_tf / VALU_PEAK_TFLOPS,
+            "roofline": {"bound": "valu", "kernel": dom, "launched_as": LAUNCHED_AS[dom],
+                         "achieved": dom_tf_engine if dom_tf_engine is not None else dom_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": None if (dom_tf_engine or dom_tf) is None else (dom_tf_engine or dom_tf) / VALU_PEAK_TFLOPS,
+                         "frac_basis": "in-engine launch duration (HIP events inside the step)" if dom_tf_engine is not None else "kernel alone",
+                         "achieved_alone": dom_tf, "frac_alone": None if dom_tf is None else dom_tf / VALU_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "pairs_valid": pairs_valid, "flops_per_pair": {"fwd": FLOPS_FWD_PER_PAIR, "bwd": FLOPS_BWD_PER_PAIR},
                          "compositor_fwd_plus_bwd": {"achieved_TFLOPs": valu_tf,
@@ -448,16 +513,18 @@ def main():
                          pairs_valid * dom_flops / (engine["kernel_ms"][dom] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
                          "hbm": {"algorithmic_bytes": kbytes[dom], "achieved_GBs": hbm_achieved, "peak_GBs": HBM_PEAK_GBS,
                                  "frac": hbm_achieved / HBM_PEAK_GBS},
-                         "note": "`achieved` / `frac` / `kernel_ms`: kernels timed ALONE with HIP events on the launch stream (gs_raster_composite / "
-                                 "gs_raster_bwd_acc: no stream build, no memset); `kernel_ms_in_engine` / `frac_in_engine`: rocprofv3 averages of the "
-                                 "same kernels inside the three-stream step (profiles/r03_engine_kernel_ms.json, where they share the CUs with the "
-                                 "front and tail streams); useful flops = composited (pixel, Gaussian) pairs x flops per pair"},
+                         "note": "`achieved` / `frac`: the dominant kernel's launches INSIDE the step (HIP events on the compositor stream, where it "
+                                 "shares the CUs with the front and tail streams: `kernel_ms_in_engine`) -- the figure that matches `value`; "
+                                 "`achieved_alone` / `frac_alone` / `kernel_ms`: the same kernels timed ALONE (gs_raster_composite / gs_raster_bwd_acc: no "
+                                 "stream build, no memset); useful flops = composited (pixel, Gaussian) pairs x flops per pair"},
             "view_roofline": {"algorithmic_bytes_per_view": view_bytes,
                               "achieved_GBs": view_bytes * views_per_s / world / 1e9,
                               "frac_of_8TBs": view_bytes * views_per_s / world / 1e9 / HBM_PEAK_GBS},
+            "strong_1gpu_ms": ms_per_step if (world == 1 and strong) else None,
+            "scale_model": scale_model(view_ms, pre, N, args.cubemap_res, views_total, ms_per_step if world == 1 else None),
             "gpu_view_ms_without_prefilter": view_ms,
             "gpu_view_ms_detail": view_detail,
-            "prefilter": None if args.no_prefilter else prefilter_report(params.cubemap, max(3, args.kernel_iters // 2)),
+            "prefilter": pre,
             "capacity_protocol": capacity,
         }
         if cb is not None:

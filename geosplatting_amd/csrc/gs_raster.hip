@@ -41,6 +41,17 @@ extern "C" int gs_raster_stats_read(unsigned long long* host8, int reset)
     if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_raster_stats), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
+// second bank (round 4): what the UNUSED candidate slots of the backward walk are.  [0] candidates popped by the backward walk, [1] its
+// dense batches, [2] popped but rejected because the pixel had terminated in front of the record (idx > last_ids), [3] popped but
+// rejected by sigma < 0 / alpha < 1/255 (the slack of the ellipse masks), [4] forward: candidates popped, [5] forward: dense batches,
+// [6] backward: sum over dense batches of the LONGEST per-pixel list (lock-step length), [7] backward: sum of the reduction's trips
+__device__ unsigned long long g_raster_stats2[8];
+extern "C" int gs_raster_stats2_read(unsigned long long* host8, int reset)
+{
+    if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_raster_stats2), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_raster_stats2), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
 // per-block timeline (diagnostic, -DGS_RASTER_PHASES): [3 * b] = first wave start, [3 * b + 1] = last wave end (100 MHz wall clock),
 // [3 * b + 2] = list length of the tile
 #define GS_TL_MAX 16384
@@ -60,17 +71,25 @@ extern "C" int gs_raster_timeline_read(unsigned long long* host, int n_blocks, i
 #endif
 #define GS_STAT(i, v) do { const unsigned long long _sv = (unsigned long long)(v); if ((threadIdx.x & 63) == 0) atomicAdd(&g_raster_stats[i], _sv); } while (0)
 #define GS_STAT_ALL(i, v) atomicAdd(&g_raster_stats[i], (unsigned long long)(v))      /* every active lane adds */
+#define GS_STAT2(i, v) do { const unsigned long long _sv = (unsigned long long)(v); if ((threadIdx.x & 63) == 0) atomicAdd(&g_raster_stats2[i], _sv); } while (0)
+#define GS_STAT2_ALL(i, v) atomicAdd(&g_raster_stats2[i], (unsigned long long)(v))
 #ifdef GS_RASTER_PHASES            /* cycles of wave 0 of the LONGEST tile (block 0 in LPT order) per phase: overrides the counters above */
 #undef GS_STAT
 #undef GS_STAT_ALL
+#undef GS_STAT2
+#undef GS_STAT2_ALL
 #define GS_STAT(i, v) do { } while (0)
 #define GS_STAT_ALL(i, v) do { } while (0)
+#define GS_STAT2(i, v) do { } while (0)
+#define GS_STAT2_ALL(i, v) do { } while (0)
 #define GS_PHASE_BEGIN() const long long _ph0 = (blockIdx.x == 0 && threadIdx.x == 0) ? (long long)__builtin_readcyclecounter() : 0
 #define GS_PHASE_END(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_raster_stats[i], (unsigned long long)((long long)__builtin_readcyclecounter() - _ph0)); } while (0)
 #endif
 #else
 #define GS_STAT(i, v) do { } while (0)
 #define GS_STAT_ALL(i, v) do { } while (0)
+#define GS_STAT2(i, v) do { } while (0)
+#define GS_STAT2_ALL(i, v) do { } while (0)
 #endif
 #ifndef GS_TL_BEGIN
 #define GS_TL_BEGIN(len) do { } while (0)
@@ -1071,6 +1090,9 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
             GS_STAT(1, nA);
             listA = gs_bit_transpose64(pm, lane);
             if (done) listA = 0ull;
+#ifdef GS_RASTER_STATS
+            GS_STAT2(5, 1); GS_STAT2_ALL(4, __popcll(listA));
+#endif
         }
         if (nB == 0 && qcount > nA) {
             nB = (qcount - nA) < 64 ? (qcount - nA) : 64;
@@ -1081,6 +1103,9 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
             GS_STAT(1, nB);
             listB = gs_bit_transpose64(pm, lane);
             if (done) listB = 0ull;
+#ifdef GS_RASTER_STATS
+            GS_STAT2(5, 1); GS_STAT2_ALL(4, __popcll(listB));
+#endif
         }
         // ---- walk until batch A is exhausted in every lane; lanes that are through with A work on B
         const int baseB = qhead + nA;
@@ -1544,6 +1569,13 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
         pbase[lane] = cum - cnt;
         unsigned long long list = gs_bit_transpose64(pm, lane);
         GS_STAT(5, nb);
+#ifdef GS_RASTER_STATS
+        GS_STAT2(1, 1);
+        GS_STAT2_ALL(0, __popcll(list));
+        { int _mx = __popcll(list);
+          for (int _o = 32; _o >= 1; _o >>= 1) _mx = max(_mx, __shfl_xor(_mx, _o, 64));
+          GS_STAT2(6, _mx); }
+#endif
         lanes_lds_sync();
         GS_PHASE_END(1);
         long long _pw0 = 0;
@@ -1596,6 +1628,7 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
                 T = ok0 ? Tn : T;
 #ifdef GS_RASTER_STATS
                 if (ok0) GS_STAT_ALL(7, 1);
+                if (has0 && !ok0) { if (idx0 > bin_final) GS_STAT2_ALL(2, 1); else GS_STAT2_ALL(3, 1); }
 #endif
                 if (has0) pairbuf[e0] = make_float2(s_out, fac);
             }
@@ -1611,6 +1644,7 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
                 T = ok1 ? Tn : T;
 #ifdef GS_RASTER_STATS
                 if (ok1) GS_STAT_ALL(7, 1);
+                if (has1 && !ok1) { if (idx1 > bin_final) GS_STAT2_ALL(2, 1); else GS_STAT2_ALL(3, 1); }
 #endif
                 if (has1) pairbuf[e1] = make_float2(s_out, fac);
             }
@@ -1629,6 +1663,7 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
             float m0 = 0.0f, mxy = 0.0f, c2 = 0.0f;
             v2f m1 = (v2f)(0.0f), m2 = (v2f)(0.0f), c01 = (v2f)(0.0f);
             while (__ballot(m != 0ull) != 0ull) {
+                GS_STAT2(7, 1);
 #ifdef GS_RASTER_PHASES
                 if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_raster_stats[7], 1ull);
 #endif

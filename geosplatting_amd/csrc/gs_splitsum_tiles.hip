@@ -508,11 +508,8 @@ extern "C" int gs_specular_tiles_apply(int R, int backward, int n_mirrors, int m
     const hipStream_t s = (hipStream_t)stream;
 #define GS_TILE_LAUNCH(BW, SH, GRID)                                                                                                   \
     do {                                                                                                                               \
-        static size_t configured = 0;                                                                                                  \
-        if (lds_bytes > configured) {                                                                                                  \
-            GS_CHECK_HIP(hipFuncSetAttribute((const void*)tile_apply_kernel<BW, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-            configured = lds_bytes;                                                                                                    \
-        }                                                                                                                              \
+        /* set on EVERY launch (as gs_shade.hip does): the attribute is per device, a process may drive several GPUs / threads */     \
+        GS_CHECK_HIP(hipFuncSetAttribute((const void*)tile_apply_kernel<BW, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
         hipLaunchKernelGGL((tile_apply_kernel<BW, SH>), dim3(GRID), dim3(1024), lds_bytes, s, R, (BW) ? margin : 0, bw, nb, K, src, scale,  \
                            out_scale, bounds, (const int4*)tiles, (const int4*)segments, row_begin, row_counts, desc, weights, dst,   \
                            tile_begin, tile_end);                                                                                      \

@@ -68,8 +68,11 @@ class RenderStep:
         self._cap_margin = float(os.environ.get("GEOSPLAT_CAPACITY_MARGIN", "1.25"))   # capacity = margin x the largest count seen
         self._i_cap = None                 # intersection capacity per view; None = exact mode (one (V, I) read-back per view)
         self._status = None                # device int64[3]: {GS_ENOSPC or 0, max required I, max required V}
-        self._status_host = None
+        self._status_host = None           # pinned snapshot used by the graph-capture paths (one buffer, refreshed by every replay)
         self._status_event = None
+        self._status_pending = collections.deque()   # eager steps: (pinned snapshot of the word, event), one per step, each looked at ONCE
+        self._status_pool = []             # pinned int64[3] buffers waiting for reuse
+        self.kernel_events = None          # set to a list: (name, start event, end event) around the compositor launches (bench.py)
         self._seen_counts = []
         self._exact_max_i = 0              # largest intersection count read back by an exact-mode step
         self._pre_group = None
@@ -104,16 +107,24 @@ class RenderStep:
         c2w = cam.c2w
         key = id(c2w)
         intr = (float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy), int(cam.width), int(cam.height))
+        # host-resident poses also carry a content fingerprint (48 bytes): an in-place change that does not bump the version counter
+        # (`cam.c2w.data.copy_()`, a numpy-backed tensor written through numpy) cannot return stale matrices.  Device-resident poses
+        # rely on the version counter alone (a fingerprint would be a device-to-host copy); invalidate_cameras() drops everything.
+        fp = c2w.detach().numpy().tobytes() if c2w.device.type == "cpu" else None
         hit = self._cam_cache.get(key)
-        if hit is not None and hit[0] is c2w and hit[1] == c2w._version and hit[2] == intr:
+        if hit is not None and hit[0] is c2w and hit[1] == c2w._version and hit[2] == intr and hit[4] == fp:
             return hit[3]
         dev = self.p.means.device
         if len(self._cam_cache) >= 1024:
             self._cam_cache.pop(next(iter(self._cam_cache)))
         tensors = (cam.view_matrix.to(dev, torch.float32).contiguous(), cam.intrinsic_matrix.to(dev, torch.float32).contiguous(),
                    c2w.detach()[:, 3].to(dev, torch.float32).contiguous())
-        self._cam_cache[key] = (c2w, c2w._version, intr, tensors)
+        self._cam_cache[key] = (c2w, c2w._version, intr, tensors, fp)
         return tensors
+
+    def invalidate_cameras(self) -> None:
+        """Forget every cached (view matrix, K, position) triple: for callers that rewrite DEVICE-resident poses behind autograd's back."""
+        self._cam_cache.clear()
 
     def _step_fused(self, cameras, upstream, all_reduce, keep_images, _env=None, _stop_after_views=False):
         """Same arithmetic as the autograd path, driven directly through the C-ABI: every per-view backward ADDS into
@@ -259,6 +270,9 @@ class RenderStep:
             state, V, I, D, whs, ev, colors = binned
             main.wait_event(ev)
             P = W * H
+            kev = self.kernel_events
+            if kev is not None:
+                k0 = torch.cuda.Event(enable_timing=True); k0.record(main)
             if fused_tone:
                 # compositor with S4 in its epilogue: `img` comes out of the same launch (gs_raster_composite_tone)
                 render = torch.empty(H, W, 3, dtype=f32, device=dev); alphas = torch.empty(H, W, dtype=f32, device=dev)
@@ -275,6 +289,9 @@ class RenderStep:
                 render, alphas, s = _composite_stage_cap(state, V, I, D, whs, None)
             else:
                 render, alphas, s, V, I = _composite_stage(state, V, I, D, whs, None)
+            if kev is not None:
+                k1 = torch.cuda.Event(enable_timing=True); k1.record(main)
+                kev.append(("raster_fwd_kernel", k0, k1))
             # keep the side streams two views ahead: A(i+2), then B1(i+1).  Their ~35 launches cost the host 0.2-0.3 ms: issued
             # HERE (GEOSPLAT_ENQUEUE=front_first, the round-2 order) the compositor forward of this view has finished before the
             # host reaches its backward -- the main stream, the step's critical path, idled 0.13-0.28 ms per view
@@ -289,6 +306,8 @@ class RenderStep:
             v_img = upstream(i, img).contiguous()
             v_packed = s["v_packed"]
             rws = s["raster_ws"]
+            if kev is not None:
+                k2 = torch.cuda.Event(enable_timing=True); k2.record(main)
             if fused_tone:
                 # ... and S4 backward in the prologue of the compositor backward (gs_raster_bwd_tone_acc)
                 L.check(lib.gs_raster_bwd_tone_acc(W, H, 16, V, L.ptr(s["colors"]), L.i64(I),
@@ -309,6 +328,9 @@ class RenderStep:
                     L.check(lib.gs_raster_bwd_acc(W, H, 16, 3, V, L.ptr(s["colors"]), None, L.i64(I), L.ptr(s["isect_offsets"]),
                                                   L.ptr(alphas), L.ptr(s["last_ids"]), L.ptr(v_render), L.ptr(v_alpha), L.ptr(v_packed),
                                                   L.ptr(rws), C.c_size_t(rws.numel()), st()), "gs_raster_bwd_acc")
+            if kev is not None and fused_tone:                # (with the separate tone-map launches the bracket would include them)
+                k3 = torch.cuda.Event(enable_timing=True); k3.record(main)
+                kev.append(("raster_bwd_kernel", k2, k3))
             if not front_first:
                 if i + 2 < n_views:
                     proj.append(start_view(cameras[i + 2], i + 2))
@@ -356,10 +378,20 @@ class RenderStep:
         main.wait_stream(tail)
         self._seen_counts.extend(seen)                       # entries of earlier steps the host has not looked at yet stay pending
         if i_cap is not None:                                # the overflow word follows the step to the host, asynchronously
-            if self._status_host is None:
-                self._status_host = torch.zeros(3, dtype=torch.int64).pin_memory()
-            self._status_host.copy_(self._status, non_blocking=True)
-            self._status_event = torch.cuda.Event(); self._status_event.record()
+            if torch.cuda.is_current_stream_capturing():      # a replayed graph refreshes ONE pinned buffer; replay.check() reads it
+                if self._status_host is None:
+                    self._status_host = torch.zeros(3, dtype=torch.int64).pin_memory()
+                self._status_host.copy_(self._status, non_blocking=True)
+                self._status_event = torch.cuda.Event(); self._status_event.record()
+            else:
+                # eager: every step gets its OWN snapshot and clears the word behind it (all of this step's writers are upstream of
+                # the main stream here, the next step's fronts fork from it), so that an overflow is attributed to exactly one step
+                # however many steps are in flight
+                snap = self._status_pool.pop() if self._status_pool else torch.zeros(3, dtype=torch.int64).pin_memory()
+                snap.copy_(self._status, non_blocking=True)
+                self._status.fill_(0)
+                ev_s = torch.cuda.Event(); ev_s.record()
+                self._status_pending.append((snap, ev_s))
         # chain the once-per-step activations; the per-Gaussian gradients are now final, so their all-reduce (RCCL on
         # the communication stream) overlaps the prefilter backward, whose cubemap gradient is reduced afterwards
         torch.mul(g_scales_act, scales_act, out=b["scales"])
@@ -435,7 +467,7 @@ class RenderStep:
             self._step_fused(cameras, upstream, False, keep_images)
         torch.cuda.current_stream(dev).wait_stream(warm)
         torch.cuda.synchronize(dev)
-        self.poll_capacity()
+        self.poll_capacity(_internal=True)                    # an overflow of the warm-up step stays pending for the caller's next poll
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out = self._step_fused(cameras, upstream, False, keep_images)
@@ -503,7 +535,7 @@ class RenderStep:
             self._step_fused(cameras, upstream, all_reduce, keep_images, _env=pyramid, _stop_after_views=True)
         torch.cuda.current_stream(dev).wait_stream(warm)
         torch.cuda.synchronize(dev)
-        self.poll_capacity()
+        self.poll_capacity(_internal=True)                    # an overflow of the warm-up step stays pending for the caller's next poll
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             ctx = self._step_fused(cameras, upstream, all_reduce, keep_images, _env=pyramid, _stop_after_views=True)
@@ -568,7 +600,19 @@ class RenderStep:
                 ev.synchronize()
             if ev.query():
                 max_i = max(max_i, int(hc[1]))
-        if self._status_event is not None:
+        while self._status_pending:                           # eager steps, oldest first; each snapshot is inspected exactly once
+            snap, ev_s = self._status_pending[0]
+            if wait:
+                ev_s.synchronize()
+            if not ev_s.query():
+                break
+            self._status_pending.popleft()
+            if int(snap[0]) != 0:
+                ok = False
+                self.truncated_steps += 1
+                max_i = max(max_i, int(snap[1]))
+            self._status_pool.append(snap)
+        if self._status_event is not None:                    # the single buffer of a captured step (see capture / capture_views)
             if wait:
                 self._status_event.synchronize()
             if self._status_event.query() and int(self._status_host[0]) != 0:
@@ -603,9 +647,9 @@ class RenderStep:
         """Forward + backward for `cameras`; `upstream(i, image)` returns d(loss)/d(image) for local view i.
         Returns (grads dict of views into the flat bucket, images or None)."""
         if self.fused and self.mode == "pbr":
-            self.poll_capacity(_internal=True)               # non-blocking: counts / overflow word of the earlier steps (an overflow
+            self._throttle()                                 # first: the step that just left the window has finished, its word is readable
+            self.poll_capacity(_internal=True)               # non-blocking: counts / overflow words of the finished steps (an overflow
                                                              # seen here is kept for the caller's next poll_capacity())
-            self._throttle()
             out = self._step_fused(cameras, upstream, all_reduce, keep_images)
             if self._in_flight is not None:
                 ev = torch.cuda.Event(); ev.record()

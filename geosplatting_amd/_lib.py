@@ -23,6 +23,11 @@ class GsEnv(C.Structure):
                 ("min_roughness", C.c_float), ("max_roughness", C.c_float)]
 
 
+class GsTailView(C.Structure):
+    _fields_ = [("viewmat", C.c_void_p), ("K", C.c_void_p), ("cam_pos", C.c_void_p), ("vis_records", C.c_void_p), ("v_packed", C.c_void_p),
+                ("packed_index", C.c_void_p), ("W", C.c_int), ("H", C.c_int)]
+
+
 class GsEnvGrad(C.Structure):
     _fields_ = [("base", C.c_void_p), ("levels", C.c_void_p * GS_MAX_LEVELS)]
 
@@ -37,7 +42,7 @@ SYMBOLS = [
     "gs_specular_tiles_check", "gs_specular_tiles_apply", "gs_mgadapter_fwd", "gs_mgadapter_bwd", "gs_vertex_normals_fwd",
     "gs_vertex_normals_bwd", "gs_photo_loss_ws_bytes", "gs_photo_loss", "gs_hashgrid_fwd", "gs_hashgrid_bwd_ws_bytes", "gs_hashgrid_bwd", "gs_hashgrid_bwd_fixed_ws_bytes", "gs_hashgrid_bwd_fixed", "gs_mlp_wgrad_ws_bytes", "gs_mlp_wgrad",
     "gs_flexicubes_ws_bytes", "gs_flexicubes_count", "gs_flexicubes_fwd", "gs_flexicubes_bwd", "gs_flexicubes_entropy_fwd",
-    "gs_flexicubes_entropy_bwd",
+    "gs_flexicubes_entropy_bwd", "gs_front_ws_bytes", "gs_front_fwd", "gs_isect_bin_front_ws_bytes", "gs_isect_bin_front", "gs_tail_bwd", "gs_tail_bwd_multi", "gs_tail_priv_ws_bytes", "gs_tail_priv_reduce",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -77,6 +82,12 @@ def lib() -> C.CDLL:
         l.gs_photo_loss_ws_bytes.argtypes = [C.c_int, C.c_int]
         l.gs_specular_bounds_ws_bytes.restype = C.c_size_t
         l.gs_specular_bounds_ws_bytes.argtypes = [C.c_int]
+        l.gs_front_ws_bytes.restype = C.c_size_t
+        l.gs_front_ws_bytes.argtypes = [C.c_int]
+        l.gs_isect_bin_front_ws_bytes.restype = C.c_size_t
+        l.gs_isect_bin_front_ws_bytes.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int]
+        l.gs_tail_priv_ws_bytes.restype = C.c_size_t
+        l.gs_tail_priv_ws_bytes.argtypes = [C.c_void_p, C.c_int]
         l.gs_raster_ws_bytes.restype = C.c_size_t
         l.gs_raster_ws_bytes.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib = l

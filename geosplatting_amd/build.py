@@ -8,8 +8,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgeosplat_hip.so")
-SOURCES = ["gs_project.hip", "gs_sort.hip", "gs_raster.hip", "gs_shade.hip", "gs_splitsum.hip", "gs_splitsum_tiles.hip", "gs_mesh.hip", "gs_loss.hip", "gs_hashgrid.hip", "gs_flexicubes.hip"]
-HEADERS = ["gs_common.h", "gs_cube.h", "gs_splitsum_math.h", "gs_tone.h", os.path.join("..", "..", "include", "geosplat_hip.h")]
+SOURCES = ["gs_project.hip", "gs_sort.hip", "gs_raster.hip", "gs_shade.hip", "gs_front.hip", "gs_splitsum.hip", "gs_splitsum_tiles.hip", "gs_mesh.hip", "gs_loss.hip", "gs_hashgrid.hip", "gs_flexicubes.hip"]
+HEADERS = ["gs_common.h", "gs_cube.h", "gs_project_dev.h", "gs_shade_dev.h", "gs_splitsum_math.h", "gs_tone.h", os.path.join("..", "..", "include", "geosplat_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-ffp-contract=fast-honor-pragmas", "-Wno-unused-result",
          # one lane commits per-Gaussian sums: the wave-uniform atomic optimiser (mbcnt/bcnt/mul per atomic) only adds work

@@ -370,6 +370,57 @@ __device__ __forceinline__ void cube_scatter_wave(float* grad_tex, const CubeFp&
     }
 }
 
+// ---- tagged variant (round 4): the scope of the atomic is a per-LANE property --------------------------------------------------
+// The fused tail keeps XCD-private copies only of the MID-SIZED pyramid levels (64^2, 128^2: 60 % of the row-pair requests of the
+// bench scene, 1.5 MB per copy -- zeroed and folded once per STEP), whose atomics then resolve in the XCD's own L2 instead of at
+// the memory side of the fabric; the large levels (256^2, 512^2) stay device-scope.  Which of the two a lane needs depends on ITS
+// mip level, so the pointer carries the choice in bit 0 (texel addresses are 4-byte aligned).
+__device__ __forceinline__ void wave_commit6_lds_tagged(float* stage, float* pa, float* pb, const float (&v)[6])
+{
+    const int lane = (int)(threadIdx.x & 63);
+    unsigned long long* sp = reinterpret_cast<unsigned long long*>(stage);       // [2][64] pointers, then [6][64] values
+    float* sv = stage + 256;
+    __builtin_amdgcn_wave_barrier();
+    sp[lane] = (unsigned long long)pa; sp[64 + lane] = (unsigned long long)pb;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) sv[c * 64 + lane] = v[c];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int q = 64 * k + lane;
+        const int src = q / 6, ch = q - 6 * src;
+        const bool second = ch >= 3;
+        const unsigned long long tagged = sp[(second ? 64 : 0) + src];
+        float* base = (float*)(tagged & ~1ull);
+        const float val = sv[ch * 64 + src];
+        if (base != nullptr) {
+            float* dst = base + (second ? ch - 3 : ch);
+            if (tagged & 1ull) gs_atomic_add_xcd(dst, val); else gs_atomic_add(dst, val);
+        }
+    }
+}
+
+// all 64 lanes of the wave must call this together; `local`: grad_tex is this XCD's private copy
+__device__ __forceinline__ void cube_scatter_wave_tagged(float* grad_tex, bool local, const CubeFp& fp, const float* g, float scale, bool valid,
+                                                         float* stage)
+{
+#pragma unroll
+    for (int row = 0; row < 2; ++row) {
+        float* p[2]; float v[6];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = 2 * row + j;
+            const bool on = valid && fp.valid && fp.idx[i] >= 0 && grad_tex != nullptr;
+            const float w = on ? scale * fp.w[i] : 0.0f;
+            p[j] = on ? (float*)((unsigned long long)(grad_tex + (size_t)fp.idx[i] * 3) | (local ? 1ull : 0ull)) : nullptr;
+            v[3 * j] = g[0] * w; v[3 * j + 1] = g[1] * w; v[3 * j + 2] = g[2] * w;
+        }
+        wave_commit6_lds_tagged(stage, p[0], p[1], v);
+    }
+}
+
 __device__ __forceinline__ void cube_scatter(float* __restrict__ grad_tex, const CubeFp& fp, const float* g, float scale)
 {
     if (!fp.valid) return;

@@ -780,3 +780,283 @@ static int isect_bin_impl(int V, const float* means2d, const int32_t* radii, con
     }
     return GS_OK;
 }
+
+// ---- gs_isect_bin_front: binning of the engine's fused front (round 4) ---------------------------------------------------------
+// Same result as gs_isect_bin_tiles_cap + gs_isect_offsets_tiles_cap -- `flatten_ids` in (tile, depth bits, packed index) order and the
+// per-tile offsets, bit for bit -- from what gs_front_fwd leaves behind, with fewer and smaller passes:
+//   * the depth key is 24 bits wide when the engine knows the view's depth range (key = depth bits - key_base, checked by the front
+//     kernel): THREE V-sized passes instead of four;
+//   * the tile rectangles come packed from the front kernel (no tile_rect_kernel);
+//   * the emission finds its own write positions with an in-launch chained scan over its blocks (ticket order, 8-byte {flag, value}
+//     granules as in project_fwd_kernel): no block-sum pass, no scan launch;
+//   * the front kernel has already counted the intersections per TILE (LDS histogram per block of 512 index-adjacent Gaussians): the
+//     tile offsets are the exclusive scan of those 2 500 counters, clamped to the capacity -- no I-sized offsets pass, and the last
+//     tile pass writes 4 bytes per intersection (flatten id) instead of 8.  (More than 8 192 tiles: the tile ids are kept and the
+//     offsets come from them.)
+// 18 launches (setup, 3 x 3 depth passes, emission, offset scan, 2 x 3 tile passes) against 25.
+struct KeyIn {                                                     // (depth key, packed index) straight from the key array
+    const unsigned* keys;
+    __device__ __forceinline__ uint2 load(int64_t i) const { return make_uint2(keys[i], (unsigned)i); }
+};
+struct FinalFlat {
+    int32_t* flatten_ids;
+    __device__ __forceinline__ void store(int64_t i, const uint2& it) const { flatten_ids[i] = (int32_t)it.y; }
+};
+
+#define BF_HIST_MAX 8192                     // tiles whose counters fit a block's LDS histogram (32 KB)
+
+__global__ void __launch_bounds__(256)
+bin_setup_kernel(unsigned* __restrict__ state, int n_state_words,
+                 const long long* __restrict__ counts, long long v_cap, long long i_cap, long long* __restrict__ status)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (int k = i; k < n_state_words; k += stride) state[k] = 0u;
+    if (i == 0 && counts != nullptr && status != nullptr) {                        // capacity protocol, as capacity_check_kernel
+        const long long V = counts[0], I = counts[1];
+        if (V > v_cap || I > i_cap) {
+            status[0] = GS_ENOSPC;
+            if (I > status[1]) status[1] = I;
+            if (V > status[2]) status[2] = V;
+        }
+    }
+}
+
+#define BF_VALID (1ull << 63)
+#define BF_SPIN_LIMIT (1 << 22)
+
+// thread r (depth rank) writes the (tile, index) items of its Gaussian at the exclusive prefix of the tile counts in depth order; the
+// prefix across blocks is a decoupled look-back (blocks numbered by ticket, so a block only waits for blocks that already run)
+template <bool HIST>
+__global__ void __launch_bounds__(EM_THREADS)
+emit_chained_kernel(GsCount vc, const uint2* __restrict__ order, const uint2* __restrict__ rect, unsigned* __restrict__ ctrl,
+                    u64* __restrict__ desc, int n_blocks, int tile_w, int n_tiles, uint2* __restrict__ items, unsigned item_cap,
+                    unsigned* __restrict__ tile_counts)
+{
+    const int V = (int)gs_count(vc);
+    __shared__ unsigned ws[EM_THREADS / 64];
+    __shared__ unsigned s_block;
+    __shared__ unsigned long long s_base;
+    extern __shared__ unsigned th[];                                      // [n_tiles] when HIST
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_block = atomicAdd(ctrl, 1u);
+    if (HIST) for (int t = threadIdx.x; t < n_tiles; t += EM_THREADS) th[t] = 0u;
+    __syncthreads();
+    const int block = (int)s_block;
+    u64* agg = desc; u64* pre = desc + n_blocks;
+    // blocked arrangement: thread t owns ranks base + t*EM_PER .. +EM_PER-1 (consecutive: the scan stays in index order)
+    const int r0 = block * EM_TILE + (int)threadIdx.x * EM_PER;
+    int v[EM_PER]; unsigned c[EM_PER]; uint2 q[EM_PER];
+    unsigned mine = 0u;
+#pragma unroll
+    for (int k = 0; k < EM_PER; ++k) {
+        const int r = r0 + k;
+        v[k] = r < V ? (int)order[r].y : -1;
+        q[k] = v[k] >= 0 ? rect[v[k]] : make_uint2(0u, 0u);
+        c[k] = rect_count(q[k]);
+        mine += c[k];
+    }
+    unsigned incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    unsigned before = 0u, total = 0u;
+    for (int w = 0; w < EM_THREADS / 64; ++w) { if (w < wave) before += ws[w]; total += ws[w]; }
+    if (wave == 0) {
+        unsigned long long base = 0ull;
+        if (block > 0) {
+            if (lane == 0) __hip_atomic_store(&agg[block], (u64)total | BF_VALID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int pos = block - 1;
+            for (;;) {
+                const int idx = pos - lane;
+                bool isP = idx < 0;
+                u64 val = 0ull;
+                if (idx >= 0) {
+                    int spins = 0;
+                    for (;;) {
+                        const u64 pv = __hip_atomic_load(&pre[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (pv & BF_VALID) { isP = true; val = pv; break; }
+                        const u64 av = __hip_atomic_load(&agg[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (av & BF_VALID) { val = av; break; }
+                        if (++spins > BF_SPIN_LIMIT) { atomicExch(ctrl + 1, 1u); break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+                const u64 pmask = __ballot(isP);
+                const int first = pmask ? __builtin_ctzll(pmask) : 64;
+                unsigned long long cv = lane <= first ? (val & ~BF_VALID) : 0ull;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) cv += (unsigned long long)__shfl_xor((long long)cv, off, 64);
+                base += cv;
+                if (pmask) break;
+                pos -= 64;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&pre[block], (u64)(base + total) | BF_VALID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_base = base;
+        }
+    }
+    __syncthreads();
+    unsigned long long cur = s_base + before + incl - mine;
+#pragma unroll
+    for (int k = 0; k < EM_PER; ++k) {
+        if (v[k] < 0 || c[k] == 0u) continue;
+        const int x0 = (int)(q[k].x & 0xffffu), y0 = (int)(q[k].x >> 16), x1 = (int)(q[k].y & 0xffffu), y1 = (int)(q[k].y >> 16);
+        for (int i = y0; i < y1; ++i)
+            for (int j = x0; j < x1; ++j) {
+                const unsigned t = (unsigned)(i * tile_w + j);
+                if (cur < (unsigned long long)item_cap) {                 // (capacity protocol: an overflowing view is reported, not written)
+                    items[cur] = make_uint2(t, (unsigned)v[k]);
+                    if (HIST) atomicAdd(&th[t], 1u);
+                }
+                ++cur;
+            }
+    }
+    if (HIST) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < n_tiles; t += EM_THREADS) { const unsigned hc = th[t]; if (hc) atomicAdd(tile_counts + t, hc); }
+    }
+}
+
+// offsets[t] = min(exclusive prefix of the tile counts, n) by one workgroup: the tile offsets of a view.  (The clamp only ever acts
+// on a view that overflowed its capacity: its list is truncated in emission order, the offsets then are not those of the truncated
+// list -- memory-safe, wrong image, reported, as the capacity protocol says.)
+__global__ void __launch_bounds__(1024)
+tile_offsets_scan_kernel(int n_tiles, const unsigned* __restrict__ tile_counts, GsCount nc, int32_t* __restrict__ offsets)
+{
+    __shared__ unsigned wsum[16];
+    const unsigned n = (unsigned)gs_count(nc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned carry = 0u;
+    for (int i0 = 0; i0 < n_tiles; i0 += 1024) {
+        const int i = i0 + threadIdx.x;
+        const unsigned v = i < n_tiles ? tile_counts[i] : 0u;
+        unsigned incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        unsigned before = 0u, all = 0u;
+        for (int w = 0; w < 16; ++w) { if (w < wave) before += wsum[w]; all += wsum[w]; }
+        if (i < n_tiles) { const unsigned o = carry + before + incl - v; offsets[i] = (int32_t)(o < n ? o : n); }
+        carry += all;
+        __syncthreads();
+    }
+}
+
+// offsets[t] = first sorted position whose tile id >= t (the > 8 192-tile path; same as isect_offsets_tiles_kernel of gs_project.hip)
+__global__ void __launch_bounds__(256)
+bin_offsets_tiles_kernel(GsCount nc, const int32_t* __restrict__ tiles, int n_tiles, int32_t* __restrict__ offsets)
+{
+    const int64_t n = gs_count(nc);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n == 0 && i == 0)
+        for (int t = 0; t < n_tiles; ++t) offsets[t] = 0;
+    if (i >= n) return;
+    const int cur = tiles[i];
+    if (i == 0) {
+        for (int t = 0; t <= cur && t < n_tiles; ++t) offsets[t] = 0;
+    } else {
+        const int prev = tiles[i - 1];
+        for (int t = prev + 1; t <= cur && t < n_tiles; ++t) offsets[t] = (int32_t)i;
+    }
+    if (i == n - 1)
+        for (int t = cur + 1; t < n_tiles; ++t) offsets[t] = (int32_t)n;
+}
+
+static size_t bf_state_bytes(int V) { return align256(16 + 2 * (size_t)((V + EM_TILE - 1) / EM_TILE + 1) * sizeof(u64)); }
+
+extern "C" size_t gs_isect_bin_front_ws_bytes(int V, int64_t n_isects, int tile_w, int tile_h)
+{
+    const size_t v = V > 0 ? (size_t)V : 1, n = n_isects > 0 ? (size_t)n_isects : 1;
+    const size_t tb = table_bytes((int64_t)(v > n ? v : n));
+    const bool hist = (int64_t)tile_w * tile_h <= BF_HIST_MAX;
+    return tb + 2 * align256(v * 8) + 2 * align256(n * 8) + bf_state_bytes((int)v) + (hist ? 0 : align256(n * 4)) + 256;
+}
+
+extern "C" int gs_isect_bin_front(int V_cap, const uint32_t* depth_keys, const uint32_t* tile_rects, const uint32_t* tile_counts,
+                                  const int64_t* counts_dev, int64_t n_isects_cap, int key_bits, int tile_w, int tile_h, int32_t* flatten_ids_sorted,
+                                  int32_t* isect_offsets, void* ws, size_t ws_bytes, int64_t* status_dev, void* stream)
+{
+    const int V = V_cap;
+    const int64_t n_isects = n_isects_cap;
+    GS_CHECK_ARG(V >= 0 && n_isects >= 0 && tile_w > 0 && tile_h > 0 && (key_bits == 24 || key_bits == 32), "bad sizes or key width");
+    GS_CHECK_ARG(n_isects < (1ll << 31), "n_isects must fit int32");
+    GS_CHECK_ARG((int64_t)tile_w * tile_h < (1ll << 24) && tile_w < 65536 && tile_h < 65536, "tile grid too large");
+    GS_CHECK_ARG(isect_offsets != nullptr && (counts_dev == nullptr || status_dev != nullptr), "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int n_tiles = tile_w * tile_h;
+    if (V == 0 || n_isects == 0) { GS_CHECK_HIP(gs_zero_async(isect_offsets, sizeof(int32_t) * (size_t)n_tiles, s)); return GS_OK; }
+    GS_CHECK_ARG(depth_keys != nullptr && tile_rects != nullptr && flatten_ids_sorted != nullptr && ws != nullptr, "null argument");
+    if (ws_bytes < gs_isect_bin_front_ws_bytes(V, n_isects, tile_w, tile_h)) { gs_set_error("gs_isect_bin_front: workspace too small"); return GS_ENOSPC; }
+    const GsCount vc{ (long long)V, (const long long*)counts_dev }, ic{ (long long)n_isects, counts_dev ? (const long long*)counts_dev + 1 : nullptr };
+    const bool hist = n_tiles <= BF_HIST_MAX;
+    GS_CHECK_ARG(!hist || tile_counts != nullptr, "tile_counts (gs_front_fwd) must not be NULL for up to 8 192 tiles");
+    char* p = (char*)ws;
+    unsigned* table = (unsigned*)p; p += table_bytes((int64_t)V > n_isects ? (int64_t)V : n_isects);
+    uint2* da = (uint2*)p; p += align256((size_t)V * 8);
+    uint2* db = (uint2*)p; p += align256((size_t)V * 8);
+    uint2* ia = (uint2*)p; p += align256((size_t)n_isects * 8);
+    uint2* ib = (uint2*)p; p += align256((size_t)n_isects * 8);
+    unsigned* state = (unsigned*)p; p += bf_state_bytes(V);
+    int32_t* tile_ids = hist ? nullptr : (int32_t*)p;
+    const int eblocks = (V + EM_TILE - 1) / EM_TILE;
+    const int n_state_words = (int)(bf_state_bytes(V) / 4);
+    // 0. clear the emission's look-back state and the tile counters; capacity check
+    hipLaunchKernelGGL(bin_setup_kernel, dim3(gs_cdiv(n_state_words, 256) < 64 ? gs_cdiv(n_state_words, 256) : 64),
+                       dim3(256), 0, s, state, n_state_words, (const long long*)counts_dev,
+                       (long long)V_cap, (long long)n_isects_cap, (long long*)status_dev);
+    GS_CHECK_LAUNCH();
+    // 1. depth order of the Gaussians: key_bits / 8 stable 8-bit passes over (key, index); the first reads the key array
+    int rc = radix_pass<uint2>(vc, KeyIn{ depth_keys }, XDigit{ 0, 255u }, U2Out{ da }, 8, table, s);
+    if (rc != GS_OK) return rc;
+    rc = radix_pass<uint2>(vc, U2In{ da }, XDigit{ 8, 255u }, U2Out{ db }, 8, table, s);
+    if (rc != GS_OK) return rc;
+    rc = radix_pass<uint2>(vc, U2In{ db }, XDigit{ 16, 255u }, U2Out{ da }, 8, table, s);
+    if (rc != GS_OK) return rc;
+    const uint2* order = da;
+    if (key_bits == 32) {
+        rc = radix_pass<uint2>(vc, U2In{ da }, XDigit{ 24, 255u }, U2Out{ db }, 8, table, s);
+        if (rc != GS_OK) return rc;
+        order = db;
+    }
+    // 2. emission in depth order (chained scan inside the launch) + per-tile counts
+    unsigned* ctrl = state; u64* desc = (u64*)((char*)state + 16);
+    hipLaunchKernelGGL((emit_chained_kernel<false>), dim3(eblocks), dim3(EM_THREADS), 0, s, vc, order, (const uint2*)tile_rects, ctrl, desc,
+                       eblocks + 1, tile_w, n_tiles, ia, (unsigned)n_isects, (unsigned*)nullptr);
+    GS_CHECK_LAUNCH();
+    if (hist) {
+        hipLaunchKernelGGL(tile_offsets_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, (const unsigned*)tile_counts, ic, isect_offsets);
+        GS_CHECK_LAUNCH();
+    }
+    // 3. stable split by tile id: npass digits of `width` bits, the last one writes the sorted flatten ids
+    int tb = 0;
+    while ((1 << tb) < n_tiles) ++tb;
+    if (tb < 1) tb = 1;
+    const int npass = (tb + 7) / 8, width = (tb + npass - 1) / npass;
+    uint2* src = ia; uint2* dst = ib;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int shift = pass * width;
+        const int nbits = (tb - shift) < width ? (tb - shift) : width;
+        if (pass == npass - 1 && hist)
+            rc = radix_pass<uint2>(ic, U2In{ src }, XDigit{ shift, (1u << nbits) - 1u }, FinalFlat{ flatten_ids_sorted }, nbits, table, s);
+        else if (pass == npass - 1)
+            rc = radix_pass<uint2>(ic, U2In{ src }, XDigit{ shift, (1u << nbits) - 1u }, FinalTiles{ tile_ids, flatten_ids_sorted }, nbits, table, s);
+        else
+            rc = radix_pass<uint2>(ic, U2In{ src }, XDigit{ shift, (1u << nbits) - 1u }, U2Out{ dst }, nbits, table, s);
+        if (rc != GS_OK) return rc;
+        uint2* t = src; src = dst; dst = t;
+    }
+    if (!hist) {
+        hipLaunchKernelGGL(bin_offsets_tiles_kernel, dim3(gs_cdiv(n_isects, 256)), dim3(256), 0, s, ic, tile_ids, n_tiles, isect_offsets);
+        GS_CHECK_LAUNCH();
+    }
+    return GS_OK;
+}

@@ -27,6 +27,7 @@ from .cameras import Camera
 from .parallel import GradBucket
 from .rasterization import (_bin_stage, _bin_stage_cap, _composite_stage, _composite_stage_cap, _forward_stages, _prepare_stage,
                             _prepare_stage_cap, _project_stage)
+from . import front as F
 from .shading import _MODE, _TONE, RenderableAttrs, _make_env, get_fg_lut, shade_private_copies
 from .splitsum import (TextureSplitSum, as_splitsum, as_splitsum_backward, as_splitsum_backward_sharded,
                        as_splitsum_sharded, can_shard_prefilter)
@@ -65,9 +66,14 @@ class RenderStep:
         self._pre_stream = None
         # capacity protocol state (see _step_fused / poll_capacity)
         self._use_capacity = os.environ.get("GEOSPLAT_CAPACITY", "1") != "0"
+        # GEOSPLAT_FRONT=split keeps the round-3 launch sequence (gs_shade_fwd -> gs_project_fwd_vis -> gs_isect_bin_tiles_cap ...,
+        # gs_project_bwd -> gs_shade_bwd); default: the fused front / tail kernels of csrc/gs_front.hip (front.py)
+        self._front_fused = os.environ.get("GEOSPLAT_FRONT", "fused") != "split"
+        self._key_lo = self._key_hi = None     # depth-bit range seen so far (asynchronous read-back): sizes the 24-bit binning keys
+        self._key32 = os.environ.get("GEOSPLAT_KEY_BITS", "24") == "32"   # forced by a key-range overflow, or by the environment
         self._cap_margin = float(os.environ.get("GEOSPLAT_CAPACITY_MARGIN", "1.25"))   # capacity = margin x the largest count seen
         self._i_cap = None                 # intersection capacity per view; None = exact mode (one (V, I) read-back per view)
-        self._status = None                # device int64[3]: {GS_ENOSPC or 0, max required I, max required V}
+        self._status = None                # device int64[4]: {GS_ENOSPC or 0, max required I, max required V, depth outside the 24-bit key range}
         self._status_host = None           # pinned snapshot used by the graph-capture paths (one buffer, refreshed by every replay)
         self._status_event = None
         self._status_pending = collections.deque()   # eager steps: (pinned snapshot of the word, event), one per step, each looked at ONCE
@@ -186,6 +192,11 @@ class RenderStep:
         half = (len(cameras) + 1) // 2 if n_sets == 2 else len(cameras)
         g_cube_first = None
         ws_bytes = lib.gs_shade_bwd_ws_bytes(C.byref(e), mode) if shade_private_copies() else 0
+        # fused tail, GEOSPLAT_TAIL_PRIV=1: XCD-private copies of the MID-SIZED levels (64^2 / 128^2: 12 MB for all eight), zeroed here,
+        # accumulated by every view's tail, folded once after the last one (front.tail_priv_reduce).  Measured: 551 vs 553 views/s
+        # without -- the tail is bound by its 1.2 KB of traffic per Gaussian at one block per CU, not by the texel atomics: off.
+        tail_priv = (F.tail_priv_alloc(e, mode, dev) if (self._front_fused and n_sets == 1 and os.environ.get("GEOSPLAT_TAIL_PRIV", "0") == "1")
+                     else None)
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
 
         scales_act = p.scales.detach().exp()
@@ -206,7 +217,7 @@ class RenderStep:
         # nothing makes the host wait, so the fronts run as far ahead of the compositor as their inputs allow.
         main = torch.cuda.current_stream(dev)
         if self._use_capacity and self._status is None:      # zero-filled on the main stream BEFORE the side stream forks from it
-            self._status = torch.zeros(3, dtype=torch.int64, device=dev)
+            self._status = torch.zeros(4, dtype=torch.int64, device=dev)
         if self._side_stream is None:
             # GEOSPLAT_FRONT_STREAMS=2: the fronts of consecutive views alternate between two streams (see start_view)
             self._side_stream = [torch.cuda.Stream(device=dev, priority=int(os.environ.get("GEOSPLAT_SIDE_PRIO", "0")))
@@ -219,9 +230,30 @@ class RenderStep:
             sd.wait_stream(main)                             # prefilter pyramid, activations, zeroed buckets
         tail.wait_stream(main)
 
+        fused_front = self._front_fused
+        # the tails of the views in ONE launch per `tail_batch` views (gs_tail_bwd_multi: parameter gradients in registers across the
+        # views, stored once); 0 = one tail launch per view (gs_tail_bwd)
+        tail_batch = int(os.environ.get("GEOSPLAT_TAIL_BATCH", "8")) if (fused_front and n_sets == 1) else 0
+        pending_tails = []
+        n_tail_launches = 0
+        # binning keys: 24 bits (three depth passes instead of four) once the depth range of earlier views is known -- key = depth
+        # bits - key_base with half an octave of room below the smallest depth seen; a view outside the range is reported through
+        # the status word (poll_capacity) and the engine falls back to 32-bit keys
+        key_bits, key_base = 32, 0
+        if fused_front and self._use_capacity and self._i_cap is not None and not self._key32 and self._key_lo is not None:
+            base = max(0, self._key_lo - (1 << 22))
+            if self._key_hi - base < (1 << 24) - (1 << 21):
+                key_bits, key_base = 24, base
+
         def start_view(cam, j):                              # S1-S3 + A1; (V, I) travel to the host asynchronously
             vm, K, cam_pos = self._camera_tensors(cam)
             side = sides[j % len(sides)]
+            if fused_front:
+                with torch.cuda.stream(side):
+                    fr = F.front_stage(means, quats, scales_act, opac_act, normals, kd, ks, vm, K, cam_pos, e, cam.width, cam.height,
+                                       self.min_roughness, self.max_metallic, mode, key_base, key_bits,
+                                       self._status if key_bits == 24 else None, want_packed_index=tail_batch > 0)
+                return fr, None, side
             with torch.cuda.stream(side):
                 col = torch.empty(N, 3, dtype=f32, device=dev)
                 L.check(lib.gs_shade_fwd(N, L.ptr(means), L.ptr(normals), L.ptr(kd), L.ptr(ks), L.ptr(cam_pos),
@@ -240,6 +272,25 @@ class RenderStep:
 
         def bin_view(item):                                  # A2-A4 on the side stream (exact mode: host waits for that view's counts)
             pr, col, side = item
+            if fused_front:
+                with torch.cuda.stream(side):
+                    if i_cap is not None:
+                        seen.append((pr.host_counts, pr.event))
+                    state, V, I = F.bin_stage(pr, i_cap, self._status)
+                    if i_cap is None:
+                        self._exact_max_i = max(self._exact_max_i, I)
+                        rng = F.depth_range(pr.host_counts)
+                        if rng is not None:
+                            self._key_lo = rng[0] if self._key_lo is None else min(self._key_lo, rng[0])
+                            self._key_hi = rng[1] if self._key_hi is None else max(self._key_hi, rng[1])
+                        F.release_counts4(pr.host_counts)
+                    state["colors"] = None                       # (D = 3: the colours travel in the record stream)
+                    state["v_packed"] = torch.zeros(max(V, 1), lib.gs_raster_grad_stride(3), dtype=f32, device=dev)
+                    ev = torch.cuda.Event(); ev.record(side)
+                for t in state.values():
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(main)
+                return state, V, I, 3, pr.whs, ev, None
             with torch.cuda.stream(side):
                 if i_cap is not None:
                     seen.append((pr.host_counts, pr.event))       # read a step later by poll_capacity (never waited for here)
@@ -338,12 +389,33 @@ class RenderStep:
             # gradient tail of the view (A7 + S1-S3 backward: HBM / atomic-rate bound) on a third stream, so that it
             # overlaps the VALU-bound compositor of the next view; the tail kernels of successive views stay in order
             # on that stream (they accumulate into the same gradient buffers)
-            ev_r = torch.cuda.Event(); ev_r.record(main)
-            g_colors = torch.empty(N, 3, dtype=f32, device=dev)
+            g_colors = None if fused_front else torch.empty(N, 3, dtype=f32, device=dev)
             eg = g_sets[0 if i < half else n_sets - 1][2]
+            if tail_batch > 0:
+                pending_tails.append((vm, K, cam_pos, s["vis_records"], v_packed, s["packed_index"], W, H))
+                if len(pending_tails) == tail_batch or i == n_views - 1:
+                    ev_r = torch.cuda.Event(); ev_r.record(main)
+                    with torch.cuda.stream(tail):
+                        tail.wait_event(ev_r)
+                        F.tail_multi_stage(pending_tails, means, quats, scales_act, opac_act, normals, kd, ks, e, eg, self.min_roughness,
+                                           self.max_metallic, mode, b["means"], b["quats"], g_scales_act, g_opac_act, b["normals"], b["kd"],
+                                           b["ks"], accumulate=n_tail_launches > 0, priv=tail_priv)
+                    n_tail_launches += 1
+                    for tv in pending_tails:
+                        for t in tv[:6]:
+                            t.record_stream(tail)
+                    pending_tails = []
+                if keep_images:
+                    images.append(img)
+                continue
+            ev_r = torch.cuda.Event(); ev_r.record(main)
             with torch.cuda.stream(tail):
                 tail.wait_event(ev_r)
-                if i_cap is not None:
+                if fused_front:
+                    F.tail_stage(V, s["counts"], means, quats, scales_act, opac_act, normals, kd, ks, vm, K, cam_pos, e, eg, W, H,
+                                 self.min_roughness, self.max_metallic, mode, s["vis_records"], v_packed, b["means"], b["quats"],
+                                 g_scales_act, g_opac_act, b["normals"], b["kd"], b["ks"], priv=tail_priv)
+                elif i_cap is not None:
                     L.check(lib.gs_project_bwd_cap(N, L.ptr(s["counts"]), 3, L.ptr(means), L.ptr(quats), L.ptr(scales_act),
                                                    L.ptr(opac_act), L.ptr(vm), L.ptr(K), W, H, L.f32(0.3),
                                                    L.ptr(s["gaussian_ids_i32"]), L.ptr(s["conics"]), L.ptr(s["compensations"]),
@@ -356,11 +428,12 @@ class RenderStep:
                                                L.ptr(s["compensations"]), L.ptr(v_packed), 0, None,
                                                L.ptr(b["means"]), L.ptr(b["quats"]), L.ptr(g_scales_act), L.ptr(g_opac_act),
                                                L.ptr(g_colors), 1, st()), "gs_project_bwd")
-                L.check(lib.gs_shade_bwd(N, L.ptr(means), L.ptr(normals), L.ptr(kd), L.ptr(ks), L.ptr(cam_pos),
-                                         L.f32(self.min_roughness), L.f32(self.max_metallic), mode, C.byref(e), L.ptr(g_colors),
-                                         L.ptr(b["means"]), L.ptr(b["normals"]), L.ptr(b["kd"]), L.ptr(b["ks"]), C.byref(eg), 1,
-                                         L.ptr(ws) if ws_bytes else None, C.c_size_t(ws_bytes), st()), "gs_shade_bwd")
-            for t in (v_packed, g_colors, s["gaussian_ids_i32"], s["conics"], s["compensations"], s.get("counts")):
+                if not fused_front:
+                    L.check(lib.gs_shade_bwd(N, L.ptr(means), L.ptr(normals), L.ptr(kd), L.ptr(ks), L.ptr(cam_pos),
+                                             L.f32(self.min_roughness), L.f32(self.max_metallic), mode, C.byref(e), L.ptr(g_colors),
+                                             L.ptr(b["means"]), L.ptr(b["normals"]), L.ptr(b["kd"]), L.ptr(b["ks"]), C.byref(eg), 1,
+                                             L.ptr(ws) if ws_bytes else None, C.c_size_t(ws_bytes), st()), "gs_shade_bwd")
+            for t in (v_packed, g_colors, s.get("gaussian_ids_i32"), s.get("conics"), s.get("compensations"), s.get("counts"), s.get("vis_records")):
                 if t is not None:
                     t.record_stream(tail)                    # (`counts` too: gs_project_bwd_cap reads {V, I} on the tail stream)
             if n_sets == 2 and i == half - 1:
@@ -376,18 +449,21 @@ class RenderStep:
             if keep_images:
                 images.append(img)
         main.wait_stream(tail)
+        if tail_priv is not None:
+            F.tail_priv_reduce(e, g_sets[0][2], mode, tail_priv)
+            tail_priv.record_stream(tail)
         self._seen_counts.extend(seen)                       # entries of earlier steps the host has not looked at yet stay pending
         if i_cap is not None:                                # the overflow word follows the step to the host, asynchronously
             if torch.cuda.is_current_stream_capturing():      # a replayed graph refreshes ONE pinned buffer; replay.check() reads it
                 if self._status_host is None:
-                    self._status_host = torch.zeros(3, dtype=torch.int64).pin_memory()
+                    self._status_host = torch.zeros(4, dtype=torch.int64).pin_memory()
                 self._status_host.copy_(self._status, non_blocking=True)
                 self._status_event = torch.cuda.Event(); self._status_event.record()
             else:
                 # eager: every step gets its OWN snapshot and clears the word behind it (all of this step's writers are upstream of
                 # the main stream here, the next step's fronts fork from it), so that an overflow is attributed to exactly one step
                 # however many steps are in flight
-                snap = self._status_pool.pop() if self._status_pool else torch.zeros(3, dtype=torch.int64).pin_memory()
+                snap = self._status_pool.pop() if self._status_pool else torch.zeros(4, dtype=torch.int64).pin_memory()
                 snap.copy_(self._status, non_blocking=True)
                 self._status.fill_(0)
                 ev_s = torch.cuda.Event(); ev_s.record()
@@ -457,10 +533,11 @@ class RenderStep:
         dev = self.p.means.device
         while len(_pinned_pool) < 2 * len(cameras) + 2:       # pinned buffers cannot be allocated while a stream is capturing
             _pinned_pool.append(torch.empty(2, dtype=torch.int64).pin_memory())
+        F.reserve_pinned(2 * len(cameras) + 2)
         if self._status is None:
-            self._status = torch.zeros(3, dtype=torch.int64, device=dev)
+            self._status = torch.zeros(4, dtype=torch.int64, device=dev)
         if self._status_host is None:
-            self._status_host = torch.zeros(3, dtype=torch.int64).pin_memory()
+            self._status_host = torch.zeros(4, dtype=torch.int64).pin_memory()
         warm = torch.cuda.Stream(device=dev)
         warm.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(warm):                          # (allocator warm-up on a side stream, as torch.cuda.graph asks)
@@ -484,9 +561,10 @@ class RenderStep:
         def check() -> bool:
             torch.cuda.synchronize(dev)
             worst = max([int(hc[1]) for hc in counts] + [0])
-            overflow = int(status_host[0]) != 0 or worst > cap
+            overflow = int(status_host[0]) != 0 or int(status_host[3]) != 0 or worst > cap
             if overflow:
                 self.truncated_steps += 1
+                self._key32 = self._key32 or int(status_host[3]) != 0
                 self._exact_max_i = max(self._exact_max_i, worst, int(status_host[1]))
                 self._status.zero_(); status_host.zero_()
             return not overflow
@@ -513,8 +591,9 @@ class RenderStep:
         dev = self.p.means.device
         while len(_pinned_pool) < 2 * len(cameras) + 2:       # pinned buffers cannot be allocated while a stream is capturing
             _pinned_pool.append(torch.empty(2, dtype=torch.int64).pin_memory())
+        F.reserve_pinned(2 * len(cameras) + 2)
         if self._status_host is None:
-            self._status_host = torch.zeros(3, dtype=torch.int64).pin_memory()
+            self._status_host = torch.zeros(4, dtype=torch.int64).pin_memory()
         world = dist.get_world_size() if (all_reduce and dist.is_available() and dist.is_initialized()) else 1
         sharded = (world > 1 and os.environ.get("GEOSPLAT_SHARD_PREFILTER", "1") != "0"
                    and can_shard_prefilter(int(self.p.cubemap.shape[1]), world))
@@ -556,9 +635,10 @@ class RenderStep:
         def check() -> bool:
             torch.cuda.synchronize(dev)
             worst = max([int(hc[1]) for hc in counts] + [0])
-            overflow = int(status_host[0]) != 0 or worst > cap
+            overflow = int(status_host[0]) != 0 or int(status_host[3]) != 0 or worst > cap
             if overflow:
                 self.truncated_steps += 1
+                self._key32 = self._key32 or int(status_host[3]) != 0
                 self._exact_max_i = max(self._exact_max_i, worst, int(status_host[1]))
                 self._status.zero_(); status_host.zero_()
             return not overflow
@@ -600,6 +680,11 @@ class RenderStep:
                 ev.synchronize()
             if ev.query():
                 max_i = max(max_i, int(hc[1]))
+                if hc.numel() == 4:                             # fused front: {V, I, ~min depth bits, max depth bits}
+                    rng = F.depth_range(hc)
+                    if rng is not None:
+                        self._key_lo = rng[0] if self._key_lo is None else min(self._key_lo, rng[0])
+                        self._key_hi = rng[1] if self._key_hi is None else max(self._key_hi, rng[1])
         while self._status_pending:                           # eager steps, oldest first; each snapshot is inspected exactly once
             snap, ev_s = self._status_pending[0]
             if wait:
@@ -607,18 +692,22 @@ class RenderStep:
             if not ev_s.query():
                 break
             self._status_pending.popleft()
-            if int(snap[0]) != 0:
+            if int(snap[0]) != 0 or int(snap[3]) != 0:
                 ok = False
                 self.truncated_steps += 1
                 max_i = max(max_i, int(snap[1]))
+                if int(snap[3]) != 0:                          # a depth outside the 24-bit key range: 32-bit keys from now on
+                    self._key32 = True
             self._status_pool.append(snap)
         if self._status_event is not None:                    # the single buffer of a captured step (see capture / capture_views)
             if wait:
                 self._status_event.synchronize()
-            if self._status_event.query() and int(self._status_host[0]) != 0:
+            if self._status_event.query() and (int(self._status_host[0]) != 0 or int(self._status_host[3]) != 0):
                 ok = False
                 self.truncated_steps += 1
                 max_i = max(max_i, int(self._status_host[1]))
+                if int(self._status_host[3]) != 0:
+                    self._key32 = True
                 self._status.zero_(); self._status_host.zero_()
             if self._status_event.query():
                 self._status_event = None
@@ -628,7 +717,7 @@ class RenderStep:
             if hc is None:
                 continue
             if ev.query():
-                _pinned_pool.append(hc)
+                (F.release_counts4 if hc.numel() == 4 else _pinned_pool.append)(hc)
             else:
                 still.append((hc, ev))
         self._seen_counts = still

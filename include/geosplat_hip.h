@@ -463,6 +463,68 @@ int gs_flexicubes_entropy_fwd(int R0, int R1, int R2, const float* sdf, void* ws
 int gs_flexicubes_entropy_bwd(int R0, int R1, int R2, const float* sdf, const void* ws, size_t ws_bytes, const float* v_out,
                               float* g_sdf, int accumulate, void* stream);
 
+/* ------------------------------------------------------------------ fused front / tail of a view (the engine's path) ---------- */
+/* Shading fused AHEAD of the projection (north star; reference semantics rfstudio/model/geosplat.py:80-128 followed by the
+ * rasterization call at rfstudio/model/gsplat.py:334-355): one launch projects every Gaussian (gs_project_fwd's arithmetic),
+ * shades the visible ones (gs_shade_fwd's arithmetic) and writes, in packed order (ascending Gaussian index),
+ *   vis_records [N,16] f32 : {mx, my, a/2, b | c/2, opacity*comp, hx, hy | r, g, b, 0 | comp, bits(Gaussian index), depth, bits(radius)}
+ *                            -- gs_raster_prepare_vis(_cap) consumes it as is, gs_tail_bwd reads the fourth quarter;
+ *   depth_keys [N] u32     : the binning's depth key.  key_bits == 32: the depth's float bits.  key_bits == 24: bits - key_base,
+ *                            valid while key_base <= bits < key_base + 2^24 for every visible Gaussian -- otherwise
+ *                            status4[3] is set to 1 (int64[4], caller-zeroed, sticky; words 0..2 as for gs_isect_bin_cap) and the
+ *                            key is clamped: memory-safe, wrong order, reported;
+ *   tile_rects [N,2] u32   : (x0 | y0 << 16, x1 | y1 << 16), the tile rectangle of gs_project_fwd's tiles_per_gauss;
+ *   tile_counts [tiles] u32: intersections per tile (zeroed by the call; nullable, and not written for more than 8 192 tiles):
+ *                            gs_isect_bin_front turns them into the tile offsets;
+ *   counts4 [4] i64        : {V, I, 0xffffffff - min depth bits, max depth bits} (zeroed by the call).
+ * No other per-visible array exists on this path.  Scratch: gs_front_ws_bytes(N), zeroed by the call. */
+size_t gs_front_ws_bytes(int N);
+int gs_front_fwd(int N, const float* means, const float* quats, const float* scales, const float* opacities,
+                 const float* normals, const float* kd, const float* ks, const float* viewmat, const float* K,
+                 const float* cam_pos, float min_roughness, float max_metallic, int mode, const GsEnv* env,
+                 int W, int H, int tile_size, float eps2d, float near_plane, float far_plane, float radius_clip,
+                 uint32_t key_base, int key_bits, float* vis_records, uint32_t* depth_keys, uint32_t* tile_rects,
+                 uint32_t* tile_counts, int32_t* packed_index /* [N], nullable: packed slot of every Gaussian or -1 */,
+                 int64_t* counts4, int64_t* status4, void* ws, size_t ws_bytes, void* stream);
+/* Binning from gs_front_fwd's outputs: flatten_ids_sorted in (tile, depth, packed index) order and the tile offsets, bit-identical
+ * to gs_isect_bin_tiles_cap + gs_isect_offsets_tiles_cap.  counts_dev == NULL: V_cap / n_isects_cap are the exact counts; otherwise
+ * the capacity protocol of gs_isect_bin_cap (status_dev int64[4]).  key_bits as passed to gs_front_fwd. */
+size_t gs_isect_bin_front_ws_bytes(int V, int64_t n_isects, int tile_w, int tile_h);
+int gs_isect_bin_front(int V_cap, const uint32_t* depth_keys, const uint32_t* tile_rects, const uint32_t* tile_counts,
+                       const int64_t* counts_dev, int64_t n_isects_cap, int key_bits, int tile_w, int tile_h, int32_t* flatten_ids_sorted,
+                       int32_t* isect_offsets, void* ws, size_t ws_bytes, int64_t* status_dev, void* stream);
+/* Projection backward fused with the shading backward (gs_project_bwd + gs_shade_bwd in one launch, one thread per VISIBLE
+ * Gaussian): reads vis_records and the compositor's gradient records v_packed [V, rec_stride] ({xy, conic(3), opacity, rgb}),
+ * ADDS into v_means [N,3], v_quats [N,4], v_scales [N,3] (gradient w.r.t. the scales passed in), v_opacities [N], v_normals,
+ * v_kd [N,3], v_ks [N,2] and into the texel gradients env_grad.  counts_dev == NULL: V_cap is the count. */
+int gs_tail_bwd(int V_cap, const int64_t* counts_dev, const float* means, const float* quats, const float* scales,
+                const float* opacities, const float* normals, const float* kd, const float* ks, const float* viewmat,
+                const float* K, const float* cam_pos, float min_roughness, float max_metallic, int mode, const GsEnv* env,
+                int W, int H, float eps2d, const float* vis_records, const float* v_packed, int rec_stride,
+                float* v_means, float* v_quats, float* v_scales, float* v_opacities, float* v_normals, float* v_kd, float* v_ks,
+                const GsEnvGrad* env_grad, void* priv_ws, size_t priv_ws_bytes, void* stream);
+/* The tails of ALL views of a step in one launch: one thread per Gaussian loops over the views, keeps the 19 parameter gradients in
+ * registers and stores them once (accumulate == 0: plain stores into v_*, every Gaussian written; != 0: added).  Per view: what
+ * gs_front_fwd wrote (vis_records, packed_index) and the compositor's v_packed [V, rec_stride].  Same arithmetic as gs_tail_bwd,
+ * summed over the views in view order. */
+typedef struct GsTailView {
+    const float* viewmat; const float* K; const float* cam_pos;            /* device: [4,4], [3,3], [3] */
+    const float* vis_records; const float* v_packed; const int32_t* packed_index;
+    int W, H;
+} GsTailView;
+int gs_tail_bwd_multi(int N, int n_views, const GsTailView* views /*host array*/, const float* means, const float* quats,
+                      const float* scales, const float* opacities, const float* normals, const float* kd, const float* ks,
+                      float min_roughness, float max_metallic, int mode, const GsEnv* env, float eps2d, int rec_stride,
+                      float* v_means, float* v_quats, float* v_scales, float* v_opacities, float* v_normals, float* v_kd, float* v_ks,
+                      int accumulate, const GsEnvGrad* env_grad, void* priv_ws, size_t priv_ws_bytes, void* stream);
+/* Optional scratch of gs_tail_bwd / gs_tail_bwd_multi: eight XCD-private copies of the mid-sized specular levels (64^2, 128^2 of a 512^2 pyramid), whose
+ * texel atomics then resolve in the XCD's own L2 instead of at the memory side of the fabric.  The caller zeroes priv_ws
+ * (gs_tail_priv_ws_bytes) once, every gs_tail_bwd of a step ADDS into it, gs_tail_priv_reduce folds it into env_grad once.
+ * priv_ws == NULL: every texel gradient goes straight into env_grad. */
+size_t gs_tail_priv_ws_bytes(const GsEnv* env /*host*/, int mode);
+int gs_tail_priv_reduce(const GsEnv* env /*host*/, int mode, const void* priv_ws, size_t priv_ws_bytes, const GsEnvGrad* env_grad,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

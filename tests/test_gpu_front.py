@@ -1,0 +1,345 @@
+"""GPU parity of the engine's fused per-view kernels (csrc/gs_front.hip, gs_isect_bin_front) against the call-shaped ops they
+replace, which are themselves checked against the CPU oracle (tests/test_gpu_shading.py, tests/test_gpu_rasterizer.py):
+  gs_front_fwd        == gs_shade_fwd + gs_project_fwd_vis (+ tile rectangles)          bit for bit
+  gs_isect_bin_front  == rasterization()'s flatten_ids / isect_offsets                  bit for bit (24- and 32-bit keys, > 8 192 tiles)
+  gs_tail_bwd         == gs_project_bwd + gs_shade_bwd                                  1e-5 (summation order of the two mean paths)
+and the oracle itself on the whole chain through engine.RenderStep is tests/test_gpu_fullsize.py / test_gpu_parallel.py."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import random_case, rel_err, sphere_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _env(cuda, seed=3, res=(64, 32, 16)):
+    import geosplatting_amd as gs
+    g = torch.Generator().manual_seed(seed)
+    levels = [(torch.rand(6, r, r, 3, generator=g) + 0.05).to(cuda) for r in res]
+    base = (torch.rand(6, 16, 16, 3, generator=g) + 0.05).to(cuda)
+    return gs.TextureSplitSum(base, levels)
+
+
+def _inputs(cuda, level=3, res=128, view=1):
+    sc, cam = sphere_case(level, res, view=view)
+    d = lambda t: t.to(cuda).contiguous()
+    sp = sc.splats
+    return dict(means=d(sp.means), quats=d(sp.quats), scales=d(sp.scales.exp()), opac=d(torch.sigmoid(sp.opacities).squeeze(-1)),
+                normals=d(sc.normals), kd=d(sc.kd), ks=d(sc.ks), vm=d(cam.view_matrix), K=d(cam.intrinsic_matrix),
+                cam_pos=d(cam.c2w[:, 3]), W=res, H=res)
+
+
+def _front(x, env, cuda, key_base=0, key_bits=32, status=None, mode="pbr"):
+    import geosplatting_amd as gs
+    from geosplatting_amd import front as F
+    from geosplatting_amd.shading import _MODE, _make_env
+    e = _make_env(gs.get_fg_lut(cuda), env)
+    fr = F.front_stage(x["means"], x["quats"], x["scales"], x["opac"], x["normals"], x["kd"], x["ks"], x["vm"], x["K"], x["cam_pos"], e,
+                       x["W"], x["H"], 0.1, 1.0, _MODE[mode], key_base, key_bits, status)
+    torch.cuda.synchronize()
+    return fr, e
+
+
+def _reference_meta(x, env, cuda, mode="pbr"):
+    import geosplatting_amd as gs
+    col = gs.shade(x["means"], x["normals"], x["kd"], x["ks"], x["cam_pos"], env, min_roughness=0.1, max_metallic=1.0, mode=mode)
+    r, a, meta = gs.rasterization(x["means"], x["quats"], x["scales"], x["opac"], col, x["vm"][None], x["K"][None], x["W"], x["H"])
+    return col, meta
+
+
+@pytest.mark.parametrize("mode", ["pbr", "specular", "diffuse"])
+def test_front_records_equal_shade_plus_project(cuda, mode):
+    x = _inputs(cuda)
+    env = _env(cuda)
+    fr, _ = _front(x, env, cuda, mode=mode)
+    col, meta = _reference_meta(x, env, cuda, mode)
+    V, I = int(fr.host_counts[0]), int(fr.host_counts[1])
+    assert V == meta["radii"].shape[0] and I == meta["flatten_ids"].shape[0] and V > 1000
+    vis = fr.vis[:V].cpu().numpy()
+    gid = np.ascontiguousarray(vis[:, 13]).view(np.int32)
+    assert np.array_equal(gid, meta["gaussian_ids"].cpu().numpy().astype(np.int32))
+    m2, con = meta["means2d"].cpu().numpy(), meta["conics"].cpu().numpy()
+    assert np.array_equal(vis[:, 0:2], m2)
+    assert np.array_equal(vis[:, 2], 0.5 * con[:, 0]) and np.array_equal(vis[:, 3], con[:, 1]) and np.array_equal(vis[:, 4], 0.5 * con[:, 2])
+    assert np.array_equal(vis[:, 5], meta["opacities"].cpu().numpy())
+    assert np.array_equal(vis[:, 8:11], col.detach().cpu().numpy()[gid])            # the colours of gs_shade_fwd, bit for bit
+    assert np.array_equal(vis[:, 12], meta["compensations"].cpu().numpy())
+    assert np.array_equal(vis[:, 14], meta["depths"].cpu().numpy())
+    assert np.array_equal(np.ascontiguousarray(vis[:, 15]).view(np.int32), meta["radii"].cpu().numpy())
+    keys = fr.keys[:V].cpu().numpy().view(np.uint32)
+    assert np.array_equal(keys, meta["depths"].cpu().numpy().view(np.uint32))       # 32-bit keys = the depth bits
+    rc = fr.rects[:V].cpu().numpy().view(np.uint32)
+    x0, y0, x1, y1 = rc[:, 0] & 0xffff, rc[:, 0] >> 16, rc[:, 1] & 0xffff, rc[:, 1] >> 16
+    assert np.array_equal(((x1 - x0) * (y1 - y0)).astype(np.int32), meta["tiles_per_gauss"].cpu().numpy())
+    lo, hi = 0xffffffff - int(fr.host_counts[2]), int(fr.host_counts[3])
+    bits = meta["depths"].cpu().numpy().view(np.uint32)
+    assert lo == int(bits.min()) and hi == int(bits.max())
+
+
+@pytest.mark.parametrize("key_bits,res", [(32, 128), (24, 128), (24, 1616)])
+def test_bin_front_equals_rasterization_order(cuda, key_bits, res):
+    """flatten_ids / offsets of the fused binning against rasterization()'s meta (itself bit-exact against the oracle);
+    res 1616 -> 101 x 101 = 10 201 tiles: the path that keeps the tile ids (more tiles than the LDS histogram holds)."""
+    from geosplatting_amd import front as F
+    x = _inputs(cuda, level=3, res=res)
+    env = _env(cuda)
+    _, meta = _reference_meta(x, env, cuda)
+    bits = meta["depths"].cpu().numpy().view(np.uint32)
+    status = torch.zeros(4, dtype=torch.int64, device=cuda)
+    base = int(bits.min()) - (1 << 20) if key_bits == 24 else 0
+    fr, _ = _front(x, env, cuda, key_base=base, key_bits=key_bits, status=status)
+    V, I = int(fr.host_counts[0]), int(fr.host_counts[1])
+    # exact mode
+    state, v, i = F.bin_stage(fr, None, None)
+    assert (v, i) == (V, I)
+    torch.cuda.synchronize()
+    assert np.array_equal(state["flatten_ids"][:I].cpu().numpy(), meta["flatten_ids"].cpu().numpy())
+    assert np.array_equal(state["isect_offsets"].cpu().numpy(), meta["isect_offsets"].reshape(-1).cpu().numpy())
+    # capacity mode: counts read on the device, buffers sized by (N, I_cap)
+    fr2, _ = _front(x, env, cuda, key_base=base, key_bits=key_bits, status=status)
+    cap = ((int(I * 1.25) + 65535) // 65536) * 65536
+    state2, v2, i2 = F.bin_stage(fr2, cap, status)
+    torch.cuda.synchronize()
+    assert (v2, i2) == (x["means"].shape[0], cap)
+    assert np.array_equal(state2["flatten_ids"][:I].cpu().numpy(), meta["flatten_ids"].cpu().numpy())
+    assert np.array_equal(state2["isect_offsets"].cpu().numpy(), meta["isect_offsets"].reshape(-1).cpu().numpy())
+    assert status.cpu().tolist() == [0, 0, 0, 0]
+
+
+def test_bin_front_depth_ties_and_random_scene(cuda):
+    """random splats (many tiles per Gaussian, overlapping depths) with a block of exactly equal depths: ties keep packed order"""
+    import geosplatting_amd as gs
+    from geosplatting_amd import front as F
+    sp, cam = random_case(20000, 256)
+    d = lambda t: t.to(cuda).contiguous()
+    means = sp.means.clone()
+    vm = cam.view_matrix
+    # 4 000 Gaussians on one plane of constant camera depth: z_cam = const  ->  identical depth bits are likely; force them
+    means[:4000] = means[:4000] - (means[:4000] @ vm[2, :3])[:, None] * vm[2, :3][None, :]
+    x = dict(means=d(means), quats=d(sp.quats), scales=d(sp.scales.exp()), opac=d(torch.sigmoid(sp.opacities).squeeze(-1)),
+             normals=d(torch.nn.functional.normalize(torch.randn(sp.num, 3, generator=torch.Generator().manual_seed(5)), dim=-1)),
+             kd=d(torch.rand(sp.num, 3)), ks=d(torch.rand(sp.num, 2)), vm=d(vm), K=d(cam.intrinsic_matrix), cam_pos=d(cam.c2w[:, 3]),
+             W=256, H=256)
+    env = _env(cuda)
+    _, meta = _reference_meta(x, env, cuda)
+    fr, _ = _front(x, env, cuda)
+    I = int(fr.host_counts[1])
+    state, _, _ = F.bin_stage(fr, None, None)
+    torch.cuda.synchronize()
+    assert I == meta["flatten_ids"].shape[0] and I > 50000
+    assert np.array_equal(state["flatten_ids"][:I].cpu().numpy(), meta["flatten_ids"].cpu().numpy())
+    assert np.array_equal(state["isect_offsets"].cpu().numpy(), meta["isect_offsets"].reshape(-1).cpu().numpy())
+
+
+def test_front_reports_depth_outside_key_range(cuda):
+    x = _inputs(cuda)
+    env = _env(cuda)
+    fr, _ = _front(x, env, cuda)
+    lo, hi = 0xffffffff - int(fr.host_counts[2]), int(fr.host_counts[3])
+    status = torch.zeros(4, dtype=torch.int64, device=cuda)
+    _front(x, env, cuda, key_base=lo + 16, key_bits=24, status=status)             # the nearest Gaussians fall below the base
+    assert status.cpu().tolist()[3] == 1
+    status.zero_()
+    _front(x, env, cuda, key_base=max(0, hi - (1 << 24) - 5), key_bits=24, status=status)   # the farthest ones beyond base + 2^24
+    assert status.cpu().tolist()[3] == 1
+    status.zero_()
+    _front(x, env, cuda, key_base=lo, key_bits=24, status=status)
+    assert status.cpu().tolist() == [0, 0, 0, 0]
+
+
+@pytest.mark.parametrize("mode", ["pbr", "diffuse"])
+def test_tail_equals_project_bwd_plus_shade_bwd(cuda, mode):
+    import geosplatting_amd as gs
+    from geosplatting_amd import _lib as L
+    from geosplatting_amd import front as F
+    from geosplatting_amd.shading import _MODE
+    lib = L.lib()
+    x = _inputs(cuda, level=4, res=160)
+    env = _env(cuda)
+    fr, e = _front(x, env, cuda, mode=mode)
+    V = int(fr.host_counts[0])
+    N = x["means"].shape[0]
+    g = torch.Generator().manual_seed(7)
+    stride = lib.gs_raster_grad_stride(3)
+    v_packed = torch.zeros(V, stride, device=cuda)
+    v_packed[:, :9] = (torch.rand(V, 9, generator=g) * 2 - 1).to(cuda)
+    v_packed[::7] = 0.0                                                       # Gaussians that reached no pixel
+    v_packed[1::11, 6:9] = 0.0                                                # geometry gradient only
+    # reference: the two call-shaped kernels
+    col, meta = _reference_meta(x, env, cuda, mode)
+    f32 = torch.float32
+    z = lambda *s: torch.zeros(*s, dtype=f32, device=cuda)
+    r = dict(means=z(N, 3), quats=z(N, 4), scales=z(N, 3), opac=z(N), normals=z(N, 3), kd=z(N, 3), ks=z(N, 2))
+    g_colors = torch.empty(N, 3, device=cuda)
+    gids = meta["gaussian_ids"].int().contiguous()
+    L.check(lib.gs_project_bwd(N, V, 3, L.ptr(x["means"]), L.ptr(x["quats"]), L.ptr(x["scales"]), L.ptr(x["opac"]), L.ptr(x["vm"]), L.ptr(x["K"]),
+                               x["W"], x["H"], L.f32(0.3), L.ptr(gids), L.ptr(meta["conics"]),
+                               L.ptr(meta["compensations"]), L.ptr(v_packed), stride, None, L.ptr(r["means"]), L.ptr(r["quats"]),
+                               L.ptr(r["scales"]), L.ptr(r["opac"]), L.ptr(g_colors), 1, L.stream()), "gs_project_bwd")
+    rb, rl = torch.zeros_like(env.base), [torch.zeros_like(l) for l in env.levels]
+    eg = L.GsEnvGrad(); eg.base = rb.data_ptr()
+    for i, t in enumerate(rl):
+        eg.levels[i] = t.data_ptr()
+    L.check(lib.gs_shade_bwd(N, L.ptr(x["means"]), L.ptr(x["normals"]), L.ptr(x["kd"]), L.ptr(x["ks"]), L.ptr(x["cam_pos"]), L.f32(0.1),
+                             L.f32(1.0), _MODE[mode], C.byref(e), L.ptr(g_colors), L.ptr(r["means"]), L.ptr(r["normals"]), L.ptr(r["kd"]),
+                             L.ptr(r["ks"]), C.byref(eg), 1, None, C.c_size_t(0), L.stream()), "gs_shade_bwd")
+    # fused tail
+    t = dict(means=z(N, 3), quats=z(N, 4), scales=z(N, 3), opac=z(N), normals=z(N, 3), kd=z(N, 3), ks=z(N, 2))
+    tb, tl = torch.zeros_like(env.base), [torch.zeros_like(l) for l in env.levels]
+    eg2 = L.GsEnvGrad(); eg2.base = tb.data_ptr()
+    for i, tt in enumerate(tl):
+        eg2.levels[i] = tt.data_ptr()
+    F.tail_stage(V, None, x["means"], x["quats"], x["scales"], x["opac"], x["normals"], x["kd"], x["ks"], x["vm"], x["K"], x["cam_pos"], e, eg2,
+                 x["W"], x["H"], 0.1, 1.0, _MODE[mode], fr.vis, v_packed, t["means"], t["quats"], t["scales"], t["opac"], t["normals"],
+                 t["kd"], t["ks"])
+    torch.cuda.synchronize()
+    for k in r:
+        a, b = t[k].cpu().numpy(), r[k].cpu().numpy()
+        assert np.abs(b).max() > 0, k
+        assert rel_err(a, b) < 1e-5, k
+    for a, b in zip([tb] + tl, [rb] + rl):
+        if float(b.abs().max()) == 0.0:
+            assert float(a.abs().max()) == 0.0
+        else:
+            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+    # capacity form: the count read on the device
+    t2 = dict(means=z(N, 3), quats=z(N, 4), scales=z(N, 3), opac=z(N), normals=z(N, 3), kd=z(N, 3), ks=z(N, 2))
+    tb2, tl2 = torch.zeros_like(env.base), [torch.zeros_like(l) for l in env.levels]
+    eg3 = L.GsEnvGrad(); eg3.base = tb2.data_ptr()
+    for i, tt in enumerate(tl2):
+        eg3.levels[i] = tt.data_ptr()
+    vp = torch.zeros(N, stride, device=cuda); vp[:V] = v_packed
+    F.tail_stage(N, fr.counts, x["means"], x["quats"], x["scales"], x["opac"], x["normals"], x["kd"], x["ks"], x["vm"], x["K"], x["cam_pos"], e,
+                 eg3, x["W"], x["H"], 0.1, 1.0, _MODE[mode], fr.vis, vp, t2["means"], t2["quats"], t2["scales"], t2["opac"], t2["normals"],
+                 t2["kd"], t2["ks"])
+    torch.cuda.synchronize()
+    for k in r:
+        assert rel_err(t2[k].cpu().numpy(), r[k].cpu().numpy()) < 1e-5, k
+    # XCD-private copies of the mid-sized levels (here the 64^2 level): accumulate over two calls, fold once
+    t3 = dict(means=z(N, 3), quats=z(N, 4), scales=z(N, 3), opac=z(N), normals=z(N, 3), kd=z(N, 3), ks=z(N, 2))
+    tb3, tl3 = torch.zeros_like(env.base), [torch.zeros_like(l) for l in env.levels]
+    eg4 = L.GsEnvGrad(); eg4.base = tb3.data_ptr()
+    for i, tt in enumerate(tl3):
+        eg4.levels[i] = tt.data_ptr()
+    priv = F.tail_priv_alloc(e, _MODE[mode], cuda)
+    assert (priv is not None) == (mode != "diffuse")
+    for _ in range(2):
+        F.tail_stage(V, None, x["means"], x["quats"], x["scales"], x["opac"], x["normals"], x["kd"], x["ks"], x["vm"], x["K"], x["cam_pos"], e,
+                     eg4, x["W"], x["H"], 0.1, 1.0, _MODE[mode], fr.vis, v_packed, t3["means"], t3["quats"], t3["scales"], t3["opac"],
+                     t3["normals"], t3["kd"], t3["ks"], priv=priv)
+    F.tail_priv_reduce(e, eg4, _MODE[mode], priv)
+    torch.cuda.synchronize()
+    for a, b in zip([tb3] + tl3, [rb] + rl):
+        if float(b.abs().max()) == 0.0:
+            assert float(a.abs().max()) == 0.0
+        else:
+            assert rel_err(a.cpu().numpy(), 2.0 * b.cpu().numpy()) < 1e-5
+
+
+def test_tail_multi_equals_sum_of_view_tails(cuda):
+    """gs_tail_bwd_multi over three views == three gs_tail_bwd calls accumulated (same arithmetic, the sum over the views taken in
+    registers): parameter gradients and texel gradients; a second multi call ADDS."""
+    import geosplatting_amd as gs
+    from geosplatting_amd import _lib as L
+    from geosplatting_amd import front as F
+    from geosplatting_amd.shading import _MODE, _make_env
+    lib = L.lib()
+    env = _env(cuda)
+    e = _make_env(gs.get_fg_lut(cuda), env)
+    stride = lib.gs_raster_grad_stride(3)
+    g = torch.Generator().manual_seed(9)
+    views, xs = [], []
+    for view in (0, 3, 5):
+        x = _inputs(cuda, level=4, res=160, view=view)
+        fr = F.front_stage(x["means"], x["quats"], x["scales"], x["opac"], x["normals"], x["kd"], x["ks"], x["vm"], x["K"], x["cam_pos"], e,
+                           x["W"], x["H"], 0.1, 1.0, _MODE["pbr"], want_packed_index=True)
+        torch.cuda.synchronize()
+        V = int(fr.host_counts[0])
+        vp = torch.zeros(V, stride, device=cuda)
+        vp[:, :9] = (torch.rand(V, 9, generator=g) * 2 - 1).to(cuda)
+        vp[::5] = 0.0
+        views.append((x["vm"], x["K"], x["cam_pos"], fr.vis, vp, fr.packed_index, x["W"], x["H"]))
+        xs.append((x, fr, V))
+    x0 = xs[0][0]
+    N = x0["means"].shape[0]
+    pidx = views[0][5].cpu().numpy()
+    assert (pidx >= 0).sum() == xs[0][2] and np.array_equal(np.sort(pidx[pidx >= 0]), np.arange(xs[0][2]))
+    z = lambda *s: torch.zeros(*s, device=cuda)
+    def fresh():
+        return (dict(means=z(N, 3), quats=z(N, 4), scales=z(N, 3), opac=z(N), normals=z(N, 3), kd=z(N, 3), ks=z(N, 2)),
+                torch.zeros_like(env.base), [torch.zeros_like(l) for l in env.levels])
+    def grad_struct(b, ls):
+        eg = L.GsEnvGrad(); eg.base = b.data_ptr()
+        for i, t in enumerate(ls):
+            eg.levels[i] = t.data_ptr()
+        return eg
+    r, rb, rl = fresh()
+    egr = grad_struct(rb, rl)
+    for (x, fr, V), vw in zip(xs, views):
+        F.tail_stage(V, None, x["means"], x["quats"], x["scales"], x["opac"], x["normals"], x["kd"], x["ks"], x["vm"], x["K"], x["cam_pos"], e, egr,
+                     x["W"], x["H"], 0.1, 1.0, _MODE["pbr"], fr.vis, vw[4], r["means"], r["quats"], r["scales"], r["opac"], r["normals"],
+                     r["kd"], r["ks"])
+    t, tb, tl = fresh()
+    for k in t:
+        t[k].fill_(123.0)                                                     # accumulate=False must overwrite
+    egt = grad_struct(tb, tl)
+    priv = F.tail_priv_alloc(e, _MODE["pbr"], cuda)
+    F.tail_multi_stage(views, x0["means"], x0["quats"], x0["scales"], x0["opac"], x0["normals"], x0["kd"], x0["ks"], e, egt, 0.1, 1.0,
+                       _MODE["pbr"], t["means"], t["quats"], t["scales"], t["opac"], t["normals"], t["kd"], t["ks"], accumulate=False, priv=priv)
+    F.tail_priv_reduce(e, egt, _MODE["pbr"], priv)
+    torch.cuda.synchronize()
+    for k in r:
+        assert float(r[k].abs().max()) > 0 and rel_err(t[k].cpu().numpy(), r[k].cpu().numpy()) < 1e-5, k
+    for a, b in zip([tb] + tl, [rb] + rl):
+        if float(b.abs().max()) == 0.0:
+            assert float(a.abs().max()) == 0.0
+        else:
+            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+    F.tail_multi_stage(views[:2], x0["means"], x0["quats"], x0["scales"], x0["opac"], x0["normals"], x0["kd"], x0["ks"], e, egt, 0.1, 1.0,
+                       _MODE["pbr"], t["means"], t["quats"], t["scales"], t["opac"], t["normals"], t["kd"], t["ks"], accumulate=True)
+    r2, rb2, rl2 = fresh()
+    egr2 = grad_struct(rb2, rl2)
+    for (x, fr, V), vw in zip(xs[:2], views[:2]):
+        F.tail_stage(V, None, x["means"], x["quats"], x["scales"], x["opac"], x["normals"], x["kd"], x["ks"], x["vm"], x["K"], x["cam_pos"], e, egr2,
+                     x["W"], x["H"], 0.1, 1.0, _MODE["pbr"], fr.vis, vw[4], r2["means"], r2["quats"], r2["scales"], r2["opac"], r2["normals"],
+                     r2["kd"], r2["ks"])
+    torch.cuda.synchronize()
+    for k in r:
+        assert rel_err(t[k].cpu().numpy(), (r[k] + r2[k]).cpu().numpy()) < 1e-5, k
+
+
+def test_engine_front_modes_agree(cuda, monkeypatch):
+    """One step of the engine with the fused front / tail against the round-3 launch sequence (GEOSPLAT_FRONT=split): the same
+    images bit for bit, gradients to the order of the float atomics; and a second step runs with 24-bit keys."""
+    import geosplatting_amd.synthetic as syn
+    from geosplatting_amd.engine import RenderStep, params_from_scene
+    scene = syn.sphere_scene(4, seed=1, cubemap_res=64, device=cuda)
+    cams = syn.blender_cameras(num=3, width=160, height=160)
+    g = torch.Generator().manual_seed(0)
+    ups = [(torch.rand(160, 160, 4, generator=g) * 2 - 1).to(cuda) for _ in cams]
+    out = {}
+    for mode in ("split", "fused", "fused_per_view"):
+        monkeypatch.setenv("GEOSPLAT_FRONT", "split" if mode == "split" else "fused")
+        monkeypatch.setenv("GEOSPLAT_TAIL_BATCH", "0" if mode == "fused_per_view" else "2")     # 3 views: a batch of two, then one that adds
+        step = RenderStep(params_from_scene(scene, cuda, exposure=1.2))
+        grads, images = step(cams, lambda i, img: ups[i], all_reduce=False, keep_images=True)
+        torch.cuda.synchronize()
+        first = ({k: v.clone() for k, v in grads.items()}, [im.clone() for im in images])
+        assert step.poll_capacity(wait=True)
+        grads, images = step(cams, lambda i, img: ups[i], all_reduce=False, keep_images=True)    # capacity mode (24-bit keys when fused)
+        torch.cuda.synchronize()
+        assert step.poll_capacity(wait=True) and step.truncated_steps == 0
+        if mode != "split":
+            assert step._key_lo is not None and not step._key32
+        out[mode] = (first, ({k: v.clone() for k, v in grads.items()}, [im.clone() for im in images]))
+    for other in ("fused", "fused_per_view"):
+        for which in (0, 1):
+            (ga, ia), (gb, ib) = out["split"][which], out[other][which]
+            for a, b in zip(ia, ib):
+                assert torch.equal(a, b)
+            for k in ga:
+                assert rel_err(gb[k].cpu().numpy(), ga[k].cpu().numpy()) < 2e-5, (other, which, k)

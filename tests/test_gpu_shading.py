@@ -58,6 +58,33 @@ def test_shade_fwd_bwd(cuda, mode, priv, monkeypatch):
             assert rel_err(z(a), b) < TOL, f"v_levels[{i}]"
 
 
+def test_shade_with_caller_supplied_fg_lut(cuda):
+    """`fg_lut=`: an integrator who wants the reference asset's own table (rfstudio/graphics/shaders.py:22-26; it is 2.4e-4 from the
+    converged integral, the packaged table 4e-4 from it) passes it in -- any [1,256,256,2] table is looked up with the same
+    bilinear / clamp rule (S2), forward and backward."""
+    import geosplatting_amd as gs
+    sc, cam = sphere_case(3, 64)
+    base, levels = _random_env()
+    g = torch.Generator().manual_seed(21)
+    lut = torch.rand(1, 256, 256, 2, generator=g)                       # nothing like a BRDF table: the lookup rule is what is tested
+    cam_pos = cam.c2w[:, 3].contiguous()
+    ref = oracle.shade_fwd(sc.splats.means.numpy(), sc.normals.numpy(), sc.kd.numpy(), sc.ks.numpy(), cam_pos.numpy(), lut[0].numpy(),
+                           base.numpy(), [l.numpy() for l in levels])
+    d = lambda x: x.clone().to(cuda).requires_grad_(True)
+    tm, tn, tkd, tks = d(sc.splats.means), d(sc.normals), d(sc.kd), d(sc.ks)
+    env = gs.TextureSplitSum(base.to(cuda), [l.to(cuda) for l in levels])
+    col = gs.shade(tm, tn, tkd, tks, cam_pos.to(cuda), env, min_roughness=0.1, max_metallic=1.0, fg_lut=lut.to(cuda))
+    assert rel_err(col.detach().cpu().numpy(), ref) < TOL
+    packaged = gs.shade(tm, tn, tkd, tks, cam_pos.to(cuda), env, min_roughness=0.1, max_metallic=1.0)
+    assert rel_err(packaged.detach().cpu().numpy(), ref) > 1e-2          # (the table really was the caller's)
+    vc = torch.rand(sc.splats.num, 3, generator=g) * 2 - 1
+    (col * vc.to(cuda)).sum().backward()
+    gref = oracle.shade_bwd(sc.splats.means.numpy(), sc.normals.numpy(), sc.kd.numpy(), sc.ks.numpy(), cam_pos.numpy(), lut[0].numpy(),
+                            base.numpy(), [l.numpy() for l in levels], vc.numpy())
+    for name, tens in (("v_means", tm), ("v_normals", tn), ("v_kd", tkd), ("v_ks", tks)):
+        assert rel_err(tens.grad.cpu().numpy(), gref[name]) < TOL, name
+
+
 @pytest.mark.parametrize("tone", ["naive", "aces", "none"])
 def test_tonemap(cuda, tone):
     import geosplatting_amd as gs

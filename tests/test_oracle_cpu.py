@@ -246,8 +246,12 @@ def test_fg_lut_against_reference_subsample():
     lut = np.fromfile(os.path.join(os.path.dirname(GOLD), "..", "geosplatting_amd", "assets", "fg_lut_256.bin"),
                       dtype=np.float32).reshape(256, 256, 2)
     sub = lut[np.ix_(g["rows"], g["cols"])]
-    assert np.abs(sub - g["values"]).max() < 3e-3      # worst sample sits at the N.V -> 0 column (quadrature convergence)
-    assert np.abs(sub - g["values"]).mean() < 2e-4
+    # Round 4: the packaged table is a converged float64 quadrature (scripts/gen_fg_lut.py; last refinement step <= 2.7e-5).  What is
+    # left against the reference asset is the ASSET's own distance from the integral -- scripts/fg_lut_study.py
+    # (profiles/r04_fg_lut_study.txt): asset vs a 4.2 M-point rule max 2.4e-4 with a smooth +1.2e-4 offset at high roughness,
+    # packaged vs asset max 4.0e-4 / mean 1.1e-4 over the full table.  (Round 3's 16 384-sample table was 3e-3 off.)
+    assert np.abs(sub - g["values"]).max() < 5e-4
+    assert np.abs(sub - g["values"]).mean() < 1.5e-4
 
 
 # ----------------------------------------------------------------------------- 2. known-answer micro scenes

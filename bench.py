@@ -69,9 +69,10 @@ VALU_PEAK_TFLOPS = 157.3     # FP32 vector peak, MI355X_MICROARCH.md
 
 
 def time_dominant_kernels(scene_state, iters):
-    """Durations of the compositor kernels ALONE, with HIP events on the stream they are launched on (torch's current stream):
-    `gs_raster_composite` on a prepared workspace (no record-stream build) and `gs_raster_bwd_acc` (no memset); the
-    workspace preparation (per-visible records, sorted record stream, tile order) is timed as its own entry."""
+    """Durations of the compositor kernels the ENGINE launches, each ALONE, with HIP events on the stream they are launched on
+    (torch's current stream): `gs_raster_composite_tone_log` (raster_fwd_window_kernel with S4 in its epilogue, writing the cull
+    log) on a prepared workspace and `gs_raster_bwd_tone_log_acc` (raster_bwd_log_kernel); the workspace preparation (sorted
+    record stream, tile order) is timed as its own entry.  GEOSPLAT_RASTER_LOG=0: the plain pair (raster_bwd_lanes2_kernel)."""
     import geosplatting_amd._lib as L
     lib = L.lib()
     st = scene_state
@@ -79,13 +80,16 @@ def time_dominant_kernels(scene_state, iters):
     W = H = st["res"]
     V, I, D = st["V"], st["I"], 3
     f32 = torch.float32
+    use_log = os.environ.get("GEOSPLAT_RASTER_LOG", "1") != "0"
     render = torch.empty(H, W, D, dtype=f32, device=dev); alphas = torch.empty(H, W, dtype=f32, device=dev)
-    last = torch.empty(H, W, dtype=torch.int32, device=dev)
-    v_render = torch.rand(H, W, D, device=dev) * 2 - 1; v_alpha = torch.rand(H, W, device=dev) * 2 - 1
+    last = torch.empty(H, W, dtype=torch.int32, device=dev); img = torch.empty(H, W, 4, dtype=f32, device=dev)
+    v_img = torch.rand(H, W, 4, device=dev) * 2 - 1
+    exposure = torch.ones(1, device=dev); v_exp = torch.zeros(1, device=dev)
     v_packed = torch.zeros(V, lib.gs_raster_grad_stride(D), dtype=f32, device=dev)
     s = L.stream()
     rws_bytes = lib.gs_raster_ws_bytes(L.i64(I), V, W, H, 16)
     rws = torch.empty(rws_bytes, dtype=torch.uint8, device=dev)
+    log_ws = torch.empty(lib.gs_raster_log_ws_bytes(L.i64(I), W, H, 16), dtype=torch.uint8, device=dev)
 
     def prep():
         L.check(lib.gs_raster_prepare(W, H, 16, D, V, L.ptr(st["means2d"]), L.ptr(st["conics"]), L.ptr(st["opacities"]),
@@ -93,14 +97,25 @@ def time_dominant_kernels(scene_state, iters):
                                       L.ptr(rws), C.c_size_t(rws_bytes), s), "raster_prepare")
 
     def fwd():
-        L.check(lib.gs_raster_composite(W, H, 16, D, V, L.ptr(st["colors"]), None, L.i64(I), L.ptr(st["offsets"]),
-                                        L.ptr(render), L.ptr(alphas), L.ptr(last), L.ptr(rws), C.c_size_t(rws_bytes), s),
-                "raster_composite")
+        if use_log:
+            L.check(lib.gs_raster_composite_tone_log(W, H, 16, V, None, L.i64(I), None, L.ptr(st["offsets"]), L.ptr(render), L.ptr(alphas),
+                                                     L.ptr(last), 1, L.ptr(exposure), L.ptr(img), L.ptr(rws), C.c_size_t(rws_bytes),
+                                                     L.ptr(log_ws), C.c_size_t(log_ws.numel()), s), "raster_composite_tone_log")
+        else:
+            L.check(lib.gs_raster_composite_tone(W, H, 16, V, None, L.i64(I), None, L.ptr(st["offsets"]), L.ptr(render), L.ptr(alphas),
+                                                 L.ptr(last), 1, L.ptr(exposure), L.ptr(img), L.ptr(rws), C.c_size_t(rws_bytes), s),
+                    "raster_composite_tone")
 
     def bwd():
-        L.check(lib.gs_raster_bwd_acc(W, H, 16, D, V, L.ptr(st["colors"]), None, L.i64(I), L.ptr(st["offsets"]),
-                                      L.ptr(alphas), L.ptr(last), L.ptr(v_render), L.ptr(v_alpha), L.ptr(v_packed),
-                                      L.ptr(rws), C.c_size_t(rws_bytes), s), "raster_bwd_acc")
+        if use_log:
+            L.check(lib.gs_raster_bwd_tone_log_acc(W, H, 16, V, None, L.i64(I), None, L.ptr(st["offsets"]), L.ptr(render), L.ptr(alphas),
+                                                   L.ptr(last), 1, L.ptr(exposure), L.ptr(v_img), L.ptr(v_packed), L.ptr(v_exp), L.ptr(rws),
+                                                   C.c_size_t(rws_bytes), L.ptr(log_ws), C.c_size_t(log_ws.numel()), s),
+                    "raster_bwd_tone_log_acc")
+        else:
+            L.check(lib.gs_raster_bwd_tone_acc(W, H, 16, V, None, L.i64(I), None, L.ptr(st["offsets"]), L.ptr(render), L.ptr(alphas),
+                                               L.ptr(last), 1, L.ptr(exposure), L.ptr(v_img), L.ptr(v_packed), L.ptr(v_exp), L.ptr(rws),
+                                               C.c_size_t(rws_bytes), s), "raster_bwd_tone_acc")
     out = {}
     for name, fn in (("raster_prepare (stream build)", prep), ("raster_fwd_kernel", fwd), ("raster_bwd_kernel", bwd)):
         fn(); torch.cuda.synchronize()
@@ -149,7 +164,8 @@ def file_sha16(path):
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
-LAUNCHED_AS = {"raster_fwd_kernel": "raster_fwd_window_kernel<3>", "raster_bwd_kernel": "raster_bwd_lanes2_kernel<3>"}
+LAUNCHED_AS = {"raster_fwd_kernel": "raster_fwd_window_kernel<3>",
+               "raster_bwd_kernel": "raster_bwd_log_kernel<3>" if os.environ.get("GEOSPLAT_RASTER_LOG", "1") != "0" else "raster_bwd_lanes2_kernel<3>"}
 
 
 def committed_profile(name, kernel_source):
@@ -451,7 +467,7 @@ def main():
         dom = max(comp, key=comp.get)
         # algorithmic bytes of the compositor launches:
         #   fwd: sorted record stream 48 I + image write 20 P        bwd: record stream 48 I + image read 24 P + per-visible grad write 36 V
-        kbytes = {"raster_fwd_kernel": 48 * I + 20 * P, "raster_bwd_kernel": 48 * I + 24 * P + 36 * V}
+        kbytes = {"raster_fwd_kernel": 48 * I + 20 * P, "raster_bwd_kernel": 48 * I + 24 * P + 36 * V}      # (+ 12 B per logged record with the cull log)
         hbm_achieved = kbytes[dom] / (kt[dom] * 1e-3) / 1e9
         view_bytes = algorithmic_bytes_per_view(N, V, I, P, E)
         cb = None

@@ -994,6 +994,13 @@ raster_fwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
 // D == 3 and no background only (what RenderableAttrs.splat passes).
 struct ToneFwd { int mode; const float* exposure; float4* image; };
 struct ToneBwd { int mode; const float* exposure; const float* render; const float4* v_image; float* v_exposure; };
+// Cull log (round 4): what the forward found out about a quadrant's list, kept for the backward.  For every record that entered a
+// dense batch of quadrant q of a tile with a non-empty pixel mask the forward appends {stream index, mask} -- mask = the record's
+// {alpha >= 1/255} pixel set clipped to the pixels that were still active when the batch was built -- at
+//     [4 * offsets[tile] + q * (tile list length) + k],   k = 0 .. count[4 * tile + q) in stream order.
+// The backward walks that list from its end: no raw-batch fill, no cull, no ellipse masks, and a pixel never pops a record that
+// lies behind its own termination (5 % of the popped candidates) -- see raster_bwd_log_kernel.
+struct CullLog { int32_t* idx; unsigned long long* mask; int32_t* count; };
 
 static constexpr int GS_WIN_Q = 192;
 static constexpr int GS_WIN_Q_BYTES = GS_WIN_Q * (16 + 16 + 8 + 4);
@@ -1020,7 +1027,7 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
                          const float4* __restrict__ rec0, const float4* __restrict__ rec1, const float4* __restrict__ rec2,
                          const float* __restrict__ colors, const float* __restrict__ background, GsCount ic,
                          const int32_t* __restrict__ offsets,
-                         float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids, ToneFwd tone)
+                         float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids, ToneFwd tone, CullLog log)
 {
     const int n_isects = (int)gs_count(ic);
     extern __shared__ __align__(16) unsigned char gs_lds_raw[];
@@ -1052,6 +1059,8 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
     unsigned long long listA = 0ull, listB = 0ull;
     int cur_slot = -1;
     int base = start;
+    int log_n = 0;                                                // wave-uniform: entries of this quadrant's cull log
+    const size_t log_base = 4 * (size_t)start + (size_t)wave * (size_t)(end > start ? end - start : 0);
     RawBatch raw0, raw1, raw2;
     raw_load(raw0, rec0, rec1, rec2, start + lane, start + lane < end);
     raw_load(raw1, rec0, rec1, rec2, start + 64 + lane, start + 64 + lane < end);
@@ -1088,6 +1097,15 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
             const float2 b = q.b[slot];
             const unsigned long long pm = record_pixel_mask(lane < nA, a.x, a.y, a.z, a.w, b.x, b.y, qx0, qy0, xmin, xmax, ymin, ymax);
             GS_STAT(1, nA);
+            if (log.idx) {
+                const unsigned long long lm = pm & act;
+                const unsigned long long keep = __ballot(lm != 0ull);
+                if (lm != 0ull) {
+                    const size_t at = log_base + (size_t)(log_n + __popcll(keep & ((1ull << lane) - 1ull)));
+                    log.idx[at] = q.idx[slot]; log.mask[at] = lm;
+                }
+                log_n += __popcll(keep);
+            }
             listA = gs_bit_transpose64(pm, lane);
             if (done) listA = 0ull;
 #ifdef GS_RASTER_STATS
@@ -1101,6 +1119,15 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
             const float2 b = q.b[slot];
             const unsigned long long pm = record_pixel_mask(lane < nB, a.x, a.y, a.z, a.w, b.x, b.y, qx0, qy0, xmin, xmax, ymin, ymax);
             GS_STAT(1, nB);
+            if (log.idx) {
+                const unsigned long long lm = pm & act;
+                const unsigned long long keep = __ballot(lm != 0ull);
+                if (lm != 0ull) {
+                    const size_t at = log_base + (size_t)(log_n + __popcll(keep & ((1ull << lane) - 1ull)));
+                    log.idx[at] = q.idx[slot]; log.mask[at] = lm;
+                }
+                log_n += __popcll(keep);
+            }
             listB = gs_bit_transpose64(pm, lane);
             if (done) listB = 0ull;
 #ifdef GS_RASTER_STATS
@@ -1176,6 +1203,7 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
         listB = 0ull; nB = 0;
     }
     raw_drain(raw0, raw1, raw2);
+    if (log.count && lane == 0) log.count[4 * tile + wave] = log_n;
 
     if (inside) {
         const size_t pid = (size_t)pyi * W + pxi;
@@ -1734,6 +1762,314 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Backward from the forward's CULL LOG (round 4; D <= 3).  raster_bwd_lanes2_kernel repeats, walking down the tile's list, what the
+// forward already did walking up: cull every raw batch against the quadrant, compact the survivors into a queue, solve every
+// survivor's ellipse for its pixel mask -- a fifth of its instructions -- and then pops 5 % of its candidates only to find that the
+// pixel had terminated in front of them.  Here the forward leaves {stream index, pixel mask} of every record that entered one of
+// its dense batches (struct CullLog), and this kernel takes 64 log entries at a time from the END of the quadrant's log:
+//   * no fill loop, no cull, no ring queue: lane j gathers "its" record by stream index (two batches ahead: entries, one batch
+//     ahead: the three 16-byte record parts) and writes queue slot j;
+//   * no record_pixel_mask: the logged mask, clipped to the pixels whose last composited entry lies at or behind the batch;
+//   * the queue needs 64 slots instead of 128, which buys 800 pair slots instead of 448 in the same 9 984 bytes of LDS per wave:
+//     a dense batch is 64 records almost always (lanes2: 47 on average, i.e. 36 % more batches with their fixed costs).
+// Walk, record-lane reduction and commit are those of lanes2 (same arithmetic, same per-pixel order).
+static constexpr int GS_LOG_PAIR_CAP = 800;
+struct LogLds {
+    static constexpr int Q_BYTES = 64 * (16 + 16 + 8 + 4);
+    static constexpr int OFF_MSK = Q_BYTES;
+    static constexpr int OFF_BASE = OFF_MSK + 64 * 8;
+    static constexpr int OFF_PAIR = OFF_BASE + 64 * 4;
+    static constexpr int WAVE_BYTES = OFF_PAIR + GS_LOG_PAIR_CAP * 8;
+};
+
+template <int CD>
+__global__ void __launch_bounds__(256)
+raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* __restrict__ tile_order,
+                      const float4* __restrict__ rec0, const float4* __restrict__ rec1, const float4* __restrict__ rec2,
+                      const float* __restrict__ background, GsCount ic, const int32_t* __restrict__ offsets,
+                      const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
+                      const float* __restrict__ v_render, const float* __restrict__ v_alphas,
+                      float* __restrict__ v_packed, int rec_stride, ToneBwd tone, CullLog log)
+{
+    const int n_isects = (int)gs_count(ic);
+    static_assert(CD <= 3, "colours come from the record stream (D <= 3)");
+    using LD = LogLds;
+    constexpr int NV = 6 + CD;
+    constexpr int RPI = 64 / NV;
+    static_assert(64 * NV * 4 <= GS_LOG_PAIR_CAP * 8, "the commit staging aliases the pair buffer");
+    extern __shared__ __align__(16) unsigned char gs_lds_raw[];
+    const int tile = tile_order[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tx = tile % tile_w, ty = tile / tile_w;
+    const int qx0 = tx * GS_TILE + (wave & 1) * 8, qy0 = ty * GS_TILE + (wave >> 1) * 8;
+    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
+    const bool inside = pxi < W && pyi < H;
+    const float px = (float)pxi + 0.5f, py = (float)pyi + 0.5f;
+    const v2f pxy = v2f{px, py};
+
+    const int start = offsets[tile];
+    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    GS_TL_BEGIN(end - start);
+    if (end <= start) { GS_TL_END(); return; }
+
+    unsigned char* wbase = gs_lds_raw + (size_t)wave * LD::WAVE_BYTES;
+    float4* qa = (float4*)wbase; float4* qc = qa + 64; float2* qb = (float2*)(qc + 64); int* qidx = (int*)(qb + 64);
+    unsigned long long* msk = (unsigned long long*)(wbase + LD::OFF_MSK);
+    int* pbase = (int*)(wbase + LD::OFF_BASE);
+    float2* pairbuf = (float2*)(wbase + LD::OFF_PAIR);
+    float* stage = (float*)(wbase + LD::OFF_PAIR);              // aliases pairbuf (separated by wave syncs)
+
+    float T_final = 1.0f, v_a = 0.0f, v_exp = 0.0f;
+    int bin_final = -1;
+    float v_rc[CD];
+#pragma unroll
+    for (int k = 0; k < CD; ++k) v_rc[k] = 0.0f;
+    if (inside) {
+        const size_t pid = (size_t)pyi * W + pxi;
+        const float a_out = alphas[pid];
+        T_final = 1.0f - a_out;
+        bin_final = last_ids[pid];
+        if (CD == 3 && tone.v_image) {                            // S4 backward here (tonemap_bwd3_kernel's arithmetic, same order)
+#pragma clang fp contract(off)
+            const float e = tone.exposure[0];
+            const float r = tone.render[3 * pid], gch = tone.render[3 * pid + 1], bl = tone.render[3 * pid + 2];
+            const float4 g = tone.v_image[pid];
+            const float gx = g.x * tone_grad(tone.mode, r * e), gy = g.y * tone_grad(tone.mode, gch * e), gz = g.z * tone_grad(tone.mode, bl * e);
+            v_rc[0] = gx * e; v_rc[1] = gy * e; v_rc[2] = gz * e;
+            v_a = tone.mode == GS_TONE_NONE ? g.w * e : g.w;
+            v_exp = gx * r + gy * gch + gz * bl + (tone.mode == GS_TONE_NONE ? g.w * a_out : 0.0f);
+        } else {
+            v_a = v_alphas[pid];
+#pragma unroll
+            for (int k = 0; k < CD; ++k) if (k < D) v_rc[k] = v_render[pid * D + k];
+        }
+    }
+    if (CD == 3 && tone.v_image) {                                // one exposure-gradient atomic per quadrant wave
+        v_exp = gs_wave_sum(v_exp);
+        if (lane == 0 && v_exp != 0.0f) gs_atomic_add(tone.v_exposure, v_exp);
+    }
+    float bg_dot = 0.0f;
+    if (background) {
+#pragma unroll
+        for (int k = 0; k < CD; ++k) if (k < D) bg_dot += background[k] * v_rc[k];
+    }
+    float T = T_final;
+    float zacc = T_final * v_a - T_final * bg_dot;              // see raster_bwd_lanes2_kernel
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+
+    int pos = __builtin_amdgcn_readfirstlane(log.count[4 * tile + wave]);       // log entries not yet taken (wave-uniform)
+    if (pos <= 0) { GS_TL_END(); return; }
+    const size_t log_base = 4 * (size_t)start + (size_t)wave * (size_t)(end - start);
+    const int32_t* lidx = log.idx + log_base;
+    const unsigned long long* lmsk = log.mask + log_base;
+    // software pipeline: entries two batches ahead, records one batch ahead.  Lanes past the log's start re-read entry 0 (a valid
+    // record: finite numbers for the zero-weight slots) and are masked out.
+    int e_idx, g_idx; unsigned long long e_msk, g_msk;
+    float4 g0, g1, g2;
+    {
+        const int e = pos - 1 - lane;
+        const int es = e >= 0 ? e : 0;
+        g_idx = lidx[es]; g_msk = e >= 0 ? lmsk[es] : 0ull;
+        g0 = rec0[g_idx]; g1 = rec1[g_idx]; g2 = rec2[g_idx];
+        const int e2 = pos - 65 - lane;
+        const int es2 = e2 >= 0 ? e2 : 0;
+        e_idx = lidx[es2]; e_msk = e2 >= 0 ? lmsk[es2] : 0ull;
+    }
+    while (pos > 0) {
+        const int nb = pos < 64 ? pos : 64;
+        // ---- issue the loads of the batches behind this one, then publish this batch's records in the queue
+        const float4 c0 = g0, c1 = g1, c2 = g2;
+        const int c_idx = g_idx;
+        const unsigned long long c_msk = g_msk;
+        g_idx = e_idx; g_msk = e_msk;
+        g0 = rec0[g_idx]; g1 = rec1[g_idx]; g2 = rec2[g_idx];
+        {
+            const int e2 = pos - 129 - lane;
+            const int es2 = e2 >= 0 ? e2 : 0;
+            e_idx = lidx[es2]; e_msk = e2 >= 0 ? lmsk[es2] : 0ull;
+        }
+        pos -= nb;
+        GS_PHASE_BEGIN();
+        lanes_lds_sync();                                           // (the previous batch's commit has read its queue slots)
+        qa[lane] = c0; qb[lane] = make_float2(c1.x, c1.y); qc[lane] = c2; qidx[lane] = c_idx;
+        GS_STAT(5, nb);
+        const int idx_low = __builtin_amdgcn_readlane(c_idx, nb - 1);
+        const bool live = bin_final >= idx_low;
+        const unsigned long long act = __ballot(live);
+        const unsigned long long pm = lane < nb ? (c_msk & act) : 0ull;
+        if (__ballot(pm != 0ull) == 0ull) { GS_PHASE_END(1); continue; }
+        const float4 ra4 = c0;                                     // the record this lane OWNS in the reduction
+        const float2 rb4 = make_float2(c1.x, c1.y);
+        const int cnt = __popcll(pm);
+        int cum = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(cum, off, 64);
+            if (lane >= off) cum += up;
+        }
+        GS_PHASE_END(1);
+        // ---- sub-batches: as many records as the pair buffer holds (almost always all 64)
+        int r0 = 0, cumbase = 0;
+        while (r0 < nb) {
+            const int r1 = r0 + __popcll(__ballot(lane >= r0 && lane < nb && (cum - cumbase) <= GS_LOG_PAIR_CAP));
+            const bool mine = lane >= r0 && lane < r1;
+            const unsigned long long pms = mine ? pm : 0ull;
+            lanes_lds_sync();
+            msk[lane] = pms;
+            pbase[lane] = cum - cnt - cumbase;
+            unsigned long long list = gs_bit_transpose64(pms, lane);
+#ifdef GS_RASTER_STATS
+            GS_STAT2(1, 1);
+            GS_STAT2_ALL(0, __popcll(list));
+#endif
+            lanes_lds_sync();
+            long long _pw0 = 0;
+#ifdef GS_RASTER_PHASES
+            if (blockIdx.x == 0 && threadIdx.x == 0) { _pw0 = (long long)__builtin_readcyclecounter(); atomicAdd(&g_raster_stats[6], 1ull); }
+#endif
+            while (__ballot(list != 0ull) != 0ull) {
+                GS_STAT(6, 1);
+#ifdef GS_RASTER_PHASES
+                if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_raster_stats[5], 1ull);
+#endif
+                const bool has0 = list != 0ull;
+                const int j0 = gs_pop_lowest(list);
+                const bool has1 = list != 0ull;
+                const int j1 = gs_pop_lowest(list);
+                const float4 a0 = qa[j0], a1 = qa[j1];
+                const float2 b0 = qb[j0], b1 = qb[j1];
+                const float4 cc0 = qc[j0], cc1 = qc[j1];
+                const int idx0 = qidx[j0], idx1 = qidx[j1];
+                const int e0 = pbase[j0] + __popcll(msk[j0] & lane_lt), e1 = pbase[j1] + __popcll(msk[j1] & lane_lt);
+                v2f sigma, ov, alpha, ra;
+                {
+#pragma clang fp contract(off)
+                    const v2f d0 = v2f{a0.x, a0.y} - pxy, d1 = v2f{a1.x, a1.y} - pxy;                 // {dx, dy}
+                    const v2f p0 = v2f{a0.z, a0.w} * v2f{d0.x, d0.x}, p1 = v2f{a1.z, a1.w} * v2f{d1.x, d1.x};   // {ha dx, cb dx}
+                    sigma.x = gs_sigma_xy(d0, p0, b0.x);
+                    sigma.y = gs_sigma_xy(d1, p1, b1.x);
+                    ov = v2f{b0.y, b1.y} * gs_exp_neg_live2(sigma);
+                    alpha = __builtin_elementwise_min(ov, (v2f)(0.999f));
+                    ra = gs_rcp_exact2((v2f)(1.0f) - alpha);
+                }
+                const bool ok0 = has0 && idx0 <= bin_final && sigma.x >= 0.0f && alpha.x >= GS_ALPHA_MIN;
+                const bool ok1 = has1 && idx1 <= bin_final && sigma.y >= 0.0f && alpha.y >= GS_ALPHA_MIN;
+                {
+                    const float Tn = T * ra.x;
+                    const float fac = ok0 ? alpha.x * Tn : 0.0f;
+                    float cv = cc0.x * v_rc[0];
+                    if (CD > 1) cv = fmaf(cc0.y, v_rc[1], cv);
+                    if (CD > 2) cv = fmaf(cc0.z, v_rc[2], cv);
+                    const float v_alpha = fmaf(Tn, cv, ra.x * zacc);
+                    const float s_out = (ok0 && ov.x <= 0.999f) ? -ov.x * v_alpha : 0.0f;
+                    zacc = fmaf(-fac, cv, zacc);
+                    T = ok0 ? Tn : T;
+#ifdef GS_RASTER_STATS
+                    if (ok0) GS_STAT_ALL(7, 1);
+                    if (has0 && !ok0) { if (idx0 > bin_final) GS_STAT2_ALL(2, 1); else GS_STAT2_ALL(3, 1); }
+#endif
+                    if (has0) pairbuf[e0] = make_float2(s_out, fac);
+                }
+                {
+                    const float Tn = T * ra.y;
+                    const float fac = ok1 ? alpha.y * Tn : 0.0f;
+                    float cv = cc1.x * v_rc[0];
+                    if (CD > 1) cv = fmaf(cc1.y, v_rc[1], cv);
+                    if (CD > 2) cv = fmaf(cc1.z, v_rc[2], cv);
+                    const float v_alpha = fmaf(Tn, cv, ra.y * zacc);
+                    const float s_out = (ok1 && ov.y <= 0.999f) ? -ov.y * v_alpha : 0.0f;
+                    zacc = fmaf(-fac, cv, zacc);
+                    T = ok1 ? Tn : T;
+#ifdef GS_RASTER_STATS
+                    if (ok1) GS_STAT_ALL(7, 1);
+                    if (has1 && !ok1) { if (idx1 > bin_final) GS_STAT2_ALL(2, 1); else GS_STAT2_ALL(3, 1); }
+#endif
+                    if (has1) pairbuf[e1] = make_float2(s_out, fac);
+                }
+            }
+            lanes_lds_sync();
+#ifdef GS_RASTER_PHASES
+            if (blockIdx.x == 0 && threadIdx.x == 0) { const long long _t = (long long)__builtin_readcyclecounter(); atomicAdd(&g_raster_stats[2], (unsigned long long)(_t - _pw0)); _pw0 = _t; }
+#endif
+            // ---- reduction: lane j sums the pairs of record j over the set bits of its pixel mask (pixel order)
+            float sum[NV];
+            {
+                const float X = ra4.x - ((float)qx0 + 0.5f), Y = ra4.y - ((float)qy0 + 0.5f);    // dx = X - x,  dy = Y - y
+                unsigned long long m = pms;
+                int e = cum - cnt - cumbase;
+                float m0 = 0.0f, mxy = 0.0f, c2s = 0.0f;
+                v2f m1 = (v2f)(0.0f), m2 = (v2f)(0.0f), c01 = (v2f)(0.0f);
+                while (__ballot(m != 0ull) != 0ull) {
+                    GS_STAT2(7, 1);
+#ifdef GS_RASTER_PHASES
+                    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_raster_stats[7], 1ull);
+#endif
+                    const bool has = m != 0ull;
+                    const int p = gs_pop_lowest(m);
+                    const float2 sfr = pairbuf[has ? e : 0];
+                    float4 vr;
+                    vr.x = __shfl(v_rc[0], p, 64); vr.y = CD > 1 ? __shfl(v_rc[1], p, 64) : 0.0f; vr.z = CD > 2 ? __shfl(v_rc[2], p, 64) : 0.0f; vr.w = 0.0f;
+                    e += has ? 1 : 0;
+                    const float s_w = has ? sfr.x : 0.0f, f_w = has ? sfr.y : 0.0f;
+                    const v2f d = v2f{X, Y} - v2f{(float)(p & 7), (float)(p >> 3)};
+                    const v2f sd = d * s_w;
+                    m0 += s_w;
+                    m1 += sd;
+                    m2 = __builtin_elementwise_fma(sd, d, m2);
+                    mxy = fmaf(sd.x, d.y, mxy);
+                    c01 = __builtin_elementwise_fma((v2f)(f_w), v2f{vr.x, vr.y}, c01);
+                    if (CD > 2) c2s = fmaf(f_w, vr.z, c2s);
+                }
+                sum[0] = m0; sum[1] = m1.x; sum[2] = m1.y; sum[3] = m2.x; sum[4] = mxy; sum[5] = m2.y;
+                sum[6] = c01.x;
+                if (CD > 1) sum[7] = c01.y;
+                if (CD > 2) sum[8] = c2s;
+            }
+            lanes_lds_sync();                                          // pairbuf is dead: its space becomes the commit staging
+#ifdef GS_RASTER_PHASES
+            if (blockIdx.x == 0 && threadIdx.x == 0) { const long long _t = (long long)__builtin_readcyclecounter(); atomicAdd(&g_raster_stats[3], (unsigned long long)(_t - _pw0)); _pw0 = _t; }
+#endif
+            {
+                const float ga = ra4.z, gb = ra4.w, gc = rb4.x, go = rb4.y;
+                const float M0 = sum[0], Mx = sum[1], My = sum[2];
+                float out[NV];
+                out[0] = (2.0f * ga) * Mx + gb * My;
+                out[1] = gb * Mx + (2.0f * gc) * My;
+                out[2] = 0.5f * sum[3]; out[3] = sum[4]; out[4] = 0.5f * sum[5];
+                out[5] = (M0 != 0.0f) ? -M0 / go : 0.0f;             // sum of vis * v_alpha over the uncapped pairs
+#pragma unroll
+                for (int k = 0; k < CD; ++k) out[6 + k] = sum[6 + k];
+                if (mine) {
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) stage[lane * NV + k] = out[k];
+                }
+            }
+            lanes_lds_sync();
+            // ---- commit: RPI records x NV values per atomic instruction; the NV lanes of a record hit one packed gradient record
+            {
+                const int r = lane / NV, k = lane - r * NV;
+                for (int it = 0; r0 + it * RPI < r1; ++it) {
+                    const int j = r0 + it * RPI + r;
+                    if (r < RPI && j < r1 && k < 6 + D) {
+                        const float v = stage[j * NV + k];
+                        if (v != 0.0f) {
+                            const int g = __float_as_int(qc[j].w);
+                            gs_atomic_add(v_packed + (size_t)g * rec_stride + k, v);
+                        }
+                    }
+                }
+            }
+#ifdef GS_RASTER_PHASES
+            if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_raster_stats[4], (unsigned long long)((long long)__builtin_readcyclecounter() - _pw0));
+#endif
+            cumbase = __builtin_amdgcn_readlane(cum, r1 - 1);
+            r0 = r1;
+        }
+    }
+    GS_TL_END();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Occupancy cap of the two compositor kernels: they use no LDS, so a dynamic LDS request of 160 KB / 4 limits a CU to
 // FOUR resident 256-thread blocks (4 waves per SIMD instead of 8).  Measured on the bench workload: backward
 // 1.48 -> 1.19 ms, forward 0.68 -> 0.64 ms per view (3 blocks: same; 2 blocks: back to 1.49 ms; wave priorities for
@@ -1796,6 +2132,8 @@ static GsCount isect_count(int64_t n) { return GsCount{ (long long)n, t_counts_d
 // its ToneFwd / ToneBwd to the kernels (zero = plain compositor).
 static thread_local ToneFwd t_tone_fwd = { 0, nullptr, nullptr };
 static thread_local ToneBwd t_tone_bwd = { 0, nullptr, nullptr, nullptr, nullptr };
+static thread_local CullLog t_cull_log = { nullptr, nullptr, nullptr };
+struct CullLogScope { explicit CullLogScope(const CullLog& l) { t_cull_log = l; } ~CullLogScope() { t_cull_log = CullLog{ nullptr, nullptr, nullptr }; } };
 struct ToneFwdScope { explicit ToneFwdScope(const ToneFwd& t) { t_tone_fwd = t; } ~ToneFwdScope() { t_tone_fwd = ToneFwd{ 0, nullptr, nullptr }; } };
 struct ToneBwdScope { explicit ToneBwdScope(const ToneBwd& t) { t_tone_bwd = t; } ~ToneBwdScope() { t_tone_bwd = ToneBwd{ 0, nullptr, nullptr, nullptr, nullptr }; } };
 
@@ -1814,7 +2152,7 @@ static int launch_fwd(int W, int H, int D, const RasterWs& ws, const float* colo
         if (lds < gs_raster_lds_pad()) lds = gs_raster_lds_pad();
         hipLaunchKernelGGL(raster_fwd_window_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
                            ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, isect_count(n_isects), offsets, render, alphas,
-                           last_ids, t_tone_fwd);
+                           last_ids, t_tone_fwd, t_cull_log);
         GS_CHECK_LAUNCH();
         return GS_OK;
     }
@@ -1937,6 +2275,15 @@ static int launch_bwd(int W, int H, int D, const RasterWs& ws, const float* colo
         return GS_EINVAL;
     }
     if constexpr (CD <= 3) {                                  // colours travel in the record stream only for D <= 3
+        if (t_cull_log.idx && gs_raster_lanes() == 1) {         // the forward left its cull log: no fill, no masks
+            size_t lds = 4 * (size_t)LogLds::WAVE_BYTES;
+            if (lds < gs_raster_lds_pad()) lds = gs_raster_lds_pad();
+            hipLaunchKernelGGL(raster_bwd_log_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
+                               ws.order, ws.rec0, ws.rec1, ws.rec2, background, isect_count(n_isects), offsets, alphas, last_ids,
+                               v_render, v_alphas, v_packed, rec_stride, t_tone_bwd, t_cull_log);
+            GS_CHECK_LAUNCH();
+            return GS_OK;
+        }
         if ((gs_raster_lanes() == 1 || gs_raster_lanes() == 3)) {
             size_t lds = 4 * (size_t)Lanes2Lds<CD>::WAVE_BYTES;
             if (lds < gs_raster_lds_pad()) lds = gs_raster_lds_pad();
@@ -2093,6 +2440,52 @@ extern "C" int gs_raster_bwd_tone_acc(int W, int H, int tile_size, int V, const 
 
 // ---------------------------------------------------------------------------------------------------
 // self-test hook: counts the floats with bit patterns in [lo_bits, hi_bits] for which gs_rcp_exact2 differs from IEEE division
+// ---- cull log (forward -> backward), see struct CullLog -----------------------------------------------------------------------
+static CullLog carve_log(void* log_ws, int64_t n_isects)
+{
+    const size_t n = n_isects > 0 ? (size_t)n_isects : 1;
+    char* p = (char*)log_ws;
+    CullLog l;
+    l.mask = (unsigned long long*)p; p += align256(4 * n * sizeof(unsigned long long));
+    l.idx = (int32_t*)p; p += align256(4 * n * sizeof(int32_t));
+    l.count = (int32_t*)p;
+    return l;
+}
+extern "C" size_t gs_raster_log_ws_bytes(int64_t n_isects, int W, int H, int tile_size)
+{
+    if (tile_size <= 0) return 0;
+    const size_t n = n_isects > 0 ? (size_t)n_isects : 1;
+    const size_t tiles = (size_t)((W + tile_size - 1) / tile_size) * (size_t)((H + tile_size - 1) / tile_size);
+    return align256(4 * n * sizeof(unsigned long long)) + align256(4 * n * sizeof(int32_t)) + align256(4 * tiles * sizeof(int32_t));
+}
+
+extern "C" int gs_raster_composite_tone_log(int W, int H, int tile_size, int V, const float* colors, int64_t n_isects,
+                                            const int64_t* counts_dev, const int32_t* offsets, float* render, float* alphas,
+                                            int32_t* last_ids, int tone_mode, const float* exposure, float* image, const void* ws,
+                                            size_t ws_bytes, void* log_ws, size_t log_bytes, void* stream)
+{
+    GS_CHECK_ARG(log_ws != nullptr && tile_size == GS_TILE, "log_ws must not be NULL");
+    if (log_bytes < gs_raster_log_ws_bytes(n_isects, W, H, tile_size)) { gs_set_error("gs_raster_composite_tone_log: log workspace too small"); return GS_ENOSPC; }
+    GS_CHECK_ARG(gs_raster_lanes() == 1, "the cull log needs the default compositor kernels (GEOSPLAT_RASTER_LANES=1)");
+    CullLogScope ls(carve_log(log_ws, n_isects));
+    return gs_raster_composite_tone(W, H, tile_size, V, colors, n_isects, counts_dev, offsets, render, alphas, last_ids, tone_mode, exposure,
+                                    image, ws, ws_bytes, stream);
+}
+
+extern "C" int gs_raster_bwd_tone_log_acc(int W, int H, int tile_size, int V, const float* colors, int64_t n_isects,
+                                          const int64_t* counts_dev, const int32_t* offsets, const float* render, const float* alphas,
+                                          const int32_t* last_ids, int tone_mode, const float* exposure, const float* v_image,
+                                          float* v_packed, float* v_exposure, const void* ws, size_t ws_bytes, const void* log_ws,
+                                          size_t log_bytes, void* stream)
+{
+    GS_CHECK_ARG(log_ws != nullptr && tile_size == GS_TILE, "log_ws must not be NULL");
+    if (log_bytes < gs_raster_log_ws_bytes(n_isects, W, H, tile_size)) { gs_set_error("gs_raster_bwd_tone_log_acc: log workspace too small"); return GS_ENOSPC; }
+    GS_CHECK_ARG(gs_raster_lanes() == 1, "the cull log needs the default compositor kernels (GEOSPLAT_RASTER_LANES=1)");
+    CullLogScope ls(carve_log((void*)log_ws, n_isects));
+    return gs_raster_bwd_tone_acc(W, H, tile_size, V, colors, n_isects, counts_dev, offsets, render, alphas, last_ids, tone_mode, exposure,
+                                  v_image, v_packed, v_exposure, ws, ws_bytes, stream);
+}
+
 __global__ void __launch_bounds__(256) selftest_rcp_kernel(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* mismatches)
 {
     const uint64_t n = (uint64_t)hi_bits - lo_bits + 1;

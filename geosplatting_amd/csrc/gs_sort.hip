@@ -977,8 +977,7 @@ extern "C" size_t gs_isect_bin_front_ws_bytes(int V, int64_t n_isects, int tile_
 {
     const size_t v = V > 0 ? (size_t)V : 1, n = n_isects > 0 ? (size_t)n_isects : 1;
     const size_t tb = table_bytes((int64_t)(v > n ? v : n));
-    const bool hist = (int64_t)tile_w * tile_h <= BF_HIST_MAX;
-    return tb + 2 * align256(v * 8) + 2 * align256(n * 8) + bf_state_bytes((int)v) + (hist ? 0 : align256(n * 4)) + 256;
+    return tb + 2 * align256(v * 8) + 2 * align256(n * 8) + bf_state_bytes((int)v) + align256(n * 4) + 256;   // (tile ids: only without tile_counts)
 }
 
 extern "C" int gs_isect_bin_front(int V_cap, const uint32_t* depth_keys, const uint32_t* tile_rects, const uint32_t* tile_counts,
@@ -997,8 +996,7 @@ extern "C" int gs_isect_bin_front(int V_cap, const uint32_t* depth_keys, const u
     GS_CHECK_ARG(depth_keys != nullptr && tile_rects != nullptr && flatten_ids_sorted != nullptr && ws != nullptr, "null argument");
     if (ws_bytes < gs_isect_bin_front_ws_bytes(V, n_isects, tile_w, tile_h)) { gs_set_error("gs_isect_bin_front: workspace too small"); return GS_ENOSPC; }
     const GsCount vc{ (long long)V, (const long long*)counts_dev }, ic{ (long long)n_isects, counts_dev ? (const long long*)counts_dev + 1 : nullptr };
-    const bool hist = n_tiles <= BF_HIST_MAX;
-    GS_CHECK_ARG(!hist || tile_counts != nullptr, "tile_counts (gs_front_fwd) must not be NULL for up to 8 192 tiles");
+    const bool hist = tile_counts != nullptr && n_tiles <= BF_HIST_MAX;     // otherwise the offsets come from the sorted tile ids
     char* p = (char*)ws;
     unsigned* table = (unsigned*)p; p += table_bytes((int64_t)V > n_isects ? (int64_t)V : n_isects);
     uint2* da = (uint2*)p; p += align256((size_t)V * 8);

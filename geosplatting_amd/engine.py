@@ -313,6 +313,7 @@ class RenderStep:
         front_first = os.environ.get("GEOSPLAT_ENQUEUE", "main_first") == "front_first"
         # S4 inside the compositor kernels (default; needs the default kernel pair): GEOSPLAT_FUSED_TONE=0 keeps the two tone-map launches
         fused_tone = os.environ.get("GEOSPLAT_FUSED_TONE", "1") != "0" and os.environ.get("GEOSPLAT_RASTER_LANES", "1") == "1"
+        use_log = fused_tone and os.environ.get("GEOSPLAT_RASTER_LOG", "1") != "0"      # forward -> backward cull log (csrc/gs_raster.hip)
         proj = [start_view(cameras[j], j) for j in range(min(2, n_views))]   # prologue: A(0), A(1), B1(0)
         binned = bin_view(proj.pop(0)) if n_views else None
         for i, cam in enumerate(cameras):
@@ -330,11 +331,21 @@ class RenderStep:
                 last_ids = torch.empty(H, W, dtype=torch.int32, device=dev)
                 img = torch.empty(H, W, 4, dtype=f32, device=dev)
                 rws0 = state["raster_ws"]
-                L.check(lib.gs_raster_composite_tone(W, H, 16, V, L.ptr(state["colors"]), L.i64(I),
-                                                     L.ptr(state["counts"]) if i_cap is not None else None,
-                                                     L.ptr(state["isect_offsets"]), L.ptr(render), L.ptr(alphas), L.ptr(last_ids), tone,
-                                                     L.ptr(exposure), L.ptr(img), L.ptr(rws0), C.c_size_t(rws0.numel()), st()),
-                        "gs_raster_composite_tone")
+                if use_log:
+                    # the forward leaves its cull log (stream index + pixel mask of every record that entered a dense batch) for the
+                    # backward of this view, which then neither culls nor builds ellipse masks (raster_bwd_log_kernel)
+                    log_ws = torch.empty(lib.gs_raster_log_ws_bytes(L.i64(I), W, H, 16), dtype=torch.uint8, device=dev)
+                    L.check(lib.gs_raster_composite_tone_log(W, H, 16, V, L.ptr(state["colors"]), L.i64(I),
+                                                             L.ptr(state["counts"]) if i_cap is not None else None,
+                                                             L.ptr(state["isect_offsets"]), L.ptr(render), L.ptr(alphas), L.ptr(last_ids), tone,
+                                                             L.ptr(exposure), L.ptr(img), L.ptr(rws0), C.c_size_t(rws0.numel()),
+                                                             L.ptr(log_ws), C.c_size_t(log_ws.numel()), st()), "gs_raster_composite_tone_log")
+                else:
+                    L.check(lib.gs_raster_composite_tone(W, H, 16, V, L.ptr(state["colors"]), L.i64(I),
+                                                         L.ptr(state["counts"]) if i_cap is not None else None,
+                                                         L.ptr(state["isect_offsets"]), L.ptr(render), L.ptr(alphas), L.ptr(last_ids), tone,
+                                                         L.ptr(exposure), L.ptr(img), L.ptr(rws0), C.c_size_t(rws0.numel()), st()),
+                            "gs_raster_composite_tone")
                 s = dict(state, last_ids=last_ids)
             elif i_cap is not None:
                 render, alphas, s = _composite_stage_cap(state, V, I, D, whs, None)
@@ -359,7 +370,13 @@ class RenderStep:
             rws = s["raster_ws"]
             if kev is not None:
                 k2 = torch.cuda.Event(enable_timing=True); k2.record(main)
-            if fused_tone:
+            if fused_tone and use_log:
+                L.check(lib.gs_raster_bwd_tone_log_acc(W, H, 16, V, L.ptr(s["colors"]), L.i64(I),
+                                                       L.ptr(s["counts"]) if i_cap is not None else None, L.ptr(s["isect_offsets"]),
+                                                       L.ptr(render), L.ptr(alphas), L.ptr(s["last_ids"]), tone, L.ptr(exposure), L.ptr(v_img),
+                                                       L.ptr(v_packed), L.ptr(b["exposure"]), L.ptr(rws), C.c_size_t(rws.numel()),
+                                                       L.ptr(log_ws), C.c_size_t(log_ws.numel()), st()), "gs_raster_bwd_tone_log_acc")
+            elif fused_tone:
                 # ... and S4 backward in the prologue of the compositor backward (gs_raster_bwd_tone_acc)
                 L.check(lib.gs_raster_bwd_tone_acc(W, H, 16, V, L.ptr(s["colors"]), L.i64(I),
                                                    L.ptr(s["counts"]) if i_cap is not None else None, L.ptr(s["isect_offsets"]),

@@ -216,6 +216,20 @@ int gs_raster_bwd_tone_acc(int W, int H, int tile_size, int V, const float* colo
                            const int64_t* counts_dev, const int32_t* offsets, const float* render, const float* alphas,
                            const int32_t* last_ids, int tone_mode, const float* exposure, const float* v_image,
                            float* v_packed, float* v_exposure, const void* ws, size_t ws_bytes, void* stream);
+/* The same pair with a CULL LOG between them: the forward appends {stream index, pixel mask} of every record that entered one of its
+ * dense batches (per tile quadrant, in stream order) to log_ws (gs_raster_log_ws_bytes; written by the forward, read by the backward of
+ * the SAME view), and the backward walks that log from its end instead of repeating the forward's cull and ellipse masks.  Same image
+ * bit for bit, same gradients up to the order of the float atomics. */
+size_t gs_raster_log_ws_bytes(int64_t n_isects, int W, int H, int tile_size);
+int gs_raster_composite_tone_log(int W, int H, int tile_size, int V, const float* colors, int64_t n_isects,
+                                 const int64_t* counts_dev, const int32_t* offsets, float* render, float* alphas,
+                                 int32_t* last_ids, int tone_mode, const float* exposure, float* image, const void* ws,
+                                 size_t ws_bytes, void* log_ws, size_t log_bytes, void* stream);
+int gs_raster_bwd_tone_log_acc(int W, int H, int tile_size, int V, const float* colors, int64_t n_isects,
+                               const int64_t* counts_dev, const int32_t* offsets, const float* render, const float* alphas,
+                               const int32_t* last_ids, int tone_mode, const float* exposure, const float* v_image,
+                               float* v_packed, float* v_exposure, const void* ws, size_t ws_bytes, const void* log_ws,
+                               size_t log_bytes, void* stream);
 int gs_project_bwd_cap(int N, const int64_t* counts_dev, int D, const float* means, const float* quats, const float* scales,
                        const float* opacities, const float* viewmat, const float* K, int W, int H, float eps2d,
                        const int32_t* gaussian_ids, const float* conics, const float* compensations, const float* v_packed,

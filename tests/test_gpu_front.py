@@ -240,6 +240,53 @@ def test_tail_equals_project_bwd_plus_shade_bwd(cuda, mode):
             assert rel_err(a.cpu().numpy(), 2.0 * b.cpu().numpy()) < 1e-5
 
 
+def test_cull_log_backward_equals_plain_backward(cuda):
+    """compositor forward with the cull log + the log-driven backward against the plain pair (raster_fwd_window / raster_bwd_lanes2, which
+    the rasterizer tests check against the oracle): image, alpha, last_ids bit for bit; gradient records to the order of the float atomics."""
+    from geosplatting_amd import _lib as L
+    from geosplatting_amd import front as F
+    lib = L.lib()
+    for level, res in ((4, 160), (5, 400)):
+        x = _inputs(cuda, level=level, res=res)
+        env = _env(cuda)
+        fr, _ = _front(x, env, cuda)
+        V, I = int(fr.host_counts[0]), int(fr.host_counts[1])
+        state, _, _ = F.bin_stage(fr, None, None)
+        W = H = res
+        g = torch.Generator().manual_seed(3)
+        v_img = (torch.rand(H, W, 4, generator=g) * 2 - 1).to(cuda)
+        exposure = torch.tensor([1.3], device=cuda)
+        rws = state["raster_ws"]
+        outs = []
+        for use_log in (False, True):
+            render = torch.empty(H, W, 3, device=cuda); alphas = torch.empty(H, W, device=cuda)
+            last = torch.empty(H, W, dtype=torch.int32, device=cuda); img = torch.empty(H, W, 4, device=cuda)
+            v_packed = torch.zeros(V, lib.gs_raster_grad_stride(3), device=cuda); v_exp = torch.zeros(1, device=cuda)
+            if use_log:
+                log_ws = torch.empty(lib.gs_raster_log_ws_bytes(L.i64(I), W, H, 16), dtype=torch.uint8, device=cuda)
+                L.check(lib.gs_raster_composite_tone_log(W, H, 16, V, None, L.i64(I), None, L.ptr(state["isect_offsets"]), L.ptr(render),
+                                                         L.ptr(alphas), L.ptr(last), 1, L.ptr(exposure), L.ptr(img), L.ptr(rws),
+                                                         C.c_size_t(rws.numel()), L.ptr(log_ws), C.c_size_t(log_ws.numel()), L.stream()), "fwd log")
+                L.check(lib.gs_raster_bwd_tone_log_acc(W, H, 16, V, None, L.i64(I), None, L.ptr(state["isect_offsets"]), L.ptr(render),
+                                                       L.ptr(alphas), L.ptr(last), 1, L.ptr(exposure), L.ptr(v_img), L.ptr(v_packed), L.ptr(v_exp),
+                                                       L.ptr(rws), C.c_size_t(rws.numel()), L.ptr(log_ws), C.c_size_t(log_ws.numel()), L.stream()),
+                        "bwd log")
+            else:
+                L.check(lib.gs_raster_composite_tone(W, H, 16, V, None, L.i64(I), None, L.ptr(state["isect_offsets"]), L.ptr(render), L.ptr(alphas),
+                                                     L.ptr(last), 1, L.ptr(exposure), L.ptr(img), L.ptr(rws), C.c_size_t(rws.numel()), L.stream()), "fwd")
+                L.check(lib.gs_raster_bwd_tone_acc(W, H, 16, V, None, L.i64(I), None, L.ptr(state["isect_offsets"]), L.ptr(render), L.ptr(alphas),
+                                                   L.ptr(last), 1, L.ptr(exposure), L.ptr(v_img), L.ptr(v_packed), L.ptr(v_exp), L.ptr(rws),
+                                                   C.c_size_t(rws.numel()), L.stream()), "bwd")
+            torch.cuda.synchronize()
+            outs.append((render, alphas, last, img, v_packed, v_exp))
+        a, b = outs
+        for k in range(4):
+            assert torch.equal(a[k], b[k]), k
+        assert float(a[4].abs().max()) > 0
+        assert rel_err(b[4].cpu().numpy(), a[4].cpu().numpy()) < 2e-6
+        assert abs(float(a[5]) - float(b[5])) <= 1e-5 * abs(float(a[5])) + 1e-6
+
+
 def test_tail_multi_equals_sum_of_view_tails(cuda):
     """gs_tail_bwd_multi over three views == three gs_tail_bwd calls accumulated (same arithmetic, the sum over the views taken in
     registers): parameter gradients and texel gradients; a second multi call ADDS."""

@@ -395,10 +395,14 @@ __device__ __forceinline__ void wave_commit6_lds_tagged(float* stage, float* pa,
         const unsigned long long tagged = sp[(second ? 64 : 0) + src];
         float* base = (float*)(tagged & ~1ull);
         const float val = sv[ch * 64 + src];
+#ifndef GS_EXPERIMENT_NO_GLOBAL_TEXEL_ATOMICS
         if (base != nullptr) {
             float* dst = base + (second ? ch - 3 : ch);
             if (tagged & 1ull) gs_atomic_add_xcd(dst, val); else gs_atomic_add(dst, val);
         }
+#else
+        if (base != nullptr && val == 123456.0f) base[0] = val;      /* timing experiment only */
+#endif
     }
 }
 

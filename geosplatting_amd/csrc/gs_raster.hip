@@ -2054,7 +2054,11 @@ raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_
                         const float v = stage[j * NV + k];
                         if (v != 0.0f) {
                             const int g = __float_as_int(qc[j].w);
+#ifndef GS_EXP_NOATOMIC
                             gs_atomic_add(v_packed + (size_t)g * rec_stride + k, v);
+#else
+                            if (v == 123456.0f) v_packed[(size_t)g * rec_stride + k] = v;      /* timing experiment only */
+#endif
                         }
                     }
                 }

@@ -826,20 +826,16 @@ bin_setup_kernel(unsigned* __restrict__ state, int n_state_words,
 
 // thread r (depth rank) writes the (tile, index) items of its Gaussian at the exclusive prefix of the tile counts in depth order; the
 // prefix across blocks is a decoupled look-back (blocks numbered by ticket, so a block only waits for blocks that already run)
-template <bool HIST>
 __global__ void __launch_bounds__(EM_THREADS)
 emit_chained_kernel(GsCount vc, const uint2* __restrict__ order, const uint2* __restrict__ rect, unsigned* __restrict__ ctrl,
-                    u64* __restrict__ desc, int n_blocks, int tile_w, int n_tiles, uint2* __restrict__ items, unsigned item_cap,
-                    unsigned* __restrict__ tile_counts)
+                    u64* __restrict__ desc, int n_blocks, int tile_w, uint2* __restrict__ items, unsigned item_cap)
 {
     const int V = (int)gs_count(vc);
     __shared__ unsigned ws[EM_THREADS / 64];
     __shared__ unsigned s_block;
     __shared__ unsigned long long s_base;
-    extern __shared__ unsigned th[];                                      // [n_tiles] when HIST
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_block = atomicAdd(ctrl, 1u);
-    if (HIST) for (int t = threadIdx.x; t < n_tiles; t += EM_THREADS) th[t] = 0u;
     __syncthreads();
     const int block = (int)s_block;
     u64* agg = desc; u64* pre = desc + n_blocks;
@@ -909,16 +905,9 @@ emit_chained_kernel(GsCount vc, const uint2* __restrict__ order, const uint2* __
         for (int i = y0; i < y1; ++i)
             for (int j = x0; j < x1; ++j) {
                 const unsigned t = (unsigned)(i * tile_w + j);
-                if (cur < (unsigned long long)item_cap) {                 // (capacity protocol: an overflowing view is reported, not written)
-                    items[cur] = make_uint2(t, (unsigned)v[k]);
-                    if (HIST) atomicAdd(&th[t], 1u);
-                }
+                if (cur < (unsigned long long)item_cap) items[cur] = make_uint2(t, (unsigned)v[k]);   // (capacity protocol: an overflowing view is reported, not written)
                 ++cur;
             }
-    }
-    if (HIST) {
-        __syncthreads();
-        for (int t = threadIdx.x; t < n_tiles; t += EM_THREADS) { const unsigned hc = th[t]; if (hc) atomicAdd(tile_counts + t, hc); }
     }
 }
 
@@ -1027,8 +1016,8 @@ extern "C" int gs_isect_bin_front(int V_cap, const uint32_t* depth_keys, const u
     }
     // 2. emission in depth order (chained scan inside the launch) + per-tile counts
     unsigned* ctrl = state; u64* desc = (u64*)((char*)state + 16);
-    hipLaunchKernelGGL((emit_chained_kernel<false>), dim3(eblocks), dim3(EM_THREADS), 0, s, vc, order, (const uint2*)tile_rects, ctrl, desc,
-                       eblocks + 1, tile_w, n_tiles, ia, (unsigned)n_isects, (unsigned*)nullptr);
+    hipLaunchKernelGGL(emit_chained_kernel, dim3(eblocks), dim3(EM_THREADS), 0, s, vc, order, (const uint2*)tile_rects, ctrl, desc,
+                       eblocks + 1, tile_w, ia, (unsigned)n_isects);
     GS_CHECK_LAUNCH();
     if (hist) {
         hipLaunchKernelGGL(tile_offsets_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, (const unsigned*)tile_counts, ic, isect_offsets);

@@ -212,7 +212,10 @@ def test_scheduled_run_starts_with_vertex_sampling():
         for k, w in ref["autograd"].items():
             assert torch.isfinite(w).all(), k
             err = (ref["fused"][k] - w).abs().max().item() / (w.abs().max().item() + 1e-30)
-            assert err < 3e-3, (it, k, err)                   # order of the float atomics (few, large Gaussians in vertex mode: 1e-3 seen)
+            # scripts/vertex_mode_errors.py (three seeds): fused vs autograd <= 1.3e-5 in both samplings -- but the AUTOGRAD step against
+            # ITSELF, same inputs, reached 1.8e-3 once in vertex mode (2 300 large Gaussians: thousands of float atomics per gradient
+            # record, whose order is not fixed) and 2.1e-5 in face mode.  The bound is that run-to-run spread, not a bias.
+            assert err < (3e-3 if it < 2 else 1e-4), (it, k, err)
         counts.append(model.last_num_gaussians)
         before = model.cubemap.grad.clone()
         sch.scale_light_gradient(model)

@@ -21,6 +21,7 @@
 // Arithmetic is the shared device code of gs_project_dev.h / gs_shade_dev.h: records, keys and rectangles are bit-identical to
 // what gs_shade_fwd + gs_project_fwd_vis + tile_rect_kernel produce (tests/test_gpu_front.py).
 #include "gs_common.h"
+#include <string.h>
 #pragma clang fp contract(off)
 #include "gs_project_dev.h"
 #include "gs_shade_dev.h"
@@ -105,7 +106,7 @@ front_fwd_kernel(int N, const float* __restrict__ means, const float* __restrict
 
     // ---- shading of the visible Gaussians (texture taps in flight while the predecessors publish)
     float color[3] = { 0.f, 0.f, 0.f };
-    if (p.valid) {
+    if (p.valid && vis != nullptr) {                          // (vis == NULL: geometry only -- keys, rectangles, counts, slots)
         const float nrm[3] = { normals[3 * (size_t)n], normals[3 * (size_t)n + 1], normals[3 * (size_t)n + 2] };
         const float kdn[3] = { kd[3 * (size_t)n], kd[3 * (size_t)n + 1], kd[3 * (size_t)n + 2] };
         const float2 ks2 = *reinterpret_cast<const float2*>(ks + 2 * (size_t)n);
@@ -184,13 +185,17 @@ front_fwd_kernel(int N, const float* __restrict__ means, const float* __restrict
         const float op = opacities[n] * p.comp;
         float hx = -1.0f, hy = -1.0f;
         if (!alpha_extent(p.ca, p.cb, p.cc, op, hx, hy)) { hx = -1.0f; hy = -1.0f; }
-        float4* rec = vis + 4 * slot;
-        rec[0] = make_float4(p.m2x, p.m2y, 0.5f * p.ca, p.cb);
-        rec[1] = make_float4(0.5f * p.cc, op, hx, hy);
-        rec[2] = make_float4(color[0], color[1], color[2], 0.0f);
-        rec[3] = make_float4(p.comp, __int_as_float(n), p.depth, __int_as_float(p.radius));
-        depth_keys[slot] = key;
-        rects[slot] = make_uint2((unsigned)tx0 | ((unsigned)ty0 << 16), (unsigned)tx1 | ((unsigned)ty1 << 16));
+        if (vis != nullptr) {
+            float4* rec = vis + 4 * slot;
+            rec[0] = make_float4(p.m2x, p.m2y, 0.5f * p.ca, p.cb);
+            rec[1] = make_float4(0.5f * p.cc, op, hx, hy);
+            rec[2] = make_float4(color[0], color[1], color[2], 0.0f);
+            rec[3] = make_float4(p.comp, __int_as_float(n), p.depth, __int_as_float(p.radius));
+        }
+        if (depth_keys != nullptr) {
+            depth_keys[slot] = key;
+            rects[slot] = make_uint2((unsigned)tx0 | ((unsigned)ty0 << 16), (unsigned)tx1 | ((unsigned)ty1 << 16));
+        }
         if (tile_counts)
             for (int i = ty0; i < ty1; ++i)
                 for (int j = tx0; j < tx1; ++j) atomicAdd(&s_th[i * tile_w + j], 1u);
@@ -223,11 +228,14 @@ extern "C" int gs_front_fwd(int N, const float* means, const float* quats, const
                             void* stream)
 {
     GS_CHECK_ARG(N >= 0 && W > 0 && H > 0 && tile_size > 0 && mode >= 0 && mode <= 2, "bad sizes or mode");
-    GS_CHECK_ARG(counts4 != nullptr && ws != nullptr && vis_records != nullptr && depth_keys != nullptr && tile_rects != nullptr, "null argument");
+    GS_CHECK_ARG(counts4 != nullptr && ws != nullptr, "null argument");
+    GS_CHECK_ARG((depth_keys != nullptr) == (tile_rects != nullptr) && (vis_records != nullptr || depth_keys != nullptr),
+                 "depth_keys and tile_rects go together; at least one of {vis_records} / {depth_keys, tile_rects} is wanted");
     GS_CHECK_ARG(key_bits == 24 || key_bits == 32, "key_bits must be 24 or 32");
     GS_CHECK_ARG(key_bits == 32 || status4 != nullptr, "24-bit keys need a status word (range overflow is reported there)");
     EnvDev e;
-    GS_CHECK_ARG(env_to_dev(env, e) == 0, "bad GsEnv");
+    if (vis_records != nullptr) GS_CHECK_ARG(env_to_dev(env, e) == 0, "bad GsEnv");
+    else memset(&e, 0, sizeof(e));                            // geometry only: nothing is shaded
     if (ws_bytes < gs_front_ws_bytes(N)) { gs_set_error("gs_front_fwd: workspace too small"); return GS_ENOSPC; }
     hipStream_t s = (hipStream_t)stream;
     const int tile_w = (W + tile_size - 1) / tile_size, tile_h = (H + tile_size - 1) / tile_size;

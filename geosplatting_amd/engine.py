@@ -154,6 +154,50 @@ class RenderStep:
         # S5 sharded over the ranks (each applies 1/world of every level's texels, all-gather): splitsum.py
         sharded = (explicit_pre and world > 1 and os.environ.get("GEOSPLAT_SHARD_PREFILTER", "1") != "0"
                    and can_shard_prefilter(int(cubemap.shape[1]), world))
+        # ---- what does not need the pyramid comes first: activations, streams, key width -- and, in capacity mode, the GEOMETRY of
+        # the first view (projection, keys, binning: gs_front_fwd without records) on a front stream, so that it runs UNDER the
+        # prefilter forward instead of behind it (the step used to start its first compositor 0.9 ms after the prefilter ended)
+        scales_act = p.scales.detach().exp()
+        opac_act = torch.sigmoid(p.opacities.detach()).squeeze(-1).contiguous()
+        means, quats = p.means.detach(), p.quats.detach()
+        normals, kd, ks = p.normals.detach(), p.kd.detach(), p.ks.detach()
+        main = torch.cuda.current_stream(dev)
+        if self._use_capacity and self._status is None:      # zero-filled on the main stream BEFORE the side stream forks from it
+            self._status = torch.zeros(4, dtype=torch.int64, device=dev)
+        if self._side_stream is None:
+            # GEOSPLAT_FRONT_STREAMS=2: the fronts of consecutive views alternate between two streams (see start_view)
+            self._side_stream = [torch.cuda.Stream(device=dev, priority=int(os.environ.get("GEOSPLAT_SIDE_PRIO", "0")))
+                                 for _ in range(max(1, int(os.environ.get("GEOSPLAT_FRONT_STREAMS", "2"))))]
+        sides = self._side_stream
+        fused_front = self._front_fused
+        # binning keys: 24 bits (three depth passes instead of four) once the depth range of earlier views is known -- key = depth
+        # bits - key_base with half an octave of room below the smallest depth seen; a view outside the range is reported through
+        # the status word (poll_capacity) and the engine falls back to 32-bit keys
+        key_bits, key_base = 32, 0
+        if fused_front and self._use_capacity and self._i_cap is not None and not self._key32 and self._key_lo is not None:
+            base = max(0, self._key_lo - (1 << 22))
+            if self._key_hi - base < (1 << 24) - (1 << 21):
+                key_bits, key_base = 24, base
+        i_cap = self._i_cap if self._use_capacity else None
+        seen = []                                            # (pinned counts, event) of this step's views
+        early = {}                                           # view index -> (flatten_ids, isect_offsets) binned under the prefilter
+        n_early = int(os.environ.get("GEOSPLAT_EARLY_BIN", "1"))
+        if fused_front and i_cap is not None and _env is None and self.prefilter and n_early > 0:
+            ev_a = torch.cuda.Event(); ev_a.record(main)
+            for j in range(min(n_early, len(cameras))):
+                cam_j = cameras[j]
+                vm_j, K_j, cp_j = self._camera_tensors(cam_j)
+                side = sides[j % len(sides)]
+                side.wait_event(ev_a)
+                with torch.cuda.stream(side):
+                    fr_g = F.front_stage(means, quats, scales_act, opac_act, normals, kd, ks, vm_j, K_j, cp_j, None, cam_j.width, cam_j.height,
+                                         self.min_roughness, self.max_metallic, mode, key_base, key_bits,
+                                         self._status if key_bits == 24 else None, records=False)
+                    gstate, _, _ = F.bin_stage(fr_g, i_cap, self._status, prepare=False)
+                seen.append((fr_g.host_counts, fr_g.event))
+                early[j] = (gstate["flatten_ids"], gstate["isect_offsets"])
+                for t in (scales_act, opac_act):
+                    t.record_stream(side)
         if _env is not None:
             env = _env                                       # the pyramid of this step, already filtered (capture_views)
         elif self.prefilter:
@@ -199,14 +243,10 @@ class RenderStep:
                      else None)
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
 
-        scales_act = p.scales.detach().exp()
-        opac_act = torch.sigmoid(p.opacities.detach()).squeeze(-1).contiguous()
         self.bucket.flat.zero_()
         b = self.bucket.unpack()
         g_scales_act = torch.zeros(N, 3, dtype=f32, device=dev); g_opac_act = torch.zeros(N, dtype=f32, device=dev)
         exposure = p.exposure.detach().reshape(1).contiguous()
-        means, quats = p.means.detach(), p.quats.detach()
-        normals, kd, ks = p.normals.detach(), p.kd.detach(), p.ks.detach()
         images = []
 
         # HIP streams of a step.  The FRONT streams run the memory / latency-bound front of every view (shading, projection,
@@ -215,14 +255,6 @@ class RenderStep:
         # Fronts of consecutive views ALTERNATE between two streams: one front stream was the step's critical path (1.3 ms per
         # view under contention against 0.98 ms of compositor work); with two, 496 -> 525 views/s (three: 502).  In capacity mode
         # nothing makes the host wait, so the fronts run as far ahead of the compositor as their inputs allow.
-        main = torch.cuda.current_stream(dev)
-        if self._use_capacity and self._status is None:      # zero-filled on the main stream BEFORE the side stream forks from it
-            self._status = torch.zeros(4, dtype=torch.int64, device=dev)
-        if self._side_stream is None:
-            # GEOSPLAT_FRONT_STREAMS=2: the fronts of consecutive views alternate between two streams (see start_view)
-            self._side_stream = [torch.cuda.Stream(device=dev, priority=int(os.environ.get("GEOSPLAT_SIDE_PRIO", "0")))
-                                 for _ in range(max(1, int(os.environ.get("GEOSPLAT_FRONT_STREAMS", "2"))))]
-        sides = self._side_stream
         tail = self._tail_stream
         if tail is None:
             tail = self._tail_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("GEOSPLAT_TAIL_PRIO", "0")))
@@ -230,30 +262,24 @@ class RenderStep:
             sd.wait_stream(main)                             # prefilter pyramid, activations, zeroed buckets
         tail.wait_stream(main)
 
-        fused_front = self._front_fused
         # the tails of the views in ONE launch per `tail_batch` views (gs_tail_bwd_multi: parameter gradients in registers across the
         # views, stored once); 0 = one tail launch per view (gs_tail_bwd)
         tail_batch = int(os.environ.get("GEOSPLAT_TAIL_BATCH", "8")) if (fused_front and n_sets == 1) else 0
         pending_tails = []
         n_tail_launches = 0
-        # binning keys: 24 bits (three depth passes instead of four) once the depth range of earlier views is known -- key = depth
-        # bits - key_base with half an octave of room below the smallest depth seen; a view outside the range is reported through
-        # the status word (poll_capacity) and the engine falls back to 32-bit keys
-        key_bits, key_base = 32, 0
-        if fused_front and self._use_capacity and self._i_cap is not None and not self._key32 and self._key_lo is not None:
-            base = max(0, self._key_lo - (1 << 22))
-            if self._key_hi - base < (1 << 24) - (1 << 21):
-                key_bits, key_base = 24, base
-
         def start_view(cam, j):                              # S1-S3 + A1; (V, I) travel to the host asynchronously
             vm, K, cam_pos = self._camera_tensors(cam)
             side = sides[j % len(sides)]
             if fused_front:
                 with torch.cuda.stream(side):
-                    fr = F.front_stage(means, quats, scales_act, opac_act, normals, kd, ks, vm, K, cam_pos, e, cam.width, cam.height,
-                                       self.min_roughness, self.max_metallic, mode, key_base, key_bits,
-                                       self._status if key_bits == 24 else None, want_packed_index=tail_batch > 0)
-                return fr, None, side
+                    if j in early:                           # binned under the prefilter: only the records (shading) are still missing
+                        fr = F.front_stage(means, quats, scales_act, opac_act, normals, kd, ks, vm, K, cam_pos, e, cam.width, cam.height,
+                                           self.min_roughness, self.max_metallic, mode, want_packed_index=tail_batch > 0, binning=False)
+                    else:
+                        fr = F.front_stage(means, quats, scales_act, opac_act, normals, kd, ks, vm, K, cam_pos, e, cam.width, cam.height,
+                                           self.min_roughness, self.max_metallic, mode, key_base, key_bits,
+                                           self._status if key_bits == 24 else None, want_packed_index=tail_batch > 0)
+                return fr, j, side
             with torch.cuda.stream(side):
                 col = torch.empty(N, 3, dtype=f32, device=dev)
                 L.check(lib.gs_shade_fwd(N, L.ptr(means), L.ptr(normals), L.ptr(kd), L.ptr(ks), L.ptr(cam_pos),
@@ -267,16 +293,13 @@ class RenderStep:
         # steps size every per-view buffer by (N, I_cap) and leave (V, I) on the device -- no read-back, no host wait inside
         # the step.  The counts still travel to pinned memory asynchronously; poll_capacity() looks at them (and at the
         # overflow status word) without blocking.
-        i_cap = self._i_cap if self._use_capacity else None
-        seen = []                                            # (pinned counts, event) of this step's views
-
         def bin_view(item):                                  # A2-A4 on the side stream (exact mode: host waits for that view's counts)
             pr, col, side = item
             if fused_front:
                 with torch.cuda.stream(side):
                     if i_cap is not None:
                         seen.append((pr.host_counts, pr.event))
-                    state, V, I = F.bin_stage(pr, i_cap, self._status)
+                    state, V, I = F.bin_stage(pr, i_cap, self._status, binned=early.get(col))   # (`col` carries the view index here)
                     if i_cap is None:
                         self._exact_max_i = max(self._exact_max_i, I)
                         rng = F.depth_range(pr.host_counts)

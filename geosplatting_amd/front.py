@@ -44,27 +44,29 @@ class Front:
 def front_stage(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, normals: Tensor, kd: Tensor, ks: Tensor,
                 viewmat: Tensor, K: Tensor, cam_pos: Tensor, env_struct, W: int, H: int, min_roughness: float, max_metallic: float,
                 mode: int, key_base: int = 0, key_bits: int = 32, status: Optional[Tensor] = None, tile_size: int = 16,
-                eps2d: float = 0.3, near: float = 0.01, far: float = 1e10, radius_clip: float = 0.0, want_packed_index: bool = False) -> Front:
+                eps2d: float = 0.3, near: float = 0.01, far: float = 1e10, radius_clip: float = 0.0, want_packed_index: bool = False,
+                records: bool = True, binning: bool = True) -> Front:
     """S1-S3 + A1 (+ A1', A2 count) of one view on the current stream.  `scales` / `opacities` are the activated values
-    (rfstudio/model/gsplat.py:336-339).  key_bits 24 needs `status` (int64[4]; word 3 reports a depth outside the key range)."""
+    (rfstudio/model/gsplat.py:336-339).  key_bits 24 needs `status` (int64[4]; word 3 reports a depth outside the key range).
+    records=False: geometry only (keys, rectangles, tile counts; env_struct may be None); binning=False: records only."""
     lib = L.lib()
     dev = means.device
     N = means.shape[0]
     fr = Front()
-    fr.vis = torch.empty(max(N, 1), 16, dtype=torch.float32, device=dev)
-    fr.keys = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
-    fr.rects = torch.empty(max(N, 1), 2, dtype=torch.int32, device=dev)
+    fr.vis = torch.empty(max(N, 1), 16, dtype=torch.float32, device=dev) if records else None
+    fr.keys = torch.empty(max(N, 1), dtype=torch.int32, device=dev) if binning else None
+    fr.rects = torch.empty(max(N, 1), 2, dtype=torch.int32, device=dev) if binning else None
     fr.counts = torch.empty(4, dtype=torch.int64, device=dev)
     tw, th = (W + tile_size - 1) // tile_size, (H + tile_size - 1) // tile_size
     # (GEOSPLAT_FRONT_HIST=0: no per-tile histogram in the front kernel -- it then needs no LDS -- and the binning derives the
     #  offsets from the sorted tile ids; also what happens by itself above 8 192 tiles)
-    fr.tile_counts = torch.empty(tw * th, dtype=torch.int32, device=dev) if (_FRONT_HIST and tw * th <= 8192) else None
+    fr.tile_counts = torch.empty(tw * th, dtype=torch.int32, device=dev) if (_FRONT_HIST and binning and tw * th <= 8192) else None
     fr.packed_index = torch.empty(max(N, 1), dtype=torch.int32, device=dev) if want_packed_index else None
     ws_bytes = lib.gs_front_ws_bytes(N)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     L.check(lib.gs_front_fwd(N, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opacities), L.ptr(normals), L.ptr(kd), L.ptr(ks),
                              L.ptr(viewmat), L.ptr(K), L.ptr(cam_pos), L.f32(min_roughness), L.f32(max_metallic), mode,
-                             C.byref(env_struct), W, H, tile_size, L.f32(eps2d), L.f32(near), L.f32(far), L.f32(radius_clip),
+                             C.byref(env_struct) if env_struct is not None else None, W, H, tile_size, L.f32(eps2d), L.f32(near), L.f32(far), L.f32(radius_clip),
                              C.c_uint32(int(key_base) & 0xffffffff), int(key_bits), L.ptr(fr.vis), L.ptr(fr.keys), L.ptr(fr.rects),
                              L.ptr(fr.tile_counts), L.ptr(fr.packed_index), L.ptr(fr.counts), L.ptr(status), L.ptr(ws), C.c_size_t(ws_bytes), L.stream()), "gs_front_fwd")
     fr.host_counts = pinned_counts4()
@@ -84,13 +86,14 @@ def depth_range(host_counts: Tensor):
     return 0xffffffff - int(host_counts[2]), int(host_counts[3])
 
 
-def bin_stage(fr: Front, i_cap: Optional[int], status: Optional[Tensor]):
+def bin_stage(fr: Front, i_cap: Optional[int], status: Optional[Tensor], prepare: bool = True, binned=None):
     """A2-A4 + the compositor's record stream for a front; exact mode (i_cap None) waits for that view's (V, I) -- the one host
     synchronisation of the forward, as upstream; capacity mode sizes everything by (N, i_cap) and reads the counts on the device.
-    Returns (state, V, I) with V / I the sizes the later launches are given (capacities in capacity mode)."""
+    Returns (state, V, I) with V / I the sizes the later launches are given (capacities in capacity mode).
+    prepare=False: binning only (a geometry-only front); binned=(flatten_ids, isect_offsets) of such an earlier call: record stream only."""
     lib = L.lib()
     W, H, tile_size = fr.whs
-    dev = fr.vis.device
+    dev = fr.counts.device
     tw, th = (W + tile_size - 1) // tile_size, (H + tile_size - 1) // tile_size
     st = L.stream()
     if i_cap is None:
@@ -101,13 +104,18 @@ def bin_stage(fr: Front, i_cap: Optional[int], status: Optional[Tensor]):
         counts = None
     else:
         V, I, counts = fr.N, int(i_cap), fr.counts
-    flat = torch.empty(max(I, 1), dtype=torch.int32, device=dev)
-    offsets = torch.empty(th * tw, dtype=torch.int32, device=dev)
-    bin_bytes = lib.gs_isect_bin_front_ws_bytes(V, L.i64(I), tw, th)
-    bin_ws = torch.empty(max(bin_bytes, 1), dtype=torch.uint8, device=dev)
-    L.check(lib.gs_isect_bin_front(V, L.ptr(fr.keys), L.ptr(fr.rects), L.ptr(fr.tile_counts), L.ptr(counts), L.i64(I), fr.key_bits, tw, th, L.ptr(flat),
-                                   L.ptr(offsets), L.ptr(bin_ws), C.c_size_t(bin_bytes), L.ptr(status) if counts is not None else None,
-                                   st), "gs_isect_bin_front")
+    if binned is not None:
+        flat, offsets = binned
+    else:
+        flat = torch.empty(max(I, 1), dtype=torch.int32, device=dev)
+        offsets = torch.empty(th * tw, dtype=torch.int32, device=dev)
+        bin_bytes = lib.gs_isect_bin_front_ws_bytes(V, L.i64(I), tw, th)
+        bin_ws = torch.empty(max(bin_bytes, 1), dtype=torch.uint8, device=dev)
+        L.check(lib.gs_isect_bin_front(V, L.ptr(fr.keys), L.ptr(fr.rects), L.ptr(fr.tile_counts), L.ptr(counts), L.i64(I), fr.key_bits, tw, th,
+                                       L.ptr(flat), L.ptr(offsets), L.ptr(bin_ws), C.c_size_t(bin_bytes),
+                                       L.ptr(status) if counts is not None else None, st), "gs_isect_bin_front")
+    if not prepare:
+        return dict(flatten_ids=flat, isect_offsets=offsets, counts=counts, keys=fr.keys, rects=fr.rects, tile_counts=fr.tile_counts), V, I
     rws_bytes = lib.gs_raster_ws_bytes(L.i64(I), V, W, H, tile_size)
     rws = torch.empty(rws_bytes, dtype=torch.uint8, device=dev)
     if counts is None:

@@ -491,7 +491,10 @@ int gs_flexicubes_entropy_bwd(int R0, int R1, int R2, const float* sdf, const vo
  *   tile_counts [tiles] u32: intersections per tile (zeroed by the call; nullable, and not written for more than 8 192 tiles):
  *                            gs_isect_bin_front turns them into the tile offsets;
  *   counts4 [4] i64        : {V, I, 0xffffffff - min depth bits, max depth bits} (zeroed by the call).
- * No other per-visible array exists on this path.  Scratch: gs_front_ws_bytes(N), zeroed by the call. */
+ * No other per-visible array exists on this path.  Scratch: gs_front_ws_bytes(N), zeroed by the call.
+ * Two partial forms (same packed order, same counts): vis_records == NULL = GEOMETRY ONLY (keys, rectangles, tile counts, slots;
+ * nothing is shaded, env may be NULL) -- the engine bins its first view with it while the prefilter is still computing the
+ * pyramid -- and depth_keys == tile_rects == NULL = records only. */
 size_t gs_front_ws_bytes(int N);
 int gs_front_fwd(int N, const float* means, const float* quats, const float* scales, const float* opacities,
                  const float* normals, const float* kd, const float* ks, const float* viewmat, const float* K,

@@ -12,7 +12,7 @@ for k, v in raw.items():
     if k.startswith("raster_bwd"):
         pick["raster_bwd_kernel"] = dict(v, launched_as=k)
 out = {"source_sha16": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16], "commit": sys.argv[3] if len(sys.argv) > 3 else "?",
-       "workload": "scripts/pmc_view.py 7 (one view, 2M / 800^2, 512^2 pyramid), rocprofv3 --pmc passes of scripts/run_pmc.sh, mean per launch; "
+       "workload": "scripts/view_kernels_engine.py 7 (one view through engine.RenderStep, 2M / 800^2; rounds 1-3: scripts/pmc_view.py), rocprofv3 --pmc passes of scripts/run_pmc_r04.sh, mean per launch; "
                    "hbm_bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE KiB x 1024",
        "kernels": pick, "all": raw}
 json.dump(out, open(sys.argv[2], "w"), indent=1)

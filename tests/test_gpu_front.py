@@ -284,7 +284,9 @@ def test_cull_log_backward_equals_plain_backward(cuda):
             assert torch.equal(a[k], b[k]), k
         assert float(a[4].abs().max()) > 0
         assert rel_err(b[4].cpu().numpy(), a[4].cpu().numpy()) < 2e-6
-        assert abs(float(a[5]) - float(b[5])) <= 1e-5 * abs(float(a[5])) + 1e-6
+        # exposure gradient: ten thousand float atomics (one per quadrant wave) of both signs whose order is not fixed -- 1e-5 of the
+        # result was seen between two runs of the SAME kernel
+        assert abs(float(a[5]) - float(b[5])) <= 1e-4 * abs(float(a[5])) + 1e-4
 
 
 def test_tail_multi_equals_sum_of_view_tails(cuda):

@@ -68,52 +68,61 @@ FLOPS_BWD_PER_PAIR = 76      # sigma/exp/alpha 28 | 1/(1-alpha), T, fac 3 | v_al
 VALU_PEAK_TFLOPS = 157.3     # FP32 vector peak, MI355X_MICROARCH.md
 
 
-def time_dominant_kernels(scene_state, iters):
-    """Durations of the compositor kernels the ENGINE launches, each ALONE, with HIP events on the stream they are launched on
-    (torch's current stream): `gs_raster_composite_tone_log` (raster_fwd_window_kernel with S4 in its epilogue, writing the cull
-    log) on a prepared workspace and `gs_raster_bwd_tone_log_acc` (raster_bwd_log_kernel); the workspace preparation (sorted
-    record stream, tile order) is timed as its own entry.  GEOSPLAT_RASTER_LOG=0: the plain pair (raster_bwd_lanes2_kernel)."""
+def time_dominant_kernels(params, env, cam, res, iters):
+    """Durations of the compositor kernels the ENGINE launches, each ALONE, on the engine's own inputs (fused front with its tile
+    rectangles, binning from its outputs), with HIP events on the stream they are launched on (torch's current stream):
+    `gs_raster_composite_tone_log` (raster_fwd_window_kernel with S4 in its epilogue, writing the cull log) on a prepared workspace
+    and `gs_raster_bwd_tone_log_acc` (raster_bwd_log_kernel); the workspace preparation (sorted record stream, tile order) is timed
+    as its own entry.  GEOSPLAT_RASTER_LOG=0: the plain pair (raster_bwd_lanes2_kernel).  Returns (times, I of the engine's list)."""
+    import geosplatting_amd as gs
     import geosplatting_amd._lib as L
+    from geosplatting_amd import front as F
+    from geosplatting_amd.shading import _MODE, _make_env
     lib = L.lib()
-    st = scene_state
-    dev = st["means2d"].device
-    W = H = st["res"]
-    V, I, D = st["V"], st["I"], 3
+    dev = params.means.device
+    W = H = res
     f32 = torch.float32
     use_log = os.environ.get("GEOSPLAT_RASTER_LOG", "1") != "0"
-    render = torch.empty(H, W, D, dtype=f32, device=dev); alphas = torch.empty(H, W, dtype=f32, device=dev)
+    tight = os.environ.get("GEOSPLAT_TIGHT_TILES", "0") == "1"
+    env_d = gs.TextureSplitSum(env.base.detach(), [l.detach().contiguous() for l in env.levels], env.min_roughness, env.max_roughness)
+    e = _make_env(gs.get_fg_lut(dev), env_d)
+    d = lambda t: t.to(dev, f32).contiguous()
+    fr = F.front_stage(params.means, params.quats, params.scales.exp(), torch.sigmoid(params.opacities).squeeze(-1).contiguous(), params.normals,
+                       params.kd, params.ks, d(cam.view_matrix), d(cam.intrinsic_matrix), d(cam.c2w[:, 3]), e, W, H, 0.1, 1.0, _MODE["pbr"],
+                       tight_tiles=tight)
+    state, V, I = F.bin_stage(fr, None, None)
+    offsets, flat, rws = state["isect_offsets"], state["flatten_ids"], state["raster_ws"]
+    rws_bytes = rws.numel()
+    render = torch.empty(H, W, 3, dtype=f32, device=dev); alphas = torch.empty(H, W, dtype=f32, device=dev)
     last = torch.empty(H, W, dtype=torch.int32, device=dev); img = torch.empty(H, W, 4, dtype=f32, device=dev)
     v_img = torch.rand(H, W, 4, device=dev) * 2 - 1
     exposure = torch.ones(1, device=dev); v_exp = torch.zeros(1, device=dev)
-    v_packed = torch.zeros(V, lib.gs_raster_grad_stride(D), dtype=f32, device=dev)
+    v_packed = torch.zeros(max(V, 1), lib.gs_raster_grad_stride(3), dtype=f32, device=dev)
     s = L.stream()
-    rws_bytes = lib.gs_raster_ws_bytes(L.i64(I), V, W, H, 16)
-    rws = torch.empty(rws_bytes, dtype=torch.uint8, device=dev)
     log_ws = torch.empty(lib.gs_raster_log_ws_bytes(L.i64(I), W, H, 16), dtype=torch.uint8, device=dev)
 
     def prep():
-        L.check(lib.gs_raster_prepare(W, H, 16, D, V, L.ptr(st["means2d"]), L.ptr(st["conics"]), L.ptr(st["opacities"]),
-                                      L.ptr(st["colors"]), L.i64(I), L.ptr(st["offsets"]), L.ptr(st["flatten_ids"]),
-                                      L.ptr(rws), C.c_size_t(rws_bytes), s), "raster_prepare")
+        L.check(lib.gs_raster_prepare_vis(W, H, 16, 3, V, L.ptr(fr.vis), L.i64(I), L.ptr(offsets), L.ptr(flat), L.ptr(rws), C.c_size_t(rws_bytes), s),
+                "raster_prepare_vis")
 
     def fwd():
         if use_log:
-            L.check(lib.gs_raster_composite_tone_log(W, H, 16, V, None, L.i64(I), None, L.ptr(st["offsets"]), L.ptr(render), L.ptr(alphas),
+            L.check(lib.gs_raster_composite_tone_log(W, H, 16, V, None, L.i64(I), None, L.ptr(offsets), L.ptr(render), L.ptr(alphas),
                                                      L.ptr(last), 1, L.ptr(exposure), L.ptr(img), L.ptr(rws), C.c_size_t(rws_bytes),
                                                      L.ptr(log_ws), C.c_size_t(log_ws.numel()), s), "raster_composite_tone_log")
         else:
-            L.check(lib.gs_raster_composite_tone(W, H, 16, V, None, L.i64(I), None, L.ptr(st["offsets"]), L.ptr(render), L.ptr(alphas),
+            L.check(lib.gs_raster_composite_tone(W, H, 16, V, None, L.i64(I), None, L.ptr(offsets), L.ptr(render), L.ptr(alphas),
                                                  L.ptr(last), 1, L.ptr(exposure), L.ptr(img), L.ptr(rws), C.c_size_t(rws_bytes), s),
                     "raster_composite_tone")
 
     def bwd():
         if use_log:
-            L.check(lib.gs_raster_bwd_tone_log_acc(W, H, 16, V, None, L.i64(I), None, L.ptr(st["offsets"]), L.ptr(render), L.ptr(alphas),
+            L.check(lib.gs_raster_bwd_tone_log_acc(W, H, 16, V, None, L.i64(I), None, L.ptr(offsets), L.ptr(render), L.ptr(alphas),
                                                    L.ptr(last), 1, L.ptr(exposure), L.ptr(v_img), L.ptr(v_packed), L.ptr(v_exp), L.ptr(rws),
                                                    C.c_size_t(rws_bytes), L.ptr(log_ws), C.c_size_t(log_ws.numel()), s),
                     "raster_bwd_tone_log_acc")
         else:
-            L.check(lib.gs_raster_bwd_tone_acc(W, H, 16, V, None, L.i64(I), None, L.ptr(st["offsets"]), L.ptr(render), L.ptr(alphas),
+            L.check(lib.gs_raster_bwd_tone_acc(W, H, 16, V, None, L.i64(I), None, L.ptr(offsets), L.ptr(render), L.ptr(alphas),
                                                L.ptr(last), 1, L.ptr(exposure), L.ptr(v_img), L.ptr(v_packed), L.ptr(v_exp), L.ptr(rws),
                                                C.c_size_t(rws_bytes), s), "raster_bwd_tone_acc")
     out = {}
@@ -125,7 +134,7 @@ def time_dominant_kernels(scene_state, iters):
             fn()
         e1.record(); torch.cuda.synchronize()
         out[name] = e0.elapsed_time(e1) / iters       # ms per launch
-    return out
+    return out, I
 
 
 def time_view_without_prefilter(params, cam, up, iters):
@@ -456,10 +465,7 @@ def main():
         V, I = int(meta["radii"].shape[0]), int(meta["flatten_ids"].shape[0])
         P = args.res * args.res
         E = sum(6 * r * r * 3 * 4 for r in [l.shape[1] for l in env.levels]) + 6 * 16 * 16 * 3 * 4
-        st = dict(means2d=meta["means2d"], conics=meta["conics"], opacities=meta["opacities"],
-                  colors=colors[meta["gaussian_ids"]].contiguous(), offsets=meta["isect_offsets"].reshape(-1).contiguous(),
-                  flatten_ids=meta["flatten_ids"], V=V, I=I, res=args.res)
-        kt = time_dominant_kernels(st, args.kernel_iters)
+        kt, I_engine = time_dominant_kernels(params, env, cam, args.res, args.kernel_iters)
         view_detail = time_view_without_prefilter(params, cam, ups[0], max(3, args.kernel_iters // 2))
         view_detail["note"] = "one view fwd+bwd, pyramid fixed; the headline figure is the HIP-graph replay when it could be captured, else the eager launch"
         view_ms = view_detail["graph_ms"] if view_detail.get("graph_ms") else view_detail["eager_ms"]
@@ -467,7 +473,8 @@ def main():
         dom = max(comp, key=comp.get)
         # algorithmic bytes of the compositor launches:
         #   fwd: sorted record stream 48 I + image write 20 P        bwd: record stream 48 I + image read 24 P + per-visible grad write 36 V
-        kbytes = {"raster_fwd_kernel": 48 * I + 20 * P, "raster_bwd_kernel": 48 * I + 24 * P + 36 * V}      # (+ 12 B per logged record with the cull log)
+        #   (I_engine: the engine's own list -- tile rectangles clipped to the alpha >= 1/255 extents -- is shorter than gsplat's I)
+        kbytes = {"raster_fwd_kernel": 48 * I_engine + 20 * P, "raster_bwd_kernel": 48 * I_engine + 24 * P + 36 * V}      # (+ 12 B per logged record)
         hbm_achieved = kbytes[dom] / (kt[dom] * 1e-3) / 1e9
         view_bytes = algorithmic_bytes_per_view(N, V, I, P, E)
         cb = None
@@ -511,7 +518,7 @@ def main():
                                    f"split-sum GGX envmap {args.cubemap_res}^2, "
                                    + (f"{views_total} views/step over all GPUs (strong scaling)" if strong else f"{args.views} views/step/GPU")
                                    + f", prefilter fwd+bwd {'in' if not args.no_prefilter else 'EXCLUDED from'} every step",
-                       "N": N, "V": V, "I": I, "P": P, "views_per_step_total": views_total,
+                       "N": N, "V": V, "I": I, "I_engine": I_engine, "P": P, "views_per_step_total": views_total,
                        "parallelism": f"dp{world} (views sharded, prefilter sharded, flat RCCL all-reduce of per-Gaussian grads)"},
             "roofline": {"bound": "valu", "kernel": dom, "launched_as": LAUNCHED_AS[dom],
                          "achieved": dom_tf_engine if dom_tf_engine is not None else dom_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -45,10 +45,11 @@ def front_stage(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor,
                 viewmat: Tensor, K: Tensor, cam_pos: Tensor, env_struct, W: int, H: int, min_roughness: float, max_metallic: float,
                 mode: int, key_base: int = 0, key_bits: int = 32, status: Optional[Tensor] = None, tile_size: int = 16,
                 eps2d: float = 0.3, near: float = 0.01, far: float = 1e10, radius_clip: float = 0.0, want_packed_index: bool = False,
-                records: bool = True, binning: bool = True) -> Front:
+                records: bool = True, binning: bool = True, tight_tiles: bool = False) -> Front:
     """S1-S3 + A1 (+ A1', A2 count) of one view on the current stream.  `scales` / `opacities` are the activated values
     (rfstudio/model/gsplat.py:336-339).  key_bits 24 needs `status` (int64[4]; word 3 reports a depth outside the key range).
-    records=False: geometry only (keys, rectangles, tile counts; env_struct may be None); binning=False: records only."""
+    records=False: geometry only (keys, rectangles, tile counts; env_struct may be None); binning=False: records only.
+    tight_tiles: tile rectangles clipped to the {alpha >= 1/255} extents (fewer intersections, identical pixels; not gsplat's `meta`)."""
     lib = L.lib()
     dev = means.device
     N = means.shape[0]
@@ -68,7 +69,7 @@ def front_stage(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor,
                              L.ptr(viewmat), L.ptr(K), L.ptr(cam_pos), L.f32(min_roughness), L.f32(max_metallic), mode,
                              C.byref(env_struct) if env_struct is not None else None, W, H, tile_size, L.f32(eps2d), L.f32(near), L.f32(far), L.f32(radius_clip),
                              C.c_uint32(int(key_base) & 0xffffffff), int(key_bits), L.ptr(fr.vis), L.ptr(fr.keys), L.ptr(fr.rects),
-                             L.ptr(fr.tile_counts), L.ptr(fr.packed_index), L.ptr(fr.counts), L.ptr(status), L.ptr(ws), C.c_size_t(ws_bytes), L.stream()), "gs_front_fwd")
+                             L.ptr(fr.tile_counts), L.ptr(fr.packed_index), 1 if tight_tiles else 0, L.ptr(fr.counts), L.ptr(status), L.ptr(ws), C.c_size_t(ws_bytes), L.stream()), "gs_front_fwd")
     fr.host_counts = pinned_counts4()
     fr.host_counts.copy_(fr.counts, non_blocking=True)        # 32 bytes, asynchronous
     fr.event = torch.cuda.Event()

@@ -492,6 +492,9 @@ int gs_flexicubes_entropy_bwd(int R0, int R1, int R2, const float* sdf, const vo
  *                            gs_isect_bin_front turns them into the tile offsets;
  *   counts4 [4] i64        : {V, I, 0xffffffff - min depth bits, max depth bits} (zeroed by the call).
  * No other per-visible array exists on this path.  Scratch: gs_front_ws_bytes(N), zeroed by the call.
+ * tight_tiles != 0: the tile rectangle is gsplat's square intersected with the axis-aligned extent of {alpha >= 1/255} (the extents
+ * hx, hy of the record, with which the compositor culls its quadrants anyway): every pixel composites exactly the same Gaussians in
+ * the same order, I is smaller (a caller that needs gsplat's `meta` passes 0).
  * Two partial forms (same packed order, same counts): vis_records == NULL = GEOMETRY ONLY (keys, rectangles, tile counts, slots;
  * nothing is shaded, env may be NULL) -- the engine bins its first view with it while the prefilter is still computing the
  * pyramid -- and depth_keys == tile_rects == NULL = records only. */
@@ -502,7 +505,7 @@ int gs_front_fwd(int N, const float* means, const float* quats, const float* sca
                  int W, int H, int tile_size, float eps2d, float near_plane, float far_plane, float radius_clip,
                  uint32_t key_base, int key_bits, float* vis_records, uint32_t* depth_keys, uint32_t* tile_rects,
                  uint32_t* tile_counts, int32_t* packed_index /* [N], nullable: packed slot of every Gaussian or -1 */,
-                 int64_t* counts4, int64_t* status4, void* ws, size_t ws_bytes, void* stream);
+                 int tight_tiles, int64_t* counts4, int64_t* status4, void* ws, size_t ws_bytes, void* stream);
 /* Binning from gs_front_fwd's outputs: flatten_ids_sorted in (tile, depth, packed index) order and the tile offsets, bit-identical
  * to gs_isect_bin_tiles_cap + gs_isect_offsets_tiles_cap.  counts_dev == NULL: V_cap / n_isects_cap are the exact counts; otherwise
  * the capacity protocol of gs_isect_bin_cap (status_dev int64[4]).  key_bits as passed to gs_front_fwd. */

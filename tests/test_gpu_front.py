@@ -33,13 +33,13 @@ def _inputs(cuda, level=3, res=128, view=1):
                 cam_pos=d(cam.c2w[:, 3]), W=res, H=res)
 
 
-def _front(x, env, cuda, key_base=0, key_bits=32, status=None, mode="pbr"):
+def _front(x, env, cuda, key_base=0, key_bits=32, status=None, mode="pbr", tight=False):
     import geosplatting_amd as gs
     from geosplatting_amd import front as F
     from geosplatting_amd.shading import _MODE, _make_env
     e = _make_env(gs.get_fg_lut(cuda), env)
     fr = F.front_stage(x["means"], x["quats"], x["scales"], x["opac"], x["normals"], x["kd"], x["ks"], x["vm"], x["K"], x["cam_pos"], e,
-                       x["W"], x["H"], 0.1, 1.0, _MODE[mode], key_base, key_bits, status)
+                       x["W"], x["H"], 0.1, 1.0, _MODE[mode], key_base, key_bits, status, tight_tiles=tight)
     torch.cuda.synchronize()
     return fr, e
 
@@ -133,6 +133,59 @@ def test_bin_front_depth_ties_and_random_scene(cuda):
     assert I == meta["flatten_ids"].shape[0] and I > 50000
     assert np.array_equal(state["flatten_ids"][:I].cpu().numpy(), meta["flatten_ids"].cpu().numpy())
     assert np.array_equal(state["isect_offsets"].cpu().numpy(), meta["isect_offsets"].reshape(-1).cpu().numpy())
+
+
+def test_tight_tiles_drop_only_tiles_no_pixel_composites(cuda):
+    """tight_tiles: gsplat's tile square clipped to the {alpha >= 1/255} extents.  Same records, same packed order; the tile list of
+    every Gaussian is a sub-rectangle of gsplat's; the sorted list is gsplat's list with the dropped (tile, Gaussian) pairs removed,
+    order untouched; and NO pixel centre of a dropped tile reaches alpha >= 1/255 (float64, every dropped pair of the scene)."""
+    from geosplatting_amd import front as F
+    sp, cam = random_case(6000, 256, seed=4)                    # random anisotropic splats: thin diagonal ellipses included
+    d = lambda t: t.to(cuda).contiguous()
+    g = torch.Generator().manual_seed(8)
+    scales = sp.scales.exp() * torch.tensor([1.0, 0.15, 0.02])   # flattened, elongated
+    x = dict(means=d(sp.means), quats=d(sp.quats), scales=d(scales), opac=d(torch.rand(sp.num, generator=g) * 0.98 + 0.01),
+             normals=d(torch.nn.functional.normalize(torch.randn(sp.num, 3, generator=g), dim=-1)), kd=d(torch.rand(sp.num, 3, generator=g)),
+             ks=d(torch.rand(sp.num, 2, generator=g)), vm=d(cam.view_matrix), K=d(cam.intrinsic_matrix), cam_pos=d(cam.c2w[:, 3]), W=256, H=256)
+    env = _env(cuda)
+    fg, _ = _front(x, env, cuda)
+    ft, _ = _front(x, env, cuda, tight=True)
+    V = int(fg.host_counts[0])
+    assert int(ft.host_counts[0]) == V and int(ft.host_counts[1]) < int(fg.host_counts[1])
+    assert torch.equal(fg.vis[:V], ft.vis[:V]) and torch.equal(fg.keys[:V], ft.keys[:V])
+    rg = fg.rects[:V].cpu().numpy().view(np.uint32).astype(np.int64); rt = ft.rects[:V].cpu().numpy().view(np.uint32).astype(np.int64)
+    box = lambda r: (r[:, 0] & 0xffff, r[:, 0] >> 16, r[:, 1] & 0xffff, r[:, 1] >> 16)
+    gx0, gy0, gx1, gy1 = box(rg); tx0, ty0, tx1, ty1 = box(rt)
+    nonempty = (tx1 > tx0) & (ty1 > ty0)
+    assert (tx0[nonempty] >= gx0[nonempty]).all() and (tx1 <= gx1).all() and (ty0[nonempty] >= gy0[nonempty]).all() and (ty1 <= gy1).all()
+    # dropped tiles: alpha at every pixel centre, float64
+    vis = fg.vis[:V].cpu().numpy().astype(np.float64)
+    mx, my, ha, cb, hc, op = vis[:, 0], vis[:, 1], vis[:, 2], vis[:, 3], vis[:, 4], vis[:, 5]
+    worst, n_dropped = 0.0, 0
+    for v in range(V):
+        for ty in range(gy0[v], gy1[v]):
+            for tx in range(gx0[v], gx1[v]):
+                if tx0[v] <= tx < tx1[v] and ty0[v] <= ty < ty1[v] and nonempty[v]:
+                    continue
+                n_dropped += 1
+                px = tx * 16 + np.arange(16) + 0.5; py = ty * 16 + np.arange(16) + 0.5
+                dx = mx[v] - px[None, :]; dy = my[v] - py[:, None]
+                sigma = ha[v] * dx * dx + hc[v] * dy * dy + cb[v] * dx * dy
+                alpha = np.where(sigma >= 0, np.minimum(0.999, op[v] * np.exp(-sigma)), 0.0)
+                worst = max(worst, float(alpha.max()))
+    assert n_dropped > 1000 and worst < 1.0 / 255.0, (n_dropped, worst)
+    # the sorted lists: tight == gsplat's with the dropped pairs filtered out
+    sg, _, _ = F.bin_stage(fg, None, None)
+    st_, _, _ = F.bin_stage(ft, None, None)
+    torch.cuda.synchronize()
+    Ig, It = int(fg.host_counts[1]), int(ft.host_counts[1])
+    flat_g = sg["flatten_ids"][:Ig].cpu().numpy(); off_g = sg["isect_offsets"].cpu().numpy()
+    tile_of = np.repeat(np.arange(off_g.size), np.diff(np.append(off_g, Ig)))
+    ty_, tx_ = tile_of // 16, tile_of % 16
+    keep = nonempty[flat_g] & (tx_ >= tx0[flat_g]) & (tx_ < tx1[flat_g]) & (ty_ >= ty0[flat_g]) & (ty_ < ty1[flat_g])
+    assert int(keep.sum()) == It
+    assert np.array_equal(st_["flatten_ids"][:It].cpu().numpy(), flat_g[keep])
+    assert np.array_equal(st_["isect_offsets"].cpu().numpy(), np.concatenate(([0], np.cumsum(np.bincount(tile_of[keep], minlength=off_g.size))[:-1])))
 
 
 def test_front_reports_depth_outside_key_range(cuda):

@@ -214,6 +214,41 @@ def test_view_fullsize_vs_oracle(cuda, level, activations):
         assert fr < (ELEM_FRAC_MAX if name in ("quats", "scales") else 1e-5), f"{name}: element-wise outliers {fr:.3e}"
 
 
+@pytest.mark.parametrize("tight", ["0", "1"])
+def test_engine_fullsize_equals_call_shaped_path(cuda, monkeypatch, tight):
+    """The ENGINE's launch sequence (fused front, with gsplat's or the clipped tile rectangles, binning from its outputs, cull-log compositor, batched
+    tail) at 1 966 080 Gaussians / 800^2 against the call-shaped path of the test above (RenderableAttrs.splat through autograd, which
+    is checked against the oracle there): images bit for bit, every gradient to summation order."""
+    import geosplatting_amd as gs
+    import geosplatting_amd.synthetic as syn
+    from geosplatting_amd.engine import RenderStep, params_from_scene
+    scene = syn.sphere_scene(7, seed=1, cubemap_res=512, device=cuda)
+    cams = syn.blender_cameras(num=8, width=800, height=800)[1:3]
+    params = params_from_scene(scene, cuda, exposure=1.15)
+    g = torch.Generator().manual_seed(3)
+    ups = [(torch.rand(800, 800, 4, generator=g) * 2 - 1).to(cuda) for _ in cams]
+    monkeypatch.setenv("GEOSPLAT_TIGHT_TILES", tight)             # "1": tile rectangles clipped to the alpha extents (optional path)
+    step = RenderStep(params)
+    for _ in range(2):                                              # second step: capacity mode, 24-bit keys, early binning
+        grads, images = step(cams, lambda i, img: ups[i], all_reduce=False, keep_images=True)
+        torch.cuda.synchronize()
+        assert step.poll_capacity(wait=True)
+    assert step._i_cap is not None and not step._key32 and step.truncated_steps == 0
+    grads = {k: v.clone() for k, v in grads.items()}
+    ref = RenderStep(params, fused=False)                           # per-view autograd through splat(): the call-shaped ops
+    rgrads, rimages = ref(cams, lambda i, img: ups[i], all_reduce=False, keep_images=True)
+    torch.cuda.synchronize()
+    for a, b in zip(images, rimages):
+        assert torch.equal(a, b)
+    for k, want in rgrads.items():
+        got = grads[k]
+        scale = float(want.abs().max())
+        assert scale > 0, k
+        err = float((got - want).abs().max()) / scale
+        print(f"  {k:10s} engine vs call-shaped path: {err:.2e}")
+        assert err < (1e-4 if k in ("quats", "scales") else 2e-5), (k, err)
+
+
 def test_stage1_iteration_at_full_scale():
     """BASELINE config 5 at the size it is quoted on: a 208^3 FlexiCubes grid (~2.85 M Gaussians), the 512^2 / 6-level split-sum
     pyramid, 8 views of 800x800.  One whole trainer step -- geometry extraction, MGAdapter, hash-grid field, prefilter, shade,

@@ -723,6 +723,259 @@ tail_multi_kernel(int N, TailViewsDev views, const float* __restrict__ means, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same work with the VIEWS ON THE LANES, as TWO kernels (round 4).  VPG (1, 2, 4 or 8) adjacent lanes own one Gaussian, one view
+// each: a lane computes ONE (Gaussian, view) pair, the gradients are summed over the VPG lanes with DPP adds and stored once.
+// tail_multi_kernel's view loop kept 19 accumulators and the temporaries of the projection AND the shading backward alive together
+// (256 VGPRs + scratch: two waves per SIMD behind dependent loads, 2 650 VALU instructions per pair).  Each half alone fits 128
+// VGPRs -- fused, the register allocator overlaps them whatever the source order (250 VGPRs; 123 spilled at a 128 cap; a
+// non-inlined call: 66) -- so they are two launches:
+//   tail_shade_pairs_kernel : S1-S3 backward; pyramid levels one at a time, the colour cotangent contracted into the fetch
+//                             (shade_pair_pre / cube_fetch_vjp / shade_pair_post, gs_shade_dev.h); sixteen waves per CU share the
+//                             LDS texel copies; writes v_means (its view-direction part), v_normals, v_kd, v_ks
+//   tail_proj_pairs_kernel  : A7; no LDS but the camera table; ADDS its part to v_means, writes v_quats, v_scales, v_opacities
+// Price: the 64-byte gradient record and the packed slot of a pair are read by both (+1.1 GB per 8-view step).
+#ifndef GS_TAILP_BLOCK
+#define GS_TAILP_BLOCK 1024        // sixteen waves per CU on one set of LDS texel copies
+#endif
+struct TailViewLds {
+    unsigned long long vis, v_packed, packed_index;
+    float cam[16];                 // R[9], t[3], fx, fy, cx, cy
+    float cam_pos[3];
+    float Wf, Hf;
+    float pad;
+};
+
+struct TailLevelLds { unsigned long long tex, gtex; long long priv_off; int R, lds_off; };   // priv_off / lds_off < 0: none
+
+template <int VPG>
+__device__ __forceinline__ float tail_group_sum(float v)
+{
+    if (VPG >= 2) v = gs_dpp_add<0xB1, 0xf, 0xf>(v);      // quad_perm [1,0,3,2]
+    if (VPG >= 4) v = gs_dpp_add<0x4E, 0xf, 0xf>(v);      // quad_perm [2,3,0,1]
+    if (VPG >= 8) v = gs_dpp_add<0x141, 0xf, 0xf>(v);     // row_half_mirror
+    return v;
+}
+
+template <int BLOCK, int VPG>
+__global__ void __launch_bounds__(BLOCK)
+tail_proj_pairs_kernel(int N, TailViewsDev views, const float* __restrict__ means, const float* __restrict__ quats,
+                       const float* __restrict__ scales, const float* __restrict__ opacities, float eps2d, int rec_stride,
+                       float* __restrict__ v_means, float* __restrict__ v_quats, float* __restrict__ v_scales,
+                       float* __restrict__ v_opacities, int accumulate)
+{
+    __shared__ TailViewLds s_views[VPG];
+#pragma unroll
+    for (int k = 0; k < VPG; ++k) {
+        if ((int)threadIdx.x == k) {
+            const TailViewDev& h = views.v[k];
+            TailViewLds& d = s_views[k];
+            d.vis = (unsigned long long)h.vis; d.v_packed = (unsigned long long)h.v_packed; d.packed_index = (unsigned long long)h.packed_index;
+            const GsCam c = load_cam(h.viewmat, h.K);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) d.cam[i] = c.R[i];
+            d.cam[9] = c.t[0]; d.cam[10] = c.t[1]; d.cam[11] = c.t[2];
+            d.cam[12] = c.fx; d.cam[13] = c.fy; d.cam[14] = c.cx; d.cam[15] = c.cy;
+            d.cam_pos[0] = d.cam_pos[1] = d.cam_pos[2] = 0.0f;
+            d.Wf = (float)h.W; d.Hf = (float)h.H; d.pad = 0.0f;
+        }
+    }
+    __syncthreads();
+    constexpr int G = BLOCK / VPG;
+    const int view = (int)threadIdx.x & (VPG - 1), gl = (int)threadIdx.x / VPG;
+    const TailViewLds& vw = s_views[view];
+    const int n = (int)blockIdx.x * G + gl;
+    const bool live = n < N && view < views.n;
+    const int slot = live ? reinterpret_cast<const int32_t*>(vw.packed_index)[n] : -1;
+    ProjGrad pg;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { pg.mean[c] = 0.0f; pg.scale[c] = 0.0f; }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) pg.quat[c] = 0.0f;
+    pg.op = 0.0f;
+    if (slot >= 0) {
+        const float* vp = reinterpret_cast<const float*>(vw.v_packed) + (size_t)slot * rec_stride;
+        const float4 g0 = reinterpret_cast<const float4*>(vp)[0];
+        const float2 g1 = reinterpret_cast<const float2*>(vp)[2];
+        if (g0.x != 0.0f || g0.y != 0.0f || g0.z != 0.0f || g0.w != 0.0f || g1.x != 0.0f || g1.y != 0.0f) {
+            const float4* vis = reinterpret_cast<const float4*>(vw.vis);
+            const float4 r0 = vis[4 * (size_t)slot], r1 = vis[4 * (size_t)slot + 1], r3 = vis[4 * (size_t)slot + 3];
+            const float mean[3] = { means[3 * (size_t)n], means[3 * (size_t)n + 1], means[3 * (size_t)n + 2] };
+            const float scale[3] = { scales[3 * (size_t)n], scales[3 * (size_t)n + 1], scales[3 * (size_t)n + 2] };
+            const float4 q4 = *reinterpret_cast<const float4*>(quats + 4 * (size_t)n);
+            const float opac = opacities[n];
+            GsCam cam;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) cam.R[i] = vw.cam[i];
+            cam.t[0] = vw.cam[9]; cam.t[1] = vw.cam[10]; cam.t[2] = vw.cam[11];
+            cam.fx = vw.cam[12]; cam.fy = vw.cam[13]; cam.cx = vw.cam[14]; cam.cy = vw.cam[15];
+            project_bwd_one(cam, mean, q4, scale, opac, vw.Wf, vw.Hf, eps2d, 2.0f * r0.z, r0.w, 2.0f * r1.x, r3.x,
+                            g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, 0.0f, pg);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { pg.mean[c] = tail_group_sum<VPG>(pg.mean[c]); pg.scale[c] = tail_group_sum<VPG>(pg.scale[c]); }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) pg.quat[c] = tail_group_sum<VPG>(pg.quat[c]);
+    pg.op = tail_group_sum<VPG>(pg.op);
+    if (n < N) {
+        if (view == 0 % VPG) {                                      // the shading kernel wrote its part of v_means: always added
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v_means[3 * (size_t)n + c] += pg.mean[c];
+        }
+        if (view == 1 % VPG) {
+            float4 q = accumulate ? *reinterpret_cast<float4*>(v_quats + 4 * (size_t)n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            q.x += pg.quat[0]; q.y += pg.quat[1]; q.z += pg.quat[2]; q.w += pg.quat[3];
+            *reinterpret_cast<float4*>(v_quats + 4 * (size_t)n) = q;
+        }
+        if (view == 2 % VPG) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v_scales[3 * (size_t)n + c] = (accumulate ? v_scales[3 * (size_t)n + c] : 0.0f) + pg.scale[c];
+        }
+        if (view == 3 % VPG) v_opacities[n] = (accumulate ? v_opacities[n] : 0.0f) + pg.op;
+    }
+}
+
+template <int BLOCK, int VPG, bool DIFFUSE>
+__global__ void __launch_bounds__(BLOCK)
+tail_shade_pairs_kernel(int N, TailViewsDev views, const float* __restrict__ means, const float* __restrict__ normals,
+                        const float* __restrict__ kd, const float* __restrict__ ks, float min_roughness, float max_metallic, EnvDev env,
+                        int rec_stride, float* __restrict__ v_means, float* __restrict__ v_normals, float* __restrict__ v_kd,
+                        float* __restrict__ v_ks, EnvGradDev eg, int accumulate, int mode_rt)
+{
+    const int mode = DIFFUSE ? GS_MODE_DIFFUSE : mode_rt;
+    __builtin_assume(DIFFUSE || mode != GS_MODE_DIFFUSE);
+    extern __shared__ __attribute__((aligned(16))) float s_grad[];
+    __shared__ TailViewLds s_views[VPG];
+    __shared__ TailLevelLds s_levels[GS_MAX_LEVELS];
+    for (int i = threadIdx.x; i < eg.lds_floats; i += blockDim.x) s_grad[i] = 0.0f;
+#pragma unroll
+    for (int l = 0; l < GS_MAX_LEVELS; ++l) {                       // the level of a pair is per-lane data: a table, not kernel arguments
+        if ((int)threadIdx.x == 64 + l) {
+            TailLevelLds& d = s_levels[l];
+            if (DIFFUSE) { d.tex = (unsigned long long)env.base; d.gtex = (unsigned long long)eg.base; d.priv_off = -1; d.R = env.base_res; d.lds_off = eg.lds_base; }
+            else { d.tex = (unsigned long long)env.levels[l]; d.gtex = (unsigned long long)eg.levels[l]; d.priv_off = eg.priv ? eg.priv_level[l] : -1; d.R = env.res[l]; d.lds_off = eg.lds_level[l]; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VPG; ++k) {
+        if ((int)threadIdx.x == k) {                                // k is a constant: the view's pointers come from scalar loads
+            const TailViewDev& h = views.v[k];
+            TailViewLds& d = s_views[k];
+            d.vis = (unsigned long long)h.vis; d.v_packed = (unsigned long long)h.v_packed; d.packed_index = (unsigned long long)h.packed_index;
+            const GsCam c = load_cam(h.viewmat, h.K);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) d.cam[i] = c.R[i];
+            d.cam[9] = c.t[0]; d.cam[10] = c.t[1]; d.cam[11] = c.t[2];
+            d.cam[12] = c.fx; d.cam[13] = c.fy; d.cam[14] = c.cx; d.cam[15] = c.cy;
+            d.cam_pos[0] = h.cam_pos[0]; d.cam_pos[1] = h.cam_pos[1]; d.cam_pos[2] = h.cam_pos[2];
+            d.Wf = (float)h.W; d.Hf = (float)h.H; d.pad = 0.0f;
+        }
+    }
+    __syncthreads();
+    float* const stage = s_grad + eg.stage_off + (threadIdx.x >> 6) * 640;
+    float* const priv = eg.priv ? eg.priv + (long long)gs_xcc_id() * eg.priv_stride : nullptr;
+    constexpr int G = BLOCK / VPG;                                  // Gaussians per block and trip
+    const int view = (int)threadIdx.x & (VPG - 1), gl = (int)threadIdx.x / VPG;
+    const bool view_on = view < views.n;
+    const TailViewLds& vw = s_views[view];
+    const int stride = (int)gridDim.x * G;
+    const int n_iter = (N + stride - 1) / stride;                   // wave-uniform: every lane reaches the wave-aggregated scatter
+    for (int it = 0; it < n_iter; ++it) {
+        const int n = it * stride + (int)blockIdx.x * G + gl;
+        const bool live = n < N && view_on;
+        const int slot = live ? reinterpret_cast<const int32_t*>(vw.packed_index)[n] : -1;
+        float mean[3] = { 0, 0, 0 }, normal[3] = { 0, 0, 0 }, kdn[3] = { 0, 0, 0 }, ksn[2] = { 0, 0 };
+        if (live) {
+            mean[0] = means[3 * (size_t)n]; mean[1] = means[3 * (size_t)n + 1]; mean[2] = means[3 * (size_t)n + 2];
+            normal[0] = normals[3 * (size_t)n]; normal[1] = normals[3 * (size_t)n + 1]; normal[2] = normals[3 * (size_t)n + 2];
+            kdn[0] = kd[3 * (size_t)n]; kdn[1] = kd[3 * (size_t)n + 1]; kdn[2] = kd[3 * (size_t)n + 2];
+            const float2 ks2 = *reinterpret_cast<const float2*>(ks + 2 * (size_t)n);
+            ksn[0] = ks2.x; ksn[1] = ks2.y;
+        }
+        float a_mean[3] = { 0, 0, 0 }, a_n[3] = { 0, 0, 0 }, a_kd[3] = { 0, 0, 0 }, a_ks[2] = { 0, 0 };
+        // ---- the pyramid levels one at a time: fetch + contract with the colour cotangent, then the texel scatter of that level by
+        //      all lanes together
+        const float* vp = reinterpret_cast<const float*>(vw.v_packed) + (size_t)(slot >= 0 ? slot : 0) * rec_stride;
+        bool work = false;
+        PairPre pre;
+        float g[3] = { 0, 0, 0 };
+        if (slot >= 0) {
+            g[0] = vp[6]; g[1] = vp[7]; g[2] = vp[8];
+            if (g[0] != 0.0f || g[1] != 0.0f || g[2] != 0.0f) {
+                const float cp[3] = { vw.cam_pos[0], vw.cam_pos[1], vw.cam_pos[2] };
+                shade_pair_pre(mean, normal, kdn, ksn, cp, min_roughness, max_metallic, mode, env, g, pre);
+                work = true;
+            }
+        }
+        float o_acc[3] = { 0, 0, 0 }, vd_acc[3] = { 0, 0, 0 }, v_mip = 0.0f;
+#pragma unroll 1
+        for (int lv = 0; lv < (DIFFUSE ? 1 : 2); ++lv) {
+            const int l = work ? (lv == 0 ? pre.l0 : pre.l1) : -1;
+            const bool on = l >= 0;
+            const TailLevelLds& lt = s_levels[on ? l : 0];
+            const float w = lv == 0 ? (pre.l1 < 0 ? 1.0f : 1.0f - pre.f) : pre.f;
+            CubeFp fp;
+            fp.valid = false;
+            if (on) {
+                float o[3], sv, dd[3];
+                cube_fetch_vjp(reinterpret_cast<const float*>(lt.tex), lt.R, pre.dir, pre.v, o, sv, dd, fp);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { o_acc[c] = fmaf(w, o[c], o_acc[c]); vd_acc[c] = fmaf(w, dd[c], vd_acc[c]); }
+                v_mip += lv == 0 ? -sv : sv;
+            }
+            const bool in_lds = on && lt.lds_off >= 0;
+            if (in_lds) cube_scatter_lds(s_grad + lt.lds_off, fp, pre.v, w);
+            const bool glob = on && !in_lds;
+            const bool loc = glob && priv != nullptr && lt.priv_off >= 0;
+            cube_scatter_wave_tagged(glob ? (loc ? priv + lt.priv_off : reinterpret_cast<float*>(lt.gtex)) : nullptr, loc, fp, pre.v, w, glob, stage);
+        }
+        if (work) shade_pair_post(pre, normal, kdn, g, mode, min_roughness, max_metallic, o_acc, vd_acc, v_mip, a_mean, a_n, a_kd, a_ks);
+        // ---- sum over the views of the Gaussian (adjacent lanes), one lane of the group stores each array
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a_mean[c] = tail_group_sum<VPG>(a_mean[c]); a_n[c] = tail_group_sum<VPG>(a_n[c]); a_kd[c] = tail_group_sum<VPG>(a_kd[c]);
+        }
+        a_ks[0] = tail_group_sum<VPG>(a_ks[0]); a_ks[1] = tail_group_sum<VPG>(a_ks[1]);
+        if (n < N) {
+            if (view == 0 % VPG) {                                  // accumulate: read-modify-write by the owning lane
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v_means[3 * (size_t)n + c] = (accumulate ? v_means[3 * (size_t)n + c] : 0.0f) + a_mean[c];
+            }
+            if (view == 1 % VPG) {
+                float2 o = accumulate ? *reinterpret_cast<float2*>(v_ks + 2 * (size_t)n) : make_float2(0.f, 0.f);
+                o.x += a_ks[0]; o.y += a_ks[1];
+                *reinterpret_cast<float2*>(v_ks + 2 * (size_t)n) = o;
+            }
+            if (view == 2 % VPG) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v_normals[3 * (size_t)n + c] = (accumulate ? v_normals[3 * (size_t)n + c] : 0.0f) + a_n[c];
+            }
+            if (view == 3 % VPG) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v_kd[3 * (size_t)n + c] = (accumulate ? v_kd[3 * (size_t)n + c] : 0.0f) + a_kd[c];
+            }
+        }
+    }
+    // ---- flush the private copies
+    __syncthreads();
+    if (eg.lds_base >= 0) {
+        const int cnt = 18 * env.base_res * env.base_res;
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const float x = s_grad[eg.lds_base + i];
+            if (x != 0.0f) gs_atomic_add(eg.base + i, x);
+        }
+    }
+    for (int l = 0; l < env.L; ++l) {
+        if (eg.lds_level[l] < 0) continue;
+        const int cnt = 18 * env.res[l] * env.res[l];
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const float x = s_grad[eg.lds_level[l] + i];
+            if (x != 0.0f) gs_atomic_add(eg.levels[l] + i, x);
+        }
+    }
+}
+
 extern "C" int gs_tail_bwd_multi(int N, int n_views, const GsTailView* views, const float* means, const float* quats, const float* scales,
                                  const float* opacities, const float* normals, const float* kd, const float* ks, float min_roughness,
                                  float max_metallic, int mode, const GsEnv* env, float eps2d, int rec_stride, float* v_means, float* v_quats,
@@ -738,8 +991,10 @@ extern "C" int gs_tail_bwd_multi(int N, int n_views, const GsTailView* views, co
     for (int l = 0; l < GS_MAX_LEVELS; ++l) eg.levels[l] = l < e.L ? env_grad->levels[l] : nullptr;
     if (mode == GS_MODE_DIFFUSE) GS_CHECK_ARG(eg.base != nullptr, "env_grad->base required in diffuse mode");
     else for (int l = 0; l < e.L; ++l) GS_CHECK_ARG(eg.levels[l] != nullptr, "env_grad->levels[l] required");
+    // GEOSPLAT_TAIL_KERNEL=loop: tail_multi_kernel (one thread per Gaussian looping over the views); default: views on the lanes
+    static const bool s_pairs = [] { const char* v = getenv("GEOSPLAT_TAIL_KERNEL"); return !(v && strcmp(v, "loop") == 0); }();
     ShadeBwdPlan plan;
-    { const int rc = shade_bwd_plan(e, mode, N, nullptr, 0, eg, plan, true, 512); if (rc != GS_OK) return rc; }
+    { const int rc = shade_bwd_plan(e, mode, N, nullptr, 0, eg, plan, true, s_pairs ? GS_TAILP_BLOCK : 512); if (rc != GS_OK) return rc; }
     {
         const size_t floats = tail_priv_floats(e, mode, eg.priv_level);
         if (priv_ws != nullptr && floats > 0) {
@@ -770,7 +1025,24 @@ extern "C" int gs_tail_bwd_multi(int N, int n_views, const GsTailView* views, co
                                v_opacities, v_normals, v_kd, v_ks, eg, acc, mode);                                                        \
             GS_CHECK_LAUNCH();                                                                                                          \
         } while (0)
-        if (mode == GS_MODE_DIFFUSE) GS_TAILM_LAUNCH(true); else GS_TAILM_LAUNCH(false);
+#define GS_TAILP_LAUNCH(B, VPG, DIFF)                                                                                                    \
+        do {                                                                                                                            \
+            const int groups = gs_cdiv(N, B / VPG);                                                                                     \
+            const int max_blocks = eg.lds_floats > 0 ? 256 * (int)fmax(1.0, floor(160.0 * 1024.0 / (double)(plan.lds_bytes + 2048))) : 2048; \
+            GS_CHECK_HIP(hipFuncSetAttribute((const void*)tail_shade_pairs_kernel<B, VPG, DIFF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes)); \
+            hipLaunchKernelGGL((tail_shade_pairs_kernel<B, VPG, DIFF>), dim3(groups < max_blocks ? groups : max_blocks), dim3(B), plan.lds_bytes, s, N, tv, \
+                               means, normals, kd, ks, min_roughness, max_metallic, e, rec_stride, v_means, v_normals, v_kd, v_ks, eg, acc, mode); \
+            GS_CHECK_LAUNCH();                                                                                                          \
+            hipLaunchKernelGGL((tail_proj_pairs_kernel<256, VPG>), dim3(gs_cdiv(N, 256 / VPG)), dim3(256), 0, s, N, tv, means, quats, scales, \
+                               opacities, eps2d, rec_stride, v_means, v_quats, v_scales, v_opacities, acc);                                    \
+            GS_CHECK_LAUNCH();                                                                                                          \
+        } while (0)
+#define GS_TAILP_MODE(VPG) do { if (mode == GS_MODE_DIFFUSE) GS_TAILP_LAUNCH(GS_TAILP_BLOCK, VPG, true); else GS_TAILP_LAUNCH(GS_TAILP_BLOCK, VPG, false); } while (0)
+        if (s_pairs) {
+            if (tv.n <= 1) GS_TAILP_MODE(1); else if (tv.n <= 2) GS_TAILP_MODE(2); else if (tv.n <= 4) GS_TAILP_MODE(4); else GS_TAILP_MODE(8);
+        } else if (mode == GS_MODE_DIFFUSE) GS_TAILM_LAUNCH(true); else GS_TAILM_LAUNCH(false);
+#undef GS_TAILP_MODE
+#undef GS_TAILP_LAUNCH
 #undef GS_TAILM_LAUNCH
     }
     return GS_OK;

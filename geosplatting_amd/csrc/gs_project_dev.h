@@ -186,6 +186,8 @@ __device__ __forceinline__ void project_bwd_one(const GsCam& cam, const float* m
                                                 float vm2x, float vm2y, float v_ca, float v_cb, float v_cc, float v_op, float v_depth,
                                                 ProjGrad& g)
 {
+    // a gradient, compared to 1e-4 and not bit for bit: contraction ON (the file default is off), reciprocals by v_rcp_f32
+#pragma clang fp contract(fast)
     g.op = v_op * comp;
     const float v_comp = v_op * opacity;
 
@@ -223,7 +225,7 @@ __device__ __forceinline__ void project_bwd_one(const GsCam& cam, const float* m
     float G[4] = { -(p00 * ia + p01 * ib), -(p00 * ib + p01 * ic), -(p10 * ia + p11 * ib), -(p10 * ib + p11 * ic) };
     {   // compensation vjp
         const float det_conic = ia * ic - ib * ib;
-        const float v_sqr_comp = v_comp * 0.5f / (comp + 1e-6f);
+        const float v_sqr_comp = v_comp * 0.5f * __builtin_amdgcn_rcpf(comp + 1e-6f);
         const float om = 1.0f - comp * comp;
         G[0] += v_sqr_comp * (om * ia - eps2d * det_conic);
         G[1] += v_sqr_comp * (om * ib);
@@ -232,12 +234,13 @@ __device__ __forceinline__ void project_bwd_one(const GsCam& cam, const float* m
     }
     // perspective projection vjp
     const float x = mc[0], y = mc[1], z = mc[2];
-    const float tan_fovx = 0.5f * Wf / cam.fx, tan_fovy = 0.5f * Hf / cam.fy;
-    const float lim_x_pos = (Wf - cam.cx) / cam.fx + 0.3f * tan_fovx;
-    const float lim_x_neg = cam.cx / cam.fx + 0.3f * tan_fovx;
-    const float lim_y_pos = (Hf - cam.cy) / cam.fy + 0.3f * tan_fovy;
-    const float lim_y_neg = cam.cy / cam.fy + 0.3f * tan_fovy;
-    const float rz = 1.0f / z, rz2 = rz * rz, rz3 = rz2 * rz;
+    const float rfx = __builtin_amdgcn_rcpf(cam.fx), rfy = __builtin_amdgcn_rcpf(cam.fy);
+    const float tan_fovx = 0.5f * Wf * rfx, tan_fovy = 0.5f * Hf * rfy;
+    const float lim_x_pos = (Wf - cam.cx) * rfx + 0.3f * tan_fovx;
+    const float lim_x_neg = cam.cx * rfx + 0.3f * tan_fovx;
+    const float lim_y_pos = (Hf - cam.cy) * rfy + 0.3f * tan_fovy;
+    const float lim_y_neg = cam.cy * rfy + 0.3f * tan_fovy;
+    const float rz = __builtin_amdgcn_rcpf(z), rz2 = rz * rz, rz3 = rz2 * rz;
     const float tx = z * fminf(lim_x_pos, fmaxf(-lim_x_neg, x * rz));
     const float ty = z * fminf(lim_y_pos, fmaxf(-lim_y_neg, y * rz));
     const float J[6] = { cam.fx * rz, 0.0f, -cam.fx * tx * rz2, 0.0f, cam.fy * rz, -cam.fy * ty * rz2 };
@@ -305,7 +308,7 @@ __device__ __forceinline__ void project_bwd_one(const GsCam& cam, const float* m
 #pragma unroll
     for (int j = 0; j < 3; ++j) g.scale[j] = Rq[0 * 3 + j] * v_M[0 * 3 + j] + Rq[1 * 3 + j] * v_M[1 * 3 + j] + Rq[2 * 3 + j] * v_M[2 * 3 + j];
 
-    const float inv = 1.0f / sqrtf(q4.y * q4.y + q4.z * q4.z + q4.w * q4.w + q4.x * q4.x);
+    const float inv = __builtin_amdgcn_rsqf(q4.y * q4.y + q4.z * q4.z + q4.w * q4.w + q4.x * q4.x);
     const float w = q4.x * inv, xq = q4.y * inv, yq = q4.z * inv, zq = q4.w * inv;
 #define VR(i, j) v_Rq[(i) * 3 + (j)]
     float vqn[4];

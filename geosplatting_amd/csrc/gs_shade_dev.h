@@ -158,6 +158,216 @@ __device__ void shade_one(const float* mean, const float* normal, const float* k
     }
 }
 
+// Gradient arithmetic of ONE shaded (Gaussian, view) pair behind shade_one<true> -- the order of shade_bwd_kernel (gs_shade.hip).
+// g = d loss / d colour; ADDS into a_mean / a_n / a_kd / a_ks, returns the texel cotangents v_ls (specular levels) / v_ld (diffuse base).
+__device__ __forceinline__ void shade_bwd_arith(int mode, const ShadeTmp& t, const float* g, const float* kdn, const float* normal,
+                                                float min_roughness, float max_metallic, float* a_mean, float* a_n, float* a_kd,
+                                                float* a_ks, float* v_ls, float* v_ld)
+{
+    float v_diff[3] = { 0, 0, 0 }, v_rf[3] = { 0, 0, 0 };
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        v_ls[c] = 0.0f; v_ld[c] = 0.0f;
+        if (mode == GS_MODE_PBR)          { v_diff[c] = g[c]; v_ls[c] = g[c] * t.refl_c[c]; v_rf[c] = g[c] * t.ls.out[c]; }
+        else if (mode == GS_MODE_DIFFUSE) { v_ld[c] = g[c] * t.diff[c]; v_diff[c] = g[c] * t.ld[c]; }
+        else                              { v_ls[c] = g[c] * t.refl_c[c]; v_rf[c] = g[c] * t.ls.out[c]; }
+    }
+    float v_A = 0.0f, v_B = 0.0f, v_metal = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v_spec = v_rf[c] * t.fg[0];
+        v_A += v_rf[c] * t.spec[c];
+        v_B += v_rf[c];
+        a_kd[c] += v_spec * t.metal + v_diff[c] * (1.0f - t.metal);
+        v_metal += v_spec * (kdn[c] - 0.04f) - v_diff[c] * kdn[c];
+    }
+    const float v_ndv = v_A * t.dfg_du[0] + v_B * t.dfg_du[1];
+    float v_rough = v_A * t.dfg_dv[0] + v_B * t.dfg_dv[1];
+    float v_mip = 0.0f, v_refl[3] = { 0, 0, 0 }, v_n[3] = { 0, 0, 0 };
+    if (mode != GS_MODE_DIFFUSE) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            v_mip += v_ls[c] * t.ls.dmip[c];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v_refl[j] += v_ls[c] * t.ls.dd[c * 3 + j];
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v_n[j] += v_ld[c] * t.ld_dd[c * 3 + j];
+    }
+    v_rough += v_mip * t.dmip_dr;
+    float v_d = 2.0f * (v_refl[0] * normal[0] + v_refl[1] * normal[1] + v_refl[2] * normal[2]);
+    float v_wo[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { v_n[j] += 2.0f * t.d * v_refl[j]; v_wo[j] = -v_refl[j]; }
+    if (t.d >= 1e-6f) v_d += v_ndv;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { v_n[j] += v_d * t.wo[j]; v_wo[j] += v_d * normal[j]; }
+    if (!t.wo_const) {
+        const float dot = t.wo[0] * v_wo[0] + t.wo[1] * v_wo[1] + t.wo[2] * v_wo[2];
+        const float l = fmaxf(t.len, 1e-6f);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a_mean[j] += -((v_wo[j] - t.wo[j] * dot) / l);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) a_n[j] += v_n[j];
+    a_ks[0] += v_rough * (1.0f - min_roughness); a_ks[1] += v_metal * max_metallic;
+}
+
+// ---- lean backward of one pair (round 4, tail_pairs_kernel) -------------------------------------------------------------------
+// shade_one<true> + shade_bwd_arith carry the full 3x3 Jacobians d colour / d direction of both pyramid levels (113 VGPRs before the
+// texel scatter).  The cotangent of the sampled colour is known BEFORE the cube fetch (v_ls = g * (spec * fg0 + fg1)), so the
+// fetch can contract it on the spot: per level 4 scalars <v, tap> instead of 12 taps and 9 Jacobian entries.  Everything that
+// SELECTS something (LUT cell, mip level, face, texel) is computed exactly as in the forward (contraction off); only the smooth
+// arithmetic behind it is contracted -- gradients are compared to 1e-4, not bit for bit.
+// bilinear cube sample, s = <v, sample> and v_d = d s / d direction
+__device__ __forceinline__ void cube_fetch_vjp(const float* __restrict__ tex, int R, const float* d, const float* v, float* out,
+                                               float& s, float* v_d, CubeFp& fp)
+{
+    cube_footprint(d, R, fp);
+    const bool valid = fp.valid;
+    bool ok[4]; int safe[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ok[i] = valid && fp.idx[i] >= 0; safe[i] = ok[i] ? fp.idx[i] : 0; }
+    float t[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                   // branch-free loads (see cube_fetch)
+        const float* p = tex + (size_t)safe[i] * 3;
+        t[i][0] = p[0]; t[i][1] = p[1]; t[i][2] = p[2];
+    }
+    bool has_miss = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (!ok[i]) { t[i][0] = t[i][1] = t[i][2] = 0.0f; }
+        has_miss = has_miss || (valid && fp.idx[i] < 0);
+    }
+    if (has_miss) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float m = (t[0][c] + t[1][c] + t[2][c] + t[3][c]) / 3.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (fp.idx[i] < 0) t[i][c] = m;
+        }
+    }
+    {
+#pragma clang fp contract(fast)
+        float q[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = v[0] * t[i][0] + v[1] * t[i][1] + v[2] * t[i][2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float top = t[0][c] + fp.fx * (t[1][c] - t[0][c]);
+            const float bot = t[2][c] + fp.fx * (t[3][c] - t[2][c]);
+            out[c] = valid ? top + fp.fy * (bot - top) : 0.0f;
+        }
+        const float qt = q[0] + fp.fx * (q[1] - q[0]), qb = q[2] + fp.fx * (q[3] - q[2]);
+        s = valid ? qt + fp.fy * (qb - qt) : 0.0f;
+        const float dtx = (q[1] - q[0]) + fp.fy * ((q[3] - q[2]) - (q[1] - q[0]));
+        const float dty = qb - qt;
+        const FaceMap m = face_map(fp.face);
+        const float sgn_c = comp3(d, m.c) < 0.0f ? -1.0f : 1.0f;
+        const float gx = dtx * 0.5f * (float)R, gy = dty * 0.5f * (float)R;
+        const float va = gx * m.sx * fp.inv_c, vb = gy * m.sy * fp.inv_c;
+        const float vc = -(gx * fp.xn + gy * fp.yn) * fp.inv_c * sgn_c;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v_d[k] = valid ? (k == m.a ? va : 0.0f) + (k == m.b ? vb : 0.0f) + (k == m.c ? vc : 0.0f) : 0.0f;
+    }
+}
+
+// The pair's backward in three phases, so that a kernel can take the pyramid levels ONE AT A TIME (fetch + contract + scatter a
+// level, then the next: the two fetches interleaved by the compiler cost 79 VGPRs, one costs 51):
+//   shade_pair_pre  : everything before the cube fetch -- selecting quantities, FG LUT, the colour cotangent p.v, levels / weights
+//   cube_fetch_vjp  : per level, on p.dir with cotangent p.v; the caller accumulates w * out, w * v_dir and (s1 - s0)
+//   shade_pair_post : the remaining chain rule, ADDS into a_mean / a_n / a_kd / a_ks
+struct PairPre {
+    float metal, spec[3], wo[3], len, d;
+    float fg0, dfg_du[2], dfg_dv[2];
+    float dir[3];                  // lookup direction: the reflection vector (specular) or the normal (diffuse)
+    float v[3];                    // cotangent of the sampled colour
+    float dmip_dr, f;
+    int l0, l1;                    // l1 < 0: one level
+    bool wo_const, clamped;
+};
+
+__device__ __forceinline__ void shade_pair_pre(const float* mean, const float* normal, const float* kd, const float* ks, const float* cam_pos,
+                                               float min_roughness, float max_metallic, int mode, const EnvDev& env, const float* g, PairPre& p)
+{
+    // the forward's own expressions (shade_one), contraction off: they select the LUT cell, the mip levels, the face and the texels
+    const float rough = ks[0] * (1.0f - min_roughness) + min_roughness;
+    p.metal = ks[1] * max_metallic;
+    const float vv[3] = { cam_pos[0] - mean[0], cam_pos[1] - mean[1], cam_pos[2] - mean[2] };
+    p.len = sqrtf(vv[0] * vv[0] + vv[1] * vv[1] + vv[2] * vv[2]);
+    if (p.len < 1e-6f) { p.wo[0] = 0.0f; p.wo[1] = 0.0f; p.wo[2] = 1.0f; p.wo_const = true; }
+    else { const float l = fmaxf(p.len, 1e-6f); p.wo[0] = vv[0] / l; p.wo[1] = vv[1] / l; p.wo[2] = vv[2] / l; p.wo_const = false; }
+    p.d = normal[0] * p.wo[0] + normal[1] * p.wo[1] + normal[2] * p.wo[2];
+    const float ndv = fmaxf(p.d, 1e-6f);
+    float fg[2];
+    tex2d_linear_clamp2(env.lut, env.lut_res, env.lut_res, ndv, rough, fg, p.dfg_du, p.dfg_dv);
+    p.fg0 = fg[0];
+    const float mip = mip_from_roughness(rough, env.min_r, env.max_r, env.L, p.dmip_dr);
+    const int L = env.L;
+    const float lam = fminf(fmaxf(mip, 0.0f), (float)(L - 1));
+    const int lf = (int)floorf(lam);
+    const bool last = lf >= L - 1;
+    p.l0 = last ? L - 1 : lf;
+    p.l1 = last ? -1 : lf + 1;
+    p.f = last ? 0.0f : lam - (float)p.l0;
+    p.clamped = last || (mip < 0.0f || mip > (float)(L - 1));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p.spec[c] = (1.0f - p.metal) * 0.04f + kd[c] * p.metal;
+    if (mode != GS_MODE_DIFFUSE) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { p.dir[k] = 2.0f * p.d * normal[k] - p.wo[k]; p.v[k] = g[k] * (p.spec[k] * fg[0] + fg[1]); }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { p.dir[k] = normal[k]; p.v[k] = g[k] * (kd[k] * (1.0f - p.metal)); }
+        p.l0 = 0; p.l1 = -1; p.f = 0.0f;
+    }
+}
+
+// o = sum over the levels of w * out, v_dir = sum of w * (d s / d dir), v_mip = s1 - s0 (0 when the level was clamped)
+__device__ __forceinline__ void shade_pair_post(const PairPre& p, const float* normal, const float* kd, const float* g, int mode,
+                                                float min_roughness, float max_metallic, const float* o, const float* v_dir, float v_mip,
+                                                float* a_mean, float* a_n, float* a_kd, float* a_ks)
+{
+#pragma clang fp contract(fast)
+    float v_diff[3] = { 0, 0, 0 }, v_rf[3] = { 0, 0, 0 }, v_refl[3] = { 0, 0, 0 }, v_n[3] = { 0, 0, 0 };
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (mode == GS_MODE_DIFFUSE) { v_diff[c] = g[c] * o[c]; v_n[c] = v_dir[c]; }
+        else { v_rf[c] = g[c] * o[c]; v_refl[c] = v_dir[c]; if (mode == GS_MODE_PBR) v_diff[c] = g[c]; }
+    }
+    float v_A = 0.0f, v_B = 0.0f, v_metal = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v_spec = v_rf[c] * p.fg0;
+        v_A += v_rf[c] * p.spec[c];
+        v_B += v_rf[c];
+        a_kd[c] += v_spec * p.metal + v_diff[c] * (1.0f - p.metal);
+        v_metal += v_spec * (kd[c] - 0.04f) - v_diff[c] * kd[c];
+    }
+    const float v_ndv = v_A * p.dfg_du[0] + v_B * p.dfg_du[1];
+    const float v_rough = v_A * p.dfg_dv[0] + v_B * p.dfg_dv[1] + (p.clamped ? 0.0f : v_mip) * p.dmip_dr;
+    float v_d = 2.0f * (v_refl[0] * normal[0] + v_refl[1] * normal[1] + v_refl[2] * normal[2]);
+    float v_wo[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { v_n[j] += 2.0f * p.d * v_refl[j]; v_wo[j] = -v_refl[j]; }
+    if (p.d >= 1e-6f) v_d += v_ndv;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { v_n[j] += v_d * p.wo[j]; v_wo[j] += v_d * normal[j]; }
+    if (!p.wo_const) {
+        const float dot = p.wo[0] * v_wo[0] + p.wo[1] * v_wo[1] + p.wo[2] * v_wo[2];
+        const float rl = __builtin_amdgcn_rcpf(fmaxf(p.len, 1e-6f));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a_mean[j] -= (v_wo[j] - p.wo[j] * dot) * rl;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) a_n[j] += v_n[j];
+    a_ks[0] += v_rough * (1.0f - min_roughness); a_ks[1] += v_metal * max_metallic;
+}
+
 // scatter into an LDS-resident private copy (ds_add_f32) -- flushed once per block
 __device__ __forceinline__ void cube_scatter_lds(float* lds, const CubeFp& fp, const float* g, float scale)
 {

@@ -444,4 +444,6 @@ def test_engine_front_modes_agree(cuda, monkeypatch):
             for a, b in zip(ia, ib):
                 assert torch.equal(a, b)
             for k in ga:
-                assert rel_err(gb[k].cpu().numpy(), ga[k].cpu().numpy()) < 2e-5, (other, which, k)
+                # float atomics in another order, and the projection backward is compiled with contraction on: its fused
+                # multiply-adds differ between the kernels it is inlined into (2.7e-5 on the scale gradients)
+                assert rel_err(gb[k].cpu().numpy(), ga[k].cpu().numpy()) < 5e-5, (other, which, k)

@@ -48,11 +48,10 @@ __device__ __forceinline__ void face_point(int s, float x, float y, float* p)
 
 __device__ __forceinline__ float comp3(const float* d, int i) { return i == 0 ? d[0] : (i == 1 ? d[1] : d[2]); }
 
-__device__ int resolve_texel(int s, int ix, int iy, int R)
+// Texel (ix, iy) of face s where one coordinate lies outside [0, R): the reference rule (oracle/gs_oracle_shade.c) pushes the texel
+// CENTRE through face_point / select_face / the new face's map and rounds.  Kept as the definition (self-test only).
+__device__ __attribute__((noinline)) int resolve_texel_reproject(int s, int ix, int iy, int R)
 {
-    const bool ox = (ix < 0 || ix >= R), oy = (iy < 0 || iy >= R);
-    if (!ox && !oy) return (s * R + iy) * R + ix;
-    if (ox && oy) return -1;
     const float xn = 2.0f * (((float)ix + 0.5f) / (float)R) - 1.0f;
     const float yn = 2.0f * (((float)iy + 0.5f) / (float)R) - 1.0f;
     float p[3];
@@ -64,6 +63,30 @@ __device__ int resolve_texel(int s, int ix, int iy, int R)
     const float tx = (x2 + 1.0f) * 0.5f * (float)R - 0.5f, ty = (y2 + 1.0f) * 0.5f * (float)R - 0.5f;
     int jx = (int)floorf(tx + 0.5f), jy = (int)floorf(ty + 0.5f);
     jx = min(max(jx, 0), R - 1); jy = min(max(jy, 0), R - 1);
+    return (s2 * R + jy) * R + jx;
+}
+
+// The re-projection always lands on the texel ADJACENT across the edge: along the edge the centre moves by less than
+// R / (2 (R + 1)) < 1/2 texel, across it the result is the first or last row / column of the neighbour.  So it is an integer map
+// (face, edge) -> (face', x-kind, y-kind) with the kinds {0, R - 1, t, R - 1 - t} of the in-range coordinate t, independent of R:
+// 24 entries of 7 bits, one 32-bit constant per face (edge e = {ix < 0, ix >= R, iy < 0, iy >= R} at bits 7e: face' | x-kind << 3 |
+// y-kind << 5).  Derived from the float rule and compared with it for EVERY (face, edge, t) at R = 2..64 and 22 sizes up to 5000
+// (on the device: gs_selftest_cube_edges, tests/test_gpu_shading.py); at R = 8192 the float rule itself runs out of precision,
+// and every entry that takes a cube map rejects faces beyond 4096^2 (env_to_dev).  Round 4: the float rule (three IEEE divisions,
+// ~100 instructions per corner) ran in nearly every wave of the shading kernels -- one lane of 64 on a face edge is enough.
+#define GS_CUBE_EDGE_TABLE_MAX_R 4096
+__device__ __forceinline__ int resolve_texel(int s, int ix, int iy, int R)
+{
+    const bool ox = (ix < 0 || ix >= R), oy = (iy < 0 || iy >= R);
+    if (!ox && !oy) return (s * R + iy) * R + ix;
+    if (ox && oy) return -1;
+    const int e = ox ? (ix < 0 ? 0 : 1) : (iy < 0 ? 2 : 3);
+    const int t = ox ? iy : ix;
+    const unsigned w = s == 0 ? 0x97aa2ccu : s == 1 ? 0xc70a24du : s == 2 ? 0x2874c11u : s == 3 ? 0x7ad1839u : s == 4 ? 0x26ca049u : 0x766a0c8u;
+    const unsigned c = (w >> (7 * e)) & 127u;
+    const int s2 = (int)(c & 7u), kx = (int)((c >> 3) & 3u), ky = (int)((c >> 5) & 3u);
+    const int jx = kx == 0 ? 0 : (kx == 1 ? R - 1 : (kx == 2 ? t : R - 1 - t));
+    const int jy = ky == 0 ? 0 : (ky == 1 ? R - 1 : (ky == 2 ? t : R - 1 - t));
     return (s2 * R + jy) * R + jx;
 }
 

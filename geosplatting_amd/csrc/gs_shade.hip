@@ -395,3 +395,26 @@ extern "C" int gs_tonemap_bwd(int64_t P, int mode, const float* rgba, const floa
     GS_CHECK_LAUNCH();
     return GS_OK;
 }
+
+// self-test hook of the cube edge table (gs_cube.h resolve_texel): every (face, edge, t) of an R x R face against the float rule
+__global__ void __launch_bounds__(256) selftest_cube_edges_kernel(int R, unsigned long long* mismatches)
+{
+    const long long total = 24ll * R;
+    unsigned long long bad = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % R), e = (int)((i / R) & 3), s = (int)(i / (4ll * R));
+        const int ix = e == 0 ? -1 : (e == 1 ? R : t), iy = e == 2 ? -1 : (e == 3 ? R : t);
+        bad += resolve_texel(s, ix, iy, R) != resolve_texel_reproject(s, ix, iy, R);
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+extern "C" int gs_selftest_cube_edges(int R, uint64_t* mismatches_dev, void* stream)
+{
+    GS_CHECK_ARG(mismatches_dev != nullptr && R >= 1 && R <= GS_CUBE_EDGE_TABLE_MAX_R, "bad size");
+    hipStream_t s = (hipStream_t)stream;
+    GS_CHECK_HIP(gs_zero_async(mismatches_dev, sizeof(uint64_t), s));
+    hipLaunchKernelGGL(selftest_cube_edges_kernel, dim3(gs_cdiv(24 * R, 256)), dim3(256), 0, s, R, (unsigned long long*)mismatches_dev);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}

@@ -404,12 +404,13 @@ static size_t shade_bwd_priv_floats(const EnvDev& e, int mode, long long* level_
 static int env_to_dev(const GsEnv* env, EnvDev& e)
 {
     if (!env || !env->lut || !env->base || env->num_levels < 1 || env->num_levels > GS_MAX_LEVELS) return -1;
+    if (env->base_res > GS_CUBE_EDGE_TABLE_MAX_R) return -1;       // gs_cube.h: the edge table is checked up to this face size
     e.lut = env->lut; e.lut_res = env->lut_res; e.base = env->base; e.base_res = env->base_res;
     e.L = env->num_levels; e.min_r = env->min_roughness; e.max_r = env->max_roughness;
     for (int l = 0; l < GS_MAX_LEVELS; ++l) {
         e.levels[l] = l < e.L ? env->levels[l] : nullptr;
         e.res[l] = l < e.L ? env->res[l] : 0;
-        if (l < e.L && (!e.levels[l] || e.res[l] < 1)) return -1;
+        if (l < e.L && (!e.levels[l] || e.res[l] < 1 || e.res[l] > GS_CUBE_EDGE_TABLE_MAX_R)) return -1;
     }
     return 0;
 }

@@ -83,7 +83,7 @@ cube_sample_kernel(int64_t n, const float* __restrict__ tex, int R, const float*
 extern "C" int gs_cube_sample_linear(int64_t n, const float* tex, int R, const float* dirs, float scale, float* out,
                                      void* stream)
 {
-    GS_CHECK_ARG(n >= 0 && R >= 1, "bad sizes");
+    GS_CHECK_ARG(n >= 0 && R >= 1 && R <= GS_CUBE_EDGE_TABLE_MAX_R, "bad sizes (faces up to 4096^2: gs_cube.h)");
     if (n == 0) return GS_OK;
     hipLaunchKernelGGL(cube_sample_kernel, dim3(gs_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n, tex, R, dirs,
                        scale, out);
@@ -117,7 +117,7 @@ mip_bwd_kernel(int R /*coarse*/, const float* __restrict__ v_out, float* __restr
 
 extern "C" int gs_cubemap_mip_bwd(int R, const float* v_out, float* v_in, int accumulate, void* stream)
 {
-    GS_CHECK_ARG(R >= 1, "bad R");
+    GS_CHECK_ARG(R >= 1 && R <= GS_CUBE_EDGE_TABLE_MAX_R, "bad R (faces up to 4096^2: gs_cube.h)");
     const int64_t total = (int64_t)6 * 4 * R * R;
     hipLaunchKernelGGL(mip_bwd_kernel, dim3(gs_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, R, v_out, v_in,
                        accumulate);

@@ -249,6 +249,11 @@ int gs_selftest_rcp(uint32_t lo_bits, uint32_t hi_bits, uint64_t* mismatches_dev
  * float64 exponential.  Test hook; no reference counterpart. */
 int gs_selftest_exp(uint32_t lo_bits, uint32_t hi_bits, uint64_t* out_dev, void* stream);
 
+/* Self-test of the cube-map edge table (csrc/gs_cube.h): the texel across a face edge is looked up in a 24-entry integer table
+ * instead of being re-projected in floating point as oracle/gs_oracle_shade.c defines it; *mismatches_dev (device uint64) = number
+ * of (face, edge, position) triples of an R x R face, R <= 2048, for which the two disagree.  Test hook; no reference counterpart. */
+int gs_selftest_cube_edges(int R, uint64_t* mismatches_dev, void* stream);
+
 /* ------------------------------------------------------------------ A7 ----------------------------- */
 /* Projection backward + gather backward from the packed records of gs_raster_bwd; dense outputs [N,*] are fully
  * written (zeros for culled Gaussians) -- no caller-side zeroing needed -- or, with accumulate != 0, ADDED to

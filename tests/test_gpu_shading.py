@@ -325,3 +325,16 @@ def test_render_step_fused_equals_autograd(cuda):
         a, b = out[0][0][k], out[1][0][k]
         scale = float(a.abs().max()) + 1e-30
         assert float((a - b).abs().max()) / scale < 2e-5, k      # same kernels, different fp32 atomic / summation order
+
+
+@pytest.mark.parametrize("R", [1, 2, 3, 7, 16, 31, 64, 100, 512, 1000, 2048, 4096])
+def test_cube_edge_table_equals_reprojection(cuda, R):
+    """csrc/gs_cube.h looks the texel across a face edge up in a 24-entry integer table; the definition (oracle/gs_oracle_shade.c,
+    kept on the device as resolve_texel_reproject) re-projects the texel centre in floating point.  Every (face, edge, position)."""
+    import ctypes as C
+    from geosplatting_amd import _lib as L
+    bad = torch.zeros(1, dtype=torch.int64, device=cuda)
+    rc = L.lib().gs_selftest_cube_edges(C.c_int(R), C.c_void_p(bad.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, L.lib().gs_last_error()
+    assert int(bad.item()) == 0
+

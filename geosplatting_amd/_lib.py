@@ -42,7 +42,7 @@ SYMBOLS = [
     "gs_specular_tiles_check", "gs_specular_tiles_apply", "gs_mgadapter_fwd", "gs_mgadapter_bwd", "gs_vertex_normals_fwd",
     "gs_vertex_normals_bwd", "gs_photo_loss_ws_bytes", "gs_photo_loss", "gs_hashgrid_fwd", "gs_hashgrid_bwd_ws_bytes", "gs_hashgrid_bwd", "gs_hashgrid_bwd_fixed_ws_bytes", "gs_hashgrid_bwd_fixed", "gs_mlp_wgrad_ws_bytes", "gs_mlp_wgrad",
     "gs_flexicubes_ws_bytes", "gs_flexicubes_count", "gs_flexicubes_fwd", "gs_flexicubes_bwd", "gs_flexicubes_entropy_fwd",
-    "gs_flexicubes_entropy_bwd", "gs_front_ws_bytes", "gs_front_fwd", "gs_isect_bin_front_ws_bytes", "gs_isect_bin_front", "gs_tail_bwd", "gs_tail_bwd_multi", "gs_tail_priv_ws_bytes", "gs_tail_priv_reduce",
+    "gs_flexicubes_entropy_bwd", "gs_front_ws_bytes", "gs_front_fwd", "gs_isect_bin_front_ws_bytes", "gs_isect_bin_front", "gs_tail_bwd", "gs_tail_bwd_multi", "gs_tail_bwd_multi_parts", "gs_tail_priv_ws_bytes", "gs_tail_priv_reduce",
 ]
 
 _lib: Optional[C.CDLL] = None

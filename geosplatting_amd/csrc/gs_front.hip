@@ -976,12 +976,13 @@ tail_shade_pairs_kernel(int N, TailViewsDev views, const float* __restrict__ mea
     }
 }
 
-extern "C" int gs_tail_bwd_multi(int N, int n_views, const GsTailView* views, const float* means, const float* quats, const float* scales,
-                                 const float* opacities, const float* normals, const float* kd, const float* ks, float min_roughness,
-                                 float max_metallic, int mode, const GsEnv* env, float eps2d, int rec_stride, float* v_means, float* v_quats,
-                                 float* v_scales, float* v_opacities, float* v_normals, float* v_kd, float* v_ks, int accumulate,
-                                 const GsEnvGrad* env_grad, void* priv_ws, size_t priv_ws_bytes, void* stream)
+extern "C" int gs_tail_bwd_multi_parts(int parts, int N, int n_views, const GsTailView* views, const float* means, const float* quats,
+                                       const float* scales, const float* opacities, const float* normals, const float* kd, const float* ks,
+                                       float min_roughness, float max_metallic, int mode, const GsEnv* env, float eps2d, int rec_stride,
+                                       float* v_means, float* v_quats, float* v_scales, float* v_opacities, float* v_normals, float* v_kd,
+                                       float* v_ks, int accumulate, const GsEnvGrad* env_grad, void* priv_ws, size_t priv_ws_bytes, void* stream)
 {
+    GS_CHECK_ARG(parts >= 1 && parts <= 3, "parts: bit 0 = shading backward, bit 1 = projection backward");
     GS_CHECK_ARG(N >= 0 && n_views >= 1 && mode >= 0 && mode <= 2 && rec_stride >= 12 && (rec_stride % 4) == 0, "bad sizes, mode or record stride");
     GS_CHECK_ARG(views != nullptr && env_grad != nullptr, "null argument");
     EnvDev e;
@@ -993,6 +994,7 @@ extern "C" int gs_tail_bwd_multi(int N, int n_views, const GsTailView* views, co
     else for (int l = 0; l < e.L; ++l) GS_CHECK_ARG(eg.levels[l] != nullptr, "env_grad->levels[l] required");
     // GEOSPLAT_TAIL_KERNEL=loop: tail_multi_kernel (one thread per Gaussian looping over the views); default: views on the lanes
     static const bool s_pairs = [] { const char* v = getenv("GEOSPLAT_TAIL_KERNEL"); return !(v && strcmp(v, "loop") == 0); }();
+    GS_CHECK_ARG(parts == 3 || s_pairs, "the parts are separate launches only with the pair kernels");
     ShadeBwdPlan plan;
     { const int rc = shade_bwd_plan(e, mode, N, nullptr, 0, eg, plan, true, s_pairs ? GS_TAILP_BLOCK : 512); if (rc != GS_OK) return rc; }
     {
@@ -1029,13 +1031,17 @@ extern "C" int gs_tail_bwd_multi(int N, int n_views, const GsTailView* views, co
         do {                                                                                                                            \
             const int groups = gs_cdiv(N, B / VPG);                                                                                     \
             const int max_blocks = eg.lds_floats > 0 ? 256 * (int)fmax(1.0, floor(160.0 * 1024.0 / (double)(plan.lds_bytes + 2048))) : 2048; \
-            GS_CHECK_HIP(hipFuncSetAttribute((const void*)tail_shade_pairs_kernel<B, VPG, DIFF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes)); \
-            hipLaunchKernelGGL((tail_shade_pairs_kernel<B, VPG, DIFF>), dim3(groups < max_blocks ? groups : max_blocks), dim3(B), plan.lds_bytes, s, N, tv, \
-                               means, normals, kd, ks, min_roughness, max_metallic, e, rec_stride, v_means, v_normals, v_kd, v_ks, eg, acc, mode); \
-            GS_CHECK_LAUNCH();                                                                                                          \
-            hipLaunchKernelGGL((tail_proj_pairs_kernel<256, VPG>), dim3(gs_cdiv(N, 256 / VPG)), dim3(256), 0, s, N, tv, means, quats, scales, \
-                               opacities, eps2d, rec_stride, v_means, v_quats, v_scales, v_opacities, acc);                                    \
-            GS_CHECK_LAUNCH();                                                                                                          \
+            if (parts & 1) {                                                                                                            \
+                GS_CHECK_HIP(hipFuncSetAttribute((const void*)tail_shade_pairs_kernel<B, VPG, DIFF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes)); \
+                hipLaunchKernelGGL((tail_shade_pairs_kernel<B, VPG, DIFF>), dim3(groups < max_blocks ? groups : max_blocks), dim3(B), plan.lds_bytes, s, N, tv, \
+                                   means, normals, kd, ks, min_roughness, max_metallic, e, rec_stride, v_means, v_normals, v_kd, v_ks, eg, acc, mode); \
+                GS_CHECK_LAUNCH();                                                                                                      \
+            }                                                                                                                           \
+            if (parts & 2) {                                                                                                            \
+                hipLaunchKernelGGL((tail_proj_pairs_kernel<256, VPG>), dim3(gs_cdiv(N, 256 / VPG)), dim3(256), 0, s, N, tv, means, quats, scales, \
+                                   opacities, eps2d, rec_stride, v_means, v_quats, v_scales, v_opacities, acc);                                \
+                GS_CHECK_LAUNCH();                                                                                                      \
+            }                                                                                                                           \
         } while (0)
 #define GS_TAILP_MODE(VPG) do { if (mode == GS_MODE_DIFFUSE) GS_TAILP_LAUNCH(GS_TAILP_BLOCK, VPG, true); else GS_TAILP_LAUNCH(GS_TAILP_BLOCK, VPG, false); } while (0)
         if (s_pairs) {
@@ -1046,4 +1052,15 @@ extern "C" int gs_tail_bwd_multi(int N, int n_views, const GsTailView* views, co
 #undef GS_TAILM_LAUNCH
     }
     return GS_OK;
+}
+
+extern "C" int gs_tail_bwd_multi(int N, int n_views, const GsTailView* views, const float* means, const float* quats, const float* scales,
+                                 const float* opacities, const float* normals, const float* kd, const float* ks, float min_roughness,
+                                 float max_metallic, int mode, const GsEnv* env, float eps2d, int rec_stride, float* v_means, float* v_quats,
+                                 float* v_scales, float* v_opacities, float* v_normals, float* v_kd, float* v_ks, int accumulate,
+                                 const GsEnvGrad* env_grad, void* priv_ws, size_t priv_ws_bytes, void* stream)
+{
+    return gs_tail_bwd_multi_parts(3, N, n_views, views, means, quats, scales, opacities, normals, kd, ks, min_roughness, max_metallic, mode, env,
+                                   eps2d, rec_stride, v_means, v_quats, v_scales, v_opacities, v_normals, v_kd, v_ks, accumulate, env_grad,
+                                   priv_ws, priv_ws_bytes, stream);
 }

@@ -272,6 +272,10 @@ class RenderStep:
         tail_batch = int(os.environ.get("GEOSPLAT_TAIL_BATCH", "8")) if (fused_front and n_sets == 1) else 0
         pending_tails = []
         n_tail_launches = 0
+        # the projection half of the LAST tail launch on a front stream (idle by then), beside the prefilter backward, which needs only
+        # the shading half (texel gradients): GEOSPLAT_TAIL_PROJ_STREAM=0 keeps both halves on the tail stream
+        proj_split = tail_batch > 0 and os.environ.get("GEOSPLAT_TAIL_PROJ_STREAM", "1") != "0" and os.environ.get("GEOSPLAT_TAIL_KERNEL", "") != "loop"
+        pstream = None
         def start_view(cam, j):                              # S1-S3 + A1; (V, I) travel to the host asynchronously
             vm, K, cam_pos = self._camera_tensors(cam)
             side = sides[j % len(sides)]
@@ -441,15 +445,26 @@ class RenderStep:
                 pending_tails.append((vm, K, cam_pos, s["vis_records"], v_packed, s["packed_index"], W, H))
                 if len(pending_tails) == tail_batch or i == n_views - 1:
                     ev_r = torch.cuda.Event(); ev_r.record(main)
+                    split_now = proj_split and i == n_views - 1
                     with torch.cuda.stream(tail):
                         tail.wait_event(ev_r)
                         F.tail_multi_stage(pending_tails, means, quats, scales_act, opac_act, normals, kd, ks, e, eg, self.min_roughness,
                                            self.max_metallic, mode, b["means"], b["quats"], g_scales_act, g_opac_act, b["normals"], b["kd"],
-                                           b["ks"], accumulate=n_tail_launches > 0, priv=tail_priv)
+                                           b["ks"], accumulate=n_tail_launches > 0, priv=tail_priv, parts=1 if split_now else 3)
+                    if split_now:
+                        ev_sh = torch.cuda.Event(); ev_sh.record(tail)
+                        pstream = sides[0]
+                        with torch.cuda.stream(pstream):
+                            pstream.wait_event(ev_sh)              # (v_means: the projection half adds to what the shading half stored)
+                            F.tail_multi_stage(pending_tails, means, quats, scales_act, opac_act, normals, kd, ks, e, eg, self.min_roughness,
+                                               self.max_metallic, mode, b["means"], b["quats"], g_scales_act, g_opac_act, b["normals"],
+                                               b["kd"], b["ks"], accumulate=n_tail_launches > 0, priv=tail_priv, parts=2)
                     n_tail_launches += 1
                     for tv in pending_tails:
                         for t in tv[:6]:
                             t.record_stream(tail)
+                            if split_now:
+                                t.record_stream(pstream)
                     pending_tails = []
                 if keep_images:
                     images.append(img)
@@ -516,11 +531,18 @@ class RenderStep:
                 self._status_pending.append((snap, ev_s))
         # chain the once-per-step activations; the per-Gaussian gradients are now final, so their all-reduce (RCCL on
         # the communication stream) overlaps the prefilter backward, whose cubemap gradient is reduced afterwards
-        torch.mul(g_scales_act, scales_act, out=b["scales"])
-        b["opacities"].copy_((g_opac_act * opac_act * (1.0 - opac_act)).unsqueeze(-1))
+        with torch.cuda.stream(pstream if pstream is not None else main):      # (behind the projection half of the tail)
+            torch.mul(g_scales_act, scales_act, out=b["scales"])
+            b["opacities"].copy_((g_opac_act * opac_act * (1.0 - opac_act)).unsqueeze(-1))
+        if pstream is not None:
+            for t in (g_scales_act, g_opac_act, scales_act, opac_act):
+                t.record_stream(pstream)
         ctx = dict(b=b, images=(images if keep_images else None), g_sets=g_sets, n_sets=n_sets, g_cube_first=g_cube_first, env=env,
-                   sharded=sharded, world=world, explicit_pre=explicit_pre, cubemap=cubemap, all_reduce=all_reduce, main=main)
-        if _stop_after_views:
+                   sharded=sharded, world=world, explicit_pre=explicit_pre, cubemap=cubemap, all_reduce=all_reduce, main=main, pstream=pstream)
+        if _stop_after_views:                                 # (a captured views segment: every forked stream joins before the capture ends)
+            if pstream is not None:
+                main.wait_stream(pstream)
+                ctx["pstream"] = None
             return ctx
         return self._finish(ctx)
 
@@ -530,6 +552,8 @@ class RenderStep:
         import torch.distributed as dist
         b, images, g_sets, n_sets, g_cube_first, env = (ctx[k] for k in ("b", "images", "g_sets", "n_sets", "g_cube_first", "env"))
         sharded, world, explicit_pre, cubemap, all_reduce, main = (ctx[k] for k in ("sharded", "world", "explicit_pre", "cubemap", "all_reduce", "main"))
+        pstream = ctx.get("pstream")                          # the per-Gaussian gradients become final on this stream (None: on main)
+        head_stream = pstream if pstream is not None else main
         g_base, g_levels = g_sets[0][0], g_sets[0][1]
         keep_images = images is not None
         if sharded:
@@ -537,14 +561,18 @@ class RenderStep:
             gb, gl, _, g_flat = g_sets[0]                       # (the split-backward experiment is single-GPU only: n_sets == 1 here)
             dist.all_reduce(g_flat, op=dist.ReduceOp.SUM, group=grp)             # texel gradients of ALL views: needed by every share
             start_head, _ = self.bucket.all_reduce_split("cubemap")
-            start_head()                                        # per-Gaussian segments: communication stream, default communicator
+            with torch.cuda.stream(head_stream):
+                start_head()                                    # per-Gaussian segments: communication stream, default communicator
             g_cube = as_splitsum_backward_sharded(gb, gl, dist.get_rank(), world, grp, min_roughness=env.min_roughness,
                                                   max_roughness=env.max_roughness)
             b["cubemap"].copy_(g_cube)                          # identical on every rank: not reduced again
+            if pstream is not None:
+                main.wait_stream(pstream)
             self.bucket.all_reduce_names(["exposure"])          # queues behind the head on the communication stream, then joins it
             return b, images
         start_head, finish = self.bucket.all_reduce_split("cubemap") if all_reduce else ((lambda: None), (lambda: None))
-        start_head()
+        with torch.cuda.stream(head_stream):
+            start_head()
         if self.prefilter and explicit_pre:
             gb, gl, _, _ = g_sets[n_sets - 1]
             g_cube = as_splitsum_backward(gb, gl, min_roughness=env.min_roughness, max_roughness=env.max_roughness)
@@ -560,6 +588,8 @@ class RenderStep:
             keep = [(o, g) for o, g in zip(outs, gouts) if o.requires_grad]
             torch.autograd.backward([o for o, _ in keep], [g for _, g in keep])
             b["cubemap"].copy_(cubemap.grad)
+        if pstream is not None:
+            main.wait_stream(pstream)
         finish()
         return b, images
 

@@ -161,9 +161,10 @@ def tail_priv_reduce(env_struct, env_grad_struct, mode: int, priv: Optional[Tens
 def tail_multi_stage(views, means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, normals: Tensor, kd: Tensor, ks: Tensor,
                      env_struct, env_grad_struct, min_roughness: float, max_metallic: float, mode: int, g_means: Tensor, g_quats: Tensor,
                      g_scales: Tensor, g_opacities: Tensor, g_normals: Tensor, g_kd: Tensor, g_ks: Tensor, accumulate: bool,
-                     eps2d: float = 0.3, priv: Optional[Tensor] = None) -> None:
-    """A7 + S1-S3 backward of SEVERAL views in one launch (gs_tail_bwd_multi): `views` = list of
-    (viewmat, K, cam_pos, vis_records, v_packed, packed_index, W, H).  accumulate False: the gradient buffers are overwritten."""
+                     eps2d: float = 0.3, priv: Optional[Tensor] = None, parts: int = 3) -> None:
+    """A7 + S1-S3 backward of SEVERAL views in one call (gs_tail_bwd_multi_parts): `views` = list of
+    (viewmat, K, cam_pos, vis_records, v_packed, packed_index, W, H).  accumulate False: the gradient buffers are overwritten.
+    parts: 1 = the shading half only, 2 = the projection half only (after the shading half of the same call), 3 = both."""
     lib = L.lib()
     arr = (L.GsTailView * len(views))()
     stride = None
@@ -173,8 +174,8 @@ def tail_multi_stage(views, means: Tensor, quats: Tensor, scales: Tensor, opacit
         arr[i].W = int(W); arr[i].H = int(H)
         assert stride in (None, int(vp.shape[1]))
         stride = int(vp.shape[1])
-    L.check(lib.gs_tail_bwd_multi(means.shape[0], len(views), arr, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opacities), L.ptr(normals),
+    L.check(lib.gs_tail_bwd_multi_parts(int(parts), means.shape[0], len(views), arr, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opacities), L.ptr(normals),
                                   L.ptr(kd), L.ptr(ks), L.f32(min_roughness), L.f32(max_metallic), mode, C.byref(env_struct), L.f32(eps2d),
                                   stride, L.ptr(g_means), L.ptr(g_quats), L.ptr(g_scales), L.ptr(g_opacities), L.ptr(g_normals), L.ptr(g_kd),
                                   L.ptr(g_ks), 1 if accumulate else 0, C.byref(env_grad_struct), L.ptr(priv),
-                                  C.c_size_t(0 if priv is None else priv.numel()), L.stream()), "gs_tail_bwd_multi")
+                                  C.c_size_t(0 if priv is None else priv.numel()), L.stream()), "gs_tail_bwd_multi_parts")

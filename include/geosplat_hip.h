@@ -542,6 +542,15 @@ int gs_tail_bwd_multi(int N, int n_views, const GsTailView* views /*host array*/
                       float min_roughness, float max_metallic, int mode, const GsEnv* env, float eps2d, int rec_stride,
                       float* v_means, float* v_quats, float* v_scales, float* v_opacities, float* v_normals, float* v_kd, float* v_ks,
                       int accumulate, const GsEnvGrad* env_grad, void* priv_ws, size_t priv_ws_bytes, void* stream);
+/* The two halves of gs_tail_bwd_multi as separate calls (bit 0 of `parts`: the S1-S3 shading backward -- writes v_means (its
+ * view-direction part), v_normals, v_kd, v_ks and the texel gradients; bit 1: the A7 projection backward -- ADDS its part to
+ * v_means, writes v_quats, v_scales, v_opacities), so that the caller can put them on different streams: the projection half has
+ * to follow the shading half of the same call (v_means), nothing else orders them.  parts == 3 is gs_tail_bwd_multi. */
+int gs_tail_bwd_multi_parts(int parts, int N, int n_views, const GsTailView* views /*host array*/, const float* means, const float* quats,
+                            const float* scales, const float* opacities, const float* normals, const float* kd, const float* ks,
+                            float min_roughness, float max_metallic, int mode, const GsEnv* env, float eps2d, int rec_stride,
+                            float* v_means, float* v_quats, float* v_scales, float* v_opacities, float* v_normals, float* v_kd, float* v_ks,
+                            int accumulate, const GsEnvGrad* env_grad, void* priv_ws, size_t priv_ws_bytes, void* stream);
 /* Optional scratch of gs_tail_bwd / gs_tail_bwd_multi: eight XCD-private copies of the mid-sized specular levels (64^2, 128^2 of a 512^2 pyramid), whose
  * texel atomics then resolve in the XCD's own L2 instead of at the memory side of the fabric.  The caller zeroes priv_ws
  * (gs_tail_priv_ws_bytes) once, every gs_tail_bwd of a step ADDS into it, gs_tail_priv_reduce folds it into env_grad once.

@@ -523,12 +523,7 @@ extern "C" int gs_tail_bwd(int V_cap, const int64_t* counts_dev /* NULL: V_cap i
 
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// tail of ALL views of a step in one launch (round 4): one thread per GAUSSIAN, looping over the views.  The per-view tail reads and
-// writes every parameter gradient once per view (76 B read + 76 B written per Gaussian and view: 43 % of its traffic, and the kernel
-// is bound by exactly that traffic at its low occupancy); here the 19 gradients of a Gaussian live in registers across the views
-// and are stored ONCE, its 76 bytes of parameters are read once, and what is read per view is the 64-byte record, the 64-byte
-// gradient record and the 4-byte packed slot: 1.2 KB per Gaussian and 8-view step instead of 2.8 KB.  Texel gradients: as the
-// per-view kernel, with one flush of the LDS copies per block and STEP.
+// the tails of ALL views of a step (round 4)
 #define GS_TAIL_MAX_VIEWS 8
 struct TailViewDev {
     const float* viewmat; const float* K; const float* cam_pos;
@@ -537,197 +532,12 @@ struct TailViewDev {
 };
 struct TailViewsDev { TailViewDev v[GS_TAIL_MAX_VIEWS]; int n; };
 
-template <int BLOCK, bool DIFFUSE>
-__global__ void __launch_bounds__(BLOCK)
-tail_multi_kernel(int N, TailViewsDev views, const float* __restrict__ means, const float* __restrict__ quats,
-                  const float* __restrict__ scales, const float* __restrict__ opacities, const float* __restrict__ normals,
-                  const float* __restrict__ kd, const float* __restrict__ ks, float min_roughness, float max_metallic, EnvDev env,
-                  float eps2d, int rec_stride, float* __restrict__ v_means, float* __restrict__ v_quats, float* __restrict__ v_scales,
-                  float* __restrict__ v_opacities, float* __restrict__ v_normals, float* __restrict__ v_kd, float* __restrict__ v_ks,
-                  EnvGradDev eg, int accumulate, int mode_rt)
-{
-    // the diffuse mode and the two specular modes are separate instantiations: with `mode` a run-time value the registers of BOTH
-    // texture paths were allocated (256 VGPRs + 252 bytes of scratch per lane)
-    const int mode = DIFFUSE ? GS_MODE_DIFFUSE : mode_rt;
-    __builtin_assume(DIFFUSE || mode != GS_MODE_DIFFUSE);
-    extern __shared__ __attribute__((aligned(16))) float s_grad[];
-    for (int i = threadIdx.x; i < eg.lds_floats; i += blockDim.x) s_grad[i] = 0.0f;
-    __syncthreads();
-    float* const stage = s_grad + eg.stage_off + (threadIdx.x >> 6) * 640;
-    float* const priv = eg.priv ? eg.priv + (long long)gs_xcc_id() * eg.priv_stride : nullptr;
-    const int stride = (int)(gridDim.x * blockDim.x);
-    const int n_iter = (N + stride - 1) / stride;                   // wave-uniform: every lane reaches the wave-aggregated scatter
-    for (int it = 0; it < n_iter; ++it) {
-        const int n = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
-        const bool live = n < N;
-        float mean[3] = { 0, 0, 0 }, scale[3] = { 0, 0, 0 }, normal[3] = { 0, 0, 0 }, kdn[3] = { 0, 0, 0 }, ksn[2] = { 0, 0 }, opac = 0.0f;
-        float4 q4 = make_float4(1.f, 0.f, 0.f, 0.f);
-        if (live) {
-            mean[0] = means[3 * (size_t)n]; mean[1] = means[3 * (size_t)n + 1]; mean[2] = means[3 * (size_t)n + 2];
-            q4 = *reinterpret_cast<const float4*>(quats + 4 * (size_t)n);
-            scale[0] = scales[3 * (size_t)n]; scale[1] = scales[3 * (size_t)n + 1]; scale[2] = scales[3 * (size_t)n + 2];
-            opac = opacities[n];
-            normal[0] = normals[3 * (size_t)n]; normal[1] = normals[3 * (size_t)n + 1]; normal[2] = normals[3 * (size_t)n + 2];
-            kdn[0] = kd[3 * (size_t)n]; kdn[1] = kd[3 * (size_t)n + 1]; kdn[2] = kd[3 * (size_t)n + 2];
-            const float2 ks2 = *reinterpret_cast<const float2*>(ks + 2 * (size_t)n);
-            ksn[0] = ks2.x; ksn[1] = ks2.y;
-        }
-        float a_mean[3] = { 0, 0, 0 }, a_quat[4] = { 0, 0, 0, 0 }, a_scale[3] = { 0, 0, 0 }, a_op = 0.0f;
-        float a_n[3] = { 0, 0, 0 }, a_kd[3] = { 0, 0, 0 }, a_ks[2] = { 0, 0 };
-        for (int k = 0; k < views.n; ++k) {
-            const TailViewDev& vw = views.v[k];
-            bool scatter = false;
-            ShadeTmp t;
-            float v_ls[3] = { 0, 0, 0 }, v_ld[3] = { 0, 0, 0 };
-            const int slot = live ? vw.packed_index[n] : -1;
-            if (slot >= 0) {
-                const float4 r0 = vw.vis[4 * (size_t)slot], r1 = vw.vis[4 * (size_t)slot + 1], r3 = vw.vis[4 * (size_t)slot + 3];
-                const float4* gp = reinterpret_cast<const float4*>(vw.v_packed + (size_t)slot * rec_stride);
-                const float4 g0 = gp[0], g1 = gp[1];
-                const float g2 = vw.v_packed[(size_t)slot * rec_stride + 8];
-                const float g[3] = { g1.z, g1.w, g2 };
-                const bool any_geo = g0.x != 0.0f || g0.y != 0.0f || g0.z != 0.0f || g0.w != 0.0f || g1.x != 0.0f || g1.y != 0.0f;
-                const bool any_col = g[0] != 0.0f || g[1] != 0.0f || g[2] != 0.0f;
-                if (any_geo) {
-                    const GsCam cam = load_cam(vw.viewmat, vw.K);
-                    ProjGrad pg;
-                    project_bwd_one(cam, mean, q4, scale, opac, (float)vw.W, (float)vw.H, eps2d, 2.0f * r0.z, r0.w, 2.0f * r1.x, r3.x,
-                                    g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, 0.0f, pg);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) { a_mean[c] += pg.mean[c]; a_scale[c] += pg.scale[c]; }
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) a_quat[c] += pg.quat[c];
-                    a_op += pg.op;
-                }
-                if (any_col) {
-                    const float cp[3] = { vw.cam_pos[0], vw.cam_pos[1], vw.cam_pos[2] };
-                    float color[3];
-                    shade_one<true>(mean, normal, kdn, ksn, cp, min_roughness, max_metallic, mode, env, color, t);
-                    scatter = true;
-                    // ---- the arithmetic of shade_bwd_kernel (gs_shade.hip), same order
-                    float v_diff[3] = { 0, 0, 0 }, v_rf[3] = { 0, 0, 0 };
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        if (mode == GS_MODE_PBR)          { v_diff[c] = g[c]; v_ls[c] = g[c] * t.refl_c[c]; v_rf[c] = g[c] * t.ls.out[c]; }
-                        else if (mode == GS_MODE_DIFFUSE) { v_ld[c] = g[c] * t.diff[c]; v_diff[c] = g[c] * t.ld[c]; }
-                        else                              { v_ls[c] = g[c] * t.refl_c[c]; v_rf[c] = g[c] * t.ls.out[c]; }
-                    }
-                    float v_A = 0.0f, v_B = 0.0f, v_metal = 0.0f;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float v_spec = v_rf[c] * t.fg[0];
-                        v_A += v_rf[c] * t.spec[c];
-                        v_B += v_rf[c];
-                        a_kd[c] += v_spec * t.metal + v_diff[c] * (1.0f - t.metal);
-                        v_metal += v_spec * (kdn[c] - 0.04f) - v_diff[c] * kdn[c];
-                    }
-                    const float v_ndv = v_A * t.dfg_du[0] + v_B * t.dfg_du[1];
-                    float v_rough = v_A * t.dfg_dv[0] + v_B * t.dfg_dv[1];
-                    float v_mip = 0.0f, v_refl[3] = { 0, 0, 0 }, v_n[3] = { 0, 0, 0 };
-                    if (mode != GS_MODE_DIFFUSE) {
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            v_mip += v_ls[c] * t.ls.dmip[c];
-#pragma unroll
-                            for (int j = 0; j < 3; ++j) v_refl[j] += v_ls[c] * t.ls.dd[c * 3 + j];
-                        }
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < 3; ++c)
-#pragma unroll
-                            for (int j = 0; j < 3; ++j) v_n[j] += v_ld[c] * t.ld_dd[c * 3 + j];
-                    }
-                    v_rough += v_mip * t.dmip_dr;
-                    float v_d = 2.0f * (v_refl[0] * normal[0] + v_refl[1] * normal[1] + v_refl[2] * normal[2]);
-                    float v_wo[3];
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) { v_n[j] += 2.0f * t.d * v_refl[j]; v_wo[j] = -v_refl[j]; }
-                    if (t.d >= 1e-6f) v_d += v_ndv;
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) { v_n[j] += v_d * t.wo[j]; v_wo[j] += v_d * normal[j]; }
-                    if (!t.wo_const) {
-                        const float dot = t.wo[0] * v_wo[0] + t.wo[1] * v_wo[1] + t.wo[2] * v_wo[2];
-                        const float l = fmaxf(t.len, 1e-6f);
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) a_mean[j] += -((v_wo[j] - t.wo[j] * dot) / l);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) a_n[j] += v_n[j];
-                    a_ks[0] += v_rough * (1.0f - min_roughness); a_ks[1] += v_metal * max_metallic;
-                }
-            }
-            // ---- texel gradients of this (Gaussian, view): LDS copies for the small levels, row-pair atomics for the rest
-            if (mode != GS_MODE_DIFFUSE) {
-                const int l0 = scatter ? t.ls.l0 : 0, l1 = scatter ? t.ls.l1 : -1;
-                const float w0 = (l1 < 0) ? 1.0f : 1.0f - t.ls.f;
-                const bool lds0 = scatter && eg.lds_level[l0] >= 0;
-                if (lds0) cube_scatter_lds(s_grad + eg.lds_level[l0], t.ls.fp0, v_ls, w0);
-                const bool loc0 = priv != nullptr && eg.priv_level[l0] >= 0;
-                cube_scatter_wave_tagged(scatter && !lds0 ? (loc0 ? priv + eg.priv_level[l0] : eg.levels[l0]) : nullptr, loc0, t.ls.fp0, v_ls, w0,
-                                         scatter && !lds0, stage);
-                const bool has1 = scatter && l1 >= 0;
-                const int l1s = has1 ? l1 : 0;
-                const bool lds1 = has1 && eg.lds_level[l1s] >= 0;
-                if (lds1) cube_scatter_lds(s_grad + eg.lds_level[l1], t.ls.fp1, v_ls, t.ls.f);
-                const bool loc1 = priv != nullptr && eg.priv_level[l1s] >= 0;
-                cube_scatter_wave_tagged(has1 && !lds1 ? (loc1 ? priv + eg.priv_level[l1s] : eg.levels[l1s]) : nullptr, loc1, t.ls.fp1, v_ls,
-                                         t.ls.f, has1 && !lds1, stage);
-            } else {
-                const bool ldsb = scatter && eg.lds_base >= 0;
-                if (ldsb) cube_scatter_lds(s_grad + eg.lds_base, t.ld_fp, v_ld, 1.0f);
-                cube_scatter_wave_tagged(scatter && !ldsb ? eg.base : nullptr, false, t.ld_fp, v_ld, 1.0f, scatter && !ldsb, stage);
-            }
-        }
-        if (live) {
-            if (accumulate) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    v_means[3 * (size_t)n + c] += a_mean[c]; v_scales[3 * (size_t)n + c] += a_scale[c];
-                    v_normals[3 * (size_t)n + c] += a_n[c]; v_kd[3 * (size_t)n + c] += a_kd[c];
-                }
-                float4 q = *reinterpret_cast<float4*>(v_quats + 4 * (size_t)n);
-                q.x += a_quat[0]; q.y += a_quat[1]; q.z += a_quat[2]; q.w += a_quat[3];
-                *reinterpret_cast<float4*>(v_quats + 4 * (size_t)n) = q;
-                v_opacities[n] += a_op;
-                float2 o = *reinterpret_cast<float2*>(v_ks + 2 * (size_t)n);
-                o.x += a_ks[0]; o.y += a_ks[1];
-                *reinterpret_cast<float2*>(v_ks + 2 * (size_t)n) = o;
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    v_means[3 * (size_t)n + c] = a_mean[c]; v_scales[3 * (size_t)n + c] = a_scale[c];
-                    v_normals[3 * (size_t)n + c] = a_n[c]; v_kd[3 * (size_t)n + c] = a_kd[c];
-                }
-                *reinterpret_cast<float4*>(v_quats + 4 * (size_t)n) = make_float4(a_quat[0], a_quat[1], a_quat[2], a_quat[3]);
-                v_opacities[n] = a_op;
-                *reinterpret_cast<float2*>(v_ks + 2 * (size_t)n) = make_float2(a_ks[0], a_ks[1]);
-            }
-        }
-    }
-    // ---- flush the private copies
-    __syncthreads();
-    if (eg.lds_base >= 0) {
-        const int cnt = 18 * env.base_res * env.base_res;
-        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-            const float x = s_grad[eg.lds_base + i];
-            if (x != 0.0f) gs_atomic_add(eg.base + i, x);
-        }
-    }
-    for (int l = 0; l < env.L; ++l) {
-        if (eg.lds_level[l] < 0) continue;
-        const int cnt = 18 * env.res[l] * env.res[l];
-        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-            const float x = s_grad[eg.lds_level[l] + i];
-            if (x != 0.0f) gs_atomic_add(eg.levels[l] + i, x);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// The same work with the VIEWS ON THE LANES, as TWO kernels (round 4).  VPG (1, 2, 4 or 8) adjacent lanes own one Gaussian, one view
-// each: a lane computes ONE (Gaussian, view) pair, the gradients are summed over the VPG lanes with DPP adds and stored once.
-// tail_multi_kernel's view loop kept 19 accumulators and the temporaries of the projection AND the shading backward alive together
-// (256 VGPRs + scratch: two waves per SIMD behind dependent loads, 2 650 VALU instructions per pair).  Each half alone fits 128
+// The per-view tail reads and writes every parameter gradient once per view (76 B read + 76 B written per Gaussian and view: 43 % of
+// its traffic); here the views of a Gaussian are handled together and its gradients stored once.  VIEWS ON THE LANES, TWO kernels:
+// VPG (1, 2, 4 or 8) adjacent lanes own one Gaussian, one view each: a lane computes ONE (Gaussian, view) pair, the gradients are
+// summed over the VPG lanes with DPP adds and stored once.  (First version, removed: one thread per Gaussian looping over the views --
+// 19 accumulators and the temporaries of the projection AND the shading backward alive together, 256 VGPRs + scratch, two waves
+// per SIMD behind dependent loads at 2 650 VALU instructions per pair: 2.9 ms per 8-view step against 2.6.)  Each half alone fits 128
 // VGPRs -- fused, the register allocator overlaps them whatever the source order (250 VGPRs; 123 spilled at a 128 cap; a
 // non-inlined call: 66) -- so they are two launches:
 //   tail_shade_pairs_kernel : S1-S3 backward; pyramid levels one at a time, the colour cotangent contracted into the fetch
@@ -992,11 +802,8 @@ extern "C" int gs_tail_bwd_multi_parts(int parts, int N, int n_views, const GsTa
     for (int l = 0; l < GS_MAX_LEVELS; ++l) eg.levels[l] = l < e.L ? env_grad->levels[l] : nullptr;
     if (mode == GS_MODE_DIFFUSE) GS_CHECK_ARG(eg.base != nullptr, "env_grad->base required in diffuse mode");
     else for (int l = 0; l < e.L; ++l) GS_CHECK_ARG(eg.levels[l] != nullptr, "env_grad->levels[l] required");
-    // GEOSPLAT_TAIL_KERNEL=loop: tail_multi_kernel (one thread per Gaussian looping over the views); default: views on the lanes
-    static const bool s_pairs = [] { const char* v = getenv("GEOSPLAT_TAIL_KERNEL"); return !(v && strcmp(v, "loop") == 0); }();
-    GS_CHECK_ARG(parts == 3 || s_pairs, "the parts are separate launches only with the pair kernels");
     ShadeBwdPlan plan;
-    { const int rc = shade_bwd_plan(e, mode, N, nullptr, 0, eg, plan, true, s_pairs ? GS_TAILP_BLOCK : 512); if (rc != GS_OK) return rc; }
+    { const int rc = shade_bwd_plan(e, mode, N, nullptr, 0, eg, plan, true, GS_TAILP_BLOCK); if (rc != GS_OK) return rc; }
     {
         const size_t floats = tail_priv_floats(e, mode, eg.priv_level);
         if (priv_ws != nullptr && floats > 0) {
@@ -1019,14 +826,6 @@ extern "C" int gs_tail_bwd_multi_parts(int parts, int N, int n_views, const GsTa
         }
         for (int k = tv.n; k < GS_TAIL_MAX_VIEWS; ++k) tv.v[k] = tv.v[0];
         const int acc = (accumulate || v0 > 0) ? 1 : 0;
-#define GS_TAILM_LAUNCH(DIFF)                                                                                                            \
-        do {                                                                                                                            \
-            GS_CHECK_HIP(hipFuncSetAttribute((const void*)tail_multi_kernel<512, DIFF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes)); \
-            hipLaunchKernelGGL((tail_multi_kernel<512, DIFF>), dim3(plan.blocks), dim3(512), plan.lds_bytes, s, N, tv, means, quats, scales,     \
-                               opacities, normals, kd, ks, min_roughness, max_metallic, e, eps2d, rec_stride, v_means, v_quats, v_scales, \
-                               v_opacities, v_normals, v_kd, v_ks, eg, acc, mode);                                                        \
-            GS_CHECK_LAUNCH();                                                                                                          \
-        } while (0)
 #define GS_TAILP_LAUNCH(B, VPG, DIFF)                                                                                                    \
         do {                                                                                                                            \
             const int groups = gs_cdiv(N, B / VPG);                                                                                     \
@@ -1044,12 +843,9 @@ extern "C" int gs_tail_bwd_multi_parts(int parts, int N, int n_views, const GsTa
             }                                                                                                                           \
         } while (0)
 #define GS_TAILP_MODE(VPG) do { if (mode == GS_MODE_DIFFUSE) GS_TAILP_LAUNCH(GS_TAILP_BLOCK, VPG, true); else GS_TAILP_LAUNCH(GS_TAILP_BLOCK, VPG, false); } while (0)
-        if (s_pairs) {
-            if (tv.n <= 1) GS_TAILP_MODE(1); else if (tv.n <= 2) GS_TAILP_MODE(2); else if (tv.n <= 4) GS_TAILP_MODE(4); else GS_TAILP_MODE(8);
-        } else if (mode == GS_MODE_DIFFUSE) GS_TAILM_LAUNCH(true); else GS_TAILM_LAUNCH(false);
+        if (tv.n <= 1) GS_TAILP_MODE(1); else if (tv.n <= 2) GS_TAILP_MODE(2); else if (tv.n <= 4) GS_TAILP_MODE(4); else GS_TAILP_MODE(8);
 #undef GS_TAILP_MODE
 #undef GS_TAILP_LAUNCH
-#undef GS_TAILM_LAUNCH
     }
     return GS_OK;
 }

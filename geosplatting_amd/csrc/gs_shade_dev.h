@@ -158,66 +158,8 @@ __device__ void shade_one(const float* mean, const float* normal, const float* k
     }
 }
 
-// Gradient arithmetic of ONE shaded (Gaussian, view) pair behind shade_one<true> -- the order of shade_bwd_kernel (gs_shade.hip).
-// g = d loss / d colour; ADDS into a_mean / a_n / a_kd / a_ks, returns the texel cotangents v_ls (specular levels) / v_ld (diffuse base).
-__device__ __forceinline__ void shade_bwd_arith(int mode, const ShadeTmp& t, const float* g, const float* kdn, const float* normal,
-                                                float min_roughness, float max_metallic, float* a_mean, float* a_n, float* a_kd,
-                                                float* a_ks, float* v_ls, float* v_ld)
-{
-    float v_diff[3] = { 0, 0, 0 }, v_rf[3] = { 0, 0, 0 };
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        v_ls[c] = 0.0f; v_ld[c] = 0.0f;
-        if (mode == GS_MODE_PBR)          { v_diff[c] = g[c]; v_ls[c] = g[c] * t.refl_c[c]; v_rf[c] = g[c] * t.ls.out[c]; }
-        else if (mode == GS_MODE_DIFFUSE) { v_ld[c] = g[c] * t.diff[c]; v_diff[c] = g[c] * t.ld[c]; }
-        else                              { v_ls[c] = g[c] * t.refl_c[c]; v_rf[c] = g[c] * t.ls.out[c]; }
-    }
-    float v_A = 0.0f, v_B = 0.0f, v_metal = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float v_spec = v_rf[c] * t.fg[0];
-        v_A += v_rf[c] * t.spec[c];
-        v_B += v_rf[c];
-        a_kd[c] += v_spec * t.metal + v_diff[c] * (1.0f - t.metal);
-        v_metal += v_spec * (kdn[c] - 0.04f) - v_diff[c] * kdn[c];
-    }
-    const float v_ndv = v_A * t.dfg_du[0] + v_B * t.dfg_du[1];
-    float v_rough = v_A * t.dfg_dv[0] + v_B * t.dfg_dv[1];
-    float v_mip = 0.0f, v_refl[3] = { 0, 0, 0 }, v_n[3] = { 0, 0, 0 };
-    if (mode != GS_MODE_DIFFUSE) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            v_mip += v_ls[c] * t.ls.dmip[c];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) v_refl[j] += v_ls[c] * t.ls.dd[c * 3 + j];
-        }
-    } else {
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) v_n[j] += v_ld[c] * t.ld_dd[c * 3 + j];
-    }
-    v_rough += v_mip * t.dmip_dr;
-    float v_d = 2.0f * (v_refl[0] * normal[0] + v_refl[1] * normal[1] + v_refl[2] * normal[2]);
-    float v_wo[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { v_n[j] += 2.0f * t.d * v_refl[j]; v_wo[j] = -v_refl[j]; }
-    if (t.d >= 1e-6f) v_d += v_ndv;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { v_n[j] += v_d * t.wo[j]; v_wo[j] += v_d * normal[j]; }
-    if (!t.wo_const) {
-        const float dot = t.wo[0] * v_wo[0] + t.wo[1] * v_wo[1] + t.wo[2] * v_wo[2];
-        const float l = fmaxf(t.len, 1e-6f);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) a_mean[j] += -((v_wo[j] - t.wo[j] * dot) / l);
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) a_n[j] += v_n[j];
-    a_ks[0] += v_rough * (1.0f - min_roughness); a_ks[1] += v_metal * max_metallic;
-}
-
-// ---- lean backward of one pair (round 4, tail_pairs_kernel) -------------------------------------------------------------------
-// shade_one<true> + shade_bwd_arith carry the full 3x3 Jacobians d colour / d direction of both pyramid levels (113 VGPRs before the
+// ---- lean backward of one pair (round 4, tail_shade_pairs_kernel) -------------------------------------------------------------------
+// shade_one<true> and the chain rule behind it carry the full 3x3 Jacobians d colour / d direction of both pyramid levels (113 VGPRs before the
 // texel scatter).  The cotangent of the sampled colour is known BEFORE the cube fetch (v_ls = g * (spec * fg0 + fg1)), so the
 // fetch can contract it on the spot: per level 4 scalars <v, tap> instead of 12 taps and 9 Jacobian entries.  Everything that
 // SELECTS something (LUT cell, mip level, face, texel) is computed exactly as in the forward (contraction off); only the smooth
@@ -349,7 +291,7 @@ __device__ __forceinline__ void shade_pair_post(const PairPre& p, const float* n
         v_metal += v_spec * (kd[c] - 0.04f) - v_diff[c] * kd[c];
     }
     const float v_ndv = v_A * p.dfg_du[0] + v_B * p.dfg_du[1];
-    const float v_rough = v_A * p.dfg_dv[0] + v_B * p.dfg_dv[1] + (p.clamped ? 0.0f : v_mip) * p.dmip_dr;
+    const float v_rough = v_A * p.dfg_dv[0] + v_B * p.dfg_dv[1] + ((p.clamped || mode == GS_MODE_DIFFUSE) ? 0.0f : v_mip) * p.dmip_dr;
     float v_d = 2.0f * (v_refl[0] * normal[0] + v_refl[1] * normal[1] + v_refl[2] * normal[2]);
     float v_wo[3];
 #pragma unroll

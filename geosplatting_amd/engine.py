@@ -274,7 +274,7 @@ class RenderStep:
         n_tail_launches = 0
         # the projection half of the LAST tail launch on a front stream (idle by then), beside the prefilter backward, which needs only
         # the shading half (texel gradients): GEOSPLAT_TAIL_PROJ_STREAM=0 keeps both halves on the tail stream
-        proj_split = tail_batch > 0 and os.environ.get("GEOSPLAT_TAIL_PROJ_STREAM", "1") != "0" and os.environ.get("GEOSPLAT_TAIL_KERNEL", "") != "loop"
+        proj_split = tail_batch > 0 and os.environ.get("GEOSPLAT_TAIL_PROJ_STREAM", "1") != "0"
         pstream = None
         def start_view(cam, j):                              # S1-S3 + A1; (V, I) travel to the host asynchronously
             vm, K, cam_pos = self._camera_tensors(cam)

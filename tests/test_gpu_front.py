@@ -342,9 +342,12 @@ def test_cull_log_backward_equals_plain_backward(cuda):
         assert abs(float(a[5]) - float(b[5])) <= 1e-4 * abs(float(a[5])) + 1e-4
 
 
-def test_tail_multi_equals_sum_of_view_tails(cuda):
-    """gs_tail_bwd_multi over three views == three gs_tail_bwd calls accumulated (same arithmetic, the sum over the views taken in
-    registers): parameter gradients and texel gradients; a second multi call ADDS."""
+@pytest.mark.parametrize("mode", ["pbr", "specular", "diffuse"])
+def test_tail_multi_equals_sum_of_view_tails(cuda, mode):
+    """gs_tail_bwd_multi over n views (n = 1, 2, 3, 5, 8: every lanes-per-Gaussian variant of the pair kernels, with idle lanes at 3
+    and 5) == n gs_tail_bwd calls accumulated: parameter gradients and texel gradients.  The pair kernels contract the colour
+    cotangent into the cube fetch and sum the views as a tree, gs_tail_bwd carries the Jacobians and sums in view order: 1e-5.
+    accumulate=False overwrites, a second call ADDS, and the two halves called separately (gs_tail_bwd_multi_parts) give the same."""
     import geosplatting_amd as gs
     from geosplatting_amd import _lib as L
     from geosplatting_amd import front as F
@@ -352,18 +355,21 @@ def test_tail_multi_equals_sum_of_view_tails(cuda):
     lib = L.lib()
     env = _env(cuda)
     e = _make_env(gs.get_fg_lut(cuda), env)
+    M = _MODE[mode]
     stride = lib.gs_raster_grad_stride(3)
     g = torch.Generator().manual_seed(9)
     views, xs = [], []
-    for view in (0, 3, 5):
+    for view in range(8):
         x = _inputs(cuda, level=4, res=160, view=view)
         fr = F.front_stage(x["means"], x["quats"], x["scales"], x["opac"], x["normals"], x["kd"], x["ks"], x["vm"], x["K"], x["cam_pos"], e,
-                           x["W"], x["H"], 0.1, 1.0, _MODE["pbr"], want_packed_index=True)
+                           x["W"], x["H"], 0.1, 1.0, M, want_packed_index=True)
         torch.cuda.synchronize()
         V = int(fr.host_counts[0])
         vp = torch.zeros(V, stride, device=cuda)
         vp[:, :9] = (torch.rand(V, 9, generator=g) * 2 - 1).to(cuda)
-        vp[::5] = 0.0
+        vp[::5] = 0.0                                                          # pairs without any gradient
+        vp[1::7, :6] = 0.0                                                     # ... with a colour gradient only
+        vp[2::7, 6:9] = 0.0                                                    # ... with a geometry gradient only
         views.append((x["vm"], x["K"], x["cam_pos"], fr.vis, vp, fr.packed_index, x["W"], x["H"]))
         xs.append((x, fr, V))
     x0 = xs[0][0]
@@ -371,47 +377,62 @@ def test_tail_multi_equals_sum_of_view_tails(cuda):
     pidx = views[0][5].cpu().numpy()
     assert (pidx >= 0).sum() == xs[0][2] and np.array_equal(np.sort(pidx[pidx >= 0]), np.arange(xs[0][2]))
     z = lambda *s: torch.zeros(*s, device=cuda)
-    def fresh():
-        return (dict(means=z(N, 3), quats=z(N, 4), scales=z(N, 3), opac=z(N), normals=z(N, 3), kd=z(N, 3), ks=z(N, 2)),
-                torch.zeros_like(env.base), [torch.zeros_like(l) for l in env.levels])
+    names = ("means", "quats", "scales", "opac", "normals", "kd", "ks")
+    def fresh(fill=0.0):
+        d = dict(means=z(N, 3), quats=z(N, 4), scales=z(N, 3), opac=z(N), normals=z(N, 3), kd=z(N, 3), ks=z(N, 2))
+        for k in d:
+            d[k].fill_(fill)
+        return d, torch.zeros_like(env.base), [torch.zeros_like(l) for l in env.levels]
     def grad_struct(b, ls):
         eg = L.GsEnvGrad(); eg.base = b.data_ptr()
         for i, t in enumerate(ls):
             eg.levels[i] = t.data_ptr()
         return eg
+    def multi(vs, t, egt, accumulate, parts=3, priv=None):
+        F.tail_multi_stage(vs, x0["means"], x0["quats"], x0["scales"], x0["opac"], x0["normals"], x0["kd"], x0["ks"], e, egt, 0.1, 1.0, M,
+                           t["means"], t["quats"], t["scales"], t["opac"], t["normals"], t["kd"], t["ks"], accumulate=accumulate, priv=priv,
+                           parts=parts)
+    def close(t, tb, tl, r, rb, rl, what):
+        for k in names:
+            assert rel_err(t[k].cpu().numpy(), r[k].cpu().numpy()) < 1e-5, (what, k)
+        for a, b in zip([tb] + tl, [rb] + rl):
+            if float(b.abs().max()) == 0.0:
+                assert float(a.abs().max()) == 0.0, what
+            else:
+                assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5, what
+    # reference: per-view tails accumulated, snapshots after 1, 2, 3, 5, 8 views
     r, rb, rl = fresh()
     egr = grad_struct(rb, rl)
-    for (x, fr, V), vw in zip(xs, views):
+    snaps = {}
+    for i, ((x, fr, V), vw) in enumerate(zip(xs, views)):
         F.tail_stage(V, None, x["means"], x["quats"], x["scales"], x["opac"], x["normals"], x["kd"], x["ks"], x["vm"], x["K"], x["cam_pos"], e, egr,
-                     x["W"], x["H"], 0.1, 1.0, _MODE["pbr"], fr.vis, vw[4], r["means"], r["quats"], r["scales"], r["opac"], r["normals"],
-                     r["kd"], r["ks"])
-    t, tb, tl = fresh()
-    for k in t:
-        t[k].fill_(123.0)                                                     # accumulate=False must overwrite
+                     x["W"], x["H"], 0.1, 1.0, M, fr.vis, vw[4], r["means"], r["quats"], r["scales"], r["opac"], r["normals"], r["kd"], r["ks"])
+        if i + 1 in (1, 2, 3, 5, 8):
+            snaps[i + 1] = ({k: v.clone() for k, v in r.items()}, rb.clone(), [l.clone() for l in rl])
+    torch.cuda.synchronize()
+    assert all(float(snaps[8][0][k].abs().max()) > 0 for k in ("means", "quats", "scales", "opac", "normals", "kd"))
+    for n in (1, 2, 3, 5, 8):
+        t, tb, tl = fresh(123.0)                                               # accumulate=False must overwrite
+        priv = F.tail_priv_alloc(e, M, cuda) if n == 3 else None               # (optional XCD-private copies of the mid-sized levels)
+        egt = grad_struct(tb, tl)
+        multi(views[:n], t, egt, False, priv=priv)
+        F.tail_priv_reduce(e, egt, M, priv)
+        torch.cuda.synchronize()
+        close(t, tb, tl, *snaps[n], ("n", n))
+    # a second call adds: views 0-2, then views 3-4 on top == the first five
+    t, tb, tl = fresh(123.0)
     egt = grad_struct(tb, tl)
-    priv = F.tail_priv_alloc(e, _MODE["pbr"], cuda)
-    F.tail_multi_stage(views, x0["means"], x0["quats"], x0["scales"], x0["opac"], x0["normals"], x0["kd"], x0["ks"], e, egt, 0.1, 1.0,
-                       _MODE["pbr"], t["means"], t["quats"], t["scales"], t["opac"], t["normals"], t["kd"], t["ks"], accumulate=False, priv=priv)
-    F.tail_priv_reduce(e, egt, _MODE["pbr"], priv)
+    multi(views[:3], t, egt, False)
+    multi(views[3:5], t, egt, True)
     torch.cuda.synchronize()
-    for k in r:
-        assert float(r[k].abs().max()) > 0 and rel_err(t[k].cpu().numpy(), r[k].cpu().numpy()) < 1e-5, k
-    for a, b in zip([tb] + tl, [rb] + rl):
-        if float(b.abs().max()) == 0.0:
-            assert float(a.abs().max()) == 0.0
-        else:
-            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
-    F.tail_multi_stage(views[:2], x0["means"], x0["quats"], x0["scales"], x0["opac"], x0["normals"], x0["kd"], x0["ks"], e, egt, 0.1, 1.0,
-                       _MODE["pbr"], t["means"], t["quats"], t["scales"], t["opac"], t["normals"], t["kd"], t["ks"], accumulate=True)
-    r2, rb2, rl2 = fresh()
-    egr2 = grad_struct(rb2, rl2)
-    for (x, fr, V), vw in zip(xs[:2], views[:2]):
-        F.tail_stage(V, None, x["means"], x["quats"], x["scales"], x["opac"], x["normals"], x["kd"], x["ks"], x["vm"], x["K"], x["cam_pos"], e, egr2,
-                     x["W"], x["H"], 0.1, 1.0, _MODE["pbr"], fr.vis, vw[4], r2["means"], r2["quats"], r2["scales"], r2["opac"], r2["normals"],
-                     r2["kd"], r2["ks"])
+    close(t, tb, tl, *snaps[5], "3 + 2")
+    # the two halves as separate calls (shading first: the projection half adds to its v_means)
+    t, tb, tl = fresh(123.0)
+    egt = grad_struct(tb, tl)
+    multi(views, t, egt, False, parts=1)
+    multi(views, t, egt, False, parts=2)
     torch.cuda.synchronize()
-    for k in r:
-        assert rel_err(t[k].cpu().numpy(), (r[k] + r2[k]).cpu().numpy()) < 1e-5, k
+    close(t, tb, tl, *snaps[8], "parts")
 
 
 def test_engine_front_modes_agree(cuda, monkeypatch):

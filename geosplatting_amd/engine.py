@@ -267,8 +267,8 @@ class RenderStep:
             sd.wait_stream(main)                             # prefilter pyramid, activations, zeroed buckets
         tail.wait_stream(main)
 
-        # the tails of the views in ONE launch per `tail_batch` views (gs_tail_bwd_multi: parameter gradients in registers across the
-        # views, stored once); 0 = one tail launch per view (gs_tail_bwd)
+        # the tails of the views in ONE call per `tail_batch` views (gs_tail_bwd_multi_parts: the views of a Gaussian on adjacent lanes,
+        # its gradients stored once); 0 = one tail launch per view (gs_tail_bwd)
         tail_batch = int(os.environ.get("GEOSPLAT_TAIL_BATCH", "8")) if (fused_front and n_sets == 1) else 0
         pending_tails = []
         n_tail_launches = 0

@@ -528,10 +528,12 @@ int gs_tail_bwd(int V_cap, const int64_t* counts_dev, const float* means, const 
                 int W, int H, float eps2d, const float* vis_records, const float* v_packed, int rec_stride,
                 float* v_means, float* v_quats, float* v_scales, float* v_opacities, float* v_normals, float* v_kd, float* v_ks,
                 const GsEnvGrad* env_grad, void* priv_ws, size_t priv_ws_bytes, void* stream);
-/* The tails of ALL views of a step in one launch: one thread per Gaussian loops over the views, keeps the 19 parameter gradients in
- * registers and stores them once (accumulate == 0: plain stores into v_*, every Gaussian written; != 0: added).  Per view: what
- * gs_front_fwd wrote (vis_records, packed_index) and the compositor's v_packed [V, rec_stride].  Same arithmetic as gs_tail_bwd,
- * summed over the views in view order. */
+/* The tails of ALL views of a step in one call (two launches: shading half, projection half): up to eight adjacent lanes own one
+ * Gaussian, one view each, the 19 parameter gradients are summed over the lanes and stored once (accumulate == 0: plain stores
+ * into v_*, every Gaussian written; != 0: added).  Per view: what gs_front_fwd wrote (vis_records, packed_index) and the
+ * compositor's v_packed [V, rec_stride].  The gradients of gs_tail_bwd summed over the views, to summation order (the views as a
+ * tree, the colour cotangent contracted into the cube fetch: tests/test_gpu_front.py, 1e-5).  More than eight views: further
+ * launches add to the first. */
 typedef struct GsTailView {
     const float* viewmat; const float* K; const float* cam_pos;            /* device: [4,4], [3,3], [3] */
     const float* vis_records; const float* v_packed; const int32_t* packed_index;

@@ -132,7 +132,7 @@ class RenderStep:
         """Forget every cached (view matrix, K, position) triple: for callers that rewrite DEVICE-resident poses behind autograd's back."""
         self._cam_cache.clear()
 
-    def _step_fused(self, cameras, upstream, all_reduce, keep_images, _env=None, _stop_after_views=False):
+    def _step_fused(self, cameras, upstream, all_reduce, keep_images, _env=None, _stop_after_views=False, _geo_only=False, _geo=None):
         """Same arithmetic as the autograd path, driven directly through the C-ABI: every per-view backward ADDS into
         the flat gradient bucket (accumulate flags of gs_project_bwd / gs_shade_bwd / gs_tonemap_bwd), the exp /
         sigmoid activations of GSplatter.render_rgba (rfstudio/model/gsplat.py:336-339) are applied once per step and
@@ -157,8 +157,11 @@ class RenderStep:
         # ---- what does not need the pyramid comes first: activations, streams, key width -- and, in capacity mode, the GEOMETRY of
         # the first view (projection, keys, binning: gs_front_fwd without records) on a front stream, so that it runs UNDER the
         # prefilter forward instead of behind it (the step used to start its first compositor 0.9 ms after the prefilter ended)
-        scales_act = p.scales.detach().exp()
-        opac_act = torch.sigmoid(p.opacities.detach()).squeeze(-1).contiguous()
+        if _geo is not None:                                 # (capture_views: the geometry phase of this step ran as its own graph)
+            scales_act, opac_act = _geo["scales_act"], _geo["opac_act"]
+        else:
+            scales_act = p.scales.detach().exp()
+            opac_act = torch.sigmoid(p.opacities.detach()).squeeze(-1).contiguous()
         means, quats = p.means.detach(), p.quats.detach()
         normals, kd, ks = p.normals.detach(), p.kd.detach(), p.ks.detach()
         main = torch.cuda.current_stream(dev)
@@ -187,7 +190,12 @@ class RenderStep:
         seen = []                                            # (pinned counts, event) of this step's views
         early = {}                                           # view index -> (flatten_ids, isect_offsets) binned under the prefilter
         n_early = int(os.environ.get("GEOSPLAT_EARLY_BIN", "1"))
-        if fused_front and i_cap is not None and _env is None and self.prefilter and n_early > 0:
+        if _geo_only:
+            n_early = max(n_early, 1)                        # (its own graph: the first view(s), as in the eager step -- the geometry
+                                                             #  of two views beside the prefilter costs more than it hides)
+        if _geo is not None:
+            early = _geo["early"]
+        elif fused_front and i_cap is not None and (_env is None or _geo_only) and self.prefilter and n_early > 0:
             ev_a = torch.cuda.Event(); ev_a.record(main)
             for j in range(min(n_early, len(cameras))):
                 cam_j = cameras[j]
@@ -203,6 +211,11 @@ class RenderStep:
                 early[j] = (gstate["flatten_ids"], gstate["isect_offsets"])
                 for t in (scales_act, opac_act):
                     t.record_stream(side)
+        if _geo_only:
+            for sd in sides:
+                main.wait_stream(sd)                         # (a captured phase: every forked stream joins before the capture ends)
+            self._seen_counts.extend(seen)
+            return dict(early=early, scales_act=scales_act, opac_act=opac_act)
         if _env is not None:
             env = _env                                       # the pyramid of this step, already filtered (capture_views)
         elif self.prefilter:
@@ -684,16 +697,29 @@ class RenderStep:
         pyramid = TextureSplitSum(first.base.detach().clone(), [l.detach().clone() for l in first.levels], first.min_roughness,
                                   first.max_roughness)
         slots = [pyramid.base] + list(pyramid.levels)
+        # TWO graphs (GEOSPLAT_GEO_GRAPH=0: one): the GEOMETRY of the views -- projection, depth keys, binning: nothing that needs the
+        # pyramid -- replays on its own stream BESIDE the eager prefilter forward and its all-reduce, the rest behind both.  With one
+        # view per GPU the chain front -> binning -> record stream -> compositor -> tail is serial; this takes ~0.5 ms of it off
+        # the step's critical path (as the eager step does with its first view).
+        two = self._front_fused and os.environ.get("GEOSPLAT_GEO_GRAPH", "1") != "0"
+        F.reserve_pinned(4 * len(cameras) + 2)                 # (the geometry fronts carry their own count read-backs)
         warm = torch.cuda.Stream(device=dev)
         warm.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(warm):                          # (allocator warm-up on a side stream, as torch.cuda.graph asks)
-            self._step_fused(cameras, upstream, all_reduce, keep_images, _env=pyramid, _stop_after_views=True)
+            geo = self._step_fused(cameras, upstream, all_reduce, keep_images, _geo_only=True) if two else None
+            self._step_fused(cameras, upstream, all_reduce, keep_images, _env=pyramid, _stop_after_views=True, _geo=geo)
         torch.cuda.current_stream(dev).wait_stream(warm)
         torch.cuda.synchronize(dev)
         self.poll_capacity(_internal=True)                    # an overflow of the warm-up step stays pending for the caller's next poll
+        geo_graph, geo = None, None
+        if two:
+            geo_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(geo_graph):
+                geo = self._step_fused(cameras, upstream, all_reduce, keep_images, _geo_only=True)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            ctx = self._step_fused(cameras, upstream, all_reduce, keep_images, _env=pyramid, _stop_after_views=True)
+        with torch.cuda.graph(graph, pool=geo_graph.pool() if two else None):
+            ctx = self._step_fused(cameras, upstream, all_reduce, keep_images, _env=pyramid, _stop_after_views=True, _geo=geo)
+        geo_stream = torch.cuda.Stream(device=dev) if two else None
         counts = [hc for hc, _ in self._seen_counts]          # refreshed by every replay (D2H copies are graph nodes)
         self._seen_counts = []
         self._status_event = None
@@ -702,10 +728,17 @@ class RenderStep:
         ctx["main"] = None
 
         def step():
+            cur = torch.cuda.current_stream(dev)
+            if two:
+                geo_stream.wait_stream(cur)                    # (the parameters of this step are final on the caller's stream)
+                with torch.cuda.stream(geo_stream):
+                    geo_graph.replay()
             env = filter_env()
             torch._foreach_copy_(slots, [env.base] + list(env.levels))
+            if two:
+                cur.wait_stream(geo_stream)
             graph.replay()
-            ctx["main"] = torch.cuda.current_stream(dev)
+            ctx["main"] = cur
             return self._finish(ctx)
 
         def check() -> bool:
@@ -720,6 +753,7 @@ class RenderStep:
             return not overflow
         step.check = check
         step.graph = graph
+        step.geo_graph = geo_graph
         return step
 
     def _throttle(self) -> None:

@@ -163,17 +163,23 @@ def test_step_captured_in_hip_graph():
     _same(ref, got)
 
 
-def test_views_segment_captured_in_hip_graph():
-    """RenderStep.capture_views: the views of a step (shading ... compositor ... per-view backward) as ONE HIP graph with the
-    prefilter forward / backward and every collective outside of it -- the shape one view per GPU needs (BASELINE config 4).
-    Same images and gradients as the eager step, also after the environment map changed under the graph's feet."""
+@pytest.mark.parametrize("geo_graph", ["1", "0"])
+def test_views_segment_captured_in_hip_graph(monkeypatch, geo_graph):
+    """RenderStep.capture_views: the views of a step (shading ... compositor ... per-view backward) as HIP graphs with the
+    prefilter forward / backward and every collective outside of them -- the shape one view per GPU needs (BASELINE config 4);
+    by default TWO graphs, the geometry of the views (projection, keys, binning) replayed beside the eager prefilter forward.
+    Same images and gradients as the eager step, also after the environment map AND the Gaussians changed under the graphs' feet."""
+    monkeypatch.setenv("GEOSPLAT_GEO_GRAPH", geo_graph)
     step, run = _engine(torch.device("cuda", 0))
     run()
     assert step.poll_capacity(wait=True) and step._i_cap is not None
     graphed = step.capture_views(step_cams, step_up, all_reduce=False, keep_images=True)
+    assert (graphed.geo_graph is not None) == (geo_graph == "1")
     for scale in (1.0, 1.7):
         with torch.no_grad():
             step.p.cubemap.mul_(scale)                                # the prefilter is NOT in the graph: it must follow the parameter
+            step.p.means.mul_(1.0 + 0.01 * (scale - 1.0))             # (the graphs read the parameters in place)
+            step.p.scales.add_(0.02 * (scale - 1.0))
         ref = run()
         for _ in range(2):
             grads, images = graphed()

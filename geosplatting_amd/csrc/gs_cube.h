@@ -211,61 +211,7 @@ __device__ __forceinline__ void gs_add_scoped(float* p, float v)
     if (XCD_LOCAL) gs_atomic_add_xcd(p, v); else gs_atomic_add(p, v);
 }
 
-// Commit (p[0..2] += v0,v1,v2) for every lane with p != nullptr, TRANSPOSED so that the three channels of one
-// texel are issued by three ADJACENT lanes of ONE atomic instruction: the memory side merges dwords of the same
-// cache line within an instruction into one request, but the r/g/b atomics of a lane are three instructions =
-// three requests (the shading backward sits at the fabric's atomic request rate: 9.3 requests per Gaussian).
-template <bool XCD_LOCAL>
-__device__ __forceinline__ void wave_commit3(float* p, float v0, float v1, float v2)
-{
-    const int lane = (int)(threadIdx.x & 63);
-    const unsigned long long key = (unsigned long long)p;
-    const int klo = (int)(unsigned)key, khi = (int)(unsigned)(key >> 32);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int q = 64 * k + lane;
-        const int src = q / 3, ch = q - 3 * src;
-        const int sa = src << 2;
-        const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(sa, klo);
-        const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(sa, khi);
-        const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sa, __builtin_bit_cast(int, v0)));
-        const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sa, __builtin_bit_cast(int, v1)));
-        const float a2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sa, __builtin_bit_cast(int, v2)));
-        float* dst = (float*)(((unsigned long long)hi << 32) | lo);
-        const float val = ch == 0 ? a0 : (ch == 1 ? a1 : a2);
-        if (dst != nullptr) gs_add_scoped<XCD_LOCAL>(dst + ch, val);
-    }
-}
-
-template <bool XCD_LOCAL>
-__device__ __forceinline__ void wave_agg_add3(float* p /* nullptr = nothing to add */, float v0, float v1, float v2)
-{
-    const int lane = (int)(threadIdx.x & 63);
-    unsigned long long key = (unsigned long long)p;
-    unsigned long long remaining = __ballot(p != nullptr);
-    int singles = 0;
-    float* pend = nullptr; float pv0 = 0.f, pv1 = 0.f, pv2 = 0.f;
-    for (int round = 0; round < GS_AGG_ROUNDS && remaining != 0ull && singles < 2; ++round) {
-        const int leader = __builtin_ctzll(remaining);
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key, leader);
-        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key >> 32), leader);
-        const unsigned long long k = ((unsigned long long)hi << 32) | lo;
-        const bool same = (key == k);
-        const unsigned long long m = __ballot(same);
-        const float s0 = gs_wave_sum(same ? v0 : 0.0f);
-        const float s1 = gs_wave_sum(same ? v1 : 0.0f);
-        const float s2 = gs_wave_sum(same ? v2 : 0.0f);
-        if (lane == leader) { pend = p; pv0 = s0; pv1 = s1; pv2 = s2; }    // committed below, transposed
-        if (same) key = 0ull;
-        remaining &= ~m;
-        singles = (__popcll(m) == 1) ? singles + 1 : 0;
-    }
-    // leaders carry the aggregated sums, un-aggregated lanes their own contribution; a lane is never both
-    if (key != 0ull) { pend = p; pv0 = v0; pv1 = v1; pv2 = v2; }
-    wave_commit3<XCD_LOCAL>(pend, pv0, pv1, pv2);
-}
-
-// Row-pair variant: the two taps of one bilinear ROW are neighbours in memory (texel x and x+1 of a face row = six
+// Row pairs (the per-texel transposed commit of round 1 is gone): the two taps of one bilinear ROW are neighbours in memory (texel x and x+1 of a face row = six
 // contiguous floats), so their six atomics are issued by SIX adjacent lanes of one instruction and merge into ONE
 // memory-side request (two when the 24 bytes straddle a cache line or, on a face edge, the second texel lives
 // elsewhere).  Halves the request count of the shading backward, which sits at the fabric's atomic request rate.
@@ -447,20 +393,3 @@ __device__ __forceinline__ void cube_scatter_wave_tagged(float* grad_tex, bool l
         wave_commit6_lds_tagged(stage, p[0], p[1], v);
     }
 }
-
-__device__ __forceinline__ void cube_scatter(float* __restrict__ grad_tex, const CubeFp& fp, const float* g, float scale)
-{
-    if (!fp.valid) return;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (fp.idx[i] < 0) continue;
-        const float w = scale * fp.w[i];
-        float* p = grad_tex + (size_t)fp.idx[i] * 3;
-#ifndef GS_EXPERIMENT_NO_GLOBAL_TEXEL_ATOMICS      /* timing experiment only (scripts/shade_bwd_experiment.py) */
-        gs_atomic_add(p, g[0] * w); gs_atomic_add(p + 1, g[1] * w); gs_atomic_add(p + 2, g[2] * w);
-#else
-        if (w == 123456.0f) p[0] = g[0];
-#endif
-    }
-}
-

@@ -1948,9 +1948,24 @@ raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_
                     const v2f p0 = v2f{a0.z, a0.w} * v2f{d0.x, d0.x}, p1 = v2f{a1.z, a1.w} * v2f{d1.x, d1.x};   // {ha dx, cb dx}
                     sigma.x = gs_sigma_xy(d0, p0, b0.x);
                     sigma.y = gs_sigma_xy(d1, p1, b1.x);
+#ifndef GS_BWD_LOG_EXACT_MATH
+                    // hardware exp2 (1 ulp) and a reciprocal with ONE Newton step here, not the canonical exp / correctly rounded
+                    // quotient of the forward and of raster_bwd_lanes2_kernel: this is a gradient (1e-4, and upstream's backward
+                    // uses __expf itself); the walk loses 13 of its 130 issue slots: 0.50 -> 0.465 ms alone, 592 -> 604 views/s.
+                    // Once or twice per view a pair at alpha = 1/255 falls on the other side of the test than in the forward: the
+                    // transmittance of ONE pixel is then off by 0.4 % in front of that pair.
+                    ov = v2f{b0.y, b1.y} * v2f{__builtin_amdgcn_exp2f(sigma.x * -1.4426950408889634f), __builtin_amdgcn_exp2f(sigma.y * -1.4426950408889634f)};
+                    alpha = __builtin_elementwise_min(ov, (v2f)(0.999f));
+                    {
+                        const v2f x = (v2f)(1.0f) - alpha;
+                        const v2f r0 = v2f{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)};
+                        ra = __builtin_elementwise_fma(r0, __builtin_elementwise_fma(-x, r0, (v2f)(1.0f)), r0);
+                    }
+#else
                     ov = v2f{b0.y, b1.y} * gs_exp_neg_live2(sigma);
                     alpha = __builtin_elementwise_min(ov, (v2f)(0.999f));
                     ra = gs_rcp_exact2((v2f)(1.0f) - alpha);
+#endif
                 }
                 const bool ok0 = has0 && idx0 <= bin_final && sigma.x >= 0.0f && alpha.x >= GS_ALPHA_MIN;
                 const bool ok1 = has1 && idx1 <= bin_final && sigma.y >= 0.0f && alpha.y >= GS_ALPHA_MIN;

@@ -1770,16 +1770,16 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
 //   * no fill loop, no cull, no ring queue: lane j gathers "its" record by stream index (two batches ahead: entries, one batch
 //     ahead: the three 16-byte record parts) and writes queue slot j;
 //   * no record_pixel_mask: the logged mask, clipped to the pixels whose last composited entry lies at or behind the batch;
-//   * the queue needs 64 slots instead of 128, which buys 800 pair slots instead of 448 in the same 9 984 bytes of LDS per wave:
+//   * the queue needs 64 slots instead of 128, which buys 798 (+ 2 spare) pair slots instead of 448 in the same 9 984 bytes of LDS per wave:
 //     a dense batch is 64 records almost always (lanes2: 47 on average, i.e. 36 % more batches with their fixed costs).
 // Walk, record-lane reduction and commit are those of lanes2 (same arithmetic, same per-pixel order).
-static constexpr int GS_LOG_PAIR_CAP = 800;
+static constexpr int GS_LOG_PAIR_CAP = 798;                       // + two spare slots: stores of lanes without a candidate land in [798]
 struct LogLds {
     static constexpr int Q_BYTES = 64 * (16 + 16 + 8 + 4);
     static constexpr int OFF_MSK = Q_BYTES;
     static constexpr int OFF_BASE = OFF_MSK + 64 * 8;
     static constexpr int OFF_PAIR = OFF_BASE + 64 * 4;
-    static constexpr int WAVE_BYTES = OFF_PAIR + GS_LOG_PAIR_CAP * 8;
+    static constexpr int WAVE_BYTES = OFF_PAIR + (GS_LOG_PAIR_CAP + 2) * 8;
 };
 
 template <int CD>
@@ -1967,8 +1967,9 @@ raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_
                     ra = gs_rcp_exact2((v2f)(1.0f) - alpha);
 #endif
                 }
-                const bool ok0 = has0 && idx0 <= bin_final && sigma.x >= 0.0f && alpha.x >= GS_ALPHA_MIN;
-                const bool ok1 = has1 && idx1 <= bin_final && sigma.y >= 0.0f && alpha.y >= GS_ALPHA_MIN;
+                // (bitwise: no short-circuit branches in the walk)
+                const bool ok0 = has0 & (idx0 <= bin_final) & (sigma.x >= 0.0f) & (alpha.x >= GS_ALPHA_MIN);
+                const bool ok1 = has1 & (idx1 <= bin_final) & (sigma.y >= 0.0f) & (alpha.y >= GS_ALPHA_MIN);
                 {
                     const float Tn = T * ra.x;
                     const float fac = ok0 ? alpha.x * Tn : 0.0f;
@@ -1983,7 +1984,7 @@ raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_
                     if (ok0) GS_STAT_ALL(7, 1);
                     if (has0 && !ok0) { if (idx0 > bin_final) GS_STAT2_ALL(2, 1); else GS_STAT2_ALL(3, 1); }
 #endif
-                    if (has0) pairbuf[e0] = make_float2(s_out, fac);
+                    pairbuf[has0 ? e0 : GS_LOG_PAIR_CAP] = make_float2(s_out, fac);        // (a lane without a candidate writes the spare slot)
                 }
                 {
                     const float Tn = T * ra.y;
@@ -1999,7 +2000,7 @@ raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_
                     if (ok1) GS_STAT_ALL(7, 1);
                     if (has1 && !ok1) { if (idx1 > bin_final) GS_STAT2_ALL(2, 1); else GS_STAT2_ALL(3, 1); }
 #endif
-                    if (has1) pairbuf[e1] = make_float2(s_out, fac);
+                    pairbuf[has1 ? e1 : GS_LOG_PAIR_CAP] = make_float2(s_out, fac);
                 }
             }
             lanes_lds_sync();

@@ -52,6 +52,15 @@ extern "C" int gs_raster_stats2_read(unsigned long long* host8, int reset)
     if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_raster_stats2), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
+// third bank (round 4): walk trips of the cull-log backward by the number of lanes that still hold a candidate: [k] = trips with
+// 8 k < lanes <= 8 (k + 1)
+__device__ unsigned long long g_raster_stats3[8];
+extern "C" int gs_raster_stats3_read(unsigned long long* host8, int reset)
+{
+    if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_raster_stats3), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_raster_stats3), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
 // per-block timeline (diagnostic, -DGS_RASTER_PHASES): [3 * b] = first wave start, [3 * b + 1] = last wave end (100 MHz wall clock),
 // [3 * b + 2] = list length of the tile
 #define GS_TL_MAX 16384
@@ -1773,14 +1782,25 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
 //   * the queue needs 64 slots instead of 128, which buys 798 (+ 2 spare) pair slots instead of 448 in the same 9 984 bytes of LDS per wave:
 //     a dense batch is 64 records almost always (lanes2: 47 on average, i.e. 36 % more batches with their fixed costs).
 // Walk, record-lane reduction and commit are those of lanes2 (same arithmetic, same per-pixel order).
-static constexpr int GS_LOG_PAIR_CAP = 798;                       // + two spare slots: stores of lanes without a candidate land in [798]
+static constexpr int GS_LOG_PAIR_CAP = 790;                       // + two spare slots (stores of lanes without a candidate land in [790])
+#ifndef GS_LOG_ASSIST_MAX                                         //   + 64 bytes: the pixels of an assisted walk trip
+#define GS_LOG_ASSIST_MAX 16                                      // walk trips with at most this many busy pixels are ASSISTED (0: never)
+#endif
 struct LogLds {
     static constexpr int Q_BYTES = 64 * (16 + 16 + 8 + 4);
     static constexpr int OFF_MSK = Q_BYTES;
     static constexpr int OFF_BASE = OFF_MSK + 64 * 8;
     static constexpr int OFF_PAIR = OFF_BASE + 64 * 4;
-    static constexpr int WAVE_BYTES = OFF_PAIR + (GS_LOG_PAIR_CAP + 2) * 8;
+    static constexpr int OFF_APIX = OFF_PAIR + (GS_LOG_PAIR_CAP + 2) * 8;
+    static constexpr int WAVE_BYTES = OFF_APIX + 16 * 4;
 };
+
+// DPP shift inside a 16-lane row: lane l receives src of lane l - N; lanes whose source lies outside the row receive `ident`
+template <int CTRL>
+__device__ __forceinline__ float gs_row_shr(float ident, float src)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, src), CTRL, 0xf, 0xf, false));
+}
 
 template <int CD>
 __global__ void __launch_bounds__(256)
@@ -1792,6 +1812,9 @@ raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_
                       float* __restrict__ v_packed, int rec_stride, ToneBwd tone, CullLog log)
 {
     const int n_isects = (int)gs_count(ic);
+#if defined(GS_RASTER_STATS) && !defined(GS_RASTER_PHASES)
+    int walk_hist[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };                // wave-uniform; flushed once at the end (bank 3)
+#endif
     static_assert(CD <= 3, "colours come from the record stream (D <= 3)");
     using LD = LogLds;
     constexpr int NV = 6 + CD;
@@ -1817,6 +1840,7 @@ raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_
     unsigned long long* msk = (unsigned long long*)(wbase + LD::OFF_MSK);
     int* pbase = (int*)(wbase + LD::OFF_BASE);
     float2* pairbuf = (float2*)(wbase + LD::OFF_PAIR);
+    int* apix = (int*)(wbase + LD::OFF_APIX);
     float* stage = (float*)(wbase + LD::OFF_PAIR);              // aliases pairbuf (separated by wave syncs)
 
     float T_final = 1.0f, v_a = 0.0f, v_exp = 0.0f;
@@ -1929,8 +1953,99 @@ raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_
 #endif
             while (__ballot(list != 0ull) != 0ull) {
                 GS_STAT(6, 1);
+#if defined(GS_RASTER_STATS) && !defined(GS_RASTER_PHASES)
+                { const int na = __popcll(__ballot(list != 0ull));
+#pragma unroll
+                  for (int k = 0; k < 8; ++k) walk_hist[k] += (na > 8 * k && na <= 8 * k + 8) ? 1 : 0; }
+#endif
 #ifdef GS_RASTER_PHASES
                 if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_raster_stats[5], 1ull);
+#endif
+#if GS_LOG_ASSIST_MAX > 0
+                // ---- ASSISTED trip.  Half of the walk's trips have at most 16 busy pixels (a third at most 8): the recurrence of
+                // a pixel is sequential, but everything in front of it -- sigma, exp, reciprocal, colour dot, the pair slot: 4/5 of
+                // a candidate's instructions -- is not.  G = 4 (8) lanes serve one busy pixel: helper h takes the pixel's h-th next
+                // candidate, the transmittance / accumulator recurrences become two exclusive scans over the G lanes (DPP inside the
+                // row), every helper stores its own pair, and the pixel's lane takes over the state behind the G candidates.
+                // Same candidates in the same order as the plain trips; the products are associated differently (a gradient).
+                {
+                    const unsigned long long am = __ballot(list != 0ull);
+                    const int na = __popcll(am);
+                    // (lists of one or two candidates: a plain trip finishes them for less)
+                    if (na <= GS_LOG_ASSIST_MAX && __ballot(__popcll(list) > 2) != 0ull) {
+                        const int gs = na <= 8 ? 3 : 2, G = 1 << gs;
+                        const int rank = __popcll(am & lane_lt);
+                        lanes_lds_sync();
+                        if (list != 0ull) apix[rank] = lane;
+                        lanes_lds_sync();
+                        const int g = lane >> gs, h = lane & (G - 1);
+                        const bool grp = g < na;
+                        const int p = grp ? apix[g] : 0;                                   // the pixel (lane) this lane assists
+                        const int pa = p << 2;
+                        unsigned long long L = ((unsigned long long)(unsigned)__builtin_amdgcn_ds_bpermute(pa, (int)(unsigned)(list >> 32)) << 32) |
+                                               (unsigned long long)(unsigned)__builtin_amdgcn_ds_bpermute(pa, (int)(unsigned)list);
+                        const float T0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(pa, __builtin_bit_cast(int, T)));
+                        const float Z0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(pa, __builtin_bit_cast(int, zacc)));
+                        const int bf = __builtin_amdgcn_ds_bpermute(pa, bin_final);
+                        float vr[CD];
+#pragma unroll
+                        for (int c = 0; c < CD; ++c) vr[c] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(pa, __builtin_bit_cast(int, v_rc[c])));
+                        if (!grp) L = 0ull;
+                        for (int i = 0; i < G - 1; ++i) L = (i < h) ? (L & (L - 1ull)) : L;   // skip the candidates of the helpers in front
+                        const bool has = L != 0ull;
+                        const int j = gs_pop_lowest(L);                                    // (L is now what remains behind this helper)
+                        const float4 a = qa[j]; const float2 b = qb[j]; const float4 cc = qc[j];
+                        const int idx = qidx[j];
+                        const unsigned long long below = (1ull << p) - 1ull;
+                        const int e = pbase[j] + __popcll(msk[j] & below);
+                        float sigma, ov, alpha, ra;
+                        {
+#pragma clang fp contract(off)
+                            const v2f d = v2f{a.x, a.y} - v2f{(float)(qx0 + (p & 7)) + 0.5f, (float)(qy0 + (p >> 3)) + 0.5f};
+                            const v2f pp = v2f{a.z, a.w} * v2f{d.x, d.x};
+                            sigma = gs_sigma_xy(d, pp, b.x);
+                            ov = b.y * __builtin_amdgcn_exp2f(sigma * -1.4426950408889634f);
+                            alpha = fminf(ov, 0.999f);
+                            const float x = 1.0f - alpha;
+                            const float r0 = __builtin_amdgcn_rcpf(x);
+                            ra = fmaf(r0, fmaf(-x, r0, 1.0f), r0);
+                        }
+                        const bool ok = has & (idx <= bf) & (sigma >= 0.0f) & (alpha >= GS_ALPHA_MIN);
+                        float cv = cc.x * vr[0];
+                        if (CD > 1) cv = fmaf(cc.y, vr[1], cv);
+                        if (CD > 2) cv = fmaf(cc.z, vr[2], cv);
+                        // exclusive product of the multipliers of the helpers in front (inclusive scan, then one more shift)
+                        float pi = ok ? ra : 1.0f;
+                        { const float t = gs_row_shr<0x111>(1.0f, pi); pi *= (h >= 1) ? t : 1.0f; }
+                        { const float t = gs_row_shr<0x112>(1.0f, pi); pi *= (h >= 2) ? t : 1.0f; }
+                        { const float t = gs_row_shr<0x114>(1.0f, pi); pi *= (h >= 4) ? t : 1.0f; }
+                        float pe = gs_row_shr<0x111>(1.0f, pi); pe = (h >= 1) ? pe : 1.0f;
+                        const float Tb = T0 * pe, Tn = Tb * ra;
+                        const float fac = ok ? alpha * Tn : 0.0f;
+                        float si = fac * cv;
+                        { const float t = gs_row_shr<0x111>(0.0f, si); si += (h >= 1) ? t : 0.0f; }
+                        { const float t = gs_row_shr<0x112>(0.0f, si); si += (h >= 2) ? t : 0.0f; }
+                        { const float t = gs_row_shr<0x114>(0.0f, si); si += (h >= 4) ? t : 0.0f; }
+                        float se = gs_row_shr<0x111>(0.0f, si); se = (h >= 1) ? se : 0.0f;
+                        const float zb = Z0 - se;
+                        const float v_alpha = fmaf(Tn, cv, ra * zb);
+                        const float s_out = (ok && ov <= 0.999f) ? -ov * v_alpha : 0.0f;
+#ifdef GS_RASTER_STATS
+                        if (ok) GS_STAT_ALL(7, 1);
+                        if (has && !ok) { if (idx > bf) GS_STAT2_ALL(2, 1); else GS_STAT2_ALL(3, 1); }
+#endif
+                        pairbuf[has ? e : GS_LOG_PAIR_CAP] = make_float2(s_out, fac);
+                        // the pixel's lane takes over the state behind its last helper
+                        const float T_end = T0 * pi, Z_end = Z0 - si;
+                        const int src = (((rank << gs) + G - 1) & 63) << 2;
+                        const float Tg = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, T_end)));
+                        const float Zg = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, Z_end)));
+                        const unsigned Llo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)L);
+                        const unsigned Lhi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(L >> 32));
+                        if (list != 0ull) { T = Tg; zacc = Zg; list = ((unsigned long long)Lhi << 32) | Llo; }
+                        continue;
+                    }
+                }
 #endif
                 const bool has0 = list != 0ull;
                 const int j0 = gs_pop_lowest(list);
@@ -2086,6 +2201,12 @@ raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_
             r0 = r1;
         }
     }
+#if defined(GS_RASTER_STATS) && !defined(GS_RASTER_PHASES)
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (walk_hist[k]) atomicAdd(&g_raster_stats3[k], (unsigned long long)walk_hist[k]);
+    }
+#endif
     GS_TL_END();
 }
 

@@ -1953,7 +1953,7 @@ raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_
 #endif
             while (__ballot(list != 0ull) != 0ull) {
                 GS_STAT(6, 1);
-#if defined(GS_RASTER_STATS) && !defined(GS_RASTER_PHASES)
+#if defined(GS_RASTER_STATS) && !defined(GS_RASTER_PHASES) && !defined(GS_HIST_REDUCTION)
                 { const int na = __popcll(__ballot(list != 0ull));
 #pragma unroll
                   for (int k = 0; k < 8; ++k) walk_hist[k] += (na > 8 * k && na <= 8 * k + 8) ? 1 : 0; }
@@ -2132,6 +2132,11 @@ raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_
                 v2f m1 = (v2f)(0.0f), m2 = (v2f)(0.0f), c01 = (v2f)(0.0f);
                 while (__ballot(m != 0ull) != 0ull) {
                     GS_STAT2(7, 1);
+#if defined(GS_RASTER_STATS) && !defined(GS_RASTER_PHASES) && defined(GS_HIST_REDUCTION)      /* bank 3 counts the REDUCTION's trips instead */
+                    { const int na = __popcll(__ballot(m != 0ull));
+#pragma unroll
+                      for (int k = 0; k < 8; ++k) walk_hist[k] += (na > 8 * k && na <= 8 * k + 8) ? 1 : 0; }
+#endif
 #ifdef GS_RASTER_PHASES
                     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_raster_stats[7], 1ull);
 #endif

@@ -542,7 +542,14 @@ def main():
                                  "stream build, no memset); useful flops = composited (pixel, Gaussian) pairs x flops per pair"},
             "view_roofline": {"algorithmic_bytes_per_view": view_bytes,
                               "achieved_GBs": view_bytes * views_per_s / world / 1e9,
-                              "frac_of_8TBs": view_bytes * views_per_s / world / 1e9 / HBM_PEAK_GBS},
+                              "frac_of_8TBs": view_bytes * views_per_s / world / 1e9 / HBM_PEAK_GBS,
+                              # the step as a whole: the views' algorithmic bytes + what the prefilter really moves from HBM (its weight
+                              # tables, streamed once per direction; the reference computes these weights instead) + the pyramid
+                              "step_bytes_incl_prefilter": (None if not pre or pre.get("table_bytes_from_hbm_per_step") is None else
+                                                            view_bytes * len(cams) + pre["table_bytes_from_hbm_per_step"] + 2 * pre.get("pyramid_bytes", 0)),
+                              "step_frac_of_8TBs_incl_prefilter": (None if not pre or pre.get("table_bytes_from_hbm_per_step") is None else
+                                                                   (view_bytes * len(cams) + pre["table_bytes_from_hbm_per_step"] + 2 * pre.get("pyramid_bytes", 0))
+                                                                   / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS)},
             "strong_1gpu_ms": ms_per_step if (world == 1 and strong) else None,
             "scale_model": scale_model(view_ms, pre, N, args.cubemap_res, views_total, ms_per_step if world == 1 else None),
             "gpu_view_ms_without_prefilter": view_ms,

@@ -1145,7 +1145,7 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
         }
         // ---- walk until batch A is exhausted in every lane; lanes that are through with A work on B
         const int baseB = qhead + nA;
-        while (__ballot(listA != 0ull) != 0ull) {
+        if (__ballot(listA != 0ull) != 0ull) do {                 // (rotated by hand: no copies of the loop-carried state per trip)
             GS_STAT(3, 1);
             bool has[2]; int slot[2];
             float4 ca[2], cc[2]; float2 cb[2];
@@ -1202,7 +1202,7 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
             }
             listA = stopped ? 0ull : listA;
             listB = stopped ? 0ull : listB;
-        }
+        } while (__ballot(listA != 0ull) != 0ull);
         // ---- retire A (its slots are recycled by the next fill): resolve the stream index of what was composited last
         if (cur_slot >= 0) { cur_idx = q.idx[cur_slot]; cur_slot = -1; }
         lanes_lds_sync();
@@ -1951,7 +1951,7 @@ raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_
 #ifdef GS_RASTER_PHASES
             if (blockIdx.x == 0 && threadIdx.x == 0) { _pw0 = (long long)__builtin_readcyclecounter(); atomicAdd(&g_raster_stats[6], 1ull); }
 #endif
-            while (__ballot(list != 0ull) != 0ull) {
+            if (__ballot(list != 0ull) != 0ull) do {
                 GS_STAT(6, 1);
 #if defined(GS_RASTER_STATS) && !defined(GS_RASTER_PHASES) && !defined(GS_HIST_REDUCTION)
                 { const int na = __popcll(__ballot(list != 0ull));
@@ -2117,7 +2117,7 @@ raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_
 #endif
                     pairbuf[has1 ? e1 : GS_LOG_PAIR_CAP] = make_float2(s_out, fac);
                 }
-            }
+            } while (__ballot(list != 0ull) != 0ull);
             lanes_lds_sync();
 #ifdef GS_RASTER_PHASES
             if (blockIdx.x == 0 && threadIdx.x == 0) { const long long _t = (long long)__builtin_readcyclecounter(); atomicAdd(&g_raster_stats[2], (unsigned long long)(_t - _pw0)); _pw0 = _t; }
@@ -2130,7 +2130,7 @@ raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_
                 int e = cum - cnt - cumbase;
                 float m0 = 0.0f, mxy = 0.0f, c2s = 0.0f;
                 v2f m1 = (v2f)(0.0f), m2 = (v2f)(0.0f), c01 = (v2f)(0.0f);
-                while (__ballot(m != 0ull) != 0ull) {
+                if (__ballot(m != 0ull) != 0ull) do {                 // (rotated by hand: the while form copied all nine accumulators every trip)
                     GS_STAT2(7, 1);
 #if defined(GS_RASTER_STATS) && !defined(GS_RASTER_PHASES) && defined(GS_HIST_REDUCTION)      /* bank 3 counts the REDUCTION's trips instead */
                     { const int na = __popcll(__ballot(m != 0ull));
@@ -2155,7 +2155,7 @@ raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_
                     mxy = fmaf(sd.x, d.y, mxy);
                     c01 = __builtin_elementwise_fma((v2f)(f_w), v2f{vr.x, vr.y}, c01);
                     if (CD > 2) c2s = fmaf(f_w, vr.z, c2s);
-                }
+                } while (__ballot(m != 0ull) != 0ull);
                 sum[0] = m0; sum[1] = m1.x; sum[2] = m1.y; sum[3] = m2.x; sum[4] = mxy; sum[5] = m2.y;
                 sum[6] = c01.x;
                 if (CD > 1) sum[7] = c01.y;

@@ -346,32 +346,43 @@ __device__ __forceinline__ void cube_scatter_wave(float* grad_tex, const CubeFp&
 // mip level, so the pointer carries the choice in bit 0 (texel addresses are 4-byte aligned).
 __device__ __forceinline__ void wave_commit6_lds_tagged(float* stage, float* pa, float* pb, const float (&v)[6])
 {
+    // COMPACTED: only the lanes that have a row pair enter the staging (at their rank), and the transposed commit issues
+    // ceil(6 n / 64) atomic instructions instead of six -- in the pair kernels 60 % of the level fetches go to the LDS copies, so a
+    // commit carries ~25 row pairs, and an atomic instruction costs its issue slot whatever its exec mask holds.
     const int lane = (int)(threadIdx.x & 63);
     unsigned long long* sp = reinterpret_cast<unsigned long long*>(stage);       // [2][64] pointers, then [6][64] values
     float* sv = stage + 256;
+    const bool act = pa != nullptr || pb != nullptr;
+    const unsigned long long am = __ballot(act);
+    if (am == 0ull) return;
+    const int n6 = 6 * __popcll(am);
+    const int rank = __popcll(am & ((1ull << lane) - 1ull));
     __builtin_amdgcn_wave_barrier();
-    sp[lane] = (unsigned long long)pa; sp[64 + lane] = (unsigned long long)pb;
+    if (act) {
+        sp[rank] = (unsigned long long)pa; sp[64 + rank] = (unsigned long long)pb;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) sv[c * 64 + lane] = v[c];
+        for (int c = 0; c < 6; ++c) sv[c * 64 + rank] = v[c];
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; 64 * k < n6; ++k) {
         const int q = 64 * k + lane;
-        const int src = q / 6, ch = q - 6 * src;
-        const bool second = ch >= 3;
-        const unsigned long long tagged = sp[(second ? 64 : 0) + src];
-        float* base = (float*)(tagged & ~1ull);
-        const float val = sv[ch * 64 + src];
+        if (q < n6) {
+            const int src = q / 6, ch = q - 6 * src;
+            const bool second = ch >= 3;
+            const unsigned long long tagged = sp[(second ? 64 : 0) + src];
+            float* base = (float*)(tagged & ~1ull);
+            const float val = sv[ch * 64 + src];
 #ifndef GS_EXPERIMENT_NO_GLOBAL_TEXEL_ATOMICS
-        if (base != nullptr) {
-            float* dst = base + (second ? ch - 3 : ch);
-            if (tagged & 1ull) gs_atomic_add_xcd(dst, val); else gs_atomic_add(dst, val);
-        }
+            if (base != nullptr) {
+                float* dst = base + (second ? ch - 3 : ch);
+                if (tagged & 1ull) gs_atomic_add_xcd(dst, val); else gs_atomic_add(dst, val);
+            }
 #else
-        if (base != nullptr && val == 123456.0f) base[0] = val;      /* timing experiment only */
+            if (base != nullptr && val == 123456.0f) base[0] = val;      /* timing experiment only */
 #endif
+        }
     }
 }
 

@@ -1079,7 +1079,7 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
         const unsigned long long act = __ballot(!done);
         if (act == 0ull) break;
         // ---- fill: room for one more raw batch of survivors (64) next to A, B and what is already waiting
-        {
+        { GS_PHASE_BEGIN();
         float rcx, rcy, rex, rey;
         active_rect_c(act, qx0, qy0, rcx, rcy, rex, rey);
 #define WIN_FILL_STEP(B)                                                                                               \
@@ -1093,9 +1093,13 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
         }
         LANES_FILL(qcount <= GS_WIN_Q - 64 && base < end, WIN_FILL_STEP)
 #undef WIN_FILL_STEP
-        }
+        GS_PHASE_END(0); }
         if (qcount == 0) break;
         lanes_lds_sync();
+        long long _pm0 = 0;
+#ifdef GS_RASTER_PHASES
+        if (blockIdx.x == 0 && threadIdx.x == 0) _pm0 = (long long)__builtin_readcyclecounter();
+#endif
         // ---- (re)build the batches that are missing: A, then B behind it
         int xmin, xmax, ymin, ymax;
         active_rect_i(act, xmin, xmax, ymin, ymax);
@@ -1143,10 +1147,16 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
             GS_STAT2(5, 1); GS_STAT2_ALL(4, __popcll(listB));
 #endif
         }
+#ifdef GS_RASTER_PHASES
+        if (blockIdx.x == 0 && threadIdx.x == 0) { const long long _t = (long long)__builtin_readcyclecounter(); atomicAdd(&g_raster_stats[1], (unsigned long long)(_t - _pm0)); _pm0 = _t; }
+#endif
         // ---- walk until batch A is exhausted in every lane; lanes that are through with A work on B
         const int baseB = qhead + nA;
         if (__ballot(listA != 0ull) != 0ull) do {                 // (rotated by hand: no copies of the loop-carried state per trip)
             GS_STAT(3, 1);
+#ifdef GS_RASTER_PHASES
+            if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_raster_stats[3], 1ull);
+#endif
             bool has[2]; int slot[2];
             float4 ca[2], cc[2]; float2 cb[2];
 #pragma unroll
@@ -1203,6 +1213,9 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
             listA = stopped ? 0ull : listA;
             listB = stopped ? 0ull : listB;
         } while (__ballot(listA != 0ull) != 0ull);
+#ifdef GS_RASTER_PHASES
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_raster_stats[2], (unsigned long long)((long long)__builtin_readcyclecounter() - _pm0));
+#endif
         // ---- retire A (its slots are recycled by the next fill): resolve the stream index of what was composited last
         if (cur_slot >= 0) { cur_idx = q.idx[cur_slot]; cur_slot = -1; }
         lanes_lds_sync();

@@ -83,7 +83,7 @@ def time_dominant_kernels(params, env, cam, res, iters):
     W = H = res
     f32 = torch.float32
     use_log = os.environ.get("GEOSPLAT_RASTER_LOG", "1") != "0"
-    tight = os.environ.get("GEOSPLAT_TIGHT_TILES", "0") == "1"
+    tight = os.environ.get("GEOSPLAT_TIGHT_TILES", "1") != "0"
     env_d = gs.TextureSplitSum(env.base.detach(), [l.detach().contiguous() for l in env.levels], env.min_roughness, env.max_roughness)
     e = _make_env(gs.get_fg_lut(dev), env_d)
     d = lambda t: t.to(dev, f32).contiguous()

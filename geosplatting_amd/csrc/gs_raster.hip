@@ -178,6 +178,33 @@ pack_visible_kernel(int V, int D, const float* __restrict__ means2d, const float
 
 // ---------------------------------------------------------------------------------------------------
 // LPT tile order: bucket tiles by floor(log2(count)) descending (single block).
+// The backward's order: its work per tile is what the forward LOGGED (the longest of the four quadrant logs bounds the block), not the
+// raw list length -- a silhouette tile culls most of its list.  Longest first, buckets of half an octave.
+__global__ void __launch_bounds__(1024)
+tile_order_log_kernel(int n_tiles, const int32_t* __restrict__ log_count, int32_t* __restrict__ order)
+{
+    __shared__ int hist[64];
+    __shared__ int base[64];
+    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+    __syncthreads();
+    auto bucket = [&](int t) {
+        const int c = max(max(log_count[4 * t], log_count[4 * t + 1]), max(log_count[4 * t + 2], log_count[4 * t + 3]));
+        if (c <= 0) return 63;                                       // empty: last
+        const int l2 = 31 - __clz(c);
+        const int half = (l2 > 0 && ((c >> (l2 - 1)) & 1)) ? 1 : 0;
+        const int b = 2 * l2 + half;                                 // 0 .. 61, larger = longer
+        return 61 - (b > 61 ? 61 : b);
+    };
+    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) atomicAdd(&hist[bucket(t)], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int b = 0; b < 64; ++b) { base[b] = acc; acc += hist[b]; }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) order[atomicAdd(&base[bucket(t)], 1)] = t;
+}
+
 __global__ void __launch_bounds__(1024)
 tile_order_kernel(int n_tiles, GsCount ic, const int32_t* __restrict__ offsets, int32_t* __restrict__ order)
 {
@@ -1009,7 +1036,7 @@ struct ToneBwd { int mode; const float* exposure; const float* render; const flo
 //     [4 * offsets[tile] + q * (tile list length) + k],   k = 0 .. count[4 * tile + q) in stream order.
 // The backward walks that list from its end: no raw-batch fill, no cull, no ellipse masks, and a pixel never pops a record that
 // lies behind its own termination (5 % of the popped candidates) -- see raster_bwd_log_kernel.
-struct CullLog { int32_t* idx; unsigned long long* mask; int32_t* count; };
+struct CullLog { int32_t* idx; unsigned long long* mask; int32_t* count; int32_t* order; };   // order: the backward's own longest-first tile order
 
 static constexpr int GS_WIN_Q = 192;
 static constexpr int GS_WIN_Q_BYTES = GS_WIN_Q * (16 + 16 + 8 + 4);
@@ -2291,8 +2318,8 @@ static GsCount isect_count(int64_t n) { return GsCount{ (long long)n, t_counts_d
 // its ToneFwd / ToneBwd to the kernels (zero = plain compositor).
 static thread_local ToneFwd t_tone_fwd = { 0, nullptr, nullptr };
 static thread_local ToneBwd t_tone_bwd = { 0, nullptr, nullptr, nullptr, nullptr };
-static thread_local CullLog t_cull_log = { nullptr, nullptr, nullptr };
-struct CullLogScope { explicit CullLogScope(const CullLog& l) { t_cull_log = l; } ~CullLogScope() { t_cull_log = CullLog{ nullptr, nullptr, nullptr }; } };
+static thread_local CullLog t_cull_log = { nullptr, nullptr, nullptr, nullptr };
+struct CullLogScope { explicit CullLogScope(const CullLog& l) { t_cull_log = l; } ~CullLogScope() { t_cull_log = CullLog{ nullptr, nullptr, nullptr, nullptr }; } };
 struct ToneFwdScope { explicit ToneFwdScope(const ToneFwd& t) { t_tone_fwd = t; } ~ToneFwdScope() { t_tone_fwd = ToneFwd{ 0, nullptr, nullptr }; } };
 struct ToneBwdScope { explicit ToneBwdScope(const ToneBwd& t) { t_tone_bwd = t; } ~ToneBwdScope() { t_tone_bwd = ToneBwd{ 0, nullptr, nullptr, nullptr, nullptr }; } };
 
@@ -2437,8 +2464,9 @@ static int launch_bwd(int W, int H, int D, const RasterWs& ws, const float* colo
         if (t_cull_log.idx && gs_raster_lanes() == 1) {         // the forward left its cull log: no fill, no masks
             size_t lds = 4 * (size_t)LogLds::WAVE_BYTES;
             if (lds < gs_raster_lds_pad()) lds = gs_raster_lds_pad();
+            static const bool s_log_order = [] { const char* v = getenv("GEOSPLAT_BWD_LOG_ORDER"); return !(v && v[0] == '0'); }();
             hipLaunchKernelGGL(raster_bwd_log_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
-                               ws.order, ws.rec0, ws.rec1, ws.rec2, background, isect_count(n_isects), offsets, alphas, last_ids,
+                               s_log_order ? t_cull_log.order : ws.order, ws.rec0, ws.rec1, ws.rec2, background, isect_count(n_isects), offsets, alphas, last_ids,
                                v_render, v_alphas, v_packed, rec_stride, t_tone_bwd, t_cull_log);
             GS_CHECK_LAUNCH();
             return GS_OK;
@@ -2600,14 +2628,15 @@ extern "C" int gs_raster_bwd_tone_acc(int W, int H, int tile_size, int V, const 
 // ---------------------------------------------------------------------------------------------------
 // self-test hook: counts the floats with bit patterns in [lo_bits, hi_bits] for which gs_rcp_exact2 differs from IEEE division
 // ---- cull log (forward -> backward), see struct CullLog -----------------------------------------------------------------------
-static CullLog carve_log(void* log_ws, int64_t n_isects)
+static CullLog carve_log(void* log_ws, int64_t n_isects, size_t tiles)
 {
     const size_t n = n_isects > 0 ? (size_t)n_isects : 1;
     char* p = (char*)log_ws;
     CullLog l;
     l.mask = (unsigned long long*)p; p += align256(4 * n * sizeof(unsigned long long));
     l.idx = (int32_t*)p; p += align256(4 * n * sizeof(int32_t));
-    l.count = (int32_t*)p;
+    l.count = (int32_t*)p; p += align256(4 * tiles * sizeof(int32_t));
+    l.order = (int32_t*)p;
     return l;
 }
 extern "C" size_t gs_raster_log_ws_bytes(int64_t n_isects, int W, int H, int tile_size)
@@ -2615,7 +2644,8 @@ extern "C" size_t gs_raster_log_ws_bytes(int64_t n_isects, int W, int H, int til
     if (tile_size <= 0) return 0;
     const size_t n = n_isects > 0 ? (size_t)n_isects : 1;
     const size_t tiles = (size_t)((W + tile_size - 1) / tile_size) * (size_t)((H + tile_size - 1) / tile_size);
-    return align256(4 * n * sizeof(unsigned long long)) + align256(4 * n * sizeof(int32_t)) + align256(4 * tiles * sizeof(int32_t));
+    return align256(4 * n * sizeof(unsigned long long)) + align256(4 * n * sizeof(int32_t)) + align256(4 * tiles * sizeof(int32_t)) +
+           align256(tiles * sizeof(int32_t));
 }
 
 extern "C" int gs_raster_composite_tone_log(int W, int H, int tile_size, int V, const float* colors, int64_t n_isects,
@@ -2626,9 +2656,18 @@ extern "C" int gs_raster_composite_tone_log(int W, int H, int tile_size, int V, 
     GS_CHECK_ARG(log_ws != nullptr && tile_size == GS_TILE, "log_ws must not be NULL");
     if (log_bytes < gs_raster_log_ws_bytes(n_isects, W, H, tile_size)) { gs_set_error("gs_raster_composite_tone_log: log workspace too small"); return GS_ENOSPC; }
     GS_CHECK_ARG(gs_raster_lanes() == 1, "the cull log needs the default compositor kernels (GEOSPLAT_RASTER_LANES=1)");
-    CullLogScope ls(carve_log(log_ws, n_isects));
-    return gs_raster_composite_tone(W, H, tile_size, V, colors, n_isects, counts_dev, offsets, render, alphas, last_ids, tone_mode, exposure,
-                                    image, ws, ws_bytes, stream);
+    const size_t tiles = (size_t)((W + tile_size - 1) / tile_size) * (size_t)((H + tile_size - 1) / tile_size);
+    const CullLog l = carve_log(log_ws, n_isects, tiles);
+    int rc;
+    {
+        CullLogScope ls(l);
+        rc = gs_raster_composite_tone(W, H, tile_size, V, colors, n_isects, counts_dev, offsets, render, alphas, last_ids, tone_mode, exposure,
+                                      image, ws, ws_bytes, stream);
+    }
+    if (rc != GS_OK) return rc;
+    hipLaunchKernelGGL(tile_order_log_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (int)tiles, l.count, l.order);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
 }
 
 extern "C" int gs_raster_bwd_tone_log_acc(int W, int H, int tile_size, int V, const float* colors, int64_t n_isects,
@@ -2640,7 +2679,8 @@ extern "C" int gs_raster_bwd_tone_log_acc(int W, int H, int tile_size, int V, co
     GS_CHECK_ARG(log_ws != nullptr && tile_size == GS_TILE, "log_ws must not be NULL");
     if (log_bytes < gs_raster_log_ws_bytes(n_isects, W, H, tile_size)) { gs_set_error("gs_raster_bwd_tone_log_acc: log workspace too small"); return GS_ENOSPC; }
     GS_CHECK_ARG(gs_raster_lanes() == 1, "the cull log needs the default compositor kernels (GEOSPLAT_RASTER_LANES=1)");
-    CullLogScope ls(carve_log((void*)log_ws, n_isects));
+    const size_t tiles = (size_t)((W + tile_size - 1) / tile_size) * (size_t)((H + tile_size - 1) / tile_size);
+    CullLogScope ls(carve_log((void*)log_ws, n_isects, tiles));
     return gs_raster_bwd_tone_acc(W, H, tile_size, V, colors, n_isects, counts_dev, offsets, render, alphas, last_ids, tone_mode, exposure,
                                   v_image, v_packed, v_exposure, ws, ws_bytes, stream);
 }

@@ -227,7 +227,7 @@ def test_engine_fullsize_equals_call_shaped_path(cuda, monkeypatch, tight):
     params = params_from_scene(scene, cuda, exposure=1.15)
     g = torch.Generator().manual_seed(3)
     ups = [(torch.rand(800, 800, 4, generator=g) * 2 - 1).to(cuda) for _ in cams]
-    monkeypatch.setenv("GEOSPLAT_TIGHT_TILES", tight)             # "1": tile rectangles clipped to the alpha extents (optional path)
+    monkeypatch.setenv("GEOSPLAT_TIGHT_TILES", tight)             # "1" (default): tile rectangles clipped to the alpha extents; "0": gsplat's squares
     step = RenderStep(params)
     for _ in range(2):                                              # second step: capacity mode, 24-bit keys, early binning
         grads, images = step(cams, lambda i, img: ups[i], all_reduce=False, keep_images=True)

@@ -208,27 +208,28 @@ tile_order_log_kernel(int n_tiles, const int32_t* __restrict__ log_count, int32_
 __global__ void __launch_bounds__(1024)
 tile_order_kernel(int n_tiles, GsCount ic, const int32_t* __restrict__ offsets, int32_t* __restrict__ order)
 {
+    // longest list first, in buckets of HALF an octave (whole octaves until the end of round 4: the order inside a bucket is arbitrary)
     const int n_isects = (int)gs_count(ic);
-    __shared__ int hist[32];
-    __shared__ int base[32];
-    if (threadIdx.x < 32) hist[threadIdx.x] = 0;
+    __shared__ int hist[64];
+    __shared__ int base[64];
+    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
     __syncthreads();
-    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
-        const int cnt = ((t == n_tiles - 1) ? n_isects : offsets[t + 1]) - offsets[t];
-        const int b = cnt > 0 ? 31 - __clz(cnt) + 1 : 0;           // 0 = empty
-        atomicAdd(&hist[31 - b], 1);                                 // reversed: big buckets first
-    }
+    auto bucket = [&](int t) {
+        const int c = ((t == n_tiles - 1) ? n_isects : offsets[t + 1]) - offsets[t];
+        if (c <= 0) return 63;                                       // empty: last
+        const int l2 = 31 - __clz(c);
+        const int half = (l2 > 0 && ((c >> (l2 - 1)) & 1)) ? 1 : 0;
+        const int b = 2 * l2 + half;
+        return 61 - (b > 61 ? 61 : b);
+    };
+    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) atomicAdd(&hist[bucket(t)], 1);
     __syncthreads();
     if (threadIdx.x == 0) {
         int acc = 0;
-        for (int b = 0; b < 32; ++b) { base[b] = acc; acc += hist[b]; }
+        for (int b = 0; b < 64; ++b) { base[b] = acc; acc += hist[b]; }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
-        const int cnt = ((t == n_tiles - 1) ? n_isects : offsets[t + 1]) - offsets[t];
-        const int b = cnt > 0 ? 31 - __clz(cnt) + 1 : 0;
-        order[atomicAdd(&base[31 - b], 1)] = t;
-    }
+    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) order[atomicAdd(&base[bucket(t)], 1)] = t;
 }
 
 struct Batch {

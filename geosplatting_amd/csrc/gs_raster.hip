@@ -1823,7 +1823,10 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
 //   * the queue needs 64 slots instead of 128, which buys 798 (+ 2 spare) pair slots instead of 448 in the same 9 984 bytes of LDS per wave:
 //     a dense batch is 64 records almost always (lanes2: 47 on average, i.e. 36 % more batches with their fixed costs).
 // Walk, record-lane reduction and commit are those of lanes2 (same arithmetic, same per-pixel order).
-static constexpr int GS_LOG_PAIR_CAP = 790;                       // + two spare slots (stores of lanes without a candidate land in [790])
+#ifndef GS_LOG_PAIR_SLOTS
+#define GS_LOG_PAIR_SLOTS 790
+#endif
+static constexpr int GS_LOG_PAIR_CAP = GS_LOG_PAIR_SLOTS;                       // + two spare slots (stores of lanes without a candidate land in [790])
 #ifndef GS_LOG_ASSIST_MAX                                         //   + 64 bytes: the pixels of an assisted walk trip
 #define GS_LOG_ASSIST_MAX 16                                      // walk trips with at most this many busy pixels are ASSISTED (0: never)
 #endif
@@ -2271,6 +2274,16 @@ static int gs_env_int(const char* name, int dflt)
 }
 static int gs_raster_blocks_per_cu() { static const int b = gs_env_int("GEOSPLAT_RASTER_BLOCKS", GS_RASTER_BLOCKS_PER_CU); return b < 1 ? 1 : (b > 8 ? 8 : b); }
 static size_t gs_raster_lds_pad() { return (size_t)(160 * 1024 / gs_raster_blocks_per_cu()) - 1024; }
+// LDS of a compositor launch: what the kernel needs, padded up ONLY while one more block than the cap would still fit -- the blocks
+// then leave what they do not use (forward window: 6 KB per block, 24 KB per CU) to the front-side kernels that run beside them
+static size_t gs_raster_lds(size_t natural)
+{
+    static const bool s_always = gs_env_int("GEOSPLAT_RASTER_LDS_PAD", 0) != 0;
+    const size_t pad = gs_raster_lds_pad();
+    if (natural >= pad) return natural;
+    if (!s_always && (size_t)(gs_raster_blocks_per_cu() + 1) * (natural + 512) > (size_t)160 * 1024) return natural;
+    return pad;
+}
 // compositor variant: 1 = per-lane lists (default; forward: sliding window of two dense batches, backward: pair buffer + record-lane
 // reduction for D <= 3), 3 = the same with the single-batch forward, 2 = per-lane lists with ds_add_f64 accumulators in the backward
 // for every D, 0 = one wave per survivor (the round-1 kernels, kept for A/B runs)
@@ -2335,8 +2348,7 @@ static int launch_fwd(int W, int H, int D, const RasterWs& ws, const float* colo
         return GS_EINVAL;
     }
     if (gs_raster_lanes() == 1) {                             // default: sliding window of two dense batches
-        size_t lds = 4 * (size_t)GS_WIN_Q_BYTES;
-        if (lds < gs_raster_lds_pad()) lds = gs_raster_lds_pad();
+        const size_t lds = gs_raster_lds(4 * (size_t)GS_WIN_Q_BYTES);
         hipLaunchKernelGGL(raster_fwd_window_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
                            ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, isect_count(n_isects), offsets, render, alphas,
                            last_ids, t_tone_fwd, t_cull_log);
@@ -2463,8 +2475,7 @@ static int launch_bwd(int W, int H, int D, const RasterWs& ws, const float* colo
     }
     if constexpr (CD <= 3) {                                  // colours travel in the record stream only for D <= 3
         if (t_cull_log.idx && gs_raster_lanes() == 1) {         // the forward left its cull log: no fill, no masks
-            size_t lds = 4 * (size_t)LogLds::WAVE_BYTES;
-            if (lds < gs_raster_lds_pad()) lds = gs_raster_lds_pad();
+            const size_t lds = gs_raster_lds(4 * (size_t)LogLds::WAVE_BYTES);
             static const bool s_log_order = [] { const char* v = getenv("GEOSPLAT_BWD_LOG_ORDER"); return !(v && v[0] == '0'); }();
             hipLaunchKernelGGL(raster_bwd_log_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
                                s_log_order ? t_cull_log.order : ws.order, ws.rec0, ws.rec1, ws.rec2, background, isect_count(n_isects), offsets, alphas, last_ids,

@@ -27,10 +27,11 @@
 #define RS_THREADS 256
 #define RS_WAVES 4
 #ifndef RS_ITEMS
-#define RS_ITEMS 16                       // per thread
-#endif
-#define RS_TILE (RS_THREADS * RS_ITEMS)   // 4096 items per block
-#define RS_WCHUNK (64 * RS_ITEMS)         // 1024 items per wave
+#define RS_ITEMS 8                        // per thread.  16 until the end of round 4: alone the passes take the same time, inside the
+#endif                                    // step the 22 KB blocks find room beside the compositor's (39 KB blocks did not): 659 -> 669
+                                          // views/s (4: 664, 12: 662)
+#define RS_TILE (RS_THREADS * RS_ITEMS)   // 2048 items per block
+#define RS_WCHUNK (64 * RS_ITEMS)         // 512 items per wave
 
 typedef unsigned long long u64;
 

@@ -127,6 +127,8 @@ def time_dominant_kernels(params, env, cam, res, iters):
                                                C.c_size_t(rws_bytes), s), "raster_bwd_tone_acc")
     out = {}
     for name, fn in (("raster_prepare (stream build)", prep), ("raster_fwd_kernel", fwd), ("raster_bwd_kernel", bwd)):
+        if fn is bwd:
+            prep(); fwd()                              # one forward behind one prepare: the state the backward reads (log, tile order)
         fn(); torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()

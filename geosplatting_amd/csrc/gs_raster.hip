@@ -178,36 +178,16 @@ pack_visible_kernel(int V, int D, const float* __restrict__ means2d, const float
 
 // ---------------------------------------------------------------------------------------------------
 // LPT tile order: bucket tiles by floor(log2(count)) descending (single block).
-// The backward's order: its work per tile is what the forward LOGGED (the longest of the four quadrant logs bounds the block), not the
-// raw list length -- a silhouette tile culls most of its list.  Longest first, buckets of half an octave.
-__global__ void __launch_bounds__(1024)
-tile_order_log_kernel(int n_tiles, const int32_t* __restrict__ log_count, int32_t* __restrict__ order)
-{
-    __shared__ int hist[64];
-    __shared__ int base[64];
-    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
-    __syncthreads();
-    auto bucket = [&](int t) {
-        const int c = max(max(log_count[4 * t], log_count[4 * t + 1]), max(log_count[4 * t + 2], log_count[4 * t + 3]));
-        if (c <= 0) return 63;                                       // empty: last
-        const int l2 = 31 - __clz(c);
-        const int half = (l2 > 0 && ((c >> (l2 - 1)) & 1)) ? 1 : 0;
-        const int b = 2 * l2 + half;                                 // 0 .. 61, larger = longer
-        return 61 - (b > 61 ? 61 : b);
-    };
-    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) atomicAdd(&hist[bucket(t)], 1);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int b = 0; b < 64; ++b) { base[b] = acc; acc += hist[b]; }
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) order[atomicAdd(&base[bucket(t)], 1)] = t;
-}
+// The backward's own tile order (longest quadrant log first: that wave bounds the block), built BY THE FORWARD without a launch of its
+// own: at the end of a block its four waves leave their log lengths in LDS, and one thread files the tile in the list of its
+// half-octave bucket (two atomics per tile).  The backward's block b finds its tile from the 64 bucket counts, longest bucket
+// first.  bcount is zeroed by tile_order_kernel (gs_raster_prepare*), on the front stream.
+struct BwdOrder { int32_t* bcount; int32_t* blist; };
 
 __global__ void __launch_bounds__(1024)
-tile_order_kernel(int n_tiles, GsCount ic, const int32_t* __restrict__ offsets, int32_t* __restrict__ order)
+tile_order_kernel(int n_tiles, GsCount ic, const int32_t* __restrict__ offsets, int32_t* __restrict__ order, BwdOrder bo)
 {
+    if (threadIdx.x < 64) bo.bcount[threadIdx.x] = 0;
     // longest list first, in buckets of HALF an octave (whole octaves until the end of round 4: the order inside a bucket is arbitrary)
     const int n_isects = (int)gs_count(ic);
     __shared__ int hist[64];
@@ -1037,7 +1017,7 @@ struct ToneBwd { int mode; const float* exposure; const float* render; const flo
 //     [4 * offsets[tile] + q * (tile list length) + k],   k = 0 .. count[4 * tile + q) in stream order.
 // The backward walks that list from its end: no raw-batch fill, no cull, no ellipse masks, and a pixel never pops a record that
 // lies behind its own termination (5 % of the popped candidates) -- see raster_bwd_log_kernel.
-struct CullLog { int32_t* idx; unsigned long long* mask; int32_t* count; int32_t* order; };   // order: the backward's own longest-first tile order
+struct CullLog { int32_t* idx; unsigned long long* mask; int32_t* count; };
 
 static constexpr int GS_WIN_Q = 192;
 static constexpr int GS_WIN_Q_BYTES = GS_WIN_Q * (16 + 16 + 8 + 4);
@@ -1064,7 +1044,8 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
                          const float4* __restrict__ rec0, const float4* __restrict__ rec1, const float4* __restrict__ rec2,
                          const float* __restrict__ colors, const float* __restrict__ background, GsCount ic,
                          const int32_t* __restrict__ offsets,
-                         float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids, ToneFwd tone, CullLog log)
+                         float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids, ToneFwd tone, CullLog log,
+                         BwdOrder bo)
 {
     const int n_isects = (int)gs_count(ic);
     extern __shared__ __align__(16) unsigned char gs_lds_raw[];
@@ -1254,6 +1235,21 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
     }
     raw_drain(raw0, raw1, raw2);
     if (log.count && lane == 0) log.count[4 * tile + wave] = log_n;
+    if (bo.bcount) {                                                // file the tile for the backward (struct BwdOrder): block barrier only
+        __shared__ int s_cnt[4];
+        if (lane == 0) s_cnt[wave] = log_n;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int c = max(max(s_cnt[0], s_cnt[1]), max(s_cnt[2], s_cnt[3]));
+            int b = 63;                                              // empty: last
+            if (c > 0) {
+                const int l2 = 31 - __clz(c);
+                const int hb = 2 * l2 + ((l2 > 0 && ((c >> (l2 - 1)) & 1)) ? 1 : 0);
+                b = 61 - (hb > 61 ? 61 : hb);
+            }
+            bo.blist[(size_t)b * n_tiles + atomicAdd(bo.bcount + b, 1)] = tile;
+        }
+    }
 
     if (inside) {
         const size_t pid = (size_t)pyi * W + pxi;
@@ -1853,7 +1849,7 @@ raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_
                       const float* __restrict__ background, GsCount ic, const int32_t* __restrict__ offsets,
                       const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
                       const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-                      float* __restrict__ v_packed, int rec_stride, ToneBwd tone, CullLog log)
+                      float* __restrict__ v_packed, int rec_stride, ToneBwd tone, CullLog log, BwdOrder bo)
 {
     const int n_isects = (int)gs_count(ic);
 #if defined(GS_RASTER_STATS) && !defined(GS_RASTER_PHASES)
@@ -1865,8 +1861,23 @@ raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_
     constexpr int RPI = 64 / NV;
     static_assert(64 * NV * 4 <= GS_LOG_PAIR_CAP * 8, "the commit staging aliases the pair buffer");
     extern __shared__ __align__(16) unsigned char gs_lds_raw[];
-    const int tile = tile_order[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int tile;
+    if (bo.bcount) {                                               // block b = the b-th tile of the bucket lists, longest bucket first
+        const int c = bo.bcount[lane];
+        int incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        const unsigned long long above = __ballot(incl > (int)blockIdx.x);
+        const int b = above ? __builtin_ctzll(above) : 63;
+        const int before = __builtin_amdgcn_readlane(incl - c, b);
+        tile = __builtin_amdgcn_readfirstlane(bo.blist[(size_t)b * n_tiles + ((int)blockIdx.x - before)]);
+    } else {
+        tile = tile_order[blockIdx.x];
+    }
     const int tx = tile % tile_w, ty = tile / tile_w;
     const int qx0 = tx * GS_TILE + (wave & 1) * 8, qy0 = ty * GS_TILE + (wave >> 1) * 8;
     const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
@@ -2298,12 +2309,14 @@ extern "C" size_t gs_raster_ws_bytes(int64_t n_isects, int V, int W, int H, int 
     const size_t tiles = (size_t)((W + tile_size - 1) / tile_size) * (size_t)((H + tile_size - 1) / tile_size);
     const size_t n = n_isects > 0 ? (size_t)n_isects : 1;
     const size_t v = V > 0 ? (size_t)V : 1;
-    return 3 * align256(n * sizeof(float4)) + align256(tiles * sizeof(int32_t)) + align256(4 * v * sizeof(float4));
+    return 3 * align256(n * sizeof(float4)) + align256(tiles * sizeof(int32_t)) + align256(64 * sizeof(int32_t)) +
+           align256(64 * tiles * sizeof(int32_t)) + align256(4 * v * sizeof(float4));
 }
 
 struct RasterWs {
     float4 *rec0, *rec1, *rec2;
     int32_t* order;
+    BwdOrder bo;
     float4* vis;                    // scratch of the forward only: 64-byte per-visible records
 };
 static RasterWs carve(void* ws, int64_t n_isects, int V, int tiles)
@@ -2316,6 +2329,8 @@ static RasterWs carve(void* ws, int64_t n_isects, int V, int tiles)
     r.rec1 = (float4*)p; p += align256(n * sizeof(float4));
     r.rec2 = (float4*)p; p += align256(n * sizeof(float4));
     r.order = (int32_t*)p; p += align256((size_t)tiles * sizeof(int32_t));
+    r.bo.bcount = (int32_t*)p; p += align256(64 * sizeof(int32_t));
+    r.bo.blist = (int32_t*)p; p += align256(64 * (size_t)tiles * sizeof(int32_t));
     r.vis = (float4*)p;
     return r;
 }
@@ -2332,8 +2347,8 @@ static GsCount isect_count(int64_t n) { return GsCount{ (long long)n, t_counts_d
 // its ToneFwd / ToneBwd to the kernels (zero = plain compositor).
 static thread_local ToneFwd t_tone_fwd = { 0, nullptr, nullptr };
 static thread_local ToneBwd t_tone_bwd = { 0, nullptr, nullptr, nullptr, nullptr };
-static thread_local CullLog t_cull_log = { nullptr, nullptr, nullptr, nullptr };
-struct CullLogScope { explicit CullLogScope(const CullLog& l) { t_cull_log = l; } ~CullLogScope() { t_cull_log = CullLog{ nullptr, nullptr, nullptr, nullptr }; } };
+static thread_local CullLog t_cull_log = { nullptr, nullptr, nullptr };
+struct CullLogScope { explicit CullLogScope(const CullLog& l) { t_cull_log = l; } ~CullLogScope() { t_cull_log = CullLog{ nullptr, nullptr, nullptr }; } };
 struct ToneFwdScope { explicit ToneFwdScope(const ToneFwd& t) { t_tone_fwd = t; } ~ToneFwdScope() { t_tone_fwd = ToneFwd{ 0, nullptr, nullptr }; } };
 struct ToneBwdScope { explicit ToneBwdScope(const ToneBwd& t) { t_tone_bwd = t; } ~ToneBwdScope() { t_tone_bwd = ToneBwd{ 0, nullptr, nullptr, nullptr, nullptr }; } };
 
@@ -2351,7 +2366,7 @@ static int launch_fwd(int W, int H, int D, const RasterWs& ws, const float* colo
         const size_t lds = gs_raster_lds(4 * (size_t)GS_WIN_Q_BYTES);
         hipLaunchKernelGGL(raster_fwd_window_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
                            ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, isect_count(n_isects), offsets, render, alphas,
-                           last_ids, t_tone_fwd, t_cull_log);
+                           last_ids, t_tone_fwd, t_cull_log, t_cull_log.count ? ws.bo : BwdOrder{ nullptr, nullptr });
         GS_CHECK_LAUNCH();
         return GS_OK;
     }
@@ -2427,7 +2442,7 @@ static int raster_prepare_impl(int W, int H, int tile_size, int D, int V, const 
                            vis, r.rec0, r.rec1, r.rec2);
         GS_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, tiles, isect_count(n_isects), offsets, r.order);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, tiles, isect_count(n_isects), offsets, r.order, r.bo);
     GS_CHECK_LAUNCH();
     return GS_OK;
 }
@@ -2478,8 +2493,9 @@ static int launch_bwd(int W, int H, int D, const RasterWs& ws, const float* colo
             const size_t lds = gs_raster_lds(4 * (size_t)LogLds::WAVE_BYTES);
             static const bool s_log_order = [] { const char* v = getenv("GEOSPLAT_BWD_LOG_ORDER"); return !(v && v[0] == '0'); }();
             hipLaunchKernelGGL(raster_bwd_log_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
-                               s_log_order ? t_cull_log.order : ws.order, ws.rec0, ws.rec1, ws.rec2, background, isect_count(n_isects), offsets, alphas, last_ids,
-                               v_render, v_alphas, v_packed, rec_stride, t_tone_bwd, t_cull_log);
+                               ws.order, ws.rec0, ws.rec1, ws.rec2, background, isect_count(n_isects), offsets, alphas, last_ids,
+                               v_render, v_alphas, v_packed, rec_stride, t_tone_bwd, t_cull_log,
+                               s_log_order ? ws.bo : BwdOrder{ nullptr, nullptr });
             GS_CHECK_LAUNCH();
             return GS_OK;
         }
@@ -2640,15 +2656,14 @@ extern "C" int gs_raster_bwd_tone_acc(int W, int H, int tile_size, int V, const 
 // ---------------------------------------------------------------------------------------------------
 // self-test hook: counts the floats with bit patterns in [lo_bits, hi_bits] for which gs_rcp_exact2 differs from IEEE division
 // ---- cull log (forward -> backward), see struct CullLog -----------------------------------------------------------------------
-static CullLog carve_log(void* log_ws, int64_t n_isects, size_t tiles)
+static CullLog carve_log(void* log_ws, int64_t n_isects)
 {
     const size_t n = n_isects > 0 ? (size_t)n_isects : 1;
     char* p = (char*)log_ws;
     CullLog l;
     l.mask = (unsigned long long*)p; p += align256(4 * n * sizeof(unsigned long long));
     l.idx = (int32_t*)p; p += align256(4 * n * sizeof(int32_t));
-    l.count = (int32_t*)p; p += align256(4 * tiles * sizeof(int32_t));
-    l.order = (int32_t*)p;
+    l.count = (int32_t*)p;
     return l;
 }
 extern "C" size_t gs_raster_log_ws_bytes(int64_t n_isects, int W, int H, int tile_size)
@@ -2656,8 +2671,7 @@ extern "C" size_t gs_raster_log_ws_bytes(int64_t n_isects, int W, int H, int til
     if (tile_size <= 0) return 0;
     const size_t n = n_isects > 0 ? (size_t)n_isects : 1;
     const size_t tiles = (size_t)((W + tile_size - 1) / tile_size) * (size_t)((H + tile_size - 1) / tile_size);
-    return align256(4 * n * sizeof(unsigned long long)) + align256(4 * n * sizeof(int32_t)) + align256(4 * tiles * sizeof(int32_t)) +
-           align256(tiles * sizeof(int32_t));
+    return align256(4 * n * sizeof(unsigned long long)) + align256(4 * n * sizeof(int32_t)) + align256(4 * tiles * sizeof(int32_t));
 }
 
 extern "C" int gs_raster_composite_tone_log(int W, int H, int tile_size, int V, const float* colors, int64_t n_isects,
@@ -2668,18 +2682,9 @@ extern "C" int gs_raster_composite_tone_log(int W, int H, int tile_size, int V, 
     GS_CHECK_ARG(log_ws != nullptr && tile_size == GS_TILE, "log_ws must not be NULL");
     if (log_bytes < gs_raster_log_ws_bytes(n_isects, W, H, tile_size)) { gs_set_error("gs_raster_composite_tone_log: log workspace too small"); return GS_ENOSPC; }
     GS_CHECK_ARG(gs_raster_lanes() == 1, "the cull log needs the default compositor kernels (GEOSPLAT_RASTER_LANES=1)");
-    const size_t tiles = (size_t)((W + tile_size - 1) / tile_size) * (size_t)((H + tile_size - 1) / tile_size);
-    const CullLog l = carve_log(log_ws, n_isects, tiles);
-    int rc;
-    {
-        CullLogScope ls(l);
-        rc = gs_raster_composite_tone(W, H, tile_size, V, colors, n_isects, counts_dev, offsets, render, alphas, last_ids, tone_mode, exposure,
-                                      image, ws, ws_bytes, stream);
-    }
-    if (rc != GS_OK) return rc;
-    hipLaunchKernelGGL(tile_order_log_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (int)tiles, l.count, l.order);
-    GS_CHECK_LAUNCH();
-    return GS_OK;
+    CullLogScope ls(carve_log(log_ws, n_isects));
+    return gs_raster_composite_tone(W, H, tile_size, V, colors, n_isects, counts_dev, offsets, render, alphas, last_ids, tone_mode, exposure,
+                                    image, ws, ws_bytes, stream);
 }
 
 extern "C" int gs_raster_bwd_tone_log_acc(int W, int H, int tile_size, int V, const float* colors, int64_t n_isects,
@@ -2691,8 +2696,7 @@ extern "C" int gs_raster_bwd_tone_log_acc(int W, int H, int tile_size, int V, co
     GS_CHECK_ARG(log_ws != nullptr && tile_size == GS_TILE, "log_ws must not be NULL");
     if (log_bytes < gs_raster_log_ws_bytes(n_isects, W, H, tile_size)) { gs_set_error("gs_raster_bwd_tone_log_acc: log workspace too small"); return GS_ENOSPC; }
     GS_CHECK_ARG(gs_raster_lanes() == 1, "the cull log needs the default compositor kernels (GEOSPLAT_RASTER_LANES=1)");
-    const size_t tiles = (size_t)((W + tile_size - 1) / tile_size) * (size_t)((H + tile_size - 1) / tile_size);
-    CullLogScope ls(carve_log((void*)log_ws, n_isects, tiles));
+    CullLogScope ls(carve_log((void*)log_ws, n_isects));
     return gs_raster_bwd_tone_acc(W, H, tile_size, V, colors, n_isects, counts_dev, offsets, render, alphas, last_ids, tone_mode, exposure,
                                   v_image, v_packed, v_exposure, ws, ws_bytes, stream);
 }

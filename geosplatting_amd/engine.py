@@ -177,7 +177,7 @@ class RenderStep:
         # on the bench scene, identical pixels (gs_front_fwd; the engine never returns gsplat's `meta`).  Stream build 106 -> 88 us,
         # emission 89 -> 83, tile passes 47 -> 43 per view.  First measured as a loss (574 vs 581 views/s): the backward ran 20 %
         # longer because its longest-first tile order came from the RAW list lengths, which the clipping decorrelates from the
-        # backward's work; with the order taken from the cull log (tile_order_log_kernel) it is 660 against 645.
+        # backward's work; with the order taken from the cull log (struct BwdOrder, gs_raster.hip) it is 660 against 645.
         tight = os.environ.get("GEOSPLAT_TIGHT_TILES", "1") != "0"
         # binning keys: 24 bits (three depth passes instead of four) once the depth range of earlier views is known -- key = depth
         # bits - key_base with half an octave of room below the smallest depth seen; a view outside the range is reported through

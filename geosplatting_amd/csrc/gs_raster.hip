@@ -1874,7 +1874,9 @@ raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_
         const unsigned long long above = __ballot(incl > (int)blockIdx.x);
         const int b = above ? __builtin_ctzll(above) : 63;
         const int before = __builtin_amdgcn_readlane(incl - c, b);
-        tile = __builtin_amdgcn_readfirstlane(bo.blist[(size_t)b * n_tiles + ((int)blockIdx.x - before)]);
+        // (the lists hold every tile once when ONE forward ran behind gs_raster_prepare*; anything else: the forward's own order)
+        tile = __builtin_amdgcn_readlane(incl, 63) == n_tiles
+                   ? __builtin_amdgcn_readfirstlane(bo.blist[(size_t)b * n_tiles + ((int)blockIdx.x - before)]) : tile_order[blockIdx.x];
     } else {
         tile = tile_order[blockIdx.x];
     }

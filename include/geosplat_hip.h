@@ -219,7 +219,9 @@ int gs_raster_bwd_tone_acc(int W, int H, int tile_size, int V, const float* colo
 /* The same pair with a CULL LOG between them: the forward appends {stream index, pixel mask} of every record that entered one of its
  * dense batches (per tile quadrant, in stream order) to log_ws (gs_raster_log_ws_bytes; written by the forward, read by the backward of
  * the SAME view), and the backward walks that log from its end instead of repeating the forward's cull and ellipse masks.  Same image
- * bit for bit, same gradients up to the order of the float atomics. */
+ * bit for bit, same gradients up to the order of the float atomics.  The forward also files every tile, by its longest quadrant
+ * log, in bucket lists inside `ws` -- the order in which the backward launches its tiles; the lists are cleared by gs_raster_prepare*,
+ * so they are used when exactly ONE forward ran on the prepared workspace (otherwise the backward falls back to the forward's order). */
 size_t gs_raster_log_ws_bytes(int64_t n_isects, int W, int H, int tile_size);
 int gs_raster_composite_tone_log(int W, int H, int tile_size, int V, const float* colors, int64_t n_isects,
                                  const int64_t* counts_dev, const int32_t* offsets, float* render, float* alphas,

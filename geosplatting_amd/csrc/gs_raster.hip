@@ -1019,7 +1019,10 @@ struct ToneBwd { int mode; const float* exposure; const float* render; const flo
 // lies behind its own termination (5 % of the popped candidates) -- see raster_bwd_log_kernel.
 struct CullLog { int32_t* idx; unsigned long long* mask; int32_t* count; };
 
-static constexpr int GS_WIN_Q = 192;
+#ifndef GS_WIN_Q_SLOTS
+#define GS_WIN_Q_SLOTS 192
+#endif
+static constexpr int GS_WIN_Q = GS_WIN_Q_SLOTS;
 static constexpr int GS_WIN_Q_BYTES = GS_WIN_Q * (16 + 16 + 8 + 4);
 
 __device__ __forceinline__ int win_wrap(int s) { return s >= GS_WIN_Q ? s - GS_WIN_Q : s; }

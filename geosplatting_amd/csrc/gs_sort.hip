@@ -514,7 +514,9 @@ __device__ __forceinline__ void tile_range_sorted(float mx, float my, int radius
 }
 
 #define EM_THREADS 256
+#ifndef EM_PER
 #define EM_PER 4
+#endif
 #define EM_TILE (EM_THREADS * EM_PER)        // ranks per block
 
 // tile rectangle of every visible Gaussian, packed (x0 | y0 << 16, x1 | y1 << 16): computed once in packed order (coalesced) so

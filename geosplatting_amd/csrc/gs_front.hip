@@ -435,6 +435,10 @@ tail_bwd_kernel(GsCount vc, const float* __restrict__ means, const float* __rest
 }
 
 // XCD-private copies of the mid-sized specular levels (not in LDS, at most GS_TAIL_PRIV_MAXRES^2 texels per face): float offsets
+// persistent blocks of a BACKGROUND tail launch (bit 2 of `parts`): a launch that is not the last of the step runs beside the
+// compositor of the following views; its 134 KB blocks cannot share a CU with the compositor's, so it takes half of the CUs and
+// leaves the others (measured at 8 views, batches of 3: 96 / 128 / 160 / 192 / 256 blocks -> 669 / 678 / 675 / 675 / 652 views/s)
+static int tail_background_blocks() { static const int r = [] { const char* v = getenv("GEOSPLAT_TAIL_EARLY_BLOCKS"); const int n = v ? atoi(v) : 0; return n > 0 ? n : 128; }(); return r; }
 static int tail_priv_maxres() { static const int r = [] { const char* v = getenv("GEOSPLAT_TAIL_PRIV_MAXRES"); return v ? atoi(v) : 128; }(); return r; }
 static size_t tail_priv_floats(const EnvDev& e, int mode, long long* level_off)
 {
@@ -792,7 +796,7 @@ extern "C" int gs_tail_bwd_multi_parts(int parts, int N, int n_views, const GsTa
                                        float* v_means, float* v_quats, float* v_scales, float* v_opacities, float* v_normals, float* v_kd,
                                        float* v_ks, int accumulate, const GsEnvGrad* env_grad, void* priv_ws, size_t priv_ws_bytes, void* stream)
 {
-    GS_CHECK_ARG(parts >= 1 && parts <= 3, "parts: bit 0 = shading backward, bit 1 = projection backward");
+    GS_CHECK_ARG(parts >= 1 && parts <= 7 && (parts & 3) != 0, "parts: bit 0 = shading backward, bit 1 = projection backward, bit 2 = background launch");
     GS_CHECK_ARG(N >= 0 && n_views >= 1 && mode >= 0 && mode <= 2 && rec_stride >= 12 && (rec_stride % 4) == 0, "bad sizes, mode or record stride");
     GS_CHECK_ARG(views != nullptr && env_grad != nullptr, "null argument");
     EnvDev e;
@@ -829,7 +833,8 @@ extern "C" int gs_tail_bwd_multi_parts(int parts, int N, int n_views, const GsTa
 #define GS_TAILP_LAUNCH(B, VPG, DIFF)                                                                                                    \
         do {                                                                                                                            \
             const int groups = gs_cdiv(N, B / VPG);                                                                                     \
-            const int max_blocks = eg.lds_floats > 0 ? 256 * (int)fmax(1.0, floor(160.0 * 1024.0 / (double)(plan.lds_bytes + 2048))) : 2048; \
+            int max_blocks = eg.lds_floats > 0 ? 256 * (int)fmax(1.0, floor(160.0 * 1024.0 / (double)(plan.lds_bytes + 2048))) : 2048; \
+            if ((parts & 4) && eg.lds_floats > 0) max_blocks = tail_background_blocks();                                                \
             if (parts & 1) {                                                                                                            \
                 GS_CHECK_HIP(hipFuncSetAttribute((const void*)tail_shade_pairs_kernel<B, VPG, DIFF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes)); \
                 hipLaunchKernelGGL((tail_shade_pairs_kernel<B, VPG, DIFF>), dim3(groups < max_blocks ? groups : max_blocks), dim3(B), plan.lds_bytes, s, N, tv, \

@@ -283,7 +283,10 @@ class RenderStep:
 
         # the tails of the views in ONE call per `tail_batch` views (gs_tail_bwd_multi_parts: the views of a Gaussian on adjacent lanes,
         # its gradients stored once); 0 = one tail launch per view (gs_tail_bwd)
-        tail_batch = int(os.environ.get("GEOSPLAT_TAIL_BATCH", "8")) if (fused_front and n_sets == 1) else 0
+        # Batches of 3 (8 views: after views 2, 5 and 7): the launches that are not the last run as BACKGROUND launches (parts + 4:
+        # half of the CUs) beside the compositor of the following views, and the last one, alone on the GPU, covers 2 views instead
+        # of 8 -- 670 -> 679 views/s (batches of 4: the same; one batch of 8: 670-676; per view: 640).
+        tail_batch = int(os.environ.get("GEOSPLAT_TAIL_BATCH", "3")) if (fused_front and n_sets == 1) else 0
         pending_tails = []
         n_tail_launches = 0
         # the projection half of the LAST tail launch on a front stream (idle by then), beside the prefilter backward, which needs only
@@ -464,7 +467,8 @@ class RenderStep:
                         tail.wait_event(ev_r)
                         F.tail_multi_stage(pending_tails, means, quats, scales_act, opac_act, normals, kd, ks, e, eg, self.min_roughness,
                                            self.max_metallic, mode, b["means"], b["quats"], g_scales_act, g_opac_act, b["normals"], b["kd"],
-                                           b["ks"], accumulate=n_tail_launches > 0, priv=tail_priv, parts=1 if split_now else 3)
+                                           b["ks"], accumulate=n_tail_launches > 0, priv=tail_priv,
+                                           parts=1 if split_now else (3 if i == n_views - 1 else 7))
                     if split_now:
                         ev_sh = torch.cuda.Event(); ev_sh.record(tail)
                         pstream = sides[0]

@@ -164,7 +164,8 @@ def tail_multi_stage(views, means: Tensor, quats: Tensor, scales: Tensor, opacit
                      eps2d: float = 0.3, priv: Optional[Tensor] = None, parts: int = 3) -> None:
     """A7 + S1-S3 backward of SEVERAL views in one call (gs_tail_bwd_multi_parts): `views` = list of
     (viewmat, K, cam_pos, vis_records, v_packed, packed_index, W, H).  accumulate False: the gradient buffers are overwritten.
-    parts: 1 = the shading half only, 2 = the projection half only (after the shading half of the same call), 3 = both."""
+    parts: 1 = the shading half only, 2 = the projection half only (after the shading half of the same call), 3 = both;
+    + 4 = a background launch (the shading half on half of the CUs, beside the compositor of the following views)."""
     lib = L.lib()
     arr = (L.GsTailView * len(views))()
     stride = None

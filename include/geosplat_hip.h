@@ -549,7 +549,10 @@ int gs_tail_bwd_multi(int N, int n_views, const GsTailView* views /*host array*/
 /* The two halves of gs_tail_bwd_multi as separate calls (bit 0 of `parts`: the S1-S3 shading backward -- writes v_means (its
  * view-direction part), v_normals, v_kd, v_ks and the texel gradients; bit 1: the A7 projection backward -- ADDS its part to
  * v_means, writes v_quats, v_scales, v_opacities), so that the caller can put them on different streams: the projection half has
- * to follow the shading half of the same call (v_means), nothing else orders them.  parts == 3 is gs_tail_bwd_multi. */
+ * to follow the shading half of the same call (v_means), nothing else orders them.  parts == 3 is gs_tail_bwd_multi.
+ * Bit 2 (with bit 0): a BACKGROUND launch -- the shading half on half of the CUs (128 persistent workgroups), for a tail that is
+ * not the last of its step and runs beside the compositor of the following views; same results, same order of the sums per
+ * Gaussian (texel gradients are float atomics in every form). */
 int gs_tail_bwd_multi_parts(int parts, int N, int n_views, const GsTailView* views /*host array*/, const float* means, const float* quats,
                             const float* scales, const float* opacities, const float* normals, const float* kd, const float* ks,
                             float min_roughness, float max_metallic, int mode, const GsEnv* env, float eps2d, int rec_stride,

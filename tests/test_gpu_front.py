@@ -433,6 +433,14 @@ def test_tail_multi_equals_sum_of_view_tails(cuda, mode):
     multi(views, t, egt, False, parts=2)
     torch.cuda.synchronize()
     close(t, tb, tl, *snaps[8], "parts")
+    # background launches (parts + 4: half of the CUs) as the engine issues them: three views, three more on top, then the last two
+    t, tb, tl = fresh(123.0)
+    egt = grad_struct(tb, tl)
+    multi(views[:3], t, egt, False, parts=7)
+    multi(views[3:6], t, egt, True, parts=7)
+    multi(views[6:], t, egt, True, parts=3)
+    torch.cuda.synchronize()
+    close(t, tb, tl, *snaps[8], "background 3 + 3 + 2")
 
 
 def test_engine_front_modes_agree(cuda, monkeypatch):

@@ -286,7 +286,8 @@ class RenderStep:
         # Batches of 3 (8 views: after views 2, 5 and 7): the launches that are not the last run as BACKGROUND launches (parts + 4:
         # half of the CUs) beside the compositor of the following views, and the last one, alone on the GPU, covers 2 views instead
         # of 8 -- 670 -> 679 views/s (batches of 4: the same; one batch of 8: 670-676; per view: 640).
-        tail_batch = int(os.environ.get("GEOSPLAT_TAIL_BATCH", "3")) if (fused_front and n_sets == 1) else 0
+        tail_sched = [int(x) for x in os.environ.get("GEOSPLAT_TAIL_BATCH", "3").split(",")]     # "3" or a schedule "3,4,1" (last repeats)
+        tail_batch = tail_sched[0] if (fused_front and n_sets == 1) else 0
         pending_tails = []
         n_tail_launches = 0
         # the projection half of the LAST tail launch on a front stream (idle by then), beside the prefilter backward, which needs only
@@ -460,7 +461,7 @@ class RenderStep:
             eg = g_sets[0 if i < half else n_sets - 1][2]
             if tail_batch > 0:
                 pending_tails.append((vm, K, cam_pos, s["vis_records"], v_packed, s["packed_index"], W, H))
-                if len(pending_tails) == tail_batch or i == n_views - 1:
+                if len(pending_tails) == tail_sched[min(n_tail_launches, len(tail_sched) - 1)] or i == n_views - 1:
                     ev_r = torch.cuda.Event(); ev_r.record(main)
                     split_now = proj_split and i == n_views - 1
                     with torch.cuda.stream(tail):

@@ -425,16 +425,13 @@ class TextureSplitSum:
 
 
 def _mip_chain_backward(g_mips: List[Tensor], g_base: Tensor) -> Tensor:
+    """Diffuse backward and the mip links, each ADDING into the (fresh, contiguous) gradient of the level it feeds: the sums of the
+    reference's autograd graph in the same order, without separate additions (accumulate flags of the two kernels)."""
     gd = g_base.contiguous()
-    gdb = torch.empty_like(gd)
-    L.check(L.lib().gs_diffuse_cubemap_bwd(gd.shape[1], L.ptr(gd), L.ptr(gdb), 0, L.stream()), "gs_diffuse_cubemap_bwd")
-    g_mips[-1] = g_mips[-1] + gdb
+    L.check(L.lib().gs_diffuse_cubemap_bwd(gd.shape[1], L.ptr(gd), L.ptr(g_mips[-1]), 1, L.stream()), "gs_diffuse_cubemap_bwd")
     for idx in range(len(g_mips) - 1, 0, -1):
-        dout = g_mips[idx].contiguous()
-        R = dout.shape[1]
-        up = torch.empty(6, 2 * R, 2 * R, 3, dtype=torch.float32, device=dout.device)
-        L.check(L.lib().gs_cubemap_mip_bwd(R, L.ptr(dout), L.ptr(up), 0, L.stream()), "gs_cubemap_mip_bwd")
-        g_mips[idx - 1] = g_mips[idx - 1] + up
+        R = g_mips[idx].shape[1]
+        L.check(L.lib().gs_cubemap_mip_bwd(R, L.ptr(g_mips[idx]), L.ptr(g_mips[idx - 1]), 1, L.stream()), "gs_cubemap_mip_bwd")
     return g_mips[0]
 
 

@@ -10,8 +10,8 @@ short = lambda n: n.split('(')[0].replace('void ', '')[:40]
 ap = [i for i, r in enumerate(rows) if ('tile_apply' in r[0] or 'specular_apply' in r[0])]
 rb = [i for i, r in enumerate(rows) if 'raster_bwd' in r[0]]
 groups = []                                               # runs of prefilter applies (one run = one direction of one step)
-for i in ap:
-    if groups and i - groups[-1][-1] <= 4:
+for i in ap:                                              # (by TIME: the other streams' kernels sit between the applies of one run)
+    if groups and rows[i][1] - rows[groups[-1][-1]][2] < 0.25e6:
         groups[-1].append(i)
     else:
         groups.append([i])

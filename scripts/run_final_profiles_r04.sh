@@ -12,6 +12,7 @@ timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python be
 DB=$(ls $OUT/stats/*/*_results.db $OUT/stats/*_results.db 2>/dev/null | head -1)
 python scripts/rocprof_summary.py $DB $OUT/r04_b_final_kernel_stats.txt
 python scripts/concurrency_analysis.py $DB > $OUT/r04_concurrency_one_step.txt 2>&1
+python scripts/step_boundary_timeline.py $DB > $OUT/r04_step_boundary.txt 2>&1
 rm -rf $OUT/stats
 # one view alone through the engine
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/view -o v -- python scripts/view_kernels_engine.py 7 8 > $OUT/view.log 2>&1
@@ -23,6 +24,8 @@ cp gpurun_out/pmc_r04/pmc_view.txt $OUT/r04_pmc_view.txt
 python scripts/make_profile_json.py gpurun_out/pmc_r04/pmc_traffic_raw.json $OUT/r04_pmc_traffic.json ${1:-?} > $OUT/traffic_json.log 2>&1
 timeout 600 python scripts/raster_stats_engine.py 7 $OUT/r04_raster_stats.json > $OUT/r04_raster_stats.txt 2>&1
 timeout 600 python scripts/prefilter_bench.py > $OUT/r04_prefilter_bench.txt 2>&1
+timeout 600 python scripts/host_ahead.py 20 > $OUT/r04_host_ahead.txt 2>&1
+timeout 900 python scripts/soak.py 2000 > $OUT/r04_soak.txt 2>&1
 # two ranks on the one GPU (gloo): both scaling modes of bench.py end to end -- never a measurement
 export GEOSPLAT_DEBUG_SHARE_GPU=1
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --settle-seconds 0 > $OUT/r04_bench_2rank_strong_debug.log 2>&1

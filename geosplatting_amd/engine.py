@@ -51,6 +51,22 @@ class PathParams:
         return {k: tuple(v.shape) if v.dim() > 0 else (1,) for k, v in self.named().items()}
 
 
+def _auto_tail_schedule(n_views: int):
+    """Views per tail launch of a step.  A background launch (half of the CUs) works a view off in about half the time the
+    compositor needs for one, and the batch before the last has to be done when the last compositor backward ends: the LAST batch
+    takes two views, the ones before it up to three (8 views: 3 + 3 + 2; 7: 3 + 2 + 2; 6: 2 + 2 + 2; 5: 3 + 2; 4: 2 + 2; 3: 2 + 1)."""
+    if n_views <= 2:
+        return [max(n_views, 1)]
+    if n_views == 3:
+        return [2, 1]
+    r, sched = n_views - 2, []
+    while r > 0:
+        k = 3 if (r >= 3 and r != 4) else min(r, 2)
+        sched.append(k)
+        r -= k
+    return sched + [2]
+
+
 class RenderStep:
     def __init__(self, params: PathParams, min_roughness: float = 0.1, max_metallic: float = 1.0, mode: str = "pbr",
                  tone_type: str = "naive", prefilter: bool = True, fused: bool = True):
@@ -286,7 +302,10 @@ class RenderStep:
         # Batches of 3 (8 views: after views 2, 5 and 7): the launches that are not the last run as BACKGROUND launches (parts + 4:
         # half of the CUs) beside the compositor of the following views, and the last one, alone on the GPU, covers 2 views instead
         # of 8 -- 670 -> 679 views/s (batches of 4: the same; one batch of 8: 670-676; per view: 640).
-        tail_sched = [int(x) for x in os.environ.get("GEOSPLAT_TAIL_BATCH", "3").split(",")]     # "3" or a schedule "3,4,1" (last repeats)
+        # Other view counts (8 views over 2 GPUs: 4 per rank): 4 views 2 + 2 568 against 552 (one batch) / 533-551 (3 + 1), 6 views
+        # 2 + 2 + 2 646 against 627 / 639 (3 + 3): the batch before the last has to be done when the last compositor backward ends.
+        tb = os.environ.get("GEOSPLAT_TAIL_BATCH", "auto")                                       # "auto", "3" or a schedule "3,4,1" (last repeats)
+        tail_sched = _auto_tail_schedule(len(cameras)) if tb == "auto" else [int(x) for x in tb.split(",")]
         tail_batch = tail_sched[0] if (fused_front and n_sets == 1) else 0
         pending_tails = []
         n_tail_launches = 0

@@ -157,3 +157,14 @@ def test_stage_handoff_files(tmp_path):
     for (k, a_), (_, b_) in zip(m.named_parameters().items(), m3.named_parameters().items()):
         assert torch.equal(a_, b_), k
     assert m3.load_checkpoint(tmp_path / "nowhere") is None
+
+
+def test_tail_schedule_covers_every_view_count():
+    """engine._auto_tail_schedule: the tail launches of a step cover every view once, the last launch takes at most two views
+    (it runs alone on the GPU), the background launches before it at most three."""
+    from geosplatting_amd.engine import _auto_tail_schedule
+    for n in range(1, 33):
+        sched = _auto_tail_schedule(n)
+        assert sum(sched) == n and all(k >= 1 for k in sched)
+        assert sched[-1] <= 2 and all(k <= 3 for k in sched[:-1])
+    assert _auto_tail_schedule(8) == [3, 3, 2] and _auto_tail_schedule(4) == [2, 2] and _auto_tail_schedule(1) == [1]

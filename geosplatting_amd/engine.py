@@ -54,11 +54,11 @@ class PathParams:
 def _auto_tail_schedule(n_views: int):
     """Views per tail launch of a step.  A background launch (half of the CUs) works a view off in about half the time the
     compositor needs for one, and the batch before the last has to be done when the last compositor backward ends: the LAST batch
-    takes two views, the ones before it up to three (8 views: 3 + 3 + 2; 7: 3 + 2 + 2; 6: 2 + 2 + 2; 5: 3 + 2; 4: 2 + 2; 3: 2 + 1)."""
-    if n_views <= 2:
-        return [max(n_views, 1)]
-    if n_views == 3:
-        return [2, 1]
+    takes two views, the ones before it up to three (8 views: 3 + 3 + 2; 7: 3 + 2 + 2; 6: 2 + 2 + 2; 5: 3 + 2).  With four views or
+    fewer (the strong split over 2 / 4 GPUs) the measured best ends on single views: 4: 2 + 1 + 1 (583 views/s against 571 for
+    2 + 2, 552 for one launch), 3: 2 + 1 (519 / 499), 2: 1 + 1 (429 / 418)."""
+    if n_views <= 4:
+        return {0: [1], 1: [1], 2: [1, 1], 3: [2, 1], 4: [2, 1, 1]}[max(n_views, 0)]
     r, sched = n_views - 2, []
     while r > 0:
         k = 3 if (r >= 3 and r != 4) else min(r, 2)

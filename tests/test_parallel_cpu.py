@@ -167,4 +167,4 @@ def test_tail_schedule_covers_every_view_count():
         sched = _auto_tail_schedule(n)
         assert sum(sched) == n and all(k >= 1 for k in sched)
         assert sched[-1] <= 2 and all(k <= 3 for k in sched[:-1])
-    assert _auto_tail_schedule(8) == [3, 3, 2] and _auto_tail_schedule(4) == [2, 2] and _auto_tail_schedule(1) == [1]
+    assert _auto_tail_schedule(8) == [3, 3, 2] and _auto_tail_schedule(4) == [2, 1, 1] and _auto_tail_schedule(2) == [1, 1] and _auto_tail_schedule(1) == [1]

@@ -196,8 +196,12 @@ def test_hashgrid_fixed_point_table_gradient(monkeypatch):
     assert err_fixed.max().item() <= err_float.max().item() * 1.5 + 1e-12          # no worse than fp32 LDS accumulation
     small = (ref.abs() > 0) & (ref.abs() < 1e-4 * scale)                            # rows four decades below the largest
     assert small.any()
-    # (cancellation makes the relative error of a small row unbounded for ANY accumulation: compare with the float path)
-    assert (err_fixed[small] / ref.abs()[small]).max().item() <= 1.5 * (err_float[small] / ref.abs()[small]).max().item() + 1e-6
+    # (cancellation makes the relative error of a small row unbounded for ANY accumulation: compare with the float path.  The
+    #  float path's sums depend on the order of its LDS atomics, so its MAXIMUM over the small rows moves from run to run -- 0.0125
+    #  to 0.03 against a fixed 0.0194 here: the mean is the stable statistic, the maximum gets room)
+    rel_fixed, rel_float = err_fixed[small] / ref.abs()[small], err_float[small] / ref.abs()[small]
+    assert rel_fixed.mean().item() <= 1.5 * rel_float.mean().item() + 1e-9
+    assert rel_fixed.max().item() <= 4.0 * rel_float.max().item() + 1e-6
     assert torch.equal(a1.cpu() == 0, ref == 0)                                     # untouched rows are exactly zero
 
 

@@ -246,7 +246,9 @@ def test_engine_fullsize_equals_call_shaped_path(cuda, monkeypatch, tight):
         assert scale > 0, k
         err = float((got - want).abs().max()) / scale
         print(f"  {k:10s} engine vs call-shaped path: {err:.2e}")
-        assert err < (1e-4 if k in ("quats", "scales") else 2e-5), (k, err)
+        # (exposure: ONE scalar, the sum of 20 000 per-wave float atomics of both signs in either path -- it moves with their
+        #  order, 0.5e-5 to 2.1e-5 over a dozen runs; everything else is summed per Gaussian / per texel)
+        assert err < (1e-4 if k in ("quats", "scales", "exposure") else 2e-5), (k, err)
 
 
 def test_stage1_iteration_at_full_scale():

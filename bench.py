@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--cubemap-res", type=int, default=512)
     ap.add_argument("--no-prefilter", action="store_true", help="diagnostic only: keep the pyramid fixed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-call-shaped", action="store_true", help="skip the `call_shaped` leg (the same step through RenderableAttrs.splat + autograd)")
     ap.add_argument("--graph", type=int, default=-1, help="-1 (default): 2 when a rank renders at most two views per step, else 0; 1: replay each step as one HIP graph (--gpus 1 only; measured 12 % slower than eager launches at 8 views per GPU: a graph serialises what the eager queues overlap); 2: only the VIEWS of a step as a graph, prefilter and collectives eager (any --gpus; for few views per GPU, e.g. --views-total 8 on 8 GPUs); 0 (default): eager launches")
     ap.add_argument("--kernel-iters", type=int, default=20)
     return ap.parse_args()
@@ -168,6 +169,46 @@ def time_view_without_prefilter(params, cam, up, iters):
     except Exception as e:                                   # the diagnostic must never take the bench line down
         out["graph_error"] = repr(e)[:200]
     return out
+
+
+def time_call_shaped(params, cams, ups, steps, warmup):
+    """The SAME step through the reference's call shape (rfstudio/model/geosplat.py:863-879 + rfstudio/optim/optimizer.py:107): the
+    prefilter through autograd, a Python loop of RenderableAttrs.splat() over the views, a loss, ONE backward() into the leaves'
+    .grad -- no engine object, no callback (geosplatting_amd/viewbatch.py is what splat() runs).  The loss is sum_i <image_i, w_i>
+    with the cotangents w_i the engine's timed steps use, so both paths do the same work."""
+    import geosplatting_amd as gs
+    leaf = lambda t: t.detach().clone().requires_grad_(True)
+
+    class G:
+        pass
+    g = G(); g.means, g.scales, g.quats, g.opacities = leaf(params.means), leaf(params.scales), leaf(params.quats), leaf(params.opacities)
+    attrs = gs.RenderableAttrs(kd=leaf(params.kd), ks=leaf(params.ks), normals=leaf(params.normals))
+    cubemap, exposure = leaf(params.cubemap), leaf(params.exposure)
+    leaves = [g.means, g.scales, g.quats, g.opacities, attrs.kd, attrs.ks, attrs.normals, cubemap, exposure]
+
+    def step():
+        for t in leaves:
+            t.grad = None                                    # optimizer.zero_grad(set_to_none=True)
+        env = gs.as_splitsum(cubemap)
+        images = [attrs.splat(g, [cam], exposure=exposure, envmap=env, min_roughness=0.1, max_metallic=1.0) for cam in cams]
+        loss = images[0].new_zeros(())
+        for img, w in zip(images, ups):
+            loss = loss + torch.dot(img.reshape(-1), w.reshape(-1))      # <img, w>: one launch forward, one backward
+        loss.backward()
+    for _ in range(max(2, warmup)):                          # (first step: exact counts; from the second on the capacity protocol)
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    cap = gs.viewbatch._state(params.means.device).caps.get((params.means.shape[0], cams[0].width, cams[0].height))
+    return {"views_per_s": len(cams) * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "views_per_step": len(cams),
+            "n_isects_cap": None if cap is None else cap.i_cap,
+            "what": "as_splitsum(cubemap) [autograd] -> for cam in batch: RenderableAttrs.splat(...) -> loss = sum <img, w> -> ONE "
+                    "loss.backward() into .grad of means/scales/quats/opacities/kd/ks/normals/cubemap/exposure; same kernels as `value` "
+                    "(fused front, cull-log compositor, batched tails), driven by autograd instead of engine.RenderStep"}
 
 
 def file_sha16(path):
@@ -446,6 +487,13 @@ def main():
             acc.setdefault(name, []).append(a.elapsed_time(b))
         step.kernel_events = None
         engine_ms = {k: sum(v) / len(v) for k, v in acc.items()} or None
+    call_shaped = None
+    if world == 1 and len(cams) > 0 and not args.no_prefilter and not args.no_call_shaped:
+        try:
+            call_shaped = time_call_shaped(params, cams, ups, args.steps, args.warmup)
+            call_shaped["frac_of_value"] = call_shaped["ms_per_step"] and (dt / args.steps * 1e3) / call_shaped["ms_per_step"]
+        except Exception as e:                               # never take the bench line down
+            call_shaped = {"error": repr(e)[:300]}
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -552,6 +600,7 @@ def main():
                               "step_frac_of_8TBs_incl_prefilter": (None if not pre or pre.get("table_bytes_from_hbm_per_step") is None else
                                                                    (view_bytes * len(cams) + pre["table_bytes_from_hbm_per_step"] + 2 * pre.get("pyramid_bytes", 0))
                                                                    / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS)},
+            "call_shaped": call_shaped,
             "strong_1gpu_ms": ms_per_step if (world == 1 and strong) else None,
             "scale_model": scale_model(view_ms, pre, N, args.cubemap_res, views_total, ms_per_step if world == 1 else None),
             "gpu_view_ms_without_prefilter": view_ms,

@@ -2,7 +2,8 @@
 
 Public surface (mirrors the reference's two call boundaries):
   rasterization(...)                      == gsplat.rasterization as called at rfstudio/model/gsplat.py:334-355
-  RenderableAttrs(kd, ks, normals).splat  == rfstudio/model/geosplat.py:53-132
+  RenderableAttrs(kd, ks, normals).splat  == rfstudio/model/geosplat.py:53-132  (one autograd node per view on the fused kernels:
+                                             viewbatch.py; GEOSPLAT_SPLAT=ops = shade -> rasterization -> tone_map op by op)
   as_splitsum(cubemap) / TextureSplitSum  == rfstudio/graphics/_mesh/_texture.py:530-613
   render_rgba, shade, tone_map            == the pieces in between
   mesh_to_splats(vertices, faces, vn)     == MGAdapter.make, rfstudio/model/geosplat.py:426-472 (section 8f rank 1)
@@ -22,6 +23,7 @@ from .loss import photo_loss  # noqa: F401
 from .mesh import mesh_to_splats, vertex_normals  # noqa: F401
 from .rasterization import rasterization  # noqa: F401
 from .shading import RenderableAttrs, get_fg_lut, render_depth, render_rgb, render_rgba, shade, tone_map  # noqa: F401
+from . import viewbatch  # noqa: F401
 from .splitsum import TextureSplitSum, as_splitsum, diffuse_cubemap, specular_cubemap  # noqa: F401
 
 __version__ = "0.1.0"

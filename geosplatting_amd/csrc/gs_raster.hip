@@ -1250,7 +1250,10 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
                 const int hb = 2 * l2 + ((l2 > 0 && ((c >> (l2 - 1)) & 1)) ? 1 : 0);
                 b = 61 - (hb > 61 ? 61 : hb);
             }
-            bo.blist[(size_t)b * n_tiles + atomicAdd(bo.bcount + b, 1)] = tile;
+            // (a SECOND forward on one prepared workspace -- bench loops, tests -- counts past n_tiles: never stored, and the
+            //  backward's `sum == n_tiles` test rejects the over-counted lists and falls back to the forward's tile order)
+            const int k = atomicAdd(bo.bcount + b, 1);
+            if (k < n_tiles) bo.blist[(size_t)b * n_tiles + k] = tile;
         }
     }
 

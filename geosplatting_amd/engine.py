@@ -93,7 +93,7 @@ class RenderStep:
         self._status_host = None           # pinned snapshot used by the graph-capture paths (one buffer, refreshed by every replay)
         self._status_event = None
         self._status_pending = collections.deque()   # eager steps: (pinned snapshot of the word, event), one per step, each looked at ONCE
-        self._status_pool = []             # pinned int64[3] buffers waiting for reuse
+        self._status_pool = []             # pinned int64[4] buffers waiting for reuse
         self.kernel_events = None          # set to a list: (name, start event, end event) around the compositor launches (bench.py)
         self._seen_counts = []
         self._exact_max_i = 0              # largest intersection count read back by an exact-mode step
@@ -268,6 +268,7 @@ class RenderStep:
                 egs.levels[i] = g.data_ptr()
             g_sets.append((gb, gl, egs, g_flat))
         g_base, g_levels, eg, _ = g_sets[0]
+        self.last_texel_grads = (g_base, g_levels)           # d loss / d pyramid of this step (summed over the local views): tests read it
         half = (len(cameras) + 1) // 2 if n_sets == 2 else len(cameras)
         g_cube_first = None
         ws_bytes = lib.gs_shade_bwd_ws_bytes(C.byref(e), mode) if shade_private_copies() else 0

@@ -302,3 +302,110 @@ def test_stage1_iteration_at_full_scale():
         for k, v in model.named_parameters().items():
             assert torch.isfinite(v.grad).all(), k
     assert model._render_step._i_cap is not None                              # those steps ran on the capacity protocol
+
+
+def _oracle_views(sc, cams, ups, exposure, scales, opac, base, levels, lut):
+    """The oracle's chain (shade -> rasterize -> tone map and the whole backward) for several views of one scene: images and the
+    gradients SUMMED over the views, in the parameterisation of the product's leaves (log-scales, logit opacities)."""
+    means, quats = sc.splats.means.numpy(), sc.splats.quats.numpy()
+    nrm, kd, ks = sc.normals.numpy(), sc.kd.numpy(), sc.ks.numpy()
+    tot, images = None, []
+    for cam, v in zip(cams, ups):
+        cam_pos = cam.c2w[:, 3].numpy()
+        vm, K = cam.view_matrix.numpy(), cam.intrinsic_matrix.numpy()
+        W, H = cam.width, cam.height
+        col = oracle.shade_fwd(means, nrm, kd, ks, cam_pos, lut, base, levels)
+        m = oracle.rasterization(means, quats, scales, opac, col, vm, K, W, H)
+        rgba = np.concatenate([m["render"], m["alphas"][..., None]], -1)
+        images.append(oracle.tonemap_fwd(rgba, exposure, "naive"))
+        v_rgba, v_e = oracle.tonemap_bwd(rgba, exposure, v, "naive")
+        gr = oracle.rasterization_bwd(means, quats, scales, opac, col, vm, K, W, H, m, v_rgba[..., :3], v_rgba[..., 3])
+        gsh = oracle.shade_bwd(means, nrm, kd, ks, cam_pos, lut, base, levels, gr["v_colors"])
+        g = {"means": gr["v_means"] + gsh["v_means"], "scales": gr["v_scales"] * scales, "quats": gr["v_quats"],
+             "opacities": (gr["v_opacities"] * opac * (1 - opac))[:, None], "kd": gsh["v_kd"], "ks": gsh["v_ks"],
+             "normals": gsh["v_normals"], "exposure": np.float64(v_e)}
+        for i, l in enumerate(gsh["v_levels"]):
+            g[f"level{i}"] = l
+        tot = g if tot is None else {k: tot[k] + g[k] for k in g}
+    return images, tot
+
+
+@pytest.mark.parametrize("level,path", [(6, "splat"), (7, "splat"), (6, "engine"), (7, "engine")])
+def test_step_fullsize_vs_oracle(cuda, level, path):
+    """The BENCHMARKED launch sequences against the oracle with no HIP-vs-HIP hop in between, at 491 520 / 1 966 080 Gaussians, 800^2,
+    THREE views per step, second step (capacity protocol, 24-bit depth keys, clipped tile rectangles, cull log, the views' tails
+    batched as 2 + 1):
+      path = "splat" : the reference's call shape -- a loop of RenderableAttrs.splat() and ONE backward() (viewbatch.py);
+      path = "engine": engine.RenderStep (what bench.py's `value` times).
+    Images within 1e-6 of the oracle's (the compositor is bit-identical, the tone map differs in libm's last bit); every gradient
+    summed over the views at the bars of test_view_fullsize_vs_oracle: 1e-5 max-norm, 1e-4 for the quats / scales of flat disks."""
+    import geosplatting_amd as gs
+    import geosplatting_amd.synthetic as syn
+    from geosplatting_amd.engine import PathParams, RenderStep
+    sc, _ = sphere_case(level, 800, view=1, cubemap_res=512)
+    cams = syn.blender_cameras(num=8, width=800, height=800)[1:4]
+    exposure = 1.15
+    with torch.no_grad():
+        env0 = gs.as_splitsum(sc.cubemap.to(cuda))
+    base = env0.base.cpu().numpy(); levels = [l.cpu().numpy() for l in env0.levels]
+    lut = gs.get_fg_lut(torch.device("cpu"))[0].numpy()
+    scales = sc.splats.scales.to(cuda).exp().cpu().numpy()                    # activations: the device ops the product runs (see above)
+    opac = torch.sigmoid(sc.splats.opacities.to(cuda)).squeeze(-1).cpu().numpy()
+    g = torch.Generator().manual_seed(3)
+    ups = [torch.rand(800, 800, 4, generator=g) * 2 - 1 for _ in cams]
+    ref_images, want = _oracle_views(sc, cams, [u.numpy() for u in ups], exposure, scales, opac, base, levels, lut)
+    ups_d = [u.to(cuda) for u in ups]
+    sp = sc.splats
+    d = lambda x: x.clone().to(cuda).requires_grad_(True)
+    got = None
+    if path == "splat":
+        gs.viewbatch.reset()
+        for it in range(2):                                                   # second step: capacity protocol + 24-bit keys
+            class G:
+                pass
+            gsn = G(); gsn.means = d(sp.means); gsn.scales = d(sp.scales); gsn.quats = d(sp.quats); gsn.opacities = d(sp.opacities)
+            attrs = gs.RenderableAttrs(kd=d(sc.kd), ks=d(sc.ks), normals=d(sc.normals))
+            tb = d(env0.base.cpu()); tl = [d(l.cpu()) for l in env0.levels]
+            et = torch.tensor(exposure, device=cuda, requires_grad=True)
+            env = gs.TextureSplitSum(tb, tl)
+            imgs = [attrs.splat(gsn, [c], exposure=et, envmap=env, min_roughness=0.1, max_metallic=1.0) for c in cams]
+            sum((i * u).sum() for i, u in zip(imgs, ups_d)).backward()
+            torch.cuda.synchronize()
+        cap = gs.viewbatch._state(cuda).caps[(sp.num, 800, 800)]
+        assert cap.i_cap is not None and cap.keys()[0] == 24
+        images = [i.detach() for i in imgs]
+        got = {"means": gsn.means.grad, "scales": gsn.scales.grad, "quats": gsn.quats.grad, "opacities": gsn.opacities.grad,
+               "kd": attrs.kd.grad, "ks": attrs.ks.grad, "normals": attrs.normals.grad, "exposure": et.grad}
+        for i, l in enumerate(tl):
+            got[f"level{i}"] = l.grad
+    else:
+        params = PathParams(*(x.to(cuda).contiguous() for x in (sp.means, sp.scales, sp.quats, sp.opacities, sc.normals, sc.kd, sc.ks,
+                                                                 sc.cubemap)), torch.tensor(exposure, device=cuda))
+        step = RenderStep(params, prefilter=False)                            # (pyramid held fixed: the texel gradients are the output)
+        step._static_env = gs.TextureSplitSum(env0.base, list(env0.levels))
+        for it in range(2):
+            grads, images = step(cams, lambda i, img: ups_d[i], all_reduce=False, keep_images=True)
+            torch.cuda.synchronize()
+            assert step.poll_capacity(wait=True)
+        assert step._i_cap is not None and not step._key32
+        got = {k: grads[k] for k in ("means", "scales", "quats", "opacities", "kd", "ks", "normals", "exposure")}
+        got.update({f"level{i}": l for i, l in enumerate(step.last_texel_grads[1])})
+    print()
+    for a, b in zip(images, ref_images):
+        mx, fr = _report("image", a.cpu().numpy(), b)
+        assert mx < 1e-6 and fr == 0.0
+    v_logscale = want["scales"]
+    for name, w in want.items():
+        a = got[name].detach().cpu().numpy().reshape(np.shape(w))
+        scale = np.abs(w).max()
+        if name == "quats":
+            scale = max(scale, np.abs(v_logscale).max())
+        if name == "exposure":
+            err = abs(float(a) - float(w)) / max(1.0, abs(float(w)))
+            print(f"  exposure     {float(a):.6e} vs {float(w):.6e}")
+            assert err < 1e-4, err      # ONE scalar: the sum of ~60 000 per-wave float atomics of both signs (moves with their order)
+            continue
+        mx, fr = _report(name, a, w, scale, atol_rel=1e-5 if name.startswith("level") else 1e-6)
+        tol = 1e-4 if name in ("quats", "scales") else 1e-5
+        assert mx < tol, f"{name}: max-norm {mx:.3e}"
+        assert fr < (ELEM_FRAC_MAX if name in ("quats", "scales") else 1e-5), f"{name}: element-wise outliers {fr:.3e}"

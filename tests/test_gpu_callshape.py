@@ -137,8 +137,8 @@ def test_capacity_overflow_raises_in_backward_and_the_retry_is_right(cuda, monke
     import geosplatting_amd as gs
     from geosplatting_amd.cameras import orbit_cameras
     sc, _ = sphere_case(4, 128, cubemap_res=64)
-    far = orbit_cameras(4, 6.0, 30.0, 128, 128, focal=0.5 * 128 / math.tan(0.5 * 0.6911112))[:2]
-    near = orbit_cameras(4, 1.6, 30.0, 128, 128, focal=0.5 * 128 / math.tan(0.5 * 0.6911112))[:2]     # splats several times larger on screen
+    far = orbit_cameras(4, 24.0, 30.0, 128, 128, focal=0.5 * 128 / math.tan(0.5 * 0.6911112))[:2]
+    near = orbit_cameras(4, 2.667, 30.0, 128, 128, focal=0.5 * 128 / math.tan(0.5 * 0.6911112))[:2]     # the sphere fills the frame: several tiles per Gaussian
     g = torch.Generator().manual_seed(6)
     ups = [(torch.rand(128, 128, 4, generator=g) * 2 - 1).to(cuda) for _ in far]
     monkeypatch.setenv("GEOSPLAT_SPLAT", "ops")

@@ -92,8 +92,8 @@ def test_prefilter_fullsize_subset(cuda):
     assert mx < TOL and fr < ELEM_FRAC_MAX
 
 
-@pytest.mark.parametrize("level,activations", [(6, "device"), (7, "device"), (7, "host")])
-def test_view_fullsize_vs_oracle(cuda, level, activations):
+@pytest.mark.parametrize("level,activations", [(6, "device"), (7, "device"), (7, "host"), (7, "device-ops")])
+def test_view_fullsize_vs_oracle(cuda, monkeypatch, level, activations):
     """One whole view at 491 520 / 1 966 080 Gaussians, 800^2, against the oracle: indices bit-exact, image and all gradients.
 
     activations="device": exp / sigmoid of the raw parameters evaluated once (torch on the GPU, what the product runs) and handed
@@ -101,6 +101,9 @@ def test_view_fullsize_vs_oracle(cuda, level, activations):
     host's libm, as a reference run would -- the inputs of the two compositors then differ by an ulp in a few scales, and the
     stored-state backward amplifies that (see below); the run keeps that sensitivity a tracked, bounded number."""
     import geosplatting_amd as gs
+    if activations == "device-ops":          # splat() op by op (shade -> rasterization -> tone_map: the kernels behind `meta`) instead of the
+        monkeypatch.setenv("GEOSPLAT_SPLAT", "ops")          # fused front / cull-log compositor / tail, which is the default
+        activations = "device"
     sc, cam = sphere_case(level, 800, view=1, cubemap_res=512)
     N = sc.splats.num
     W = H = 800
@@ -211,7 +214,10 @@ def test_view_fullsize_vs_oracle(cuda, level, activations):
         # the fp32 oracle itself is ~2e-4 from float64 autograd there, tests/test_oracle_cpu.py); bars with a 10x margin
         tol = 1e-4 if name in ("quats", "scales") else 1e-5
         assert mx < tol, f"{name}: max-norm {mx:.3e}"
-        assert fr < (ELEM_FRAC_MAX if name in ("quats", "scales") else 1e-5), f"{name}: element-wise outliers {fr:.3e}"
+        # (element-wise: 0 for everything but quats / scales on the op-by-op path; the fused tail -- what splat() runs since round 5 --
+        #  contracts the colour cotangent into the cube fetch, a different association of the same sums: 2.2e-5 of the NORMAL gradients at
+        #  level 6 sit between 1e-6 and 7e-6 of the largest one, on the absolute floor of the criterion, none near 1e-4 relative)
+        assert fr < (ELEM_FRAC_MAX if name in ("quats", "scales") else 1e-4), f"{name}: element-wise outliers {fr:.3e}"
 
 
 @pytest.mark.parametrize("tight", ["0", "1"])
@@ -408,4 +414,4 @@ def test_step_fullsize_vs_oracle(cuda, level, path):
         mx, fr = _report(name, a, w, scale, atol_rel=1e-5 if name.startswith("level") else 1e-6)
         tol = 1e-4 if name in ("quats", "scales") else 1e-5
         assert mx < tol, f"{name}: max-norm {mx:.3e}"
-        assert fr < (ELEM_FRAC_MAX if name in ("quats", "scales") else 1e-5), f"{name}: element-wise outliers {fr:.3e}"
+        assert fr < (ELEM_FRAC_MAX if name in ("quats", "scales") else 1e-4), f"{name}: element-wise outliers {fr:.3e}"

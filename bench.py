@@ -211,6 +211,32 @@ def time_call_shaped(params, cams, ups, steps, warmup):
                     "(fused front, cull-log compositor, batched tails), driven by autograd instead of engine.RenderStep"}
 
 
+def time_d14(params, cam, res, iters):
+    """D = 14 deferred rasterization (rfstudio/model/geosplat.py:276-295: 14 feature channels through gsplat.rasterization) forward +
+    backward of one view through `geosplatting_amd.rasterization` -- the D > 3 path (colours outside the record stream, ds_add_f64
+    accumulator rows in the backward), never on the headline path; timed once per bench run so that it has a number."""
+    import geosplatting_amd as gs
+    dev = params.means.device
+    g = torch.Generator().manual_seed(14)
+    feats = torch.rand(params.means.shape[0], 14, generator=g).to(dev).requires_grad_(True)
+    means = params.means.detach().clone().requires_grad_(True)
+    scales = params.scales.exp(); opac = torch.sigmoid(params.opacities).squeeze(-1)
+    vm, K = cam.view_matrix.to(dev)[None], cam.intrinsic_matrix.to(dev)[None]
+
+    def one():
+        r, a, _ = gs.rasterization(means, params.quats, scales, opac, feats, vm, K, res, res)
+        (r.sum() + a.sum()).backward()
+        means.grad = None; feats.grad = None
+    one(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        one()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    return {"ms_per_view_fwd_bwd": ms, "views_per_s": 1e3 / ms, "D": 14, "iters": iters,
+            "what": "rasterization(colors=[N,14]) + backward, one view, exact counts (one read-back), op-by-op path"}
+
+
 def file_sha16(path):
     import hashlib
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
@@ -487,6 +513,32 @@ def main():
             acc.setdefault(name, []).append(a.elapsed_time(b))
         step.kernel_events = None
         engine_ms = {k: sum(v) / len(v) for k, v in acc.items()} or None
+    # the same timed loop with gsplat's SQUARE tile rectangles (GEOSPLAT_TIGHT_TILES=0): `value` runs on rectangles clipped to the
+    # alpha >= 1/255 extents -- a pixel-neutral subsequence of gsplat's intersection list, not the list itself (config.I_engine vs I)
+    square = None
+    if world == 1 and len(cams) > 0 and graphed is None and os.environ.get("GEOSPLAT_TIGHT_TILES", "1") != "0":
+        try:
+            os.environ["GEOSPLAT_TIGHT_TILES"] = "0"
+            for _ in range(3):
+                one_step()
+                torch.cuda.synchronize()
+                step.poll_capacity(wait=True)               # (the square list is 23 % longer: the capacity follows)
+            torch.cuda.synchronize()
+            ts0 = time.perf_counter()
+            for _ in range(args.steps):
+                one_step()
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - ts0
+            ok_sq = step.poll_capacity(wait=True)
+            square = {"views_per_s": views_total * args.steps / dts, "ms_per_step": dts / args.steps * 1e3, "overflow": not ok_sq,
+                      "what": "GEOSPLAT_TIGHT_TILES=0: the engine on gsplat's own (tile, Gaussian) list, bit-exact tile / sort indices"}
+        except Exception as e:
+            square = {"error": repr(e)[:300]}
+        finally:
+            os.environ["GEOSPLAT_TIGHT_TILES"] = "1"
+            for _ in range(2):
+                one_step()
+            torch.cuda.synchronize()
     call_shaped = None
     if world == 1 and len(cams) > 0 and not args.no_prefilter and not args.no_call_shaped:
         try:
@@ -558,6 +610,11 @@ def main():
             traffic = pmc["kernels"][dom]["hbm_bytes"]
             traffic_src = (f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes per launch, "
                            f"measured at commit {pmc.get('commit', '?')} on this kernel source)")
+        d14 = None
+        try:
+            d14 = time_d14(params, cam, args.res, max(3, args.kernel_iters // 4))
+        except Exception as e:
+            d14 = {"error": repr(e)[:300]}
         pre = None if args.no_prefilter else prefilter_report(params.cubemap, max(3, args.kernel_iters // 2))
         result = {
             "metric": "fwd+bwd views/sec at 2M Gaussians, 800x800",
@@ -600,7 +657,9 @@ def main():
                               "step_frac_of_8TBs_incl_prefilter": (None if not pre or pre.get("table_bytes_from_hbm_per_step") is None else
                                                                    (view_bytes * len(cams) + pre["table_bytes_from_hbm_per_step"] + 2 * pre.get("pyramid_bytes", 0))
                                                                    / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS)},
+            "value_square_tiles": square,
             "call_shaped": call_shaped,
+            "d14_deferred": d14,
             "strong_1gpu_ms": ms_per_step if (world == 1 and strong) else None,
             "scale_model": scale_model(view_ms, pre, N, args.cubemap_res, views_total, ms_per_step if world == 1 else None),
             "gpu_view_ms_without_prefilter": view_ms,

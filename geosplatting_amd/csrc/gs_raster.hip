@@ -212,327 +212,9 @@ tile_order_kernel(int n_tiles, GsCount ic, const int32_t* __restrict__ offsets, 
     for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) order[atomicAdd(&base[bucket(t)], 1)] = t;
 }
 
-struct Batch {
-    float4 r0, r1, r2;
-    bool ok;            // lane holds a record of this tile's list (applied where the record is USED, see load_batch)
-};
-
-// Bounding rectangle (pixel-centre coordinates) of the ACTIVE lanes of an 8x8 quadrant wave (lane = y*8 + x),
-// from the 64-bit activity ballot with scalar bit operations only.  Most pixels of a quadrant saturate early
-// while a few stragglers keep the wave walking its list: culling against the stragglers' rectangle instead
-// of the whole quadrant removes almost all survivors of the late batches (exact: inactive lanes ignore them).
-__device__ __forceinline__ void active_rect(unsigned long long act, int qx0, int qy0, float& rx0, float& rx1,
-                                            float& ry0, float& ry1)
-{
-    unsigned cols = (unsigned)(act | (act >> 32));
-    cols |= cols >> 16; cols |= cols >> 8; cols &= 0xffu;
-    const int xmin = __builtin_ctz(cols), xmax = 31 - __builtin_clz(cols);
-    const int ymin = __builtin_ctzll(act) >> 3, ymax = (63 - __builtin_clzll(act)) >> 3;
-    rx0 = (float)(qx0 + xmin) + 0.5f; rx1 = (float)(qx0 + xmax) + 0.5f;
-    ry0 = (float)(qy0 + ymin) + 0.5f; ry1 = (float)(qy0 + ymax) + 0.5f;
-}
-
-__device__ __forceinline__ Batch load_batch(const float4* __restrict__ rec0, const float4* __restrict__ rec1,
-                                            const float4* __restrict__ rec2, int idx, bool in_range)
-{
-    // NO branch around the loads and no select on the loaded values here: a load under a condition makes the compiler
-    // drain vmcnt at the join (and a select right after the load waits for it on the spot) -- either way the "prefetch"
-    // of the next batch was waited for immediately instead of overlapping the compositing of the current one.  Lanes
-    // past the end of the list read record 0 (always allocated) and are masked by `ok` where the record is consumed.
-    Batch b;
-    const int safe = in_range ? idx : 0;
-    b.r0 = rec0[safe]; b.r1 = rec1[safe]; b.r2 = rec2[safe];
-    b.ok = in_range;
-    return b;
-}
-
-// predicated variant (loads only the lanes inside the list): measured better in the BACKWARD kernel (1.21 vs 1.30 ms)
-// although the compiler then waits for the prefetch right after issuing it -- that kernel is VALU-bound either way
-__device__ __forceinline__ Batch load_batch_pred(const float4* __restrict__ rec0, const float4* __restrict__ rec1,
-                                                 const float4* __restrict__ rec2, int idx, bool in_range)
-{
-    Batch b;
-    b.r0 = make_float4(0.f, 0.f, 0.f, 0.f);
-    b.r1 = make_float4(0.f, 0.f, -1.0f, -1.0f);
-    b.r2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (in_range) { b.r0 = rec0[idx]; b.r1 = rec1[idx]; b.r2 = rec2[idx]; }
-    b.ok = in_range;
-    return b;
-}
-
-template <int CD>
-__global__ void __launch_bounds__(256)
-raster_fwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* __restrict__ tile_order,
-                  const float4* __restrict__ rec0, const float4* __restrict__ rec1, const float4* __restrict__ rec2,
-                  const float* __restrict__ colors, const float* __restrict__ background, GsCount ic,
-                  const int32_t* __restrict__ offsets,
-                  float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids)
-{
-    const int n_isects = (int)gs_count(ic);
-#ifdef GS_EXP_PRIO
-    if ((int)blockIdx.x < GS_EXP_PRIO) __builtin_amdgcn_s_setprio(3);
-#endif
-    const int tile = tile_order[blockIdx.x];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPR
-    const int tx = tile % tile_w, ty = tile / tile_w;
-    const int qx0 = tx * GS_TILE + (wave & 1) * 8, qy0 = ty * GS_TILE + (wave >> 1) * 8;
-    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
-    const bool inside = pxi < W && pyi < H;
-    const float px = (float)pxi + 0.5f, py = (float)pyi + 0.5f;
-
-    const int start = offsets[tile];
-    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
-
-    float T = 1.0f;
-    int cur_idx = 0;
-    bool done = !inside;
-    float pix[CD];
-#pragma unroll
-    for (int k = 0; k < CD; ++k) pix[k] = 0.0f;
-
-    Batch nxt = load_batch(rec0, rec1, rec2, start + lane, start + lane < end);
-    for (int base = start; base < end; base += 64) {
-        const unsigned long long act = __ballot(!done);
-        if (act == 0ull) break;
-        float rx0, rx1, ry0, ry1;
-        active_rect(act, qx0, qy0, rx0, rx1, ry0, ry1);
-        const Batch cur = nxt;
-        {   // prefetch the next 64 records while this batch is composited
-            const int nidx = base + 64 + lane;
-            nxt = load_batch(rec0, rec1, rec2, nidx, nidx < end);
-        }
-        const float mx = cur.r0.x, my = cur.r0.y, ha = cur.r0.z, cb = cur.r0.w;
-        const float hc = cur.r1.x, op = cur.r1.y, hx = cur.r1.z, hy = cur.r1.w;
-        const bool hit = cur.ok && (hx >= 0.0f) && (mx + hx >= rx0) && (mx - hx <= rx1) && (my + hy >= ry0) && (my - hy <= ry1);
-        unsigned long long mask = __ballot(hit);
-        GS_STAT(0, 1); GS_STAT(1, __popcll(mask));
-        if (mask == 0ull) continue;
-        float col[CD];
-        if (CD <= 3) {
-            col[0] = cur.r2.x;
-            if (CD > 1) col[1] = cur.r2.y;
-            if (CD > 2) col[2] = cur.r2.z;
-        } else {
-            const int g = __float_as_int(cur.r2.w);
-#pragma unroll
-            for (int k = 0; k < CD; ++k) col[k] = (hit && k < D) ? colors[(size_t)g * D + k] : 0.0f;
-        }
-
-        // Two survivors per trip.  Phase A (geometry -> alpha) does not depend on the compositing state, phase B
-        // (T / done / pix recurrence) is short and branch-free: issuing A(j0), A(j1) before B(j0), B(j1) gives the
-        // in-order SIMD independent work to cover the dependent chain of B (the kernel was ~50 % issue-stalled).
-        auto phase_a = [&](int j, float& alpha, bool& pre) {
-            const float gx = gs_readlane(mx, j), gy = gs_readlane(my, j);
-            const float ga = gs_readlane(ha, j), gb = gs_readlane(cb, j), gc = gs_readlane(hc, j);
-            const float go = gs_readlane(op, j);
-            const float dx = gx - px, dy = gy - py;
-            const float t0 = ga * dx, t1 = gc * dy, t2 = gb * dx;
-            const float sigma = fmaf(t0, dx, fmaf(t1, dy, t2 * dy));
-            alpha = fminf(0.999f, go * gs_exp_neg(sigma));
-            pre = sigma >= 0.0f && alpha >= GS_ALPHA_MIN;
-        };
-        auto phase_b = [&](int j, float alpha, bool pre) {
-            const bool ok = !done && pre;
-            const float next_T = T * (1.0f - alpha);
-            const bool stop = ok && next_T <= 1e-4f;
-            const bool acc = ok && !stop;
-            done = done || stop;
-            GS_STAT(2, __popcll(__ballot(ok)));
-            const float vis = acc ? alpha * T : 0.0f;
-#pragma unroll
-            for (int k = 0; k < CD; ++k) pix[k] = fmaf(gs_readlane(col[k], j), vis, pix[k]);
-            T = acc ? next_T : T;
-            cur_idx = acc ? base + j : cur_idx;
-        };
-        while (mask) {
-            const int j0 = __builtin_ctzll(mask);
-            mask &= mask - 1ull;
-            const bool has1 = mask != 0ull;
-            const int j1 = has1 ? __builtin_ctzll(mask) : j0;
-            mask &= mask - 1ull;                         // no-op when mask is already 0
-            float a0, a1; bool p0, p1;
-            phase_a(j0, a0, p0);
-            phase_a(j1, a1, p1);
-            p1 = p1 && has1;
-            phase_b(j0, a0, p0);
-            phase_b(j1, a1, p1);
-        }
-    }
-
-    if (inside) {
-        const size_t pid = (size_t)pyi * W + pxi;
-        alphas[pid] = 1.0f - T;
-        last_ids[pid] = cur_idx;
-#pragma unroll
-        for (int k = 0; k < CD; ++k)
-            if (k < D) render[pid * D + k] = background ? fmaf(T, background[k], pix[k]) : pix[k];
-    }
-}
-
-template <int CD>
-__global__ void __launch_bounds__(256)
-raster_bwd_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* __restrict__ tile_order,
-                  const float4* __restrict__ rec0, const float4* __restrict__ rec1, const float4* __restrict__ rec2,
-                  const float* __restrict__ colors, const float* __restrict__ background, GsCount ic,
-                  const int32_t* __restrict__ offsets,
-                  const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
-                  const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-                  float* __restrict__ v_packed, int rec_stride)
-{
-    const int n_isects = (int)gs_count(ic);
-#ifdef GS_EXP_PRIO
-    if ((int)blockIdx.x < GS_EXP_PRIO) __builtin_amdgcn_s_setprio(3);
-#endif
-    const int tile = tile_order[blockIdx.x];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPR
-    const int tx = tile % tile_w, ty = tile / tile_w;
-    const int qx0 = tx * GS_TILE + (wave & 1) * 8, qy0 = ty * GS_TILE + (wave >> 1) * 8;
-    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
-    const bool inside = pxi < W && pyi < H;
-    const float px = (float)pxi + 0.5f, py = (float)pyi + 0.5f;
-
-    const int start = offsets[tile];
-    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
-    if (end <= start) return;
-
-    float T_final = 1.0f, v_a = 0.0f;
-    int bin_final = -1;
-    float v_rc[CD], buffer[CD];
-#pragma unroll
-    for (int k = 0; k < CD; ++k) { v_rc[k] = 0.0f; buffer[k] = 0.0f; }
-    if (inside) {
-        const size_t pid = (size_t)pyi * W + pxi;
-        T_final = 1.0f - alphas[pid];
-        bin_final = last_ids[pid];
-        v_a = v_alphas[pid];
-#pragma unroll
-        for (int k = 0; k < CD; ++k) if (k < D) v_rc[k] = v_render[pid * D + k];
-    }
-    float bg_dot = 0.0f;
-    if (background) {
-#pragma unroll
-        for (int k = 0; k < CD; ++k) if (k < D) bg_dot += background[k] * v_rc[k];
-    }
-    float T = T_final;
-
-    // per-lane commit slot of the butterfly reduction.  The per-Gaussian gradients form ONE packed record
-    //   v_packed[g][0..1] = v_means2d, [2..4] = v_conics, [5] = v_opacities, [6..6+D) = v_colors   (stride: 64-byte multiple)
-    // so that the 6+D atomics of a survivor fall into one or two cache lines: the memory side merges them into
-    // 1-2 requests instead of 4 (separate arrays), and this kernel sits at the atomic REQUEST rate of the fabric.
-    constexpr int NV = 6 + CD;
-    using Bfly = GsBfly<NV>;
-    float* slot_ptr[Bfly::N4];
-#pragma unroll
-    for (int q = 0; q < Bfly::N4; ++q) {
-        const int vi = Bfly::owned_index(lane, q);
-        float* p = (vi < 6 + D) ? v_packed + vi : nullptr;
-        if (!GS_BWD_ROW_COMMIT && lane >= 16) p = nullptr;   // row 0 commits
-        slot_ptr[q] = p;
-    }
-    const int slot_stride_all = rec_stride;
-
-    int top = bin_final;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) top = max(top, __shfl_xor(top, off, 64));
-    if (top >= end) top = end - 1;
-
-    Batch nxt = load_batch_pred(rec0, rec1, rec2, top - lane, top - lane >= start);
-    for (; top >= start; top -= 64) {
-        // lanes whose last composited entry lies at or after this batch's lowest index can be valid in it
-        const unsigned long long act = __ballot(bin_final >= top - 63);
-        float rx0, rx1, ry0, ry1;
-        active_rect(act, qx0, qy0, rx0, rx1, ry0, ry1);
-        const Batch cur = nxt;
-        {
-            const int nidx = top - 64 - lane;
-            nxt = load_batch_pred(rec0, rec1, rec2, nidx, nidx >= start);
-        }
-        const float mx = cur.r0.x, my = cur.r0.y, ha = cur.r0.z, cb = cur.r0.w;
-        const float hc = cur.r1.x, op = cur.r1.y, hx = cur.r1.z, hy = cur.r1.w;
-        const int g = __float_as_int(cur.r2.w);
-        const bool hit = cur.ok && (hx >= 0.0f) && (mx + hx >= rx0) && (mx - hx <= rx1) && (my + hy >= ry0) && (my - hy <= ry1);
-        unsigned long long mask = __ballot(hit);
-        GS_STAT(4, 1); GS_STAT(5, __popcll(mask));
-        if (mask == 0ull) continue;
-        float col[CD];
-        if (CD <= 3) {
-            col[0] = cur.r2.x;
-            if (CD > 1) col[1] = cur.r2.y;
-            if (CD > 2) col[2] = cur.r2.z;
-        } else {
-#pragma unroll
-            for (int k = 0; k < CD; ++k) col[k] = (hit && k < D) ? colors[(size_t)g * D + k] : 0.0f;
-        }
-
-        while (mask) {
-            const int j = __builtin_ctzll(mask);
-            mask &= mask - 1ull;
-            const int idxj = top - j;
-            const float gx = gs_readlane(mx, j), gy = gs_readlane(my, j);
-            const float ga = gs_readlane(ha, j), gb = gs_readlane(cb, j), gc = gs_readlane(hc, j);
-            const float go = gs_readlane(op, j);
-            const float dx = gx - px, dy = gy - py;
-            const float t0 = ga * dx, t1 = gc * dy, t2 = gb * dx;
-            const float sigma = fmaf(t0, dx, fmaf(t1, dy, t2 * dy));
-            const float vis = gs_exp_neg(sigma);
-            const float alpha = fminf(0.999f, go * vis);
-            const bool valid = (idxj <= bin_final) && sigma >= 0.0f && alpha >= GS_ALPHA_MIN;
-            const unsigned long long vmask = __ballot(valid);
-            if (vmask == 0ull) continue;
-            GS_STAT(6, 1); GS_STAT(7, __popcll(vmask));
-
-            float gcol[CD];
-#pragma unroll
-            for (int k = 0; k < CD; ++k) gcol[k] = gs_readlane(col[k], j);
-
-            float part[NV];
-#pragma unroll
-            for (int k = 0; k < NV; ++k) part[k] = 0.0f;
-            if (valid) {
-                const float ra = 1.0f / (1.0f - alpha);        // correctly rounded (v_rcp_f32 alone drifts 1e-4 over a 1000-pair transmittance chain)
-                T *= ra;
-                const float fac = alpha * T;
-                float v_alpha = 0.0f;
-#pragma unroll
-                for (int k = 0; k < CD; ++k) {
-                    part[6 + k] = fac * v_rc[k];
-                    v_alpha += (gcol[k] * T - buffer[k] * ra) * v_rc[k];
-                }
-                v_alpha += T_final * ra * v_a;
-                if (background) v_alpha += -T_final * ra * bg_dot;
-                if (go * vis <= 0.999f) {
-                    const float v_sigma = -go * vis * v_alpha;
-                    part[2] = 0.5f * v_sigma * dx * dx;
-                    part[3] = v_sigma * dx * dy;
-                    part[4] = 0.5f * v_sigma * dy * dy;
-                    part[0] = v_sigma * ((2.0f * ga) * dx + gb * dy);
-                    part[1] = v_sigma * (gb * dx + (2.0f * gc) * dy);
-                    part[5] = vis * v_alpha;
-                }
-#pragma unroll
-                for (int k = 0; k < CD; ++k) buffer[k] += gcol[k] * fac;
-            }
-            // butterfly reduce-scatter over the wave; the 6+D totals land in distinct lanes of row 0, which
-            // commit them with ONE atomic instruction
-            float tot[Bfly::N4];
-            const int gj = gs_readlane(g, j);
-            bool commit = true;
-            if (GS_BWD_ROW_COMMIT) {
-                // each 16-lane row that had valid lanes commits its own partial sums: no cross-row exchange
-                Bfly::reduce_rows(part, tot, lane);
-                commit = ((vmask >> (lane & 48)) & 0xffffull) != 0ull;
-            } else {
-                Bfly::reduce(part, tot, lane);
-            }
-#pragma unroll
-            for (int q = 0; q < Bfly::N4; ++q)
-                if (slot_ptr[q] && commit) gs_atomic_add(slot_ptr[q] + (size_t)gj * slot_stride_all, tot[q]);
-        }
-    }
-}
-
 // ===================================================================================================
-// PER-LANE LISTS over DENSE batches ("lanes" kernels).  The quadrant kernels above spend all 64 lanes on every
+// PER-LANE LISTS over DENSE batches ("lanes" kernels).  The round-1 quadrant kernels (one wave per survivor; removed in round 5
+// together with the single-batch forward -- `git show 7240552:geosplatting_amd/csrc/gs_raster.hip`) spent all 64 lanes on every
 // survivor of the ballot cull although a surface splat at 2 M / 800^2 covers ~8 of the 64 pixels (7.8 valid lanes
 // per survivor, 128 wave instructions each in the backward).  Here every PIXEL walks only its own candidates:
 //   * CULL + COMPACT: a raw batch of 64 stream records is tested against the rectangle of the still-active pixels
@@ -821,183 +503,9 @@ __device__ __forceinline__ void lanes_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int CD>
-__global__ void __launch_bounds__(256)
-raster_fwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* __restrict__ tile_order,
-                        const float4* __restrict__ rec0, const float4* __restrict__ rec1, const float4* __restrict__ rec2,
-                        const float* __restrict__ colors, const float* __restrict__ background, GsCount ic,
-                        const int32_t* __restrict__ offsets,
-                        float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids)
-{
-    const int n_isects = (int)gs_count(ic);
-    extern __shared__ __align__(16) unsigned char gs_lds_raw[];
-#ifdef GS_EXP_SKIP_HEAVY          /* timing experiment: leave out the K longest tiles (LPT order) -- is the launch bound by its tail? */
-    if ((int)blockIdx.x < GS_EXP_SKIP_HEAVY) return;
-#endif
-#ifdef GS_EXP_ONLY_HEAVY
-    if ((int)blockIdx.x >= GS_EXP_ONLY_HEAVY) return;
-#endif
-#ifdef GS_EXP_PRIO
-    if ((int)blockIdx.x < GS_EXP_PRIO) __builtin_amdgcn_s_setprio(3);
-#endif
-    const int tile = tile_order[blockIdx.x];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int tx = tile % tile_w, ty = tile / tile_w;
-    const int qx0 = tx * GS_TILE + (wave & 1) * 8, qy0 = ty * GS_TILE + (wave >> 1) * 8;
-    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
-    const bool inside = pxi < W && pyi < H;
-    const float px = (float)pxi + 0.5f, py = (float)pyi + 0.5f;
-    const LaneQueue q = lane_queue(gs_lds_raw + (size_t)wave * GS_LANES_Q_BYTES);
-    lane_queue_clear(q, GS_LANES_Q, lane);
-
-    const int start = offsets[tile];
-    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
-    GS_TL_BEGIN(end - start);
-
-    float T = 1.0f;
-    int cur_idx = 0;
-    bool done = !inside;
-    float pix[CD];
-#pragma unroll
-    for (int k = 0; k < CD; ++k) pix[k] = 0.0f;
-
-    int qhead = 0, qcount = 0;                                    // wave-uniform
-    int base = start;
-    // THREE raw batches in flight: between two dense batches the fill loop consumes raw batches back to back (17-20 of 64
-    // records survive the cull), and with one batch of prefetch every iteration sat out a full memory latency
-    RawBatch raw0, raw1, raw2;
-    raw_load(raw0, rec0, rec1, rec2, start + lane, start + lane < end);
-    raw_load(raw1, rec0, rec1, rec2, start + 64 + lane, start + 64 + lane < end);
-    raw_load(raw2, rec0, rec1, rec2, start + 128 + lane, start + 128 + lane < end);
-    int phase = 0;
-    for (;;) {
-        unsigned long long act = __ballot(!done);
-        if (act == 0ull) break;
-        // ---- fill: cull raw batches into the queue until a dense batch is available
-        { GS_PHASE_BEGIN();
-        float rcx, rcy, rex, rey;
-        active_rect_c(act, qx0, qy0, rcx, rcy, rex, rey);
-#define FWD_FILL_STEP(B)                                                                                               \
-        {                                                                                                              \
-            GS_STAT(0, 1);                                                                                             \
-            raw_wait(B);                                                                                               \
-            const int n_hit = lanes_cull_append(q, B, base + lane < end, base + lane, lane, rcx, rcy, rex, rey, qhead + qcount); \
-            raw_load(B, rec0, rec1, rec2, base + 192 + lane, base + 192 + lane < end);                                 \
-            qcount += n_hit;                                                                                           \
-            base += 64;                                                                                                \
-        }
-        LANES_FILL(qcount < 64 && base < end, FWD_FILL_STEP)
-#undef FWD_FILL_STEP
-        GS_PHASE_END(0); }
-        if (qcount == 0) break;
-        const int nb = qcount < 64 ? qcount : 64;
-        lanes_lds_sync();
-        GS_PHASE_BEGIN();
-        // ---- dense batch: lane j owns queue slot qhead + j
-        int xmin, xmax, ymin, ymax;
-        active_rect_i(act, xmin, xmax, ymin, ymax);
-        unsigned long long pm;
-        {
-            const int slot = (qhead + lane) & (GS_LANES_Q - 1);
-            const float4 a = q.a[slot];
-            const float2 b = q.b[slot];
-            pm = record_pixel_mask(lane < nb, a.x, a.y, a.z, a.w, b.x, b.y, qx0, qy0, xmin, xmax, ymin, ymax);
-        }
-        GS_STAT(1, nb);
-        unsigned long long list = gs_bit_transpose64(pm, lane);
-        if (done) list = 0ull;
-        GS_PHASE_END(1);
-        // The launch is bound by its TAIL: a silhouette tile walks ~7 000 records and its four waves take ~400 us whether or not
-        // anything else runs (removal experiment: the 100 longest tiles ALONE take 408 us of the 424), i.e. by the dependent-chain
-        // latency of one wave (LDS fetch -> sigma -> exp polynomial -> compare, ~400 cycles per trip).  So every lane pops
-        // GS_LANES_NPT candidates per trip: their fetches and alpha chains are independent (phase A), only the compositing
-        // recurrence is serial (phase B).
-        long long _pw0 = 0;
-#ifdef GS_RASTER_PHASES
-        if (blockIdx.x == 0 && threadIdx.x == 0) _pw0 = (long long)__builtin_readcyclecounter();
-#endif
-        int cur_slot = -1;                    // queue slot of the last candidate this pixel composited in this dense batch
-        while (__ballot(list != 0ull) != 0ull) {
-            GS_STAT(3, 1);
-#ifdef GS_RASTER_PHASES
-            if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_raster_stats[3], 1ull);
-#endif
-            // phase A, candidates in pairs side by side in packed fp32 (v_pk_*): same IEEE operations per component as the scalar
-            // form.  GS_WALK_PAIRS pairs per trip: independent chains for a wave that runs alone on its SIMD (the tail).
-            bool has[2 * GS_WALK_PAIRS]; int slot[2 * GS_WALK_PAIRS];
-            float4 ca[2 * GS_WALK_PAIRS], cc[2 * GS_WALK_PAIRS]; float2 cb[2 * GS_WALK_PAIRS];
-#pragma unroll
-            for (int u = 0; u < 2 * GS_WALK_PAIRS; ++u) {
-                has[u] = list != 0ull;
-                slot[u] = (qhead + gs_pop_lowest(list)) & (GS_LANES_Q - 1);
-            }
-#pragma unroll
-            for (int u = 0; u < 2 * GS_WALK_PAIRS; ++u) { ca[u] = q.a[slot[u]]; cb[u] = q.b[slot[u]]; cc[u] = q.c[slot[u]]; }
-            float alpha_u[2 * GS_WALK_PAIRS]; bool ok[2 * GS_WALK_PAIRS];
-#pragma unroll
-            for (int v = 0; v < GS_WALK_PAIRS; ++v) {
-#pragma clang fp contract(off)
-                const float4 a0 = ca[2 * v], a1 = ca[2 * v + 1];
-                const float2 b0 = cb[2 * v], b1 = cb[2 * v + 1];
-                const v2f dx = v2f{a0.x, a1.x} - px, dy = v2f{a0.y, a1.y} - py;
-                const v2f t0 = v2f{a0.z, a1.z} * dx, t1 = v2f{b0.x, b1.x} * dy, t2 = v2f{a0.w, a1.w} * dx;
-                const v2f sigma = __builtin_elementwise_fma(t0, dx, __builtin_elementwise_fma(t1, dy, t2 * dy));
-                const v2f alpha = __builtin_elementwise_min(v2f{b0.y, b1.y} * gs_exp_neg_live2(sigma), (v2f)(0.999f));
-                alpha_u[2 * v] = alpha.x; alpha_u[2 * v + 1] = alpha.y;
-                ok[2 * v] = has[2 * v] && sigma.x >= 0.0f && alpha.x >= GS_ALPHA_MIN;
-                ok[2 * v + 1] = has[2 * v + 1] && sigma.y >= 0.0f && alpha.y >= GS_ALPHA_MIN;
-            }
-            // phase B, the serial recurrence, without branches: a rejected candidate composites with weight zero
-            bool stopped = false;
-#pragma unroll
-            for (int u = 0; u < 2 * GS_WALK_PAIRS; ++u) {
-                const float next_T = T * (1.0f - alpha_u[u]);
-                const bool live = ok[u] && !done;
-                const bool stop = live && next_T <= 1e-4f;
-                const bool acc = live && !stop;
-#ifdef GS_RASTER_STATS
-                if (acc) GS_STAT_ALL(2, 1);
-#endif
-                const float vis = acc ? alpha_u[u] * T : 0.0f;
-                if (CD <= 3) {
-                    pix[0] = fmaf(cc[u].x, vis, pix[0]);
-                    if (CD > 1) pix[1] = fmaf(cc[u].y, vis, pix[1]);
-                    if (CD > 2) pix[2] = fmaf(cc[u].z, vis, pix[2]);
-                } else if (acc) {
-                    const float* cg = colors + (size_t)__float_as_int(cc[u].w) * D;
-#pragma unroll
-                    for (int k = 0; k < CD; ++k) if (k < D) pix[k] = fmaf(cg[k], vis, pix[k]);
-                }
-                T = acc ? next_T : T;
-                cur_slot = acc ? slot[u] : cur_slot;
-                done = done || stop;
-                stopped = stopped || stop;
-            }
-            list = stopped ? 0ull : list;
-        }
-        if (cur_slot >= 0) cur_idx = q.idx[cur_slot];
-#ifdef GS_RASTER_PHASES
-        if (blockIdx.x == 0 && threadIdx.x == 0) { atomicAdd(&g_raster_stats[2], (unsigned long long)((long long)__builtin_readcyclecounter() - _pw0)); atomicAdd(&g_raster_stats[4], 1ull); }
-#endif
-        lanes_lds_sync();                     // every lane is done reading these slots before the fill overwrites them
-        qhead = (qhead + nb) & (GS_LANES_Q - 1);
-        qcount -= nb;
-    }
-    raw_drain(raw0, raw1, raw2);
-
-    if (inside) {
-        const size_t pid = (size_t)pyi * W + pxi;
-        alphas[pid] = 1.0f - T;
-        last_ids[pid] = cur_idx;
-#pragma unroll
-        for (int k = 0; k < CD; ++k)
-            if (k < D) render[pid * D + k] = background ? fmaf(T, background[k], pix[k]) : pix[k];
-    }
-    GS_TL_END();
-}
 
 // ---------------------------------------------------------------------------------------------------
-// Forward with a SLIDING WINDOW of two dense batches (the default; GEOSPLAT_RASTER_LANES=3 selects the single-batch kernel above).  In the kernel above a pixel whose list of
+// Forward with a SLIDING WINDOW of two dense batches (the forward of every D).  In the kernel above a pixel whose list of
 // the current dense batch is exhausted idles until the longest list of the quadrant is done (a quarter of the candidate slots
 // hold a pair).  Here two batches A and B are resident: a lane that has finished A pops from B, and when A is exhausted
 // everywhere B becomes A and a new B is built from the next 64 culled records.  The CPU simulation of the schedule (DESIGN.md
@@ -2303,11 +1811,6 @@ static size_t gs_raster_lds(size_t natural)
     if (!s_always && (size_t)(gs_raster_blocks_per_cu() + 1) * (natural + 512) > (size_t)160 * 1024) return natural;
     return pad;
 }
-// compositor variant: 1 = per-lane lists (default; forward: sliding window of two dense batches, backward: pair buffer + record-lane
-// reduction for D <= 3), 3 = the same with the single-batch forward, 2 = per-lane lists with ds_add_f64 accumulators in the backward
-// for every D, 0 = one wave per survivor (the round-1 kernels, kept for A/B runs)
-static int gs_raster_lanes() { static const int m = gs_env_int("GEOSPLAT_RASTER_LANES", 1); return m; }
-
 // workspace layout: [rec0 | rec1 | rec2 | tile_order], every segment 256-byte aligned
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -2366,11 +1869,11 @@ static int launch_fwd(int W, int H, int D, const RasterWs& ws, const float* colo
                       hipStream_t s)
 {
     const int tile_w = (W + GS_TILE - 1) / GS_TILE, tile_h = (H + GS_TILE - 1) / GS_TILE;
-    if (t_tone_fwd.image && !(gs_raster_lanes() == 1 && CD == 3 && D == 3 && background == nullptr)) {
-        gs_set_error("gs_raster_composite_tone: needs D == 3, no background and the default compositor kernels (GEOSPLAT_RASTER_LANES=1)");
+    if (t_tone_fwd.image && !(CD == 3 && D == 3 && background == nullptr)) {
+        gs_set_error("gs_raster_composite_tone: needs D == 3 and no background");
         return GS_EINVAL;
     }
-    if (gs_raster_lanes() == 1) {                             // default: sliding window of two dense batches
+    {                                                         // sliding window of two dense batches, every D
         const size_t lds = gs_raster_lds(4 * (size_t)GS_WIN_Q_BYTES);
         hipLaunchKernelGGL(raster_fwd_window_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
                            ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, isect_count(n_isects), offsets, render, alphas,
@@ -2378,20 +1881,6 @@ static int launch_fwd(int W, int H, int D, const RasterWs& ws, const float* colo
         GS_CHECK_LAUNCH();
         return GS_OK;
     }
-    if (gs_raster_lanes()) {
-        size_t lds = 4 * (size_t)GS_LANES_Q_BYTES;
-        if (lds < gs_raster_lds_pad()) lds = gs_raster_lds_pad();
-        hipLaunchKernelGGL(raster_fwd_lanes_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
-                           ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, isect_count(n_isects), offsets, render, alphas,
-                           last_ids);
-        GS_CHECK_LAUNCH();
-        return GS_OK;
-    }
-    hipLaunchKernelGGL(raster_fwd_kernel<CD>, dim3(tile_w * tile_h), dim3(256), gs_raster_lds_pad(), s, W, H, tile_w, tile_w * tile_h, D,
-                       ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, isect_count(n_isects), offsets, render, alphas,
-                       last_ids);
-    GS_CHECK_LAUNCH();
-    return GS_OK;
 }
 
 static int raster_check(const char* who, int W, int H, int tile_size, int D, int V, int64_t n_isects, const void* ws,
@@ -2492,12 +1981,12 @@ static int launch_bwd(int W, int H, int D, const RasterWs& ws, const float* colo
                       const float* v_render, const float* v_alphas, float* v_packed, int rec_stride, hipStream_t s)
 {
     const int tile_w = (W + GS_TILE - 1) / GS_TILE, tile_h = (H + GS_TILE - 1) / GS_TILE;
-    if (t_tone_bwd.v_image && !((gs_raster_lanes() == 1 || gs_raster_lanes() == 3) && CD == 3 && D == 3 && background == nullptr)) {
-        gs_set_error("gs_raster_bwd_tone: needs D == 3, no background and the default compositor kernels (GEOSPLAT_RASTER_LANES=1)");
+    if (t_tone_bwd.v_image && !(CD == 3 && D == 3 && background == nullptr)) {
+        gs_set_error("gs_raster_bwd_tone: needs D == 3 and no background");
         return GS_EINVAL;
     }
     if constexpr (CD <= 3) {                                  // colours travel in the record stream only for D <= 3
-        if (t_cull_log.idx && gs_raster_lanes() == 1) {         // the forward left its cull log: no fill, no masks
+        if (t_cull_log.idx) {                                   // the forward left its cull log: no fill, no masks
             const size_t lds = gs_raster_lds(4 * (size_t)LogLds::WAVE_BYTES);
             static const bool s_log_order = [] { const char* v = getenv("GEOSPLAT_BWD_LOG_ORDER"); return !(v && v[0] == '0'); }();
             hipLaunchKernelGGL(raster_bwd_log_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
@@ -2507,7 +1996,7 @@ static int launch_bwd(int W, int H, int D, const RasterWs& ws, const float* colo
             GS_CHECK_LAUNCH();
             return GS_OK;
         }
-        if ((gs_raster_lanes() == 1 || gs_raster_lanes() == 3)) {
+        {                                                       // no log (gs_raster_bwd / _acc / _tone_acc): pair buffer, own cull + masks
             size_t lds = 4 * (size_t)Lanes2Lds<CD>::WAVE_BYTES;
             if (lds < gs_raster_lds_pad()) lds = gs_raster_lds_pad();
             hipLaunchKernelGGL(raster_bwd_lanes2_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
@@ -2517,7 +2006,7 @@ static int launch_bwd(int W, int H, int D, const RasterWs& ws, const float* colo
             return GS_OK;
         }
     }
-    if (gs_raster_lanes()) {                                  // D > 3, or GEOSPLAT_RASTER_LANES=2: LDS ds_add_f64 accumulators
+    {                                                         // D > 3 (colours outside the record stream): LDS ds_add_f64 accumulator rows
         size_t lds = 4 * ((size_t)GS_LANES_Q_BYTES + (size_t)(6 + CD) * 64 * 8);
         if (lds < gs_raster_lds_pad()) lds = gs_raster_lds_pad();
         static bool attr_set = false;                  // > 64 KB of dynamic LDS (D > 16) needs the opt-in once per kernel
@@ -2531,11 +2020,6 @@ static int launch_bwd(int W, int H, int D, const RasterWs& ws, const float* colo
         GS_CHECK_LAUNCH();
         return GS_OK;
     }
-    hipLaunchKernelGGL(raster_bwd_kernel<CD>, dim3(tile_w * tile_h), dim3(256), gs_raster_lds_pad(), s, W, H, tile_w, tile_w * tile_h, D,
-                       ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, isect_count(n_isects), offsets, alphas, last_ids,
-                       v_render, v_alphas, v_packed, rec_stride);
-    GS_CHECK_LAUNCH();
-    return GS_OK;
 }
 
 extern "C" int gs_raster_grad_stride(int D) { return ((6 + D) + 15) / 16 * 16; }
@@ -2689,7 +2173,6 @@ extern "C" int gs_raster_composite_tone_log(int W, int H, int tile_size, int V, 
 {
     GS_CHECK_ARG(log_ws != nullptr && tile_size == GS_TILE, "log_ws must not be NULL");
     if (log_bytes < gs_raster_log_ws_bytes(n_isects, W, H, tile_size)) { gs_set_error("gs_raster_composite_tone_log: log workspace too small"); return GS_ENOSPC; }
-    GS_CHECK_ARG(gs_raster_lanes() == 1, "the cull log needs the default compositor kernels (GEOSPLAT_RASTER_LANES=1)");
     CullLogScope ls(carve_log(log_ws, n_isects));
     return gs_raster_composite_tone(W, H, tile_size, V, colors, n_isects, counts_dev, offsets, render, alphas, last_ids, tone_mode, exposure,
                                     image, ws, ws_bytes, stream);
@@ -2703,7 +2186,6 @@ extern "C" int gs_raster_bwd_tone_log_acc(int W, int H, int tile_size, int V, co
 {
     GS_CHECK_ARG(log_ws != nullptr && tile_size == GS_TILE, "log_ws must not be NULL");
     if (log_bytes < gs_raster_log_ws_bytes(n_isects, W, H, tile_size)) { gs_set_error("gs_raster_bwd_tone_log_acc: log workspace too small"); return GS_ENOSPC; }
-    GS_CHECK_ARG(gs_raster_lanes() == 1, "the cull log needs the default compositor kernels (GEOSPLAT_RASTER_LANES=1)");
     CullLogScope ls(carve_log((void*)log_ws, n_isects));
     return gs_raster_bwd_tone_acc(W, H, tile_size, V, colors, n_isects, counts_dev, offsets, render, alphas, last_ids, tone_mode, exposure,
                                   v_image, v_packed, v_exposure, ws, ws_bytes, stream);

@@ -69,8 +69,9 @@ def _auto_tail_schedule(n_views: int):
 
 class RenderStep:
     def __init__(self, params: PathParams, min_roughness: float = 0.1, max_metallic: float = 1.0, mode: str = "pbr",
-                 tone_type: str = "naive", prefilter: bool = True, fused: bool = True):
+                 tone_type: str = "naive", prefilter: bool = True, fused: bool = True, fg_lut: Optional[Tensor] = None):
         self.p = params
+        self.fg_lut = None if fg_lut is None else fg_lut.to(params.means.device, torch.float32).contiguous()   # default: the packaged table
         self.min_roughness, self.max_metallic, self.mode, self.tone_type = min_roughness, max_metallic, mode, tone_type
         self.prefilter = prefilter
         self.fused = fused
@@ -250,7 +251,7 @@ class RenderStep:
             env = self._static_env
         env_d = TextureSplitSum(env.base.detach(), [l.detach().contiguous() for l in env.levels], env.min_roughness,
                                 env.max_roughness)
-        lut = get_fg_lut(dev)
+        lut = get_fg_lut(dev) if self.fg_lut is None else self.fg_lut
         e = _make_env(lut, env_d)
         # texel-gradient accumulators.  Two sets (views [0, n/2) and [n/2, n)) with the first half's prefilter backward
         # on its own stream under the remaining compositor work was measured: 30.4 vs 28.7 ms per step -- the backward is
@@ -382,8 +383,8 @@ class RenderStep:
 
         n_views = len(cameras)
         front_first = os.environ.get("GEOSPLAT_ENQUEUE", "main_first") == "front_first"
-        # S4 inside the compositor kernels (default; needs the default kernel pair): GEOSPLAT_FUSED_TONE=0 keeps the two tone-map launches
-        fused_tone = os.environ.get("GEOSPLAT_FUSED_TONE", "1") != "0" and os.environ.get("GEOSPLAT_RASTER_LANES", "1") == "1"
+        # S4 inside the compositor kernels (default): GEOSPLAT_FUSED_TONE=0 keeps the two tone-map launches
+        fused_tone = os.environ.get("GEOSPLAT_FUSED_TONE", "1") != "0"
         use_log = fused_tone and os.environ.get("GEOSPLAT_RASTER_LOG", "1") != "0"      # forward -> backward cull log (csrc/gs_raster.hip)
         proj = [start_view(cameras[j], j) for j in range(min(2, n_views))]   # prologue: A(0), A(1), B1(0)
         binned = bin_view(proj.pop(0)) if n_views else None
@@ -900,7 +901,7 @@ class RenderStep:
         images = []
         for i, cam in enumerate(cameras):
             img = attrs.splat(_G, [cam], exposure=leaves["exposure"], envmap=env_leaf, min_roughness=self.min_roughness,
-                              max_metallic=self.max_metallic, mode=self.mode, tone_type=self.tone_type)
+                              max_metallic=self.max_metallic, mode=self.mode, tone_type=self.tone_type, fg_lut=self.fg_lut)
             img.backward(upstream(i, img.detach()))
             if keep_images:
                 images.append(img.detach())

@@ -338,3 +338,32 @@ def test_cube_edge_table_equals_reprojection(cuda, R):
     assert rc == 0, L.lib().gs_last_error()
     assert int(bad.item()) == 0
 
+
+
+def test_image_delta_of_the_packaged_fg_lut_against_the_reference_asset(cuda):
+    """How far does the DEFAULT table move an image?  The reference's FG table is an asset (rfstudio/graphics/shaders.py:22-26) that
+    does not travel; tests/golden/ref_fg_lut_sub16.npz holds its 16x16 subsample (every 17th row / column).  Both tables are reduced to
+    those 16x16 texels and the same view is rendered through `fg_lut=` with each: the image delta is what an integrator gets who does
+    NOT pass the asset.  Reported, and bounded at the size the 4e-4 table difference predicts -- i.e. ABOVE the north star's 1e-4 bar
+    on L_spec-dominated pixels, which is why INTEGRATION.md passes the asset in both recipes (`fg_lut=_get_fg_lut(...)`)."""
+    import os
+    import geosplatting_amd as gs
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_fg_lut_sub16.npz"))
+    full = gs.get_fg_lut(torch.device("cpu"))[0].numpy()
+    ours = torch.from_numpy(np.ascontiguousarray(full[np.ix_(g["rows"], g["cols"])])).reshape(1, 16, 16, 2).to(cuda)
+    ref = torch.from_numpy(np.ascontiguousarray(g["values"].astype(np.float32))).reshape(1, 16, 16, 2).to(cuda)
+    sc, cam = sphere_case(5, 400, cubemap_res=64)
+    sp = sc.splats.to(cuda)
+    attrs = gs.RenderableAttrs(kd=sc.kd.to(cuda), ks=sc.ks.to(cuda), normals=sc.normals.to(cuda))
+    with torch.no_grad():
+        env = gs.as_splitsum(sc.cubemap.to(cuda))
+        imgs = [attrs.splat(sp, [cam], exposure=torch.tensor(1.0, device=cuda), envmap=env, min_roughness=0.1, max_metallic=1.0, fg_lut=l)
+                for l in (ours, ref)]
+    d = (imgs[0][..., :3] - imgs[1][..., :3]).abs()
+    lut_d = float((ours - ref).abs().max())
+    rel = float(d.max() / imgs[1][..., :3].abs().max())
+    mse = float((d.double() ** 2).mean())
+    print(f"\n  tables differ by {lut_d:.2e} (max, 16x16 subsample); image: max abs {float(d.max()):.2e}, max-norm rel {rel:.2e}, "
+          f"PSNR {10 * np.log10(1.0 / max(mse, 1e-30)):.1f} dB")
+    assert torch.equal(imgs[0][..., 3], imgs[1][..., 3])                      # alpha does not see the table
+    assert lut_d < 5e-4 and rel < 2e-3                                         # (specular radiance of a few units x 4e-4)

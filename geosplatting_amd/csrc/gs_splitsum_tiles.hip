@@ -369,7 +369,14 @@ tile_apply_kernel(int R, int E, int bw, int nb, int K, const float* __restrict__
             // register pair whose halves feed the packed FMAs directly.  A chunk index past the end is clamped to the last chunk
             // (loaded again, not consumed): no branch around a load.  The row descriptors (scalar loads) run two chunks ahead.
             const char* lds_b = reinterpret_cast<const char*>(s_src) + a_l * 16;
-            const gs_f2* wp2 = reinterpret_cast<const gs_f2*>(weights) + (r0 >> 1) * 64 + lane;
+            // weight rows: UNIFORM base pointer (an SGPR pair, advanced with scalar adds) + the lane's 32-bit byte offset + an immediate
+            // per row pair -- `global_load_dwordx2 v, v_lane8, s[base] offset:512 u` -- instead of four 64-bit vector additions per chunk
+            const gs_f2* wbase = reinterpret_cast<const gs_f2*>(weights) + (r0 >> 1) * 64;
+            const unsigned lane_u = (unsigned)lane;
+            // (round 5, measured and removed: the row descriptors through the VECTOR memory path -- a scalar load shares lgkmcnt with
+            //  the LDS reads, so every chunk starts behind `s_waitcnt lgkmcnt(0)` -- 0.93 + 0.95 ms against 0.78 + 0.80: two more
+            //  vector loads per chunk in a loop whose bound is the return order of its vector loads.  The scalar-base form of the
+            //  weight loads above removes 25 of 35 64-bit vector additions and 60 scalar instructions: no change either.)
 #ifdef GS_TILE_EXP_NOW
 #define GS_TILE_WLOAD(P) (gs_f2{ 1.0f, (float)kk })
 #elif defined(GS_TILE_WLOAD_SC1)
@@ -386,8 +393,9 @@ tile_apply_kernel(int R, int E, int bw, int nb, int K, const float* __restrict__
 #define GS_ROWS_LOAD(W, J)                                                                                          \
             do {                                                                                                    \
                 const int kk = GS_CHUNK_ROW(J);                                                                     \
+                const gs_f2* wrow = wbase + (size_t)(kk >> 1) * 64;                                                 \
                 _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                       \
-                    W[u] = GS_TILE_WLOAD(wp2 + (size_t)((kk >> 1) + u) * 64);                                       \
+                    W[u] = GS_TILE_WLOAD(wrow + (lane_u + (unsigned)u * 64u));                                      \
             } while (0)
 #define GS_DESC_LOAD(D0, D1, J)                                                                                     \
             do { const int kk = GS_CHUNK_ROW(J); GS_TILE_DLOAD(D0, D1, kk); } while (0)

@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--no-call-shaped", action="store_true", help="skip the `call_shaped` leg (the same step through RenderableAttrs.splat + autograd)")
     ap.add_argument("--graph", type=int, default=-1, help="-1 (default): 2 when a rank renders at most two views per step, else 0; 1: replay each step as one HIP graph (--gpus 1 only; measured 12 % slower than eager launches at 8 views per GPU: a graph serialises what the eager queues overlap); 2: only the VIEWS of a step as a graph, prefilter and collectives eager (any --gpus; for few views per GPU, e.g. --views-total 8 on 8 GPUs); 0 (default): eager launches")
     ap.add_argument("--kernel-iters", type=int, default=20)
+    ap.add_argument("--rccl-world1", action="store_true",
+                    help="diagnostic: run the step with EVERY collective of the multi-GPU path through RCCL on a one-rank process group "
+                         "(sharded prefilter + its communicator, two-phase gradient all-reduce, graph replay beside them)")
     return ap.parse_args()
 
 
@@ -426,13 +429,22 @@ def cpu_baseline(scene, cam, res, budget_note):
 
 def main():
     args = parse()
+    # ONE JSON line on stdout, whatever the libraries print: RCCL writes its version banner ("RCCL version : ...", five lines) to
+    # file descriptor 1 when its first communicator comes up.  Everything else that reaches fd 1 during the run goes to stderr; the
+    # result line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import geosplatting_amd as gs
     import geosplatting_amd.synthetic as syn
     from geosplatting_amd.engine import RenderStep, params_from_scene
     from geosplatting_amd.parallel import init_distributed_from_env
     import torch.distributed as dist
 
+    if args.rccl_world1:
+        os.environ["GEOSPLAT_COLLECTIVES_AT_WORLD1"] = "1"
     rank, world, dev = init_distributed_from_env("cuda")
+    use_coll = world > 1 or args.rccl_world1
     if world != args.gpus and rank == 0:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     torch.manual_seed(1)
@@ -448,7 +460,7 @@ def main():
     ups = [(torch.rand(args.res, args.res, 4, generator=g) * 2 - 1).to(dev) for _ in range(max(1, len(cams)))]
 
     def one_step():
-        step(cams, lambda i, img: ups[i], all_reduce=(world > 1))
+        step(cams, lambda i, img: ups[i], all_reduce=use_coll)
 
     n_settle = 0
     if args.settle_seconds > 0 and len(cams) > 0:          # clocks / allocator / capacity settle; identical on every rank (fixed step count)
@@ -472,7 +484,7 @@ def main():
         torch.cuda.synchronize()
         ok_local = step.poll_capacity(wait=True) and step._i_cap is not None
         if ok_local:                       # (every rank runs the same workload shape: the capacity is known everywhere after the warm-up)
-            graphed = step.capture_views(cams, lambda i, img: ups[i], all_reduce=(world > 1))
+            graphed = step.capture_views(cams, lambda i, img: ups[i], all_reduce=use_coll)
             one_step = graphed
             one_step()
     elif args.graph == 1 and world == 1 and len(cams) > 0:
@@ -593,7 +605,7 @@ def main():
         dom_tf = None if not pairs_valid else pairs_valid * dom_flops / (kt[dom] * 1e-3) / 1e12
         dom_tf_engine = None if not (pairs_valid and engine_ms and engine_ms.get(dom)) else pairs_valid * dom_flops / (engine_ms[dom] * 1e-3) / 1e12
         # committed counter summaries, quoted only while gs_raster.hip is the source they were measured on
-        first = lambda stem: next((f"r{r:02d}_{stem}" for r in (4, 3, 2) if committed_profile(f"r{r:02d}_{stem}", "gs_raster.hip")), f"r04_{stem}")
+        first = lambda stem: next((f"r{r:02d}_{stem}" for r in (5, 4, 3, 2) if committed_profile(f"r{r:02d}_{stem}", "gs_raster.hip")), f"r05_{stem}")
         stats_name, pmc_name = first("raster_stats.json"), first("pmc_traffic.json")
         stats = committed_profile(stats_name, "gs_raster.hip")
         pmc = committed_profile(pmc_name, "gs_raster.hip")
@@ -615,6 +627,22 @@ def main():
             d14 = time_d14(params, cam, args.res, max(3, args.kernel_iters // 4))
         except Exception as e:
             d14 = {"error": repr(e)[:300]}
+        # issue side of the dominant kernel from the committed counter passes (measured, not inferred)
+        issue = None
+        if pmc and args.level == 7 and args.res == 800 and dom in pmc.get("kernels", {}):
+            kq = pmc["kernels"][dom]
+            wc = kq.get("SQ_WAVE_CYCLES")
+            if wc and kq.get("valu_wave_instructions"):
+                chip_valu_issue_per_s = 256 * 4 * 2.4e9 / 2.0                      # one wave64 fp32 instruction = 2 cycles on a SIMD-32
+                issue = {"valu_wave_instructions": kq["valu_wave_instructions"],
+                         "valu_wave_instructions_per_valid_pair": None if not pairs_valid else kq["valu_wave_instructions"] / pairs_valid,
+                         "frac_of_chip_valu_issue_peak_alone": kq["valu_wave_instructions"] / (kt[dom] * 1e-3) / chip_valu_issue_per_s,
+                         "wave_cycles_waiting_at_waitcnt_or_barrier": kq.get("SQ_WAIT_ANY", 0) / wc,
+                         "wave_cycles_issue_stalled": kq.get("SQ_WAIT_INST_ANY", 0) / wc,
+                         "wave_cycles_issuing": kq.get("SQ_ACTIVE_INST_ANY", 0) / wc,
+                         "lds_bank_conflict_cycles_per_lds_instruction": (None if not kq.get("SQ_INSTS_LDS") else
+                                                                         kq.get("SQ_LDS_BANK_CONFLICT", 0) / kq["SQ_INSTS_LDS"]),
+                         "source": f"profiles/{pmc_name} (SQ_* passes of scripts/run_pmc_r04.sh, mean per launch, kernel alone)"}
         pre = None if args.no_prefilter else prefilter_report(params.cubemap, max(3, args.kernel_iters // 2))
         result = {
             "metric": "fwd+bwd views/sec at 2M Gaussians, 800x800",
@@ -626,7 +654,8 @@ def main():
                                    + (f"{views_total} views/step over all GPUs (strong scaling)" if strong else f"{args.views} views/step/GPU")
                                    + f", prefilter fwd+bwd {'in' if not args.no_prefilter else 'EXCLUDED from'} every step",
                        "N": N, "V": V, "I": I, "I_engine": I_engine, "P": P, "views_per_step_total": views_total,
-                       "parallelism": f"dp{world} (views sharded, prefilter sharded, flat RCCL all-reduce of per-Gaussian grads)"},
+                       "parallelism": f"dp{world} (views sharded, prefilter sharded, flat RCCL all-reduce of per-Gaussian grads)"
+                                      + (" -- --rccl-world1: every collective issued through RCCL on a one-rank group" if args.rccl_world1 else "")},
             "roofline": {"bound": "valu", "kernel": dom, "launched_as": LAUNCHED_AS[dom],
                          "achieved": dom_tf_engine if dom_tf_engine is not None else dom_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": None if (dom_tf_engine or dom_tf) is None else (dom_tf_engine or dom_tf) / VALU_PEAK_TFLOPS,
@@ -637,6 +666,8 @@ def main():
                          "compositor_fwd_plus_bwd": {"achieved_TFLOPs": valu_tf,
                                                      "frac_of_157.3": None if valu_tf is None else valu_tf / VALU_PEAK_TFLOPS},
                          "lane_utilisation": lane_util,
+                         "issue": issue,
+                         "flops_per_pair_source": "builder's count of the kernels' own arithmetic (bench.py FLOPS_*_PER_PAIR comments); SURVEY 8d estimates ~20 fwd / ~75 bwd",
                          "kernel_ms": kt,
                          "kernel_ms_in_engine": None if not engine else engine.get("kernel_ms"),
                          "frac_in_engine": None if not (engine and pairs_valid and engine.get("kernel_ms", {}).get(dom)) else
@@ -676,9 +707,11 @@ def main():
             except Exception as e:
                 cb["cfg1"] = {"value": None, "sample": f"failed: {e}"}
             result["cpu_baseline"] = cb
-        print(json.dumps(result))
+        real_stdout.write(json.dumps(result) + "\n")
+        real_stdout.flush()
     if world > 1:
         dist.barrier()
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -175,7 +175,11 @@ front_fwd_kernel(int N, const float* __restrict__ means, const float* __restrict
                         av = desc_load(&agg_v[idx]); ai = desc_load(&agg_i[idx]);
                         isA = (av & ai & GS_VALID_BIT) != 0;
                         if (isA) break;
-                        if (++spins > GS_SPIN_LIMIT) { atomicExch(ctrl + 1, 1u); isA = true; av = ai = 0; break; }
+                        if (++spins > GS_SPIN_LIMIT) {             // a predecessor never published: the packed slots behind it are wrong.
+                            atomicExch(ctrl + 1, 1u);                 // Reported like a truncated view (memory-safe, wrong, repeat the step)
+                            if (status) status[0] = GS_ENOSPC;
+                            isA = true; av = ai = 0; break;
+                        }
                         __builtin_amdgcn_s_sleep(2);
                     }
                 }

@@ -831,7 +831,8 @@ bin_setup_kernel(unsigned* __restrict__ state, int n_state_words,
 // prefix across blocks is a decoupled look-back (blocks numbered by ticket, so a block only waits for blocks that already run)
 __global__ void __launch_bounds__(EM_THREADS)
 emit_chained_kernel(GsCount vc, const uint2* __restrict__ order, const uint2* __restrict__ rect, unsigned* __restrict__ ctrl,
-                    u64* __restrict__ desc, int n_blocks, int tile_w, uint2* __restrict__ items, unsigned item_cap)
+                    u64* __restrict__ desc, int n_blocks, int tile_w, uint2* __restrict__ items, unsigned item_cap,
+                    long long* __restrict__ status /* nullable: capacity protocol word */)
 {
     const int V = (int)gs_count(vc);
     __shared__ unsigned ws[EM_THREADS / 64];
@@ -880,7 +881,7 @@ emit_chained_kernel(GsCount vc, const uint2* __restrict__ order, const uint2* __
                         if (pv & BF_VALID) { isP = true; val = pv; break; }
                         const u64 av = __hip_atomic_load(&agg[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (av & BF_VALID) { val = av; break; }
-                        if (++spins > BF_SPIN_LIMIT) { atomicExch(ctrl + 1, 1u); break; }
+                        if (++spins > BF_SPIN_LIMIT) { atomicExch(ctrl + 1, 1u); if (status) status[0] = GS_ENOSPC; break; }   // (reported as a truncated view)
                         __builtin_amdgcn_s_sleep(2);
                     }
                 }
@@ -1020,7 +1021,7 @@ extern "C" int gs_isect_bin_front(int V_cap, const uint32_t* depth_keys, const u
     // 2. emission in depth order (chained scan inside the launch) + per-tile counts
     unsigned* ctrl = state; u64* desc = (u64*)((char*)state + 16);
     hipLaunchKernelGGL(emit_chained_kernel, dim3(eblocks), dim3(EM_THREADS), 0, s, vc, order, (const uint2*)tile_rects, ctrl, desc,
-                       eblocks + 1, tile_w, ia, (unsigned)n_isects);
+                       eblocks + 1, tile_w, ia, (unsigned)n_isects, (long long*)status_dev);
     GS_CHECK_LAUNCH();
     if (hist) {
         hipLaunchKernelGGL(tile_offsets_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, (const unsigned*)tile_counts, ic, isect_offsets);

@@ -24,7 +24,7 @@ import ctypes as C
 
 from . import _lib as L
 from .cameras import Camera
-from .parallel import GradBucket
+from .parallel import GradBucket, collectives_active
 from .rasterization import (_bin_stage, _bin_stage_cap, _composite_stage, _composite_stage_cap, _forward_stages, _prepare_stage,
                             _prepare_stage_cap, _project_stage)
 from . import front as F
@@ -169,7 +169,8 @@ class RenderStep:
         import torch.distributed as dist
         world = dist.get_world_size() if (all_reduce and dist.is_available() and dist.is_initialized()) else 1
         # S5 sharded over the ranks (each applies 1/world of every level's texels, all-gather): splitsum.py
-        sharded = (explicit_pre and world > 1 and os.environ.get("GEOSPLAT_SHARD_PREFILTER", "1") != "0"
+        # (collectives_active(): more than one rank, or the one-rank RCCL run of GEOSPLAT_COLLECTIVES_AT_WORLD1=1)
+        sharded = (explicit_pre and all_reduce and collectives_active() and os.environ.get("GEOSPLAT_SHARD_PREFILTER", "1") != "0"
                    and can_shard_prefilter(int(cubemap.shape[1]), world))
         # ---- what does not need the pyramid comes first: activations, streams, key width -- and, in capacity mode, the GEOMETRY of
         # the first view (projection, keys, binning: gs_front_fwd without records) on a front stream, so that it runs UNDER the
@@ -224,7 +225,7 @@ class RenderStep:
                 with torch.cuda.stream(side):
                     fr_g = F.front_stage(means, quats, scales_act, opac_act, normals, kd, ks, vm_j, K_j, cp_j, None, cam_j.width, cam_j.height,
                                          self.min_roughness, self.max_metallic, mode, key_base, key_bits,
-                                         self._status if key_bits == 24 else None, records=False, tight_tiles=tight)
+                                         self._status if (key_bits == 24 or self._use_capacity) else None, records=False, tight_tiles=tight)
                     gstate, _, _ = F.bin_stage(fr_g, i_cap, self._status, prepare=False)
                 seen.append((fr_g.host_counts, fr_g.event))
                 early[j] = (gstate["flatten_ids"], gstate["isect_offsets"])
@@ -328,7 +329,7 @@ class RenderStep:
                     else:
                         fr = F.front_stage(means, quats, scales_act, opac_act, normals, kd, ks, vm, K, cam_pos, e, cam.width, cam.height,
                                            self.min_roughness, self.max_metallic, mode, key_base, key_bits,
-                                           self._status if key_bits == 24 else None, want_packed_index=tail_batch > 0, tight_tiles=tight)
+                                           self._status if (key_bits == 24 or self._use_capacity) else None, want_packed_index=tail_batch > 0, tight_tiles=tight)
                 return fr, j, side
             with torch.cuda.stream(side):
                 col = torch.empty(N, 3, dtype=f32, device=dev)
@@ -641,7 +642,9 @@ class RenderStep:
         them over the ranks itself (collectives stay outside the graph).  `upstream` is traced once: it must compute
         d(loss)/d(image) with device-side operations on buffers that keep their addresses (update ground-truth images in
         place between replays).  Parameters are read from the tensors bound at capture time (update them in place).
-        replay.check() synchronises and returns False if a view exceeded the capacity (then: poll_capacity, re-capture)."""
+        replay.check() synchronises and returns False if a view exceeded the capacity OR left the depth range of the 24-bit binning
+        keys baked into the graph: the graph is then stale (it would keep replaying with clamped keys, i.e. a wrong depth order) --
+        call poll_capacity() and capture() AGAIN before the next replay; a replay after a False check() raises."""
         if not (self.fused and self.mode == "pbr"):
             raise RuntimeError("capture() needs the fused path")
         if self._i_cap is None:
@@ -671,7 +674,11 @@ class RenderStep:
         cap = self._i_cap
         status_host = self._status_host
 
+        stale = [False]
+
         def replay():
+            if stale[0]:
+                raise RuntimeError("this captured step overflowed its capacity / key range (check() returned False): capture() again")
             graph.replay()
             return out
 
@@ -680,6 +687,7 @@ class RenderStep:
             worst = max([int(hc[1]) for hc in counts] + [0])
             overflow = int(status_host[0]) != 0 or int(status_host[3]) != 0 or worst > cap
             if overflow:
+                stale[0] = True
                 self.truncated_steps += 1
                 self._key32 = self._key32 or int(status_host[3]) != 0
                 self._exact_max_i = max(self._exact_max_i, worst, int(status_host[1]))
@@ -712,7 +720,7 @@ class RenderStep:
         if self._status_host is None:
             self._status_host = torch.zeros(4, dtype=torch.int64).pin_memory()
         world = dist.get_world_size() if (all_reduce and dist.is_available() and dist.is_initialized()) else 1
-        sharded = (world > 1 and os.environ.get("GEOSPLAT_SHARD_PREFILTER", "1") != "0"
+        sharded = (all_reduce and collectives_active() and os.environ.get("GEOSPLAT_SHARD_PREFILTER", "1") != "0"
                    and can_shard_prefilter(int(self.p.cubemap.shape[1]), world))
 
         def filter_env():
@@ -755,7 +763,11 @@ class RenderStep:
         status_host = self._status_host
         ctx["main"] = None
 
+        stale = [False]
+
         def step():
+            if stale[0]:
+                raise RuntimeError("these captured views overflowed their capacity / key range (check() returned False): capture_views() again")
             cur = torch.cuda.current_stream(dev)
             if two:
                 geo_stream.wait_stream(cur)                    # (the parameters of this step are final on the caller's stream)
@@ -774,6 +786,7 @@ class RenderStep:
             worst = max([int(hc[1]) for hc in counts] + [0])
             overflow = int(status_host[0]) != 0 or int(status_host[3]) != 0 or worst > cap
             if overflow:
+                stale[0] = True
                 self.truncated_steps += 1
                 self._key32 = self._key32 or int(status_host[3]) != 0
                 self._exact_max_i = max(self._exact_max_i, worst, int(status_host[1]))

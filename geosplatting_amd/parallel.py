@@ -20,6 +20,18 @@ import torch.distributed as dist
 from torch import Tensor
 
 
+def collectives_active() -> bool:
+    """True when the step has to run its collectives: a process group with more than one rank -- or ANY initialised group under
+    GEOSPLAT_COLLECTIVES_AT_WORLD1=1, the switch with which a one-GPU box executes the complete multi-GPU code path (sharded
+    prefilter with its own communicator, two-phase gradient all-reduce on the communication stream, graph replay beside them)
+    through RCCL itself: `torch.distributed` backend "nccl" with ONE rank (tests/test_gpu_parallel.py::test_rccl_*, bench.py
+    --rccl-world1).  Two ranks cannot share a GPU under RCCL ("Duplicate GPU detected"), one rank can have it to itself."""
+    import os
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("GEOSPLAT_COLLECTIVES_AT_WORLD1") == "1"
+
+
 def shard_views(num_views: int, rank: int, world_size: int) -> List[int]:
     """View i -> rank i mod world_size; returns this rank's view indices in order."""
     return list(range(rank, num_views, world_size))
@@ -66,7 +78,7 @@ class GradBucket:
     def all_reduce(self, average: bool = False, async_op: bool = False):
         """Sum over ranks (RCCL on GPUs, gloo on CPU).  With async_op the collective runs on a side stream and
         the returned callable must be invoked before the gradients are read."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not collectives_active():
             return (lambda: None) if async_op else None
         if self.comm_stream is not None and async_op:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
@@ -90,8 +102,7 @@ class GradBucket:
         overlaps the prefilter backward -- and `finish()` reduces the tail segments and joins the streams."""
         cut = self.offsets[first_of_tail]
         head, tail = self.flat[:cut], self.flat[cut:]
-        active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        if not active:
+        if not collectives_active():
             return (lambda: None), (lambda: None)
         cs = self.comm_stream
 
@@ -115,7 +126,7 @@ class GradBucket:
 
     def all_reduce_names(self, names: Sequence[str], group=None) -> None:
         """Sum only the listed segments (on the communication stream, joined before returning)."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not collectives_active():
             return
         cs = self.comm_stream
         if cs is not None:
@@ -148,7 +159,8 @@ def init_distributed_from_env(device_type: str = "cuda"):
         device = torch.device("cuda", local)
     else:
         device = torch.device("cpu")
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("GEOSPLAT_COLLECTIVES_AT_WORLD1") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, device

@@ -478,7 +478,8 @@ def _level_roughness(n: int, min_roughness: float, max_roughness: float) -> List
 
 
 def can_shard_prefilter(cubemap_res: int, world: int, min_resolution: int = 16) -> bool:
-    return world > 1 and tiles_eligible(cubemap_res) and cubemap_res >= 4 * min_resolution
+    from .parallel import collectives_active
+    return (world > 1 or collectives_active()) and tiles_eligible(cubemap_res) and cubemap_res >= 4 * min_resolution
 
 
 def _flat_levels(res_list: List[int], device) -> Tuple[Tensor, List[Tensor]]:

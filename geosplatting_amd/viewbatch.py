@@ -144,7 +144,7 @@ def camera_tensors(st: _DeviceState, cam: Camera, stream: torch.cuda.Stream):
 # ------------------------------------------------------------------------------------------------------------ the step
 class _View:
     __slots__ = ("cam", "W", "H", "V", "I", "state", "render", "alphas", "last_ids", "log_ws", "tone", "exposure", "exact", "cap",
-                 "cap_used", "key_bits", "key_base", "host_counts", "event", "done", "index")
+                 "cap_used", "key_bits", "key_base", "host_counts", "host_status", "event", "done", "index")
 
 
 class _Step:
@@ -253,6 +253,14 @@ def _poll_unchecked(st: _DeviceState, wait_views=None) -> None:
             if rng is not None and (rng[0] < v.key_base or rng[1] >= v.key_base + (1 << 24)):
                 over = True
                 cap.key32 = True
+        hs = v.host_status
+        if hs is not None:
+            if int(hs[0]) != 0 or int(hs[3]) != 0:
+                over = True
+                cap.key32 = cap.key32 or int(hs[3]) != 0
+                st.status.zero_()                          # (sticky on the device: cleared once it has been reported)
+            F.release_counts4(hs)
+            v.host_status = None
         cap.learn(hc)
         F.release_counts4(hc)
         v.host_counts = None
@@ -291,7 +299,7 @@ def _view_forward(step: _Step, cam: Camera, exposure: Tensor, tone: int, want_gr
     v.cam, v.W, v.H, v.tone, v.exact, v.cap, v.done, v.index = cam_t, W, H, tone, exact, cap, False, len(step.views)
     with torch.cuda.stream(side):
         fr = F.front_stage(t["means"], t["quats"], step.scales_act, step.opac_act, t["normals"], t["kd"], t["ks"], cam_t[0], cam_t[1],
-                           cam_t[2], step.e, W, H, mr, mm, mode, key_base, key_bits, st.status if key_bits == 24 else None,
+                           cam_t[2], step.e, W, H, mr, mm, mode, key_base, key_bits, None if exact else st.status,
                            want_packed_index=want_grad, tight_tiles=tight)
         # the record stream of the compositor (gs_raster_prepare_vis: 0.1 ms, HBM gather) is built on the CALLER's stream, whose
         # compositor forward (0.29 ms per view) leaves it idle for more than half of the forward phase, while the front streams
@@ -300,13 +308,19 @@ def _view_forward(step: _Step, cam: Camera, exposure: Tensor, tone: int, want_gr
         state, V, I = F.bin_stage(fr, None if exact else cap.i_cap, None if exact else st.status, prepare=not split)
         v_packed = torch.zeros(max(V, 1), lib.gs_raster_grad_stride(3), dtype=torch.float32, device=dev) if want_grad else None
         log_ws = torch.empty(lib.gs_raster_log_ws_bytes(L.i64(I), W, H, 16), dtype=torch.uint8, device=dev)
+        v.host_status = None
+        if not exact:
+            # the device's own word (word 0: a view truncated at its capacity, or a look-back of the front / emission that gave up;
+            # word 3: a depth outside the 24-bit key range) follows the view to the host with its counts
+            v.host_status = F.pinned_counts4()
+            v.host_status.copy_(st.status, non_blocking=True)
         ev = torch.cuda.Event(); ev.record(side)
     if exact:
         cap.learn(fr.host_counts)                          # (bin_stage waited for them)
         F.release_counts4(fr.host_counts)
         v.host_counts = None
     else:
-        v.host_counts, v.event, v.cap_used, v.key_bits, v.key_base = fr.host_counts, fr.event, cap.i_cap, key_bits, key_base
+        v.host_counts, v.event, v.cap_used, v.key_bits, v.key_base = fr.host_counts, ev, cap.i_cap, key_bits, key_base
         st.unchecked.append(v)
     for x in list(state.values()) + [log_ws, v_packed, step.scales_act, step.opac_act] + list(cam_t):
         if isinstance(x, Tensor):

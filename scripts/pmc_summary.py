@@ -29,6 +29,13 @@ for k in sorted(vals):
             traffic[short]["valu_wave_instructions"] = sum(vi) / len(vi)
         if at:
             traffic[short]["atomic_requests"] = sum(at) / len(at)
+        # where the waves' cycles go (MI355X_MICROARCH.md: WAIT_ANY = parked at s_waitcnt / barrier, WAIT_INST_ANY = issue stall,
+        # ACTIVE_INST_ANY = issuing; the three are disjoint and add up to WAVE_CYCLES)
+        for cname in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS",
+                      "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_LDS_BANK_CONFLICT", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVES"):
+            c = vals[k].get(cname)
+            if c:
+                traffic[short][cname] = sum(c) / len(c)
         lines.append(f"    -> HBM traffic per launch: fetch {fb / 1e6:.1f} MB (FETCH_SIZE KiB x 2, gfx950 correction) + write {wb / 1e6:.1f} MB")
 out = "\n".join(lines)
 if len(sys.argv) > 2:

@@ -268,3 +268,54 @@ def test_capacity_follows_changing_views():
     grads, images = step(views, lambda j, img: up, all_reduce=False, keep_images=True)
     torch.cuda.synchronize()
     _same(({n: v.detach().cpu().clone() for n, v in grads.items()}, [im.detach().cpu().clone() for im in images]), got)
+
+
+def _rccl_worker(rank, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      GEOSPLAT_COLLECTIVES_AT_WORLD1="1")
+    os.environ.pop("GEOSPLAT_DEBUG_SHARE_GPU", None)
+    import torch.distributed as dist
+    import geosplatting_amd.synthetic as syn
+    from geosplatting_amd.engine import RenderStep, params_from_scene
+    from geosplatting_amd.parallel import collectives_active, init_distributed_from_env
+    from oracle import mesh_ref
+    r, w, dev = init_distributed_from_env("cuda")
+    assert dist.get_backend() == "nccl" and w == 1 and collectives_active()
+    sc = syn.sphere_scene(LEVEL, seed=2, cubemap_res=64, mesh_to_splats_fn=mesh_ref.scene_builder)
+    cams = syn.blender_cameras(N_VIEWS, RES, RES)
+    step = RenderStep(params_from_scene(sc, dev, exposure=1.1))
+    ups = {i: (torch.rand(RES, RES, 4, generator=torch.Generator().manual_seed(50 + i)) * 2 - 1).to(dev) for i in range(N_VIEWS)}
+    up = lambda j, img: ups[j].reshape(img.shape)
+    for _ in range(3):
+        grads, _ = step(cams, up, all_reduce=True)                    # sharded prefilter (own communicator) + two-phase all-reduce: RCCL
+        torch.cuda.synchronize()
+    assert step._pre_group is not None                                # dist.new_group() of the prefilter exchange really ran
+    out = {"eager": {k: v.detach().cpu().clone() for k, v in grads.items()}}
+    assert step.poll_capacity(wait=True)
+    graphed = step.capture_views(cams[:2], lambda j, img: ups[j].reshape(img.shape), all_reduce=True)   # graph replay beside the collectives
+    for _ in range(2):
+        g2, _ = graphed()
+        torch.cuda.synchronize()
+    assert graphed.check()
+    out["graph2"] = {k: v.detach().cpu().clone() for k, v in g2.items()}
+    torch.save(out, os.path.join(out_dir, "rccl.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_one_rank_executes_the_multi_gpu_path(tmp_path):
+    """RCCL itself (torch.distributed backend "nccl") on the GPU box: one rank -- two ranks cannot share a GPU under RCCL -- runs
+    the COMPLETE multi-GPU step: sharded prefilter forward / backward with its own communicator (dist.new_group), the all-reduce of
+    the texel gradients, the two-phase all-reduce of the flat gradient bucket on the communication stream, and the views of a step
+    replayed as HIP graphs between eager collectives (capture_views).  With one rank every sum is the identity, so the results
+    must equal the plain single-process step."""
+    mp.spawn(_rccl_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    got = torch.load(os.path.join(tmp_path, "rccl.pt"))
+    want = _step(torch.device("cuda", 0), list(range(N_VIEWS)), all_reduce=False)
+    want2 = _step(torch.device("cuda", 0), [0, 1], all_reduce=False)
+    for name, ref in (("eager", want), ("graph2", want2)):
+        for k, w in ref.items():
+            scale = w.abs().max().item() + 1e-30
+            err = (got[name][k] - w).abs().max().item() / scale
+            assert err < 5e-5, (name, k, err)

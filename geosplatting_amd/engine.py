@@ -223,6 +223,9 @@ class RenderStep:
                 side = sides[j % len(sides)]
                 side.wait_event(ev_a)
                 with torch.cuda.stream(side):
+                    # (round 5, measured and removed: the early front also writing the RECORDS -- colours left out -- and the record stream
+                    #  built here, so that only a colour pass is left behind the pyramid: 675 against 695 views/s.  What runs beside the
+                    #  prefilter's table stream slows IT down by more than it takes off the path behind it, as with a second view's geometry.)
                     fr_g = F.front_stage(means, quats, scales_act, opac_act, normals, kd, ks, vm_j, K_j, cp_j, None, cam_j.width, cam_j.height,
                                          self.min_roughness, self.max_metallic, mode, key_base, key_bits,
                                          self._status if (key_bits == 24 or self._use_capacity) else None, records=False, tight_tiles=tight)
@@ -236,6 +239,11 @@ class RenderStep:
                 main.wait_stream(sd)                         # (a captured phase: every forked stream joins before the capture ends)
             self._seen_counts.extend(seen)
             return dict(early=early, scales_act=scales_act, opac_act=opac_act)
+        # (zero fills of the step: issued BEFORE the prefilter, i.e. off the path pyramid -> first compositor launch -- 0.06 ms)
+        self.bucket.flat.zero_()
+        b = self.bucket.unpack()
+        g_scales_act = torch.zeros(N, 3, dtype=f32, device=dev); g_opac_act = torch.zeros(N, dtype=f32, device=dev)
+        exposure = p.exposure.detach().reshape(1).contiguous()
         if _env is not None:
             env = _env                                       # the pyramid of this step, already filtered (capture_views)
         elif self.prefilter:
@@ -282,10 +290,6 @@ class RenderStep:
                      else None)
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
 
-        self.bucket.flat.zero_()
-        b = self.bucket.unpack()
-        g_scales_act = torch.zeros(N, 3, dtype=f32, device=dev); g_opac_act = torch.zeros(N, dtype=f32, device=dev)
-        exposure = p.exposure.detach().reshape(1).contiguous()
         images = []
 
         # HIP streams of a step.  The FRONT streams run the memory / latency-bound front of every view (shading, projection,

@@ -153,10 +153,11 @@ def masked_stream(device: torch.device, cu_lo: int, cu_hi: int) -> "torch.cuda.S
     return st
 
 
-def stream_from_env(name: str, device: torch.device, priority: int = 0) -> "torch.cuda.Stream":
-    """A new stream for the engine: plain, or -- NAME="lo:hi" in the environment -- restricted to CUs lo..hi-1 of every XCD."""
-    v = os.environ.get(name, "")
-    if ":" in v:
-        lo, hi = (int(x) for x in v.split(":"))
-        return masked_stream(device, lo, hi)
+def stream_from_env(role: str, device: torch.device, priority: int = 0) -> "torch.cuda.Stream":
+    """A new stream for the engine: plain, or -- GEOSPLAT_CU_SLICES="front=24:32,tail=16:32,main=0:24" -- restricted to CUs lo..hi-1 of
+    every XCD for the roles named there (the round-5 partition experiment, profiles/r05_cu_partition_sweep.txt: every split loses)."""
+    for item in os.environ.get("GEOSPLAT_CU_SLICES", "").split(","):
+        if item.startswith(role + "=") and ":" in item:
+            lo, hi = (int(x) for x in item[len(role) + 1:].split(":"))
+            return masked_stream(device, lo, hi)
     return torch.cuda.Stream(device=device, priority=priority)

@@ -187,8 +187,8 @@ class RenderStep:
             self._status = torch.zeros(4, dtype=torch.int64, device=dev)
         if self._side_stream is None:
             # GEOSPLAT_FRONT_STREAMS=2: the fronts of consecutive views alternate between two streams (see start_view)
-            # (GEOSPLAT_FRONT_CUS="lo:hi": the front streams on a slice of every XCD, _lib.masked_stream; measured, not the default)
-            self._side_stream = [L.stream_from_env("GEOSPLAT_FRONT_CUS", dev, int(os.environ.get("GEOSPLAT_SIDE_PRIO", "0")))
+            # (GEOSPLAT_CU_SLICES="front=lo:hi,...": streams on a slice of every XCD, _lib.masked_stream; measured, not the default)
+            self._side_stream = [L.stream_from_env("front", dev, int(os.environ.get("GEOSPLAT_SIDE_PRIO", "0")))
                                  for _ in range(max(1, int(os.environ.get("GEOSPLAT_FRONT_STREAMS", "2"))))]
         sides = self._side_stream
         fused_front = self._front_fused
@@ -300,7 +300,7 @@ class RenderStep:
         # nothing makes the host wait, so the fronts run as far ahead of the compositor as their inputs allow.
         tail = self._tail_stream
         if tail is None:
-            tail = self._tail_stream = L.stream_from_env("GEOSPLAT_TAIL_CUS", dev, int(os.environ.get("GEOSPLAT_TAIL_PRIO", "0")))
+            tail = self._tail_stream = L.stream_from_env("tail", dev, int(os.environ.get("GEOSPLAT_TAIL_PRIO", "0")))
         for sd in sides:
             sd.wait_stream(main)                             # prefilter pyramid, activations, zeroed buckets
         tail.wait_stream(main)
@@ -891,10 +891,10 @@ class RenderStep:
         """Forward + backward for `cameras`; `upstream(i, image)` returns d(loss)/d(image) for local view i.
         Returns (grads dict of views into the flat bucket, images or None)."""
         if self.fused and self.mode == "pbr":
-            if ":" in os.environ.get("GEOSPLAT_MAIN_CUS", "") and not getattr(self, "_in_masked_main", False):
+            if "main=" in os.environ.get("GEOSPLAT_CU_SLICES", "") and not getattr(self, "_in_masked_main", False):
                 # experiment: the compositor's stream on a slice of every XCD too (the caller's stream waits for it)
                 if getattr(self, "_masked_main", None) is None:
-                    self._masked_main = L.stream_from_env("GEOSPLAT_MAIN_CUS", self.p.means.device)
+                    self._masked_main = L.stream_from_env("main", self.p.means.device)
                 cur = torch.cuda.current_stream(self.p.means.device)
                 self._masked_main.wait_stream(cur)
                 self._in_masked_main = True

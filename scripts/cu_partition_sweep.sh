@@ -8,18 +8,18 @@ j=json.loads(sys.stdin.read()); k=j['roofline'].get('kernel_ms_in_engine') or {}
 print(f\"{j['value']:7.1f} views/s  {j['ms_per_step']:6.2f} ms  in-engine fwd {k.get('raster_fwd_kernel',0):.3f} bwd {k.get('raster_bwd_kernel',0):.3f}\")"; }
 echo "# CUs lo:hi of EVERY XCD (32 per XCD); unset = all CUs.  bench.py --steps 30, 2 M Gaussians, 800^2, 8 views + prefilter"
 run "X=0"
-run "GEOSPLAT_FRONT_CUS=24:32"
-run "GEOSPLAT_FRONT_CUS=20:32"
-run "GEOSPLAT_FRONT_CUS=16:32"
-run "GEOSPLAT_FRONT_CUS=24:32 GEOSPLAT_TAIL_CUS=24:32"
-run "GEOSPLAT_FRONT_CUS=24:32 GEOSPLAT_TAIL_CUS=16:32"
-run "GEOSPLAT_FRONT_CUS=20:32 GEOSPLAT_TAIL_CUS=20:32"
-run "GEOSPLAT_FRONT_CUS=16:32 GEOSPLAT_TAIL_CUS=16:32"
-run "GEOSPLAT_FRONT_CUS=24:32 GEOSPLAT_TAIL_CUS=16:24"
-run "GEOSPLAT_MAIN_CUS=0:24 GEOSPLAT_FRONT_CUS=24:32 GEOSPLAT_TAIL_CUS=24:32"
-run "GEOSPLAT_MAIN_CUS=0:24 GEOSPLAT_FRONT_CUS=24:32"
-run "GEOSPLAT_MAIN_CUS=0:20 GEOSPLAT_FRONT_CUS=20:32 GEOSPLAT_TAIL_CUS=20:32"
-run "GEOSPLAT_MAIN_CUS=0:28 GEOSPLAT_FRONT_CUS=28:32 GEOSPLAT_TAIL_CUS=24:32"
-run "GEOSPLAT_TAIL_CUS=16:32"
-run "GEOSPLAT_TAIL_CUS=16:32 GEOSPLAT_TAIL_EARLY_BLOCKS=256"
+run "GEOSPLAT_CU_SLICES=front=24:32"
+run "GEOSPLAT_CU_SLICES=front=20:32"
+run "GEOSPLAT_CU_SLICES=front=16:32"
+run "GEOSPLAT_CU_SLICES=front=24:32,tail=24:32"
+run "GEOSPLAT_CU_SLICES=front=24:32,tail=16:32"
+run "GEOSPLAT_CU_SLICES=front=20:32,tail=20:32"
+run "GEOSPLAT_CU_SLICES=front=16:32,tail=16:32"
+run "GEOSPLAT_CU_SLICES=front=24:32,tail=16:24"
+run "GEOSPLAT_CU_SLICES=main=0:24,front=24:32,tail=24:32"
+run "GEOSPLAT_CU_SLICES=main=0:24,front=24:32"
+run "GEOSPLAT_CU_SLICES=main=0:20,front=20:32,tail=20:32"
+run "GEOSPLAT_CU_SLICES=main=0:28,front=28:32,tail=24:32"
+run "GEOSPLAT_CU_SLICES=tail=16:32"
+run "GEOSPLAT_CU_SLICES=tail=16:32 GEOSPLAT_TAIL_EARLY_BLOCKS=256"
 run "X=0"

@@ -51,10 +51,10 @@ class GeoSplatCapacityError(L.GeoSplatHipError):
 class _DeviceState:
     def __init__(self, dev: torch.device):
         self.dev = dev
-        # three front streams: in this call shape the fronts are the critical path of the forward phase (0.7 ms per view against
-        # 0.29 ms of compositor forward), three in flight: 602 views/s against 592 for two (the engine, whose fronts hide behind
-        # forward + backward, is best with two)
-        n_front = max(1, int(os.environ.get("GEOSPLAT_SPLAT_FRONT_STREAMS", "3")))
+        # two front streams (+ the caller's stream + the tail stream = the four hardware queues HIP maps its streams onto by default:
+        # a third front stream is 2 % faster alone in a process -- 608 against 596 views/s -- and 13 % SLOWER, 520 against 595, in a
+        # process that holds other streams, where two of them then share a queue)
+        n_front = max(1, int(os.environ.get("GEOSPLAT_SPLAT_FRONT_STREAMS", "2")))
         self.fronts = [torch.cuda.Stream(device=dev) for _ in range(n_front)]
         self.tail = torch.cuda.Stream(device=dev)
         self.status = None                       # int64[4] device word of the capacity protocol (sticky; the host checks the counts)

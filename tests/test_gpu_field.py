@@ -200,8 +200,14 @@ def test_hashgrid_fixed_point_table_gradient(monkeypatch):
     #  float path's sums depend on the order of its LDS atomics, so its MAXIMUM over the small rows moves from run to run -- 0.0125
     #  to 0.03 against a fixed 0.0194 here: the mean is the stable statistic, the maximum gets room)
     rel_fixed, rel_float = err_fixed[small] / ref.abs()[small], err_float[small] / ref.abs()[small]
+    print(f"\n  small rows: fixed-point rel err mean {rel_fixed.mean().item():.3e} max {rel_fixed.max().item():.3e}; "
+          f"float path mean {rel_float.mean().item():.3e} max {rel_float.max().item():.3e}")
     assert rel_fixed.mean().item() <= 1.5 * rel_float.mean().item() + 1e-9
     assert rel_fixed.max().item() <= 4.0 * rel_float.max().item() + 1e-6
+    # ... and, the fixed-point sums being integers (the same bits in every run on every box: 7.699e-07 / 1.944e-02 here), against the
+    # float64 yardstick ALONE with tight bounds: a bias in the scaling or the rounding of the fixed-point path shows here even when
+    # the float path's atomics happen to have a bad day
+    assert rel_fixed.mean().item() < 1.0e-6 and rel_fixed.max().item() < 2.5e-2
     assert torch.equal(a1.cpu() == 0, ref == 0)                                     # untouched rows are exactly zero
 
 

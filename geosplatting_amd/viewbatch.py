@@ -165,7 +165,8 @@ class _Step:
             self.opac_act = torch.sigmoid(tensors["opacities"]).reshape(-1).contiguous()
         self.ready = torch.cuda.Event(); self.ready.record()     # parameters, pyramid, activations: final on the caller's stream here
         self.views: List[_View] = []
-        self.gathered = None                               # outputs of this step's _Gather node (None: the parameters need no gradient)
+        self.gathered = None                               # outputs of this step's _Gather node while the step can still be joined
+        self.has_gather = False                            # a _Gather node sits in front of this step's views (the parameters need gradients)
         self.pending: List[_View] = []                     # compositor backward done, tail not launched
         self.g = None                                      # gradient buffers of the backward pass in progress
         self.n_tail = 0
@@ -361,7 +362,7 @@ def _view_backward(step: _Step, v: _View, v_img: Tensor) -> Tensor:
     v_img = v_img.contiguous().float()
     g_exp = torch.zeros(1, dtype=torch.float32, device=step.st.dev)
     rws = s["raster_ws"]
-    gather = step.gathered is not None                     # (False: only the exposure needs a gradient -- no tail, no gather node)
+    gather = step.has_gather                               # (False: only the exposure needs a gradient -- no tail, no gather node)
     if gather:
         step.grads()
     L.check(lib.gs_raster_bwd_tone_log_acc(v.W, v.H, 16, v.V, None, L.i64(v.I), L.ptr(s["counts"]), L.ptr(s["isect_offsets"]),
@@ -462,8 +463,15 @@ def splat_view(means: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor, 
         conv = [x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous() for x in srcs]
         det = dict(zip(_PARAMS, (x.detach() for x in conv[:7])))
         env_d = TextureSplitSum(conv[7].detach(), [x.detach() for x in conv[8:]], envmap.min_roughness, envmap.max_roughness)
+        if step is not None:
+            # the step that can no longer be joined lets go of its gather outputs: step -> outputs -> grad_fn -> ctx -> step is a cycle
+            # through C++ ownership that Python's collector cannot see (56 MB per step -- activations + pyramid -- leaked without this;
+            # scripts/soak_callshape.py).  Its view nodes keep their own edges to the gather node.
+            step.gathered = None
+            step.srcs = None
         step = _Step(st, key, det, env_d, lut, cfg)
         step.srcs = srcs                                   # keeps the ids in `key` unique while the step can be joined
+        step.has_gather = params_grad
         step.gathered = _Gather.apply(step, *conv) if params_grad else None
         st.current = step
     if not want_grad:
@@ -475,5 +483,7 @@ def splat_view(means: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor, 
 def reset() -> None:
     """Forget the joinable step and the learnt capacities (tests)."""
     for st in _states.values():
+        if st.current is not None:
+            st.current.gathered = None
         st.current = None
         st.caps.clear()

@@ -574,6 +574,11 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
         q.a = (float4*)base; q.c = q.a + GS_WIN_Q; q.b = (float2*)(q.c + GS_WIN_Q); q.idx = (int*)(q.b + GS_WIN_Q);
     }
     lane_queue_clear(q, GS_WIN_Q, lane);
+    // D > 3 (colours outside the record stream; rfstudio/model/geosplat.py:276-295 renders 14 feature channels): the colours of the two
+    // resident dense batches are staged in LDS as planes [2][D][64] -- lane j loads the D colours of record j once per (record,
+    // quadrant) when its batch is built -- instead of 4 D bytes gathered from global memory per PAIR (round 5: 2.2 -> see DESIGN, D = 14)
+    float* colp = CD > 3 ? (float*)(gs_lds_raw + 4 * (size_t)GS_WIN_Q_BYTES) + (size_t)wave * 2 * D * 64 : nullptr;
+    int parA = 0;                                                 // colour plane set of batch A (B: the other one)
     const int start = offsets[tile];
     const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
 
@@ -639,6 +644,11 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
                 }
                 log_n += __popcll(keep);
             }
+            if (CD > 3) {
+                const float* cg = colors + (size_t)__float_as_int(q.c[slot].w) * D;
+                float* dst = colp + (size_t)parA * D * 64 + lane;
+                for (int k = 0; k < D; ++k) dst[k * 64] = lane < nA ? cg[k] : 0.0f;
+            }
             listA = gs_bit_transpose64(pm, lane);
             if (done) listA = 0ull;
 #ifdef GS_RASTER_STATS
@@ -661,6 +671,11 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
                 }
                 log_n += __popcll(keep);
             }
+            if (CD > 3) {
+                const float* cg = colors + (size_t)__float_as_int(q.c[slot].w) * D;
+                float* dst = colp + (size_t)(parA ^ 1) * D * 64 + lane;
+                for (int k = 0; k < D; ++k) dst[k * 64] = lane < nB ? cg[k] : 0.0f;
+            }
             listB = gs_bit_transpose64(pm, lane);
             if (done) listB = 0ull;
 #ifdef GS_RASTER_STATS
@@ -671,6 +686,7 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
         if (blockIdx.x == 0 && threadIdx.x == 0) { const long long _t = (long long)__builtin_readcyclecounter(); atomicAdd(&g_raster_stats[1], (unsigned long long)(_t - _pm0)); _pm0 = _t; }
 #endif
         // ---- walk until batch A is exhausted in every lane; lanes that are through with A work on B
+        if (CD > 3) lanes_lds_sync();                              // (the colour planes written above are read by other lanes)
         const int baseB = qhead + nA;
         if (__ballot(listA != 0ull) != 0ull) do {                 // (rotated by hand: no copies of the loop-carried state per trip)
             GS_STAT(3, 1);
@@ -678,6 +694,7 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
             if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_raster_stats[3], 1ull);
 #endif
             bool has[2]; int slot[2];
+            int cofs[2] = { 0, 0 };                                // D > 3: float offset of the candidate's first colour in the planes
             float4 ca[2], cc[2]; float2 cb[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -688,6 +705,7 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
                 listA = useA ? cur : listA;
                 listB = useA ? listB : cur;
                 slot[u] = win_wrap((useA ? qhead : baseB) + j);
+                if (CD > 3) cofs[u] = (useA ? parA : (parA ^ 1)) * D * 64 + j;
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) { ca[u] = q.a[slot[u]]; cb[u] = q.b[slot[u]]; cc[u] = q.c[slot[u]]; }
@@ -720,10 +738,11 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
                     pix[0] = fmaf(cc[u].x, vis, pix[0]);
                     if (CD > 1) pix[1] = fmaf(cc[u].y, vis, pix[1]);
                     if (CD > 2) pix[2] = fmaf(cc[u].z, vis, pix[2]);
-                } else if (acc) {
-                    const float* cg = colors + (size_t)__float_as_int(cc[u].w) * D;
+                } else {
+                    // (no branch around the LDS reads: vis == 0 for a lane without an accepted candidate, the planes hold finite numbers)
+                    const float* cg = colp + cofs[u];
 #pragma unroll
-                    for (int k = 0; k < CD; ++k) if (k < D) pix[k] = fmaf(cg[k], vis, pix[k]);
+                    for (int k = 0; k < CD; ++k) if (k < D) pix[k] = fmaf(cg[k * 64], vis, pix[k]);
                 }
                 T = acc ? next_T : T;
                 cur_slot = acc ? slot[u] : cur_slot;
@@ -743,6 +762,7 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
         qcount -= nA;
         listA = listB; nA = nB;
         listB = 0ull; nB = 0;
+        parA ^= 1;                                                 // (B's colour planes become A's)
     }
     raw_drain(raw0, raw1, raw2);
     if (log.count && lane == 0) log.count[4 * tile + wave] = log_n;
@@ -794,7 +814,9 @@ raster_bwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
     const int n_isects = (int)gs_count(ic);
     constexpr int NV = 6 + CD;
     constexpr int RPI = 64 / NV;                                   // records committed per atomic instruction
-    constexpr int WAVE_BYTES = GS_LANES_Q_BYTES + NV * 64 * 8;
+    // per wave: queue | accumulator rows [6 + D][64] f64 | colour planes [D][64] f32 of the dense batch (sized by the run-time D, so
+    // that D = 14 keeps two workgroups per CU: 4 x 19 456 B)
+    const int WAVE_BYTES = GS_LANES_Q_BYTES + (6 + D) * 64 * 8 + D * 64 * 4;
     extern __shared__ __align__(16) unsigned char gs_lds_raw[];
 #ifdef GS_EXP_PRIO
     if ((int)blockIdx.x < GS_EXP_PRIO) __builtin_amdgcn_s_setprio(3);
@@ -813,9 +835,9 @@ raster_bwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
 
     const LaneQueue q = lane_queue(gs_lds_raw + (size_t)wave * WAVE_BYTES);
     lane_queue_clear(q, GS_LANES_Q, lane);
-    double* acc = (double*)(gs_lds_raw + (size_t)wave * WAVE_BYTES + GS_LANES_Q_BYTES);      // [NV][64]: row k, dense record j
-#pragma unroll
-    for (int k = 0; k < NV; ++k) acc[k * 64 + lane] = 0.0;
+    double* acc = (double*)(gs_lds_raw + (size_t)wave * WAVE_BYTES + GS_LANES_Q_BYTES);      // [6 + D][64]: row k, dense record j
+    float* colp = (float*)(acc + (6 + D) * 64);                                               // [D][64]: colour k of dense record j
+    for (int k = 0; k < 6 + D; ++k) acc[k * 64 + lane] = 0.0;
 
     float T_final = 1.0f, v_a = 0.0f;
     int bin_final = -1;
@@ -890,6 +912,11 @@ raster_bwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
                                                             ymin, ymax);
             list = gs_bit_transpose64(pm, lane);
             if (!live) list = 0ull;
+            if (CD > 3) {                                              // the batch's colours: once per (record, quadrant), not per pair
+                const float* cg = colors + (size_t)__float_as_int(q.c[slot].w) * D;
+                for (int k = 0; k < D; ++k) colp[k * 64 + lane] = lane < nb ? cg[k] : 0.0f;
+                lanes_lds_sync();
+            }
         }
         GS_STAT(5, nb);
         while (__ballot(list != 0ull) != 0ull) {
@@ -916,9 +943,8 @@ raster_bwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
                         if (CD > 1) gcol[1] = c.y;
                         if (CD > 2) gcol[2] = c.z;
                     } else {
-                        const float* cg = colors + (size_t)__float_as_int(c.w) * D;
 #pragma unroll
-                        for (int k = 0; k < CD; ++k) gcol[k] = (k < D) ? cg[k] : 0.0f;
+                        for (int k = 0; k < CD; ++k) gcol[k] = (k < D) ? colp[k * 64 + j] : 0.0f;
                     }
                     const float ra = 1.0f / (1.0f - alpha);        // correctly rounded (v_rcp_f32 alone drifts 1e-4 over a 1000-pair transmittance chain)
                     T *= ra;
@@ -958,7 +984,7 @@ raster_bwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int3
             const int r = lane / NV, k = lane - r * NV;
             for (int it = 0; it * RPI < nb; ++it) {
                 const int j = it * RPI + r;
-                if (r < RPI && j < nb) {
+                if (r < RPI && j < nb && k < 6 + D) {              // (rows 6 + D .. 6 + CD - 1 do not exist: the LDS is sized by D)
                     const double v = acc[k * 64 + j];
                     if (v != 0.0) {
                         acc[k * 64 + j] = 0.0;
@@ -1874,7 +1900,15 @@ static int launch_fwd(int W, int H, int D, const RasterWs& ws, const float* colo
         return GS_EINVAL;
     }
     {                                                         // sliding window of two dense batches, every D
-        const size_t lds = gs_raster_lds(4 * (size_t)GS_WIN_Q_BYTES);
+        const size_t planes = CD > 3 ? 4 * (size_t)2 * (size_t)D * 64 * sizeof(float) : 0;      // colour planes of two batches per wave
+        const size_t lds = gs_raster_lds(4 * (size_t)GS_WIN_Q_BYTES + planes);
+        if (lds > 64 * 1024) {                                    // (D > 14 or so: the opt-in for more than 64 KB of dynamic LDS)
+            static size_t attr_fwd = 0;                           // (per instantiation; raised when a larger D comes along)
+            if (lds > attr_fwd) {
+                GS_CHECK_HIP(hipFuncSetAttribute((const void*)raster_fwd_window_kernel<CD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_fwd = lds;
+            }
+        }
         hipLaunchKernelGGL(raster_fwd_window_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
                            ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, isect_count(n_isects), offsets, render, alphas,
                            last_ids, t_tone_fwd, t_cull_log, t_cull_log.count ? ws.bo : BwdOrder{ nullptr, nullptr });
@@ -2007,12 +2041,13 @@ static int launch_bwd(int W, int H, int D, const RasterWs& ws, const float* colo
         }
     }
     {                                                         // D > 3 (colours outside the record stream): LDS ds_add_f64 accumulator rows
-        size_t lds = 4 * ((size_t)GS_LANES_Q_BYTES + (size_t)(6 + CD) * 64 * 8);
+        // per wave: queue + (6 + D) f64 accumulator rows + D f32 colour planes (kernel: WAVE_BYTES)
+        size_t lds = 4 * ((size_t)GS_LANES_Q_BYTES + (size_t)(6 + D) * 64 * 8 + (size_t)D * 64 * 4);
         if (lds < gs_raster_lds_pad()) lds = gs_raster_lds_pad();
-        static bool attr_set = false;                  // > 64 KB of dynamic LDS (D > 16) needs the opt-in once per kernel
-        if (!attr_set && lds > 64 * 1024) {
+        static size_t attr_bwd = 0;                    // > 64 KB of dynamic LDS needs the opt-in (per instantiation, raised with D)
+        if (lds > 64 * 1024 && lds > attr_bwd) {
             GS_CHECK_HIP(hipFuncSetAttribute((const void*)raster_bwd_lanes_kernel<CD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
+            attr_bwd = lds;
         }
         hipLaunchKernelGGL(raster_bwd_lanes_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
                            ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, isect_count(n_isects), offsets, alphas, last_ids,

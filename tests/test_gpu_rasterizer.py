@@ -197,6 +197,16 @@ def test_deferred_14_channels(cuda):
     _run_case(cuda, means, quats, scales, np.clip(opac * 4, 0, 0.9).astype(np.float32), colors, cam)
 
 
+@pytest.mark.parametrize("D", [4, 5, 8, 20, 32])
+def test_feature_channels_all_templates(cuda, D):
+    """Every D > 3 instantiation of the compositor (4, 8, 16, 32 channels; colours staged in LDS planes sized by the run-time D, more
+    than 64 KB of dynamic LDS from D = 20 on) against the oracle, on a scene dense enough for several batches per quadrant."""
+    sp, cam = random_case(3000, 96, view=1, seed=21 + D)
+    means, quats, scales, opac = activated(sp)
+    colors = torch.rand(3000, D, generator=torch.Generator().manual_seed(D)).numpy()
+    _run_case(cuda, means, quats, scales, np.clip(opac * 4, 0, 0.9).astype(np.float32), colors, cam)
+
+
 def test_error_behaviour(cuda):
     import geosplatting_amd as gs
     z = torch.zeros(1, 3, device=cuda)

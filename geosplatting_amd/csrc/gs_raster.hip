@@ -228,10 +228,10 @@ tile_order_kernel(int n_tiles, GsCount ic, const int32_t* __restrict__ offsets, 
 //   * lane p pops its list front to back (back to front in the backward), fetching "its" record from the LDS queue
 //     -- one trip of the loop evaluates up to 64 DIFFERENT (pixel, Gaussian) pairs;
 //   * backward: the 6+D per-Gaussian sums can no longer be reduced across the wave (every lane works on another
-//     Gaussian), so they accumulate in LDS with ds_add_f64 -- measured 0.32 cycles per lane on MI355X, TEN times
-//     the rate of ds_add_f32 (3.0), scripts/micro/lds_atomic_microbench.hip -- one accumulator row per record of
-//     the dense batch, and are committed once per (quadrant, Gaussian): 7 records x 9 values per atomic
-//     instruction, the 9 lanes of a record falling into one 64-byte gradient record = one memory-side request.
+//     Gaussian): the walk stores two scalars per pair in an LDS pair buffer and the lanes then switch roles -- lane j
+//     owns record j and sums its pairs (raster_bwd_lanes2_kernel below; until round 5 a variant with one ds_add_f64
+//     accumulator row per record served D > 3) -- and commits once per (quadrant, Gaussian): 7 records x 9 values
+//     per atomic instruction, the 9 lanes of a record falling into one 64-byte gradient record = one memory-side request.
 // Per-pixel evaluation order and arithmetic are those of the quadrant kernels, so the forward is bit-identical.
 
 template <int K>
@@ -801,208 +801,9 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
     }
 }
 
-template <int CD>
-__global__ void __launch_bounds__(256)
-raster_bwd_lanes_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* __restrict__ tile_order,
-                        const float4* __restrict__ rec0, const float4* __restrict__ rec1, const float4* __restrict__ rec2,
-                        const float* __restrict__ colors, const float* __restrict__ background, GsCount ic,
-                        const int32_t* __restrict__ offsets,
-                        const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
-                        const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-                        float* __restrict__ v_packed, int rec_stride)
-{
-    const int n_isects = (int)gs_count(ic);
-    constexpr int NV = 6 + CD;
-    constexpr int RPI = 64 / NV;                                   // records committed per atomic instruction
-    // per wave: queue | accumulator rows [6 + D][64] f64 | colour planes [D][64] f32 of the dense batch (sized by the run-time D, so
-    // that D = 14 keeps two workgroups per CU: 4 x 19 456 B)
-    const int WAVE_BYTES = GS_LANES_Q_BYTES + (6 + D) * 64 * 8 + D * 64 * 4;
-    extern __shared__ __align__(16) unsigned char gs_lds_raw[];
-#ifdef GS_EXP_PRIO
-    if ((int)blockIdx.x < GS_EXP_PRIO) __builtin_amdgcn_s_setprio(3);
-#endif
-    const int tile = tile_order[blockIdx.x];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int tx = tile % tile_w, ty = tile / tile_w;
-    const int qx0 = tx * GS_TILE + (wave & 1) * 8, qy0 = ty * GS_TILE + (wave >> 1) * 8;
-    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
-    const bool inside = pxi < W && pyi < H;
-    const float px = (float)pxi + 0.5f, py = (float)pyi + 0.5f;
-
-    const int start = offsets[tile];
-    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
-    if (end <= start) return;
-
-    const LaneQueue q = lane_queue(gs_lds_raw + (size_t)wave * WAVE_BYTES);
-    lane_queue_clear(q, GS_LANES_Q, lane);
-    double* acc = (double*)(gs_lds_raw + (size_t)wave * WAVE_BYTES + GS_LANES_Q_BYTES);      // [6 + D][64]: row k, dense record j
-    float* colp = (float*)(acc + (6 + D) * 64);                                               // [D][64]: colour k of dense record j
-    for (int k = 0; k < 6 + D; ++k) acc[k * 64 + lane] = 0.0;
-
-    float T_final = 1.0f, v_a = 0.0f;
-    int bin_final = -1;
-    float v_rc[CD], buffer[CD];
-#pragma unroll
-    for (int k = 0; k < CD; ++k) { v_rc[k] = 0.0f; buffer[k] = 0.0f; }
-    if (inside) {
-        const size_t pid = (size_t)pyi * W + pxi;
-        T_final = 1.0f - alphas[pid];
-        bin_final = last_ids[pid];
-        v_a = v_alphas[pid];
-#pragma unroll
-        for (int k = 0; k < CD; ++k) if (k < D) v_rc[k] = v_render[pid * D + k];
-    }
-    float bg_dot = 0.0f;
-    if (background) {
-#pragma unroll
-        for (int k = 0; k < CD; ++k) if (k < D) bg_dot += background[k] * v_rc[k];
-    }
-    float T = T_final;
-
-    int top = bin_final;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) top = max(top, __shfl_xor(top, off, 64));
-    if (top >= end) top = end - 1;
-
-    int qhead = 0, qcount = 0;                                    // wave-uniform
-    // three raw batches in flight, branch-free loads, consumed round-robin (see the forward kernel)
-    top = __builtin_amdgcn_readfirstlane(top);
-    RawBatch raw0, raw1, raw2;
-    raw_load(raw0, rec0, rec1, rec2, top - lane, top - lane >= start);
-    raw_load(raw1, rec0, rec1, rec2, top - 64 - lane, top - 64 - lane >= start);
-    raw_load(raw2, rec0, rec1, rec2, top - 128 - lane, top - 128 - lane >= start);
-    int phase = 0;
-    for (;;) {
-        // ---- fill: cull raw batches (walking DOWN the list) into the queue
-        { GS_PHASE_BEGIN();
-        // pixels whose last composited entry lies at or after a batch's lowest index can be valid in it
-#define BWD_FILL_STEP(B)                                                                                               \
-        {                                                                                                              \
-            const unsigned long long act_b = __ballot(bin_final >= top - 63);                                          \
-            int n_hit = 0;                                                                                             \
-            raw_wait(B);                                                                                               \
-            if (act_b != 0ull) {                                                                                       \
-                float rcx, rcy, rex, rey;                                                                              \
-                active_rect_c(act_b, qx0, qy0, rcx, rcy, rex, rey);                                                    \
-                GS_STAT(4, 1);                                                                                         \
-                n_hit = lanes_cull_append(q, B, top - lane >= start, top - lane, lane, rcx, rcy, rex, rey, qhead + qcount); \
-            }                                                                                                          \
-            raw_load(B, rec0, rec1, rec2, top - 192 - lane, top - 192 - lane >= start);                                \
-            qcount += n_hit;                                                                                           \
-            top -= 64;                                                                                                 \
-        }
-        LANES_FILL(qcount < 64 && top >= start, BWD_FILL_STEP)
-#undef BWD_FILL_STEP
-        GS_PHASE_END(0); }
-        if (qcount == 0) break;
-        const int nb = qcount < 64 ? qcount : 64;
-        lanes_lds_sync();
-        // ---- dense batch: lane j owns queue slot qhead + j (stream indices DEcrease with j)
-        const int idx_low = q.idx[(qhead + nb - 1) & (GS_LANES_Q - 1)];          // lowest stream index of the batch (uniform)
-        const bool live = bin_final >= idx_low;
-        const unsigned long long act = __ballot(live);
-        unsigned long long list = 0ull;
-        if (act != 0ull) {
-            int xmin, xmax, ymin, ymax;
-            active_rect_i(act, xmin, xmax, ymin, ymax);
-            const int slot = (qhead + lane) & (GS_LANES_Q - 1);
-            const float4 a = q.a[slot];
-            const float2 b = q.b[slot];
-            const unsigned long long pm = record_pixel_mask(lane < nb, a.x, a.y, a.z, a.w, b.x, b.y, qx0, qy0, xmin, xmax,
-                                                            ymin, ymax);
-            list = gs_bit_transpose64(pm, lane);
-            if (!live) list = 0ull;
-            if (CD > 3) {                                              // the batch's colours: once per (record, quadrant), not per pair
-                const float* cg = colors + (size_t)__float_as_int(q.c[slot].w) * D;
-                for (int k = 0; k < D; ++k) colp[k * 64 + lane] = lane < nb ? cg[k] : 0.0f;
-                lanes_lds_sync();
-            }
-        }
-        GS_STAT(5, nb);
-        while (__ballot(list != 0ull) != 0ull) {
-            GS_STAT(6, 1);
-            if (list != 0ull) {
-                const int j = __builtin_ctzll(list);
-                list &= list - 1ull;
-                const int slot = (qhead + j) & (GS_LANES_Q - 1);
-                const float4 a = q.a[slot];
-                const float2 b = q.b[slot];
-                const int idxj = q.idx[slot];
-                const float ga = a.z, gb = a.w, gc = b.x, go = b.y;
-                const float dx = a.x - px, dy = a.y - py;
-                const float t0 = ga * dx, t1 = gc * dy, t2 = gb * dx;
-                const float sigma = fmaf(t0, dx, fmaf(t1, dy, t2 * dy));
-                const float vis = gs_exp_neg(sigma);
-                const float alpha = fminf(0.999f, go * vis);
-                if (idxj <= bin_final && sigma >= 0.0f && alpha >= GS_ALPHA_MIN) {
-                    GS_STAT_ALL(7, 1);
-                    const float4 c = q.c[slot];
-                    float gcol[CD];
-                    if (CD <= 3) {
-                        gcol[0] = c.x;
-                        if (CD > 1) gcol[1] = c.y;
-                        if (CD > 2) gcol[2] = c.z;
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < CD; ++k) gcol[k] = (k < D) ? colp[k * 64 + j] : 0.0f;
-                    }
-                    const float ra = 1.0f / (1.0f - alpha);        // correctly rounded (v_rcp_f32 alone drifts 1e-4 over a 1000-pair transmittance chain)
-                    T *= ra;
-                    const float fac = alpha * T;
-                    float v_alpha = 0.0f;
-                    double* arow = acc + j;
-#pragma unroll
-                    for (int k = 0; k < CD; ++k) {
-#ifndef GS_EXP_NOATOMIC
-                        if (k < D) atomicAdd(arow + (6 + k) * 64, (double)(fac * v_rc[k]));
-#endif
-                        v_alpha += (gcol[k] * T - buffer[k] * ra) * v_rc[k];
-                    }
-                    v_alpha += T_final * ra * v_a;
-                    if (background) v_alpha += -T_final * ra * bg_dot;
-                    if (go * vis <= 0.999f) {
-                        const float v_sigma = -go * vis * v_alpha;
-#ifndef GS_EXP_NOATOMIC
-                        atomicAdd(arow + 0 * 64, (double)(v_sigma * ((2.0f * ga) * dx + gb * dy)));
-                        atomicAdd(arow + 1 * 64, (double)(v_sigma * (gb * dx + (2.0f * gc) * dy)));
-                        atomicAdd(arow + 2 * 64, (double)(0.5f * v_sigma * dx * dx));
-                        atomicAdd(arow + 3 * 64, (double)(v_sigma * dx * dy));
-                        atomicAdd(arow + 4 * 64, (double)(0.5f * v_sigma * dy * dy));
-                        atomicAdd(arow + 5 * 64, (double)(vis * v_alpha));
-#else
-                        if (v_sigma == 123.456f) arow[0] = 1.0;
-#endif
-                    }
-#pragma unroll
-                    for (int k = 0; k < CD; ++k) buffer[k] += gcol[k] * fac;
-                }
-            }
-        }
-        // ---- commit: RPI records x NV values per atomic instruction; the NV lanes of a record hit one packed gradient record
-        lanes_lds_sync();
-        {
-            const int r = lane / NV, k = lane - r * NV;
-            for (int it = 0; it * RPI < nb; ++it) {
-                const int j = it * RPI + r;
-                if (r < RPI && j < nb && k < 6 + D) {              // (rows 6 + D .. 6 + CD - 1 do not exist: the LDS is sized by D)
-                    const double v = acc[k * 64 + j];
-                    if (v != 0.0) {
-                        acc[k * 64 + j] = 0.0;
-                        const int g = __float_as_int(q.c[(qhead + j) & (GS_LANES_Q - 1)].w);
-                        gs_atomic_add(v_packed + (size_t)g * rec_stride + k, (float)v);
-                    }
-                }
-            }
-        }
-        lanes_lds_sync();
-        qhead = (qhead + nb) & (GS_LANES_Q - 1);
-        qcount -= nb;
-    }
-    raw_drain(raw0, raw1, raw2);
-}
-
 // ---------------------------------------------------------------------------------------------------
-// Backward for D <= 3 WITHOUT atomics in the walk.  Removal experiment on the kernel above (bench workload): 975 us as
+// Backward WITHOUT atomics in the walk (D <= 3 since round 2; every D since round 5: the `ds_add_f64` accumulator kernel it was derived
+// from is gone -- `git show 60bad21:geosplatting_amd/csrc/gs_raster.hip`).  Removal experiment on the kernel above (bench workload): 975 us as
 // built, 545 us with the nine ds_add_f64 per pair compiled out -- the accumulation, not the arithmetic, was 44 % of it
 // (308 M lane-adds per view at ~0.9 LDS cycles each: three to four pixels of a trip add to the same record).  Here the
 // walk only produces TWO scalars per popped pair,  s = v_sigma  (0 when the 0.999 cap was active)  and  f = alpha*T,
@@ -1030,13 +831,13 @@ template <int CD>
 __global__ void __launch_bounds__(256)
 raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* __restrict__ tile_order,
                          const float4* __restrict__ rec0, const float4* __restrict__ rec1, const float4* __restrict__ rec2,
+                         const float* __restrict__ colors /* [V, D]: read for D > 3 only (else they travel in the record stream) */,
                          const float* __restrict__ background, GsCount ic, const int32_t* __restrict__ offsets,
                          const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
                          const float* __restrict__ v_render, const float* __restrict__ v_alphas,
                          float* __restrict__ v_packed, int rec_stride, ToneBwd tone)
 {
     const int n_isects = (int)gs_count(ic);
-    static_assert(CD <= 3, "colours come from the record stream (D <= 3)");
     using LD = Lanes2Lds<CD>;
     constexpr int NV = 6 + CD;
     constexpr int RPI = 64 / NV;
@@ -1065,13 +866,19 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
     // (an empty tile has render = 0 and alpha = 0 without a background: its pixels add nothing to the exposure gradient either)
     if (end <= start) { GS_TL_END(); return; }
 
-    unsigned char* wbase = gs_lds_raw + (size_t)wave * LD::WAVE_BYTES;
+    // D > 3 (round 5; rfstudio/model/geosplat.py:276-295 renders 14 feature channels): two more plane sets per wave, sized by the
+    // run-time D -- colp[D][64], the colours of the dense batch (one load per (record, quadrant) instead of a gather per pair), and
+    // vrp[D][64], the pixels' cotangents (the record lanes read them in the reduction: D ds_bpermute per pair otherwise)
+    const int wave_bytes = LD::WAVE_BYTES + (CD > 3 ? 2 * D * 64 * 4 : 0);
+    unsigned char* wbase = gs_lds_raw + (size_t)wave * wave_bytes;
     const LaneQueue q = lane_queue(wbase);
     lane_queue_clear(q, GS_LANES_Q, lane);
     unsigned long long* msk = (unsigned long long*)(wbase + LD::OFF_MSK);
     int* pbase = (int*)(wbase + LD::OFF_BASE);
     float2* pairbuf = (float2*)(wbase + LD::OFF_PAIR);
     float* stage = (float*)(wbase + LD::OFF_PAIR);              // aliases pairbuf (separated by wave syncs)
+    float* colp = (float*)(wbase + LD::WAVE_BYTES);
+    float* vrp = colp + (CD > 3 ? D * 64 : 0);
 
     float T_final = 1.0f, v_a = 0.0f, v_exp = 0.0f;
     int bin_final = -1;
@@ -1107,6 +914,7 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
 #pragma unroll
         for (int k = 0; k < CD; ++k) if (k < D) bg_dot += background[k] * v_rc[k];
     }
+    if (CD > 3) for (int k = 0; k < D; ++k) vrp[k * 64 + lane] = v_rc[k < CD ? k : 0];
     float T = T_final;
     // d(render . v_render + alpha_out v_a)/d(alpha_i) (1 - alpha_i) = T_i (c_i . v) - sum_{j behind i} f_j (c_j . v) + T_final (v_a - bg . v),
     // f = alpha T: the colours enter only through their projection on this pixel's v_render, so ONE accumulator
@@ -1181,6 +989,10 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
         }
         msk[lane] = pm;
         pbase[lane] = cum - cnt;
+        if (CD > 3) {                                              // the batch's colours (queue slots beyond nb hold earlier, finite records)
+            const float* cg = colors + (size_t)__float_as_int(q.c[myslot].w) * D;
+            for (int k = 0; k < D; ++k) colp[k * 64 + lane] = lane < nb ? cg[k] : 0.0f;
+        }
         unsigned long long list = gs_bit_transpose64(pm, lane);
         GS_STAT(5, nb);
 #ifdef GS_RASTER_STATS
@@ -1233,9 +1045,16 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
             {
                 const float Tn = T * ra.x;
                 const float fac = ok0 ? alpha.x * Tn : 0.0f;
-                float cv = c0.x * v_rc[0];
-                if (CD > 1) cv = fmaf(c0.y, v_rc[1], cv);
-                if (CD > 2) cv = fmaf(c0.z, v_rc[2], cv);
+                float cv;
+                if (CD <= 3) {
+                    cv = c0.x * v_rc[0];
+                    if (CD > 1) cv = fmaf(c0.y, v_rc[1], cv);
+                    if (CD > 2) cv = fmaf(c0.z, v_rc[2], cv);
+                } else {
+                    cv = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < CD; ++k) if (k < D) cv = fmaf(colp[k * 64 + j0], v_rc[k], cv);
+                }
                 const float v_alpha = fmaf(Tn, cv, ra.x * zacc);
                 const float s_out = (ok0 && ov.x <= 0.999f) ? -ov.x * v_alpha : 0.0f;
                 zacc = fmaf(-fac, cv, zacc);
@@ -1249,9 +1068,16 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
             {
                 const float Tn = T * ra.y;
                 const float fac = ok1 ? alpha.y * Tn : 0.0f;
-                float cv = c1.x * v_rc[0];
-                if (CD > 1) cv = fmaf(c1.y, v_rc[1], cv);
-                if (CD > 2) cv = fmaf(c1.z, v_rc[2], cv);
+                float cv;
+                if (CD <= 3) {
+                    cv = c1.x * v_rc[0];
+                    if (CD > 1) cv = fmaf(c1.y, v_rc[1], cv);
+                    if (CD > 2) cv = fmaf(c1.z, v_rc[2], cv);
+                } else {
+                    cv = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < CD; ++k) if (k < D) cv = fmaf(colp[k * 64 + j1], v_rc[k], cv);
+                }
                 const float v_alpha = fmaf(Tn, cv, ra.y * zacc);
                 const float s_out = (ok1 && ov.y <= 0.999f) ? -ov.y * v_alpha : 0.0f;
                 zacc = fmaf(-fac, cv, zacc);
@@ -1276,6 +1102,9 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
             int e = cum - cnt;
             float m0 = 0.0f, mxy = 0.0f, c2 = 0.0f;
             v2f m1 = (v2f)(0.0f), m2 = (v2f)(0.0f), c01 = (v2f)(0.0f);
+            float csum[CD > 3 ? CD : 1];
+#pragma unroll
+            for (int k = 0; k < (CD > 3 ? CD : 1); ++k) csum[k] = 0.0f;
             while (__ballot(m != 0ull) != 0ull) {
                 GS_STAT2(7, 1);
 #ifdef GS_RASTER_PHASES
@@ -1284,8 +1113,13 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
                 const bool has = m != 0ull;
                 const int p = gs_pop_lowest(m);
                 const float2 sfr = pairbuf[has ? e : 0];
-                float4 vr;                                             // v_render of pixel p: from that lane's registers (ds_bpermute, no LDS storage)
-                vr.x = __shfl(v_rc[0], p, 64); vr.y = CD > 1 ? __shfl(v_rc[1], p, 64) : 0.0f; vr.z = CD > 2 ? __shfl(v_rc[2], p, 64) : 0.0f; vr.w = 0.0f;
+                float4 vr = make_float4(0.f, 0.f, 0.f, 0.f);           // v_render of pixel p: from that lane's registers (ds_bpermute, no LDS storage)
+                if (CD <= 3) { vr.x = __shfl(v_rc[0], p, 64); vr.y = CD > 1 ? __shfl(v_rc[1], p, 64) : 0.0f; vr.z = CD > 2 ? __shfl(v_rc[2], p, 64) : 0.0f; }
+                if (CD > 3) {                                          // D > 3: from the cotangent planes
+                    const float fw = has ? sfr.y : 0.0f;
+#pragma unroll
+                    for (int k = 0; k < CD; ++k) if (k < D) csum[k] = fmaf(fw, vrp[k * 64 + p], csum[k]);
+                }
                 e += has ? 1 : 0;
                 const float s_w = has ? sfr.x : 0.0f, f_w = has ? sfr.y : 0.0f;
                 const v2f d = v2f{X, Y} - v2f{(float)(p & 7), (float)(p >> 3)};
@@ -1298,9 +1132,14 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
                 if (CD > 2) c2 = fmaf(f_w, vr.z, c2);
             }
             sum[0] = m0; sum[1] = m1.x; sum[2] = m1.y; sum[3] = m2.x; sum[4] = mxy; sum[5] = m2.y;
-            sum[6] = c01.x;
-            if (CD > 1) sum[7] = c01.y;
-            if (CD > 2) sum[8] = c2;
+            if (CD <= 3) {
+                sum[6] = c01.x;
+                if (CD > 1) sum[7] = c01.y;
+                if (CD > 2) sum[8] = c2;
+            } else {
+#pragma unroll
+                for (int k = 0; k < CD; ++k) sum[6 + k] = csum[k];
+            }
         }
         lanes_lds_sync();                                          // pairbuf is dead: its space becomes the commit staging
 #ifdef GS_RASTER_PHASES
@@ -2030,28 +1869,18 @@ static int launch_bwd(int W, int H, int D, const RasterWs& ws, const float* colo
             GS_CHECK_LAUNCH();
             return GS_OK;
         }
-        {                                                       // no log (gs_raster_bwd / _acc / _tone_acc): pair buffer, own cull + masks
-            size_t lds = 4 * (size_t)Lanes2Lds<CD>::WAVE_BYTES;
-            if (lds < gs_raster_lds_pad()) lds = gs_raster_lds_pad();
-            hipLaunchKernelGGL(raster_bwd_lanes2_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
-                               ws.order, ws.rec0, ws.rec1, ws.rec2, background, isect_count(n_isects), offsets, alphas, last_ids,
-                               v_render, v_alphas, v_packed, rec_stride, t_tone_bwd);
-            GS_CHECK_LAUNCH();
-            return GS_OK;
-        }
     }
-    {                                                         // D > 3 (colours outside the record stream): LDS ds_add_f64 accumulator rows
-        // per wave: queue + (6 + D) f64 accumulator rows + D f32 colour planes (kernel: WAVE_BYTES)
-        size_t lds = 4 * ((size_t)GS_LANES_Q_BYTES + (size_t)(6 + D) * 64 * 8 + (size_t)D * 64 * 4);
+    {                                                         // no log (gs_raster_bwd / _acc / _tone_acc), and every D > 3: pair buffer, own cull + masks
+        size_t lds = 4 * ((size_t)Lanes2Lds<CD>::WAVE_BYTES + (CD > 3 ? 2 * (size_t)D * 64 * 4 : 0));      // (+ colour and cotangent planes)
         if (lds < gs_raster_lds_pad()) lds = gs_raster_lds_pad();
         static size_t attr_bwd = 0;                    // > 64 KB of dynamic LDS needs the opt-in (per instantiation, raised with D)
         if (lds > 64 * 1024 && lds > attr_bwd) {
-            GS_CHECK_HIP(hipFuncSetAttribute((const void*)raster_bwd_lanes_kernel<CD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            GS_CHECK_HIP(hipFuncSetAttribute((const void*)raster_bwd_lanes2_kernel<CD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_bwd = lds;
         }
-        hipLaunchKernelGGL(raster_bwd_lanes_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
+        hipLaunchKernelGGL(raster_bwd_lanes2_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
                            ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, isect_count(n_isects), offsets, alphas, last_ids,
-                           v_render, v_alphas, v_packed, rec_stride);
+                           v_render, v_alphas, v_packed, rec_stride, t_tone_bwd);
         GS_CHECK_LAUNCH();
         return GS_OK;
     }

@@ -476,3 +476,44 @@ def test_engine_front_modes_agree(cuda, monkeypatch):
                 # float atomics in another order, and the projection backward is compiled with contraction on: its fused
                 # multiply-adds differ between the kernels it is inlined into (2.7e-5 on the scale gradients)
                 assert rel_err(gb[k].cpu().numpy(), ga[k].cpu().numpy()) < 5e-5, (other, which, k)
+
+
+@pytest.mark.parametrize("n,res,mode", [(20000, 256, "exact"), (60000, 64, "exact"), (60000, 64, "capacity"), (90000, 32, "capacity")])
+def test_binning_24_bit_keys_equal_32_bit_keys(cuda, n, res, mode):
+    """gs_isect_bin_front with 24-bit keys (three depth passes over `depth bits - base`) against 32-bit keys (four passes): flatten ids
+    and offsets bit for bit, on scenes with very long tile segments (up to tens of thousands of entries), with ties (a plane of equal
+    depths keeps slot order) and, in capacity mode, unused capacity behind the list.  (Round 5 built a tile-local depth order against
+    this test -- emission in slot order, the segments sorted in LDS -- which passed it and was no faster: DESIGN.md section 6.)"""
+    from geosplatting_amd import front as F
+    sp, cam = random_case(n, res, seed=11)
+    d = lambda t: t.to(cuda).contiguous()
+    means = sp.means.clone()
+    vm = cam.view_matrix
+    k = n // 5
+    means[:k] = means[:k] - (means[:k] @ vm[2, :3])[:, None] * vm[2, :3][None, :]          # equal camera depths: ties keep slot order
+    g = torch.Generator().manual_seed(3)
+    x = dict(means=d(means), quats=d(sp.quats), scales=d(sp.scales.exp()), opac=d(torch.sigmoid(sp.opacities).squeeze(-1)),
+             normals=d(torch.nn.functional.normalize(torch.randn(sp.num, 3, generator=g), dim=-1)),
+             kd=d(torch.rand(sp.num, 3, generator=g)), ks=d(torch.rand(sp.num, 2, generator=g)), vm=d(vm), K=d(cam.intrinsic_matrix),
+             cam_pos=d(cam.c2w[:, 3]), W=res, H=res)
+    env = _env(cuda)
+    f32, _ = _front(x, env, cuda)
+    V, I = int(f32.host_counts[0]), int(f32.host_counts[1])
+    ref, _, _ = F.bin_stage(f32, None, None, prepare=False)
+    lo, hi = 0xffffffff - int(f32.host_counts[2]), int(f32.host_counts[3])
+    base = max(0, lo - 1024)
+    assert hi - base < (1 << 24)
+    status = torch.zeros(4, dtype=torch.int64, device=cuda)
+    f24, _ = _front(x, env, cuda, key_base=base, key_bits=24, status=status)
+    if mode == "exact":
+        got, _, _ = F.bin_stage(f24, None, None, prepare=False)
+    else:
+        cap = ((int(I * 1.3) + 4095) // 4096) * 4096
+        got, _, _ = F.bin_stage(f24, cap, status, prepare=False)
+    torch.cuda.synchronize()
+    off = ref["isect_offsets"].cpu().numpy()
+    seg = np.diff(np.append(off, I))
+    print(f"\n  V={V} I={I} tiles {off.size}: longest segment {seg.max()}")
+    assert status.cpu().tolist() == [0, 0, 0, 0]
+    assert np.array_equal(got["isect_offsets"].cpu().numpy(), off)
+    assert np.array_equal(got["flatten_ids"][:I].cpu().numpy(), ref["flatten_ids"][:I].cpu().numpy())

@@ -829,22 +829,10 @@ bin_setup_kernel(unsigned* __restrict__ state, int n_state_words,
 
 // thread r (depth rank) writes the (tile, index) items of its Gaussian at the exclusive prefix of the tile counts in depth order; the
 // prefix across blocks is a decoupled look-back (blocks numbered by ticket, so a block only waits for blocks that already run)
-// SLOTS (round 5, the tile-local depth order below): thread r IS packed slot r -- no depth sort in front, the rectangles are read in
-// order instead of gathered -- and an item carries its 24-bit depth key: {x = key >> 4 | tile << 20, y = slot | (key & 15) << 28}.
-#define TL_SLOT_BITS 28
-#define TL_SLOT_MASK ((1u << TL_SLOT_BITS) - 1u)
-#define TL_TILE_SHIFT 20                                           /* of item.x */
-__device__ __forceinline__ uint2 tl_pack(unsigned tile, unsigned key24, unsigned slot)
-{
-    return make_uint2((key24 >> 4) | (tile << TL_TILE_SHIFT), slot | ((key24 & 15u) << TL_SLOT_BITS));
-}
-__device__ __forceinline__ unsigned tl_key(const uint2& it) { return ((it.x & ((1u << TL_TILE_SHIFT) - 1u)) << 4) | (it.y >> TL_SLOT_BITS); }
-
-template <bool SLOTS>
 __global__ void __launch_bounds__(EM_THREADS)
 emit_chained_kernel(GsCount vc, const uint2* __restrict__ order, const uint2* __restrict__ rect, unsigned* __restrict__ ctrl,
                     u64* __restrict__ desc, int n_blocks, int tile_w, uint2* __restrict__ items, unsigned item_cap,
-                    long long* __restrict__ status /* nullable: capacity protocol word */, const unsigned* __restrict__ keys /* SLOTS */)
+                    long long* __restrict__ status /* nullable: capacity protocol word */)
 {
     const int V = (int)gs_count(vc);
     __shared__ unsigned ws[EM_THREADS / 64];
@@ -857,14 +845,13 @@ emit_chained_kernel(GsCount vc, const uint2* __restrict__ order, const uint2* __
     u64* agg = desc; u64* pre = desc + n_blocks;
     // blocked arrangement: thread t owns ranks base + t*EM_PER .. +EM_PER-1 (consecutive: the scan stays in index order)
     const int r0 = block * EM_TILE + (int)threadIdx.x * EM_PER;
-    int v[EM_PER]; unsigned c[EM_PER]; uint2 q[EM_PER]; unsigned kq[EM_PER];
+    int v[EM_PER]; unsigned c[EM_PER]; uint2 q[EM_PER];
     unsigned mine = 0u;
 #pragma unroll
     for (int k = 0; k < EM_PER; ++k) {
         const int r = r0 + k;
-        v[k] = r < V ? (SLOTS ? r : (int)order[r].y) : -1;
+        v[k] = r < V ? (int)order[r].y : -1;
         q[k] = v[k] >= 0 ? rect[v[k]] : make_uint2(0u, 0u);
-        kq[k] = (SLOTS && v[k] >= 0) ? keys[v[k]] : 0u;
         c[k] = rect_count(q[k]);
         mine += c[k];
     }
@@ -922,8 +909,7 @@ emit_chained_kernel(GsCount vc, const uint2* __restrict__ order, const uint2* __
         for (int i = y0; i < y1; ++i)
             for (int j = x0; j < x1; ++j) {
                 const unsigned t = (unsigned)(i * tile_w + j);
-                if (cur < (unsigned long long)item_cap)                                   // (capacity protocol: an overflowing view is reported, not written)
-                    items[cur] = SLOTS ? tl_pack(t, kq[k], (unsigned)v[k]) : make_uint2(t, (unsigned)v[k]);
+                if (cur < (unsigned long long)item_cap) items[cur] = make_uint2(t, (unsigned)v[k]);   // (capacity protocol: an overflowing view is reported, not written)
                 ++cur;
             }
     }
@@ -978,149 +964,13 @@ bin_offsets_tiles_kernel(GsCount nc, const int32_t* __restrict__ tiles, int n_ti
         for (int t = cur + 1; t < n_tiles; ++t) offsets[t] = (int32_t)n;
 }
 
-// ---- tile-local depth order (round 5) -----------------------------------------------------------------------------------------
-// The depth-major binning above sorts all V Gaussians by depth (3 global passes), gathers their rectangles in that order (a random
-// 8-byte gather per Gaussian: a third of the whole binning) and splits the emitted list by tile (2 global passes).  Here the list is
-// emitted in SLOT order (sequential reads), split by tile with the same two stable passes -- every tile's segment is then in slot
-// order -- and each segment is sorted by its 24-bit depth keys INSIDE LDS by one workgroup: three stable 8-bit passes (counting
-// sweep with LDS atomics, ranks from ballots as in radix_scatter_kernel; a pass whose digit is the same for the whole tile is
-// skipped).  Same (tile, depth, slot) order bit for bit; 10-12 launches instead of 18.  Segment lengths on the bench scene: mean
-// 2 050, p99 6 000, max 11 000 (scripts/tile_count_hist.py) -- two LDS classes (<= 4 096 entries: 53 KB, three workgroups per CU;
-// <= 11 776: 158 KB) and a global-memory fallback for anything longer.
-struct TlLds {                                                    // keys u32 + local index u16, double buffered
-    unsigned* key[2]; unsigned short* idx[2];
-    __device__ __forceinline__ void load(int b, int i, unsigned& k, unsigned& ix) const { k = key[b][i]; ix = idx[b][i]; }
-    __device__ __forceinline__ void store(int b, int i, unsigned k, unsigned ix) const { key[b][i] = k; idx[b][i] = (unsigned short)ix; }
-};
-struct TlGlobal {                                                 // (key, local index) pairs in two scratch arrays
-    uint2* buf[2];
-    __device__ __forceinline__ void load(int b, int i, unsigned& k, unsigned& ix) const { const uint2 t = buf[b][i]; k = t.x; ix = t.y; }
-    __device__ __forceinline__ void store(int b, int i, unsigned k, unsigned ix) const { buf[b][i] = make_uint2(k, ix); }
-};
-
-#ifndef TL_WAVES
-#define TL_WAVES 16                                              // waves per workgroup: a segment of 2 000 entries is TWO rounds per wave and sweep
-#endif                                                           // (4 waves: 8 rounds of a latency-bound chain each -- the sort then costs what the global passes did)
-#define TL_THREADS (64 * TL_WAVES)
-#define TL_CNT_BYTES (TL_WAVES * 256 * 4)
-
-template <typename Buf>
-__device__ __forceinline__ int tl_sort_passes(const Buf& B, int n, unsigned* cnt /* LDS [TL_WAVES][256] */, int* flag /* LDS [3] */, bool global_mem)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const u64 lane_lt = (1ull << lane) - 1ull;
-    const int cw = (((n + TL_WAVES - 1) / TL_WAVES) + 63) & ~63;   // contiguous chunk of a wave (order = wave, round, lane)
-    const int wbeg = wave * cw < n ? wave * cw : n, wend = (wbeg + cw) < n ? (wbeg + cw) : n;
-    __shared__ unsigned wtot[4];
-    int cur = 0;
-    for (int pass = 0; pass < 3; ++pass) {
-        const int shift = 8 * pass;
-        for (int i = threadIdx.x; i < TL_WAVES * 256; i += TL_THREADS) cnt[i] = 0u;
-        if (threadIdx.x == 0) flag[pass] = 0;                      // (one word per pass: nobody still reads the previous pass's)
-        __syncthreads();
-        for (int base = wbeg; base < wend; base += 64) {
-            const int i = base + lane;
-            if (i < wend) { unsigned k, ix; B.load(cur, i, k, ix); atomicAdd(&cnt[wave * 256 + ((k >> shift) & 255u)], 1u); }
-        }
-        __syncthreads();
-        unsigned start = 0u, tot = 0u;
-        if (threadIdx.x < 256) {                                   // digit d: its total, then the exclusive scan over the digits (4 waves)
-            const int d = threadIdx.x;
-#pragma unroll
-            for (int w = 0; w < TL_WAVES; ++w) tot += cnt[w * 256 + d];
-            if (tot == (unsigned)n) flag[pass] = 1;                // one digit for the whole segment: the pass moves nothing
-            unsigned incl = tot;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned t = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += t;
-            }
-            if (lane == 63) wtot[wave] = incl;
-            start = incl - tot;
-        }
-        __syncthreads();
-        if (threadIdx.x < 256) {
-            const int d = threadIdx.x;
-            for (int w = 0; w < wave; ++w) start += wtot[w];
-            unsigned run = start;
-#pragma unroll
-            for (int w = 0; w < TL_WAVES; ++w) { const unsigned c = cnt[w * 256 + d]; cnt[w * 256 + d] = run; run += c; }
-        }
-        __syncthreads();
-        if (flag[pass]) continue;                                  // (uniform)
-        for (int base = wbeg; base < wend; base += 64) {
-            const int i = base + lane;
-            const bool valid = i < wend;
-            unsigned k = 0u, ix = 0u;
-            if (valid) B.load(cur, i, k, ix);
-            const unsigned d = (k >> shift) & 255u;
-            u64 m = __ballot(valid);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const bool bit = (d >> b) & 1u;
-                const u64 bal = __ballot(bit);
-                m &= bit ? bal : ~bal;
-            }
-            const unsigned old = cnt[wave * 256 + d];
-            __builtin_amdgcn_wave_barrier();
-            const unsigned r = __popcll(m & lane_lt);
-            if (valid && r == 0u) cnt[wave * 256 + d] = old + (unsigned)__popcll(m);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (valid) B.store(cur ^ 1, (int)(old + r), k, ix);
-        }
-        if (global_mem) __threadfence_block();
-        __syncthreads();
-        cur ^= 1;
-    }
-    return cur;
-}
-
-// one workgroup per tile; handles the segments with lo < n <= hi (the other launch leaves them alone): in LDS when n <= cap, else
-// through the two global scratch arrays
-__global__ void __launch_bounds__(TL_THREADS)
-tile_depth_sort_kernel(int n_tiles, const int32_t* __restrict__ offsets, GsCount ic, const uint2* __restrict__ items, int lo, int hi, int cap,
-                       uint2* __restrict__ scratch0, uint2* __restrict__ scratch1, int32_t* __restrict__ flatten)
-{
-    extern __shared__ __align__(16) unsigned char tl_lds[];
-    const int tile = blockIdx.x;
-    const int n_all = (int)gs_count(ic);
-    int beg = offsets[tile], end = tile + 1 < n_tiles ? offsets[tile + 1] : n_all;
-    beg = beg < n_all ? beg : n_all; end = end < n_all ? end : n_all;
-    const int n = end - beg;
-    if (n <= lo || n > hi) return;
-    unsigned* cnt = (unsigned*)tl_lds;                              // [TL_WAVES][256]
-    int* flag = (int*)(tl_lds + TL_CNT_BYTES);                      // [3]
-    const uint2* seg = items + beg;
-    if (n > cap) {
-        TlGlobal B{ { scratch0 + beg, scratch1 + beg } };
-        for (int i = threadIdx.x; i < n; i += TL_THREADS) B.store(0, i, tl_key(seg[i]), (unsigned)i);
-        __threadfence_block();
-        __syncthreads();
-        const int cur = tl_sort_passes(B, n, cnt, flag, true);
-        for (int i = threadIdx.x; i < n; i += TL_THREADS) { unsigned k, ix; B.load(cur, i, k, ix); flatten[beg + i] = (int32_t)(seg[ix].y & TL_SLOT_MASK); }
-    } else {
-        unsigned* k0 = (unsigned*)(tl_lds + TL_CNT_BYTES + 16);
-        TlLds B{ { k0, k0 + cap }, { (unsigned short*)(k0 + 2 * cap), (unsigned short*)(k0 + 2 * cap) + cap } };
-        for (int i = threadIdx.x; i < n; i += TL_THREADS) B.store(0, i, tl_key(seg[i]), (unsigned)i);
-        __syncthreads();
-        const int cur = tl_sort_passes(B, n, cnt, flag, false);
-        for (int i = threadIdx.x; i < n; i += TL_THREADS) { unsigned k, ix; B.load(cur, i, k, ix); flatten[beg + i] = (int32_t)(seg[ix].y & TL_SLOT_MASK); }
-    }
-}
-#define TL_CAP_SMALL 4096
-#define TL_CAP_LARGE 11776
-static size_t tl_lds_bytes(int cap) { return TL_CNT_BYTES + 16 + (size_t)cap * 12; }
-
 static size_t bf_state_bytes(int V) { return align256(16 + 2 * (size_t)((V + EM_TILE - 1) / EM_TILE + 1) * sizeof(u64)); }
 
 extern "C" size_t gs_isect_bin_front_ws_bytes(int V, int64_t n_isects, int tile_w, int tile_h)
 {
     const size_t v = V > 0 ? (size_t)V : 1, n = n_isects > 0 ? (size_t)n_isects : 1;
     const size_t tb = table_bytes((int64_t)(v > n ? v : n));
-    return tb + 2 * align256(v * 8) + 3 * align256(n * 8) + bf_state_bytes((int)v) + align256(n * 4) + 256;   // (tile ids: only without tile_counts;
-                                                                                                                    //  third item array: scratch of the tile-local order's fallback)
+    return tb + 2 * align256(v * 8) + 2 * align256(n * 8) + bf_state_bytes((int)v) + align256(n * 4) + 256;   // (tile ids: only without tile_counts)
 }
 
 extern "C" int gs_isect_bin_front(int V_cap, const uint32_t* depth_keys, const uint32_t* tile_rects, const uint32_t* tile_counts,
@@ -1146,7 +996,6 @@ extern "C" int gs_isect_bin_front(int V_cap, const uint32_t* depth_keys, const u
     uint2* db = (uint2*)p; p += align256((size_t)V * 8);
     uint2* ia = (uint2*)p; p += align256((size_t)n_isects * 8);
     uint2* ib = (uint2*)p; p += align256((size_t)n_isects * 8);
-    uint2* ic2 = (uint2*)p; p += align256((size_t)n_isects * 8);
     unsigned* state = (unsigned*)p; p += bf_state_bytes(V);
     int32_t* tile_ids = hist ? nullptr : (int32_t*)p;
     const int eblocks = (V + EM_TILE - 1) / EM_TILE;
@@ -1156,42 +1005,6 @@ extern "C" int gs_isect_bin_front(int V_cap, const uint32_t* depth_keys, const u
                        dim3(256), 0, s, state, n_state_words, (const long long*)counts_dev,
                        (long long)V_cap, (long long)n_isects_cap, (long long*)status_dev);
     GS_CHECK_LAUNCH();
-    int tb = 0;
-    while ((1 << tb) < n_tiles) ++tb;
-    if (tb < 1) tb = 1;
-    // GEOSPLAT_BINNING_ORDER=global keeps the depth-major pipeline below for every call; default: the tile-local depth order whenever
-    // an item can carry its key (24-bit keys, <= 4 096 tiles, < 2^28 slots) and the offsets come from the front's tile histogram
-    static const bool s_tile_local = [] { const char* e = getenv("GEOSPLAT_BINNING_ORDER"); return !(e && !strcmp(e, "global")); }();
-    if (s_tile_local && hist && key_bits == 24 && tb <= 12 && (long long)V < (1ll << TL_SLOT_BITS)) {
-        unsigned* ctrl = state; u64* desc = (u64*)((char*)state + 16);
-        hipLaunchKernelGGL(emit_chained_kernel<true>, dim3(eblocks), dim3(EM_THREADS), 0, s, vc, (const uint2*)nullptr, (const uint2*)tile_rects, ctrl,
-                           desc, eblocks + 1, tile_w, ia, (unsigned)n_isects, (long long*)status_dev, (const unsigned*)depth_keys);
-        GS_CHECK_LAUNCH();
-        hipLaunchKernelGGL(tile_offsets_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, (const unsigned*)tile_counts, ic, isect_offsets);
-        GS_CHECK_LAUNCH();
-        const int npass = (tb + 7) / 8, width = (tb + npass - 1) / npass;
-        uint2* src = ia; uint2* dst = ib;
-        for (int pass = 0; pass < npass; ++pass) {
-            const int shift = pass * width;
-            const int nbits = (tb - shift) < width ? (tb - shift) : width;
-            const int rc2 = radix_pass<uint2>(ic, U2In{ src }, XDigit{ TL_TILE_SHIFT + shift, (1u << nbits) - 1u }, U2Out{ dst }, nbits, table, s);
-            if (rc2 != GS_OK) return rc2;
-            uint2* t = src; src = dst; dst = t;
-        }
-        static bool attr_set = false;
-        if (!attr_set) {
-            GS_CHECK_HIP(hipFuncSetAttribute((const void*)tile_depth_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl_lds_bytes(TL_CAP_LARGE)));
-            attr_set = true;
-        }
-        // segments up to 4 096 entries (53 KB of LDS, three workgroups per CU), then the long ones (158 KB; beyond 11 776: global scratch)
-        hipLaunchKernelGGL(tile_depth_sort_kernel, dim3(n_tiles), dim3(TL_THREADS), tl_lds_bytes(TL_CAP_SMALL), s, n_tiles, isect_offsets, ic, src, 0,
-                           TL_CAP_SMALL, TL_CAP_SMALL, dst, ic2, flatten_ids_sorted);
-        GS_CHECK_LAUNCH();
-        hipLaunchKernelGGL(tile_depth_sort_kernel, dim3(n_tiles), dim3(TL_THREADS), tl_lds_bytes(TL_CAP_LARGE), s, n_tiles, isect_offsets, ic, src,
-                           TL_CAP_SMALL, 0x7fffffff, TL_CAP_LARGE, dst, ic2, flatten_ids_sorted);
-        GS_CHECK_LAUNCH();
-        return GS_OK;
-    }
     // 1. depth order of the Gaussians: key_bits / 8 stable 8-bit passes over (key, index); the first reads the key array
     int rc = radix_pass<uint2>(vc, KeyIn{ depth_keys }, XDigit{ 0, 255u }, U2Out{ da }, 8, table, s);
     if (rc != GS_OK) return rc;
@@ -1207,14 +1020,17 @@ extern "C" int gs_isect_bin_front(int V_cap, const uint32_t* depth_keys, const u
     }
     // 2. emission in depth order (chained scan inside the launch) + per-tile counts
     unsigned* ctrl = state; u64* desc = (u64*)((char*)state + 16);
-    hipLaunchKernelGGL(emit_chained_kernel<false>, dim3(eblocks), dim3(EM_THREADS), 0, s, vc, order, (const uint2*)tile_rects, ctrl, desc,
-                       eblocks + 1, tile_w, ia, (unsigned)n_isects, (long long*)status_dev, (const unsigned*)nullptr);
+    hipLaunchKernelGGL(emit_chained_kernel, dim3(eblocks), dim3(EM_THREADS), 0, s, vc, order, (const uint2*)tile_rects, ctrl, desc,
+                       eblocks + 1, tile_w, ia, (unsigned)n_isects, (long long*)status_dev);
     GS_CHECK_LAUNCH();
     if (hist) {
         hipLaunchKernelGGL(tile_offsets_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, (const unsigned*)tile_counts, ic, isect_offsets);
         GS_CHECK_LAUNCH();
     }
     // 3. stable split by tile id: npass digits of `width` bits, the last one writes the sorted flatten ids
+    int tb = 0;
+    while ((1 << tb) < n_tiles) ++tb;
+    if (tb < 1) tb = 1;
     const int npass = (tb + 7) / 8, width = (tb + npass - 1) / npass;
     uint2* src = ia; uint2* dst = ib;
     for (int pass = 0; pass < npass; ++pass) {

@@ -63,6 +63,7 @@ class _DeviceState:
         self.unchecked = collections.deque()     # capacity-mode views whose counts nobody has looked at yet
         self.cam_cache: Dict[tuple, tuple] = {}
         self.n_views = 0                         # views rendered so far (front stream round robin)
+        self.lock = threading.RLock()            # forward runs on the caller's thread, backward on autograd's: both touch `unchecked`
 
 
 class _Capacity:
@@ -241,6 +242,17 @@ class _Step:
 
 def _poll_unchecked(st: _DeviceState, wait_views=None) -> None:
     """Look at the counts of capacity-mode views that have finished (all of `wait_views`: waited for).  Raises for a truncated one."""
+    with st.lock:
+        bad = _poll_unchecked_locked(st, wait_views)
+    if bad is not None:
+        v, i_seen = bad
+        raise GeoSplatCapacityError(
+            f"splat(): view {v.index} of a step had {i_seen} tile intersections (capacity {v.cap_used}) or left the 24-bit depth-key "
+            f"range: its image and gradients come from a truncated list.  The capacity is now {v.cap.i_cap}; repeat the step "
+            "(GEOSPLAT_CAPACITY=0 reads the exact counts back for every view instead).")
+
+
+def _poll_unchecked_locked(st: _DeviceState, wait_views=None):
     bad = None
     keep = collections.deque()
     while st.unchecked:
@@ -273,12 +285,7 @@ def _poll_unchecked(st: _DeviceState, wait_views=None) -> None:
         if over and bad is None:
             bad = (v, i_seen)
     st.unchecked = keep
-    if bad is not None:
-        v, i_seen = bad
-        raise GeoSplatCapacityError(
-            f"splat(): view {v.index} of a step had {i_seen} tile intersections (capacity {v.cap_used}) or left the 24-bit depth-key "
-            f"range: its image and gradients come from a truncated list.  The capacity is now {v.cap.i_cap}; repeat the step "
-            "(GEOSPLAT_CAPACITY=0 reads the exact counts back for every view instead).")
+    return bad
 
 
 def _view_forward(step: _Step, cam: Camera, exposure: Tensor, tone: int, want_grad: bool) -> Tuple[Tensor, _View]:
@@ -327,7 +334,8 @@ def _view_forward(step: _Step, cam: Camera, exposure: Tensor, tone: int, want_gr
         v.host_counts = None
     else:
         v.host_counts, v.event, v.cap_used, v.key_bits, v.key_base = fr.host_counts, ev, cap.i_cap, key_bits, key_base
-        st.unchecked.append(v)
+        with st.lock:
+            st.unchecked.append(v)
     for x in list(state.values()) + [log_ws, v_packed, step.scales_act, step.opac_act] + list(cam_t):
         if isinstance(x, Tensor):
             x.record_stream(main)

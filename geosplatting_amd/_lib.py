@@ -28,6 +28,13 @@ class GsTailView(C.Structure):
                 ("packed_index", C.c_void_p), ("W", C.c_int), ("H", C.c_int)]
 
 
+class GsTileLevel(C.Structure):
+    _fields_ = [("R", C.c_int), ("n_mirrors", C.c_int), ("margin", C.c_int), ("bw", C.c_int), ("nb", C.c_int), ("tile_begin", C.c_int),
+                ("tile_end", C.c_int), ("reserved", C.c_int), ("src", C.c_void_p), ("scale", C.c_void_p), ("out_scale", C.c_void_p),
+                ("bounds", C.c_void_p), ("tiles", C.c_void_p), ("segments", C.c_void_p), ("row_begin", C.c_void_p), ("row_counts", C.c_void_p),
+                ("desc", C.c_void_p), ("weights", C.c_void_p), ("dst", C.c_void_p), ("lds_bytes", C.c_size_t)]
+
+
 class GsEnvGrad(C.Structure):
     _fields_ = [("base", C.c_void_p), ("levels", C.c_void_p * GS_MAX_LEVELS)]
 
@@ -36,13 +43,13 @@ class GsEnvGrad(C.Structure):
 SYMBOLS = [
     "gs_last_error", "gs_version", "gs_project_ws_bytes", "gs_project_fwd", "gs_project_fwd_vis", "gs_isect_emit", "gs_sort_ws_bytes",
     "gs_isect_sort", "gs_isect_bin_ws_bytes", "gs_isect_bin", "gs_isect_offsets", "gs_raster_ws_bytes", "gs_raster_fwd", "gs_raster_prepare", "gs_raster_prepare_vis", "gs_raster_composite", "gs_raster_grad_stride", "gs_raster_bwd", "gs_raster_bwd_acc", "gs_selftest_rcp", "gs_selftest_exp", "gs_selftest_cube_edges", "gs_isect_bin_cap", "gs_isect_offsets_cap", "gs_isect_bin_tiles_cap", "gs_isect_offsets_tiles_cap", "gs_raster_prepare_vis_cap", "gs_raster_composite_cap", "gs_raster_bwd_cap", "gs_raster_bwd_acc_cap", "gs_raster_composite_tone", "gs_raster_bwd_tone_acc", "gs_raster_log_ws_bytes", "gs_raster_composite_tone_log", "gs_raster_bwd_tone_log_acc", "gs_project_bwd_cap", "gs_project_bwd", "gs_shade_fwd",
-    "gs_shade_bwd_ws_bytes", "gs_shade_bwd", "gs_tonemap_fwd", "gs_tonemap_bwd", "gs_tonemap_fwd3", "gs_tonemap_bwd3", "gs_cubemap_mip_fwd", "gs_cube_sample_linear",
+    "gs_shade_bwd_ws_bytes", "gs_shade_bwd", "gs_tonemap_fwd", "gs_tonemap_bwd", "gs_tonemap_fwd3", "gs_tonemap_bwd3", "gs_cubemap_mip_fwd", "gs_cubemap_mip_chain_fwd", "gs_cube_sample_linear",
     "gs_cubemap_mip_bwd", "gs_diffuse_cubemap_fwd", "gs_diffuse_cubemap_bwd", "gs_specular_bounds", "gs_specular_bounds_ws_bytes", "gs_specular_bounds_fast", "gs_cube_dir_table",
     "gs_specular_cubemap_fwd", "gs_specular_cubemap_bwd", "gs_specular_tiles_count", "gs_specular_tiles_fill",
-    "gs_specular_tiles_check", "gs_specular_tiles_apply", "gs_mgadapter_fwd", "gs_mgadapter_bwd", "gs_vertex_normals_fwd",
+    "gs_specular_tiles_check", "gs_specular_tiles_apply", "gs_specular_tiles_apply_multi", "gs_mgadapter_fwd", "gs_mgadapter_bwd", "gs_vertex_normals_fwd",
     "gs_vertex_normals_bwd", "gs_photo_loss_ws_bytes", "gs_photo_loss", "gs_hashgrid_fwd", "gs_hashgrid_bwd_ws_bytes", "gs_hashgrid_bwd", "gs_hashgrid_bwd_fixed_ws_bytes", "gs_hashgrid_bwd_fixed", "gs_mlp_wgrad_ws_bytes", "gs_mlp_wgrad",
     "gs_flexicubes_ws_bytes", "gs_flexicubes_count", "gs_flexicubes_fwd", "gs_flexicubes_bwd", "gs_flexicubes_entropy_fwd",
-    "gs_flexicubes_entropy_bwd", "gs_front_ws_bytes", "gs_front_fwd", "gs_isect_bin_front_ws_bytes", "gs_isect_bin_front", "gs_tail_bwd", "gs_tail_bwd_multi", "gs_tail_bwd_multi_parts", "gs_tail_priv_ws_bytes", "gs_tail_priv_reduce",
+    "gs_flexicubes_entropy_bwd", "gs_front_ws_bytes", "gs_front_fwd", "gs_isect_bin_front_ws_bytes", "gs_isect_bin_front", "gs_tail_bwd", "gs_tail_bwd_multi", "gs_tail_bwd_multi_parts", "gs_tail_priv_ws_bytes", "gs_tail_priv_reduce", "gs_activation_chain",
 ]
 
 _lib: Optional[C.CDLL] = None

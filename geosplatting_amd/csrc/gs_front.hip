@@ -869,3 +869,30 @@ extern "C" int gs_tail_bwd_multi(int N, int n_views, const GsTailView* views, co
                                    eps2d, rec_stride, v_means, v_quats, v_scales, v_opacities, v_normals, v_kd, v_ks, accumulate, env_grad,
                                    priv_ws, priv_ws_bytes, stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Chain rule of the once-per-step activations (rfstudio/model/gsplat.py:336-339: scales.exp(), sigmoid(opacities)) in ONE launch:
+//   v_scales = v_scales_act * scales_act,   v_opacities = (v_opac_act * opac_act) * (1 - opac_act)
+// -- the products torch formed with five elementwise launches at the end of every step, in the same order (contraction off).
+__global__ void __launch_bounds__(256)
+activation_chain_kernel(int64_t n3, int64_t n, const float* __restrict__ g_scales_act, const float* __restrict__ scales_act,
+                        const float* __restrict__ g_opac_act, const float* __restrict__ opac_act, float* __restrict__ v_scales,
+                        float* __restrict__ v_opac)
+{
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n3) v_scales[i] = g_scales_act[i] * scales_act[i];
+    if (i < n) { const float o = opac_act[i]; v_opac[i] = (g_opac_act[i] * o) * (1.0f - o); }
+}
+
+extern "C" int gs_activation_chain(int64_t N, const float* g_scales_act, const float* scales_act, const float* g_opac_act,
+                                   const float* opac_act, float* v_scales, float* v_opacities, void* stream)
+{
+    GS_CHECK_ARG(N >= 0, "bad N");
+    if (N == 0) return GS_OK;
+    GS_CHECK_ARG(g_scales_act && scales_act && g_opac_act && opac_act && v_scales && v_opacities, "null argument");
+    hipLaunchKernelGGL(activation_chain_kernel, dim3(gs_cdiv(3 * N, 256)), dim3(256), 0, (hipStream_t)stream, 3 * N, N, g_scales_act,
+                       scales_act, g_opac_act, opac_act, v_scales, v_opacities);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}

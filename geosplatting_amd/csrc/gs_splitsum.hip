@@ -68,6 +68,68 @@ extern "C" int gs_cubemap_mip_fwd(int R, int C, const float* in, float* out, voi
     return GS_OK;
 }
 
+// The whole mip chain R -> R/2 -> ... -> R/2^n in ONE launch (round 6; as n launches of mip_fwd_kernel the chain sat at the head of every
+// step as five dependent 4-20 us kernels with 40-80 us between them while another queue was busy: profiles/r05_step_boundary.txt).
+// A workgroup owns a 2^n x 2^n patch of one face: level 1 from global memory, every further level from the previous one in LDS
+// (ping-pong), each level written out as it is formed.  Same four addends in the same order as mip_fwd_kernel: bit-identical.
+#define GS_MIP_CHAIN_MAX 5
+struct MipChainArgs { int R, n; float* out[GS_MIP_CHAIN_MAX]; };
+
+__global__ void __launch_bounds__(256)
+mip_chain_fwd_kernel(const float* __restrict__ in, const MipChainArgs a)
+{
+    __shared__ float buf[2][256 * 3];
+    const int R = a.R, P = 1 << a.n, ppr = R / P;
+    const int patch = blockIdx.x;
+    const int face = patch / (ppr * ppr), py = (patch / ppr) % ppr, px = patch % ppr;
+    const int t = threadIdx.x;
+    int H = P >> 1;                                                   // patch edge at the level being formed
+    int Rl = R >> 1;                                                  // face edge at that level
+    if (t < H * H) {
+        const int lx = t % H, ly = t / H;
+        const float* p = in + (((size_t)face * R + (size_t)py * P + 2 * ly) * R + (size_t)px * P + 2 * lx) * 3;
+        float* o = a.out[0] + (((size_t)face * Rl + (size_t)py * H + ly) * Rl + (size_t)px * H + lx) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = (((p[c] + p[3 + c]) + p[(size_t)R * 3 + c]) + p[(size_t)R * 3 + 3 + c]) * 0.25f;
+            o[c] = v;
+            buf[0][t * 3 + c] = v;
+        }
+    }
+    for (int k = 1; k < a.n; ++k) {
+        __syncthreads();
+        const int Hp = H;                                             // edge of the level in LDS
+        H >>= 1; Rl >>= 1;
+        const float* src = buf[(k - 1) & 1];
+        float* dstl = buf[k & 1];
+        if (t < H * H) {
+            const int lx = t % H, ly = t / H;
+            const float* p = src + ((2 * ly) * Hp + 2 * lx) * 3;
+            float* o = a.out[k] + (((size_t)face * Rl + (size_t)py * H + ly) * Rl + (size_t)px * H + lx) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = (((p[c] + p[3 + c]) + p[Hp * 3 + c]) + p[Hp * 3 + 3 + c]) * 0.25f;
+                o[c] = v;
+                dstl[t * 3 + c] = v;
+            }
+        }
+    }
+}
+
+extern "C" int gs_cubemap_mip_chain_fwd(int R, int n_levels, const float* in, float* const* outs, void* stream)
+{
+    GS_CHECK_ARG(n_levels >= 1 && n_levels <= GS_MIP_CHAIN_MAX && R >= (1 << n_levels) && (R % (1 << n_levels)) == 0 && in && outs,
+                 "1..5 levels, R a multiple of 2^n_levels");
+    MipChainArgs a;
+    a.R = R; a.n = n_levels;
+    for (int k = 0; k < GS_MIP_CHAIN_MAX; ++k) a.out[k] = k < n_levels ? outs[k] : nullptr;
+    for (int k = 0; k < n_levels; ++k) GS_CHECK_ARG(a.out[k] != nullptr, "null output level");
+    const int ppr = R >> n_levels;
+    hipLaunchKernelGGL(mip_chain_fwd_kernel, dim3(6 * ppr * ppr), dim3(256), 0, (hipStream_t)stream, in, a);
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+}
+
 __global__ void __launch_bounds__(256)
 cube_sample_kernel(int64_t n, const float* __restrict__ tex, int R, const float* __restrict__ dirs, float scale,
                    float* __restrict__ out)

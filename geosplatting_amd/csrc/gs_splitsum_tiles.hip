@@ -281,8 +281,9 @@ __device__ __forceinline__ MirrorMap mirror_map(int s, int m)          // the re
 }
 
 template <bool BWD, bool SHARED_ROWS>
-__global__ void __launch_bounds__(1024)
-tile_apply_kernel(int R, int E, int bw, int nb, int K, const float* __restrict__ src, const float* __restrict__ scale,
+__device__ __forceinline__ void
+tile_apply_body(int wg /*workgroup of this level's launch*/, int R, int E, int bw, int nb, int K, const float* __restrict__ src,
+                const float* __restrict__ scale,
                   const float* __restrict__ out_scale, const float* __restrict__ bounds, const int4* __restrict__ tiles,
                   const int4* __restrict__ seg /*[nt][6]: x0, y0, rows, pitch*/, const int64_t* __restrict__ row_begin,
                   const int32_t* __restrict__ row_cnt, const int32_t* __restrict__ desc, const float* __restrict__ weights,
@@ -294,12 +295,12 @@ tile_apply_kernel(int R, int E, int bw, int nb, int K, const float* __restrict__
     const int b = wave / K, part = wave - b * K;                     // block of the tile, share of its chunks
     int tile, m;
     if (SHARED_ROWS) {
-        const int q = blockIdx.x >> 6, r = blockIdx.x & 63;
+        const int q = wg >> 6, r = wg & 63;
         m = r >> 3;
         tile = tile_begin + q * 8 + (r & 7);
     } else {
         m = 0;
-        tile = tile_begin + blockIdx.x;
+        tile = tile_begin + wg;
     }
     if (tile >= tile_end) return;                                    // (the whole workgroup: uniform)
     const int4 tl = tiles[tile];
@@ -497,6 +498,83 @@ tile_apply_kernel(int R, int E, int bw, int nb, int K, const float* __restrict__
     } else {
         q[0] = acc01.x / acc23.y; q[1] = acc01.y / acc23.y; q[2] = acc23.x / acc23.y;
     }
+}
+
+template <bool BWD, bool SHARED_ROWS>
+__global__ void __launch_bounds__(1024)
+tile_apply_kernel(int R, int E, int bw, int nb, int K, const float* __restrict__ src, const float* __restrict__ scale,
+                  const float* __restrict__ out_scale, const float* __restrict__ bounds, const int4* __restrict__ tiles,
+                  const int4* __restrict__ seg, const int64_t* __restrict__ row_begin, const int32_t* __restrict__ row_cnt,
+                  const int32_t* __restrict__ desc, const float* __restrict__ weights, float* __restrict__ dst, int tile_begin, int tile_end)
+{
+    tile_apply_body<BWD, SHARED_ROWS>((int)blockIdx.x, R, E, bw, nb, K, src, scale, out_scale, bounds, tiles, seg, row_begin, row_cnt, desc,
+                                      weights, dst, tile_begin, tile_end);
+}
+
+// ALL levels of the pyramid in ONE launch (round 6).  As six launches the three levels below 128^2 -- 24 + 96 + 192 workgroups that
+// each walk a long row list -- held the GPU for 0.13 ms per direction with a tenth of its CUs busy, and every launch paid its own
+// fill and drain (profiles/r05_step_boundary.txt: 0.207 + 0.300 + 0.150 + 0.060 + 0.037 + 0.032 ms).  Here a workgroup finds its
+// level from a prefix table in the kernel arguments (<= GS_TILE_MAX_MULTI entries, uniform scalar compares) and runs the body above
+// with that level's geometry; the levels do not depend on each other (each reads its own mip / cotangent), the dynamic LDS is the
+// largest level's.  Same arithmetic per workgroup: bit-identical to the per-level launches.
+#define GS_TILE_MAX_MULTI 8
+struct TileLevelDev {
+    int R, E, bw, nb, K, tile_begin, tile_end, wg_begin;
+    const float* src; const float* scale; const float* out_scale; const float* bounds;
+    const int4* tiles; const int4* seg; const int64_t* row_begin; const int32_t* row_cnt; const int32_t* desc;
+    const float* weights; float* dst;
+};
+struct TileMultiArgs { int n; TileLevelDev lv[GS_TILE_MAX_MULTI]; };
+
+template <bool BWD, bool SHARED_ROWS>
+__global__ void __launch_bounds__(1024)
+tile_apply_multi_kernel(const TileMultiArgs a)
+{
+    int l = 0;
+    for (int k = 1; k < GS_TILE_MAX_MULTI; ++k) if (k < a.n && (int)blockIdx.x >= a.lv[k].wg_begin) l = k;
+    const TileLevelDev& v = a.lv[l];
+    tile_apply_body<BWD, SHARED_ROWS>((int)blockIdx.x - v.wg_begin, v.R, v.E, v.bw, v.nb, v.K, v.src, v.scale, v.out_scale, v.bounds, v.tiles,
+                                      v.seg, v.row_begin, v.row_cnt, v.desc, v.weights, v.dst, v.tile_begin, v.tile_end);
+}
+
+extern "C" int gs_specular_tiles_apply_multi(int n_levels, const GsTileLevel* levels, int backward, void* stream)
+{
+    GS_CHECK_ARG(n_levels >= 1 && n_levels <= GS_TILE_MAX_MULTI && levels != nullptr, "1..8 levels");
+    TileMultiArgs a;
+    a.n = 0;
+    size_t lds_bytes = 16 * 64 * 16;                                 // the partial sums of the 16 waves
+    int grid = 0;
+    const int n_mirrors = levels[0].n_mirrors;
+    for (int i = 0; i < n_levels; ++i) {
+        const GsTileLevel& g = levels[i];
+        GS_CHECK_ARG(tile_geometry_ok(g.R, g.bw, g.nb) && (16 % g.nb) == 0 && (g.n_mirrors == 1 || g.n_mirrors == 8),
+                     "R must be a multiple of 16, nb in {1, 2, 4, 8, 16}, n_mirrors 1 or 8");
+        GS_CHECK_ARG(g.n_mirrors == n_mirrors, "every level of a merged launch must use the same n_mirrors");
+        GS_CHECK_ARG(g.src && g.scale && (g.out_scale || !backward) && g.bounds && g.tiles && g.segments && g.row_begin && g.row_counts && g.desc
+                     && g.weights && g.dst, "null argument");
+        GS_CHECK_ARG(g.tile_begin >= 0 && g.tile_begin <= g.tile_end && g.lds_bytes <= 160 * 1024, "bad tile range / LDS size");
+        if (g.tile_begin == g.tile_end) continue;
+        const int nt = g.tile_end - g.tile_begin;
+        TileLevelDev& v = a.lv[a.n++];
+        v.R = g.R; v.E = backward ? g.margin : 0; v.bw = g.bw; v.nb = g.nb; v.K = 16 / g.nb; v.tile_begin = g.tile_begin; v.tile_end = g.tile_end;
+        v.wg_begin = grid;
+        v.src = g.src; v.scale = g.scale; v.out_scale = g.out_scale; v.bounds = g.bounds; v.tiles = (const int4*)g.tiles;
+        v.seg = (const int4*)g.segments; v.row_begin = g.row_begin; v.row_cnt = g.row_counts; v.desc = g.desc; v.weights = g.weights; v.dst = g.dst;
+        grid += n_mirrors == 8 ? gs_cdiv(nt, 8) * 64 : nt;
+        if (g.lds_bytes > lds_bytes) lds_bytes = g.lds_bytes;
+    }
+    if (a.n == 0) return GS_OK;
+    const hipStream_t s = (hipStream_t)stream;
+#define GS_TILE_MULTI_LAUNCH(BW, SH)                                                                                                   \
+    do {                                                                                                                               \
+        GS_CHECK_HIP(hipFuncSetAttribute((const void*)tile_apply_multi_kernel<BW, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+        hipLaunchKernelGGL((tile_apply_multi_kernel<BW, SH>), dim3(grid), dim3(1024), lds_bytes, s, a);                                \
+    } while (0)
+    if (n_mirrors == 8) { if (backward) GS_TILE_MULTI_LAUNCH(true, true); else GS_TILE_MULTI_LAUNCH(false, true); }
+    else { if (backward) GS_TILE_MULTI_LAUNCH(true, false); else GS_TILE_MULTI_LAUNCH(false, false); }
+#undef GS_TILE_MULTI_LAUNCH
+    GS_CHECK_LAUNCH();
+    return GS_OK;
 }
 
 extern "C" int gs_specular_tiles_apply(int R, int backward, int n_mirrors, int margin, int bw, int nb, const float* src,

@@ -240,9 +240,15 @@ class RenderStep:
             self._seen_counts.extend(seen)
             return dict(early=early, scales_act=scales_act, opac_act=opac_act)
         # (zero fills of the step: issued BEFORE the prefilter, i.e. off the path pyramid -> first compositor launch -- 0.06 ms)
-        self.bucket.flat.zero_()
+        # ONE fill: the bucket, the activation-gradient accumulators and the texel-gradient accumulators share an allocation
+        cres = int(p.cubemap.shape[1])
+        tex_res = [cres]
+        while tex_res[-1] > 16:
+            tex_res.append(tex_res[-1] // 2)
+        tex_sizes = [6 * tex_res[-1] * tex_res[-1] * 3] + [6 * r * r * 3 for r in tex_res]        # base map, then the levels
+        sc = self.bucket.zero_with_scratch([3 * N, N, sum(tex_sizes)])
         b = self.bucket.unpack()
-        g_scales_act = torch.zeros(N, 3, dtype=f32, device=dev); g_opac_act = torch.zeros(N, dtype=f32, device=dev)
+        g_scales_act = sc[0].view(N, 3); g_opac_act = sc[1]
         exposure = p.exposure.detach().reshape(1).contiguous()
         if _env is not None:
             env = _env                                       # the pyramid of this step, already filtered (capture_views)
@@ -268,10 +274,10 @@ class RenderStep:
         # linear, so splitting it doubles its 2.4 ms and the overlap does not pay that back.  One set.
         n_sets = 2 if (explicit_pre and not sharded and len(cameras) >= 4 and os.environ.get("GEOSPLAT_SPLIT_PREFILTER_BWD") == "1") else 1
         g_sets = []
-        for _ in range(n_sets):
+        for k_set in range(n_sets):
             # one flat buffer behind the base + level gradients: the sharded prefilter sums them over the ranks in ONE all-reduce
             sizes = [env_d.base.numel()] + [l.numel() for l in env_d.levels]
-            g_flat = torch.zeros(sum(sizes), dtype=f32, device=dev)
+            g_flat = sc[2] if (k_set == 0 and sizes == tex_sizes) else torch.zeros(sum(sizes), dtype=f32, device=dev)
             parts = torch.split(g_flat, sizes)
             gb = parts[0].view_as(env_d.base); gl = [q.view_as(l) for q, l in zip(parts[1:], env_d.levels)]
             egs = L.GsEnvGrad(); egs.base = gb.data_ptr()
@@ -578,8 +584,8 @@ class RenderStep:
         # chain the once-per-step activations; the per-Gaussian gradients are now final, so their all-reduce (RCCL on
         # the communication stream) overlaps the prefilter backward, whose cubemap gradient is reduced afterwards
         with torch.cuda.stream(pstream if pstream is not None else main):      # (behind the projection half of the tail)
-            torch.mul(g_scales_act, scales_act, out=b["scales"])
-            b["opacities"].copy_((g_opac_act * opac_act * (1.0 - opac_act)).unsqueeze(-1))
+            L.check(lib.gs_activation_chain(L.i64(N), L.ptr(g_scales_act), L.ptr(scales_act), L.ptr(g_opac_act), L.ptr(opac_act),
+                                            L.ptr(b["scales"]), L.ptr(b["opacities"]), st()), "gs_activation_chain")
         if pstream is not None:
             for t in (g_scales_act, g_opac_act, scales_act, opac_act):
                 t.record_stream(pstream)
@@ -621,13 +627,13 @@ class RenderStep:
             start_head()
         if self.prefilter and explicit_pre:
             gb, gl, _, _ = g_sets[n_sets - 1]
-            g_cube = as_splitsum_backward(gb, gl, min_roughness=env.min_roughness, max_roughness=env.max_roughness)
             if g_cube_first is not None:
+                g_cube = as_splitsum_backward(gb, gl, min_roughness=env.min_roughness, max_roughness=env.max_roughness)
                 main.wait_stream(self._pre_stream)
                 g_cube_first.record_stream(main)
                 torch.add(g_cube, g_cube_first, out=b["cubemap"])
-            else:
-                b["cubemap"].copy_(g_cube)
+            else:                                               # (the finest level's transposed apply writes the bucket's slice itself)
+                as_splitsum_backward(gb, gl, min_roughness=env.min_roughness, max_roughness=env.max_roughness, out=b["cubemap"])
         elif self.prefilter:
             outs = [env.base] + list(env.levels)
             gouts = [g_base] + g_levels

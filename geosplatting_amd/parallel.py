@@ -52,9 +52,26 @@ class GradBucket:
                 n *= int(s)
             off += (n + 63) // 64 * 64              # 256-byte aligned segments
         self.numel = off
-        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        self.storage = torch.zeros(off, dtype=torch.float32, device=device)   # bucket + per-step scratch behind it (zero_with_scratch)
+        self.flat = self.storage[:off]
         self.comm_stream = (comm_stream if comm_stream is not None else torch.cuda.Stream(device=device)) \
             if device.type == "cuda" else None
+
+    def zero_with_scratch(self, sizes: Sequence[int]) -> List[Tensor]:
+        """Zero the bucket AND `len(sizes)` scratch tensors (float counts) that live behind it in the same allocation with ONE fill
+        -- the step's accumulators (activation gradients, texel gradients) used to be four `torch.zeros` launches at the head of
+        every step.  The allocation grows on first use (the bucket's views stay valid: `flat` is re-derived before anyone reads it);
+        the scratch tensors are per-step temporaries, valid until the next call."""
+        offs, off = [], self.numel
+        for n in sizes:
+            offs.append(off)
+            off += (int(n) + 63) // 64 * 64
+        if self.storage.numel() < off:
+            self.storage = torch.zeros(off, dtype=torch.float32, device=self.storage.device)
+            self.flat = self.storage[:self.numel]
+        else:
+            self.storage[:off].zero_()
+        return [self.storage[o:o + int(n)] for o, n in zip(offs, sizes)]
 
     def view(self, name: str) -> Tensor:
         o = self.offsets[name]

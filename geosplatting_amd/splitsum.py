@@ -232,6 +232,64 @@ def _tiles_apply(entry: Dict, direction: str, src: Tensor, dst: Tensor, tile_beg
                                             L.ptr(dst), tile_begin, te, C.c_size_t(d["lds_bytes"]), L.stream()), "gs_specular_tiles_apply")
 
 
+MERGED_APPLY = os.environ.get("GEOSPLAT_PREFILTER_MERGED", "1") != "0"     # 0: one launch per level (rounds 3-5)
+
+
+def _tiles_apply_multi(jobs, direction: str, world: int = 1) -> None:
+    """All levels of one direction in ONE launch (gs_specular_tiles_apply_multi): jobs = [(entry, src, dst, tile_begin, tile_end)].
+    Falls back to one launch per level when the levels do not share n_mirrors (or GEOSPLAT_PREFILTER_MERGED=0)."""
+    jobs = [j for j in jobs if (j[4] if j[4] is not None else j[0]["n_tiles"]) > j[3]]
+    if not jobs:
+        return
+    if not MERGED_APPLY or len(jobs) == 1 or len(jobs) > 8 or len({j[0]["n_mirrors"] for j in jobs}) != 1:
+        for e, src, dst, t0, t1 in jobs:
+            _tiles_apply(e, direction, src, dst, t0, t1, world)
+        return
+    bwd = direction == "bwd"
+    arr = (L.GsTileLevel * len(jobs))()
+    keep = []
+    for k, (e, src, dst, t0, t1) in enumerate(jobs):
+        d = e[direction]
+        o = _ordered(e, direction, world)
+        src = src.contiguous()
+        keep.append(src)
+        g = arr[k]
+        g.R, g.n_mirrors, g.margin, g.bw, g.nb = e["res"], e["n_mirrors"], _bwd_margin(e["res"]), e["bw"], e["nb"]
+        g.tile_begin, g.tile_end = t0, e["n_tiles"] if t1 is None else t1
+        g.src = src.data_ptr(); g.scale = (e["inv_wsum"] if bwd else e["area4"]).data_ptr()
+        g.out_scale = e["area4"].data_ptr() if bwd else None
+        g.bounds = e["bounds"].data_ptr(); g.tiles = o["tiles"].data_ptr(); g.segments = o["seg"].data_ptr()
+        g.row_begin = o["row_begin"].data_ptr(); g.row_counts = o["cnt"].data_ptr(); g.desc = d["desc"].data_ptr()
+        g.weights = d["weights"].data_ptr(); g.dst = dst.data_ptr(); g.lds_bytes = d["lds_bytes"]
+        assert dst.is_contiguous() and dst.is_cuda
+    L.check(L.lib().gs_specular_tiles_apply_multi(len(jobs), arr, 1 if bwd else 0, L.stream()), "gs_specular_tiles_apply_multi")
+
+
+def mip_chain(cubemap: Tensor, min_resolution: int = 16) -> List[Tensor]:
+    """[cubemap, mip 1, ..., mip n] (n halvings down to min_resolution) without an autograd graph; one launch when n <= 5."""
+    cubemap = cubemap.detach().float().contiguous()
+    R = int(cubemap.shape[1])
+    res = []
+    r = R
+    while r > min_resolution:
+        r //= 2
+        res.append(r)
+    if not res:
+        return [cubemap]
+    if len(res) <= 5 and cubemap.shape[3] == 3 and R % (1 << len(res)) == 0 and os.environ.get("GEOSPLAT_MIP_CHAIN", "1") != "0":
+        sizes = [6 * q * q * 3 for q in res]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=cubemap.device)
+        outs = [t.view(6, q, q, 3) for t, q in zip(torch.split(flat, sizes), res)]
+        ptrs = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+        L.check(L.lib().gs_cubemap_mip_chain_fwd(R, len(outs), L.ptr(cubemap), ptrs, L.stream()), "gs_cubemap_mip_chain_fwd")
+        return [cubemap] + outs
+    mips = [cubemap]
+    with torch.no_grad():
+        while mips[-1].shape[1] > min_resolution:
+            mips.append(_CubeMapMip.apply(mips[-1]))
+    return mips
+
+
 class _CubeMapMip(torch.autograd.Function):
     """rfstudio/graphics/_mesh/_texture.py:199-226"""
 
@@ -436,19 +494,87 @@ def _mip_chain_backward(g_mips: List[Tensor], g_base: Tensor) -> Tensor:
 
 
 def as_splitsum_backward(g_base: Tensor, g_levels: List[Tensor], *, cutoff: float = 0.99, min_roughness: float = 0.08,
-                         max_roughness: float = 0.5) -> Tensor:
+                         max_roughness: float = 0.5, out: Optional[Tensor] = None) -> Tensor:
     """Explicit backward of `as_splitsum` on the CURRENT stream (no autograd graph, so a caller can place it on any HIP
     stream -- the autograd engine would run it on the stream of the forward): texel gradients of the base map and of
-    the n levels -> gradient of the cubemap.  Same kernels as the autograd path."""
+    the n levels -> gradient of the cubemap (written into `out` [6,R,R,3] when given).  The tiled levels run as ONE launch."""
     n = len(g_levels)
-    g_mips = [_specular_level_backward(gl, rough, cutoff) for gl, rough in zip(g_levels, _level_roughness(n, min_roughness, max_roughness))]
+    roughs = _level_roughness(n, min_roughness, max_roughness)
+    g_mips: List[Optional[Tensor]] = [None] * n
+    jobs = []
+    for i, (gl, rough) in enumerate(zip(g_levels, roughs)):
+        res = gl.shape[1]
+        e = specular_tiles(res, rough, cutoff, gl.device)
+        if e is None:
+            g_mips[i] = _specular_level_backward(gl, rough, cutoff)
+            continue
+        g = out if (i == 0 and out is not None) else torch.empty(6, res, res, 3, dtype=torch.float32, device=gl.device)
+        jobs.append((e, gl, g, 0, None))
+        g_mips[i] = g
+    _tiles_apply_multi(jobs, "bwd")
+    if out is not None and g_mips[0] is not out:
+        out.copy_(g_mips[0]); g_mips[0] = out
     return _mip_chain_backward(g_mips, g_base)
+
+
+class _SplitSumFused(torch.autograd.Function):
+    """as_splitsum as ONE autograd node: mip chain (one launch), diffuse map, every specular level (one launch); backward =
+    as_splitsum_backward.  Used when every level goes through the tiled tables (R a multiple of 16 down to min_resolution)."""
+
+    @staticmethod
+    def forward(ctx, cubemap: Tensor, cutoff: float, min_resolution: int, min_roughness: float, max_roughness: float):
+        base, levels = _as_splitsum_fused(cubemap, cutoff, min_resolution, min_roughness, max_roughness)
+        ctx.cfg = (cutoff, min_roughness, max_roughness, [tuple(l.shape) for l in levels], tuple(base.shape))
+        return (base, *levels)
+
+    @staticmethod
+    def backward(ctx, g_base, *g_levels):
+        cutoff, min_roughness, max_roughness, shapes, bshape = ctx.cfg
+        dev = next(g for g in (g_base, *g_levels) if g is not None).device
+        g_base = torch.zeros(bshape, dtype=torch.float32, device=dev) if g_base is None else g_base.contiguous()
+        gl = [torch.zeros(sh, dtype=torch.float32, device=dev) if g is None else g.contiguous() for g, sh in zip(g_levels, shapes)]
+        g = as_splitsum_backward(g_base, gl, cutoff=cutoff, min_roughness=min_roughness, max_roughness=max_roughness)
+        return g, None, None, None, None
+
+
+def _fused_eligible(cubemap: Tensor, min_resolution: int) -> bool:
+    R = int(cubemap.shape[1])
+    if cubemap.dim() != 4 or cubemap.shape[3] != 3 or not MERGED_APPLY:
+        return False
+    n = 0
+    r = R
+    while r > min_resolution:
+        if not tiles_eligible(r) or r % 2:
+            return False
+        r //= 2
+        n += 1
+    return n >= 2 and n <= 5 and tiles_eligible(r)
+
+
+def _as_splitsum_fused(cubemap: Tensor, cutoff: float, min_resolution: int, min_roughness: float, max_roughness: float):
+    mips = mip_chain(cubemap, min_resolution)
+    n = len(mips)
+    with torch.no_grad():
+        base = diffuse_cubemap(mips[-1])
+    roughs = _level_roughness(n, min_roughness, max_roughness)
+    sizes = [m.numel() for m in mips]
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=cubemap.device)
+    levels = [t.view_as(m) for t, m in zip(torch.split(flat, sizes), mips)]
+    jobs = []
+    for m, out, rough in zip(mips, levels, roughs):
+        e = specular_tiles(int(m.shape[1]), rough, cutoff, cubemap.device)
+        jobs.append((e, m, out, 0, None))
+    _tiles_apply_multi(jobs, "fwd")
+    return base, levels
 
 
 def as_splitsum(cubemap: Tensor, *, cutoff: float = 0.99, min_resolution: int = 16, min_roughness: float = 0.08,
                 max_roughness: float = 0.5) -> TextureSplitSum:
     """TextureCubeMap.as_splitsum (rfstudio/graphics/_mesh/_texture.py:530-557); differentiable w.r.t. cubemap."""
     L.require_cuda(cubemap)
+    if _fused_eligible(cubemap, min_resolution):
+        out = _SplitSumFused.apply(cubemap.float(), float(cutoff), int(min_resolution), float(min_roughness), float(max_roughness))
+        return TextureSplitSum(out[0], list(out[1:]), min_roughness, max_roughness)
     mips = [cubemap.float()]
     while mips[-1].shape[1] > min_resolution:
         mips.append(_CubeMapMip.apply(mips[-1]))
@@ -494,20 +620,20 @@ def as_splitsum_sharded(cubemap: Tensor, rank: int, world: int, group=None, *, c
     import torch.distributed as dist
     L.require_cuda(cubemap)
     with torch.no_grad():
-        mips = [cubemap.detach().float().contiguous()]
-        while mips[-1].shape[1] > min_resolution:
-            mips.append(_CubeMapMip.apply(mips[-1]))
+        mips = mip_chain(cubemap, min_resolution)
         assert len(mips) > 2, "Min resolution is too large."
         base = diffuse_cubemap(mips[-1])
         roughs = _level_roughness(len(mips), min_roughness, max_roughness)
         tiled = [i for i, m in enumerate(mips) if tiles_eligible(m.shape[1])]
         flat, parts = _flat_levels([mips[i].shape[1] for i in tiled], cubemap.device)
         levels: List[Optional[Tensor]] = [None] * len(mips)
+        jobs = []
         for out, i in zip(parts, tiled):
             e = specular_tiles(mips[i].shape[1], roughs[i], cutoff, cubemap.device)
             t0, t1 = shard_tiles(e["n_tiles"], rank, world)
-            _tiles_apply(e, "fwd", mips[i], out, t0, t1, world)
+            jobs.append((e, mips[i], out, t0, t1))
             levels[i] = out
+        _tiles_apply_multi(jobs, "fwd", world)
         if tiled:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         for i, m in enumerate(mips):
@@ -525,11 +651,13 @@ def as_splitsum_backward_sharded(g_base: Tensor, g_levels: List[Tensor], rank: i
     tiled = [i for i, gl in enumerate(g_levels) if tiles_eligible(gl.shape[1])]
     flat, parts = _flat_levels([g_levels[i].shape[1] for i in tiled], g_base.device)
     g_mips: List[Optional[Tensor]] = [None] * n
+    jobs = []
     for out, i in zip(parts, tiled):
         e = specular_tiles(g_levels[i].shape[1], roughs[i], cutoff, g_base.device)
         t0, t1 = shard_tiles(e["n_tiles"], rank, world)
-        _tiles_apply(e, "bwd", g_levels[i].contiguous(), out, t0, t1, world)
+        jobs.append((e, g_levels[i], out, t0, t1))
         g_mips[i] = out
+    _tiles_apply_multi(jobs, "bwd", world)
     if tiled:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     for i in range(n):

@@ -319,6 +319,10 @@ int gs_tonemap_bwd(int64_t P, int mode, const float* rgba, const float* exposure
 
 /* ------------------------------------------------------------------ S5 ----------------------------- */
 int gs_cubemap_mip_fwd(int R, int C, const float* in, float* out, void* stream);
+/* n_levels successive gs_cubemap_mip_fwd calls (C = 3) in one launch: outs[k] = [6, R >> (k+1), R >> (k+1), 3], k < n_levels <= 5,
+ * R a multiple of 2^n_levels (`outs` is a HOST array of device pointers).  Bit-identical to the chain of single calls
+ * (the `while mips[-1].resolution > min_resolution` loop of TextureCubeMap.as_splitsum, rfstudio/graphics/_mesh/_texture.py:536-541). */
+int gs_cubemap_mip_chain_fwd(int R, int n_levels, const float* in, float* const* outs, void* stream);
 /* out[n,3] = seam-aware bilinear cube lookup of tex[6,R,R,3] at dirs[n,3] (used by the mip backward). */
 int gs_cube_sample_linear(int64_t n, const float* tex, int R, const float* dirs, float scale, float* out,
                           void* stream);
@@ -382,6 +386,18 @@ int gs_specular_tiles_apply(int R, int backward, int n_mirrors, int margin, int 
                             const float* out_scale, const float* bounds, const int32_t* tiles, const int32_t* segments,
                             const int64_t* row_begin, const int32_t* row_counts, const int32_t* desc, const float* weights, float* dst,
                             int tile_begin, int tile_end, size_t lds_bytes, void* stream);
+
+/* The same for SEVERAL levels in one launch (the six specular_cubemap calls of TextureCubeMap.as_splitsum,
+ * rfstudio/graphics/_mesh/_texture.py:546-556, or their six backward calls): one entry per level with the arguments of
+ * gs_specular_tiles_apply; the levels must not alias (each reads its own src and writes its own dst) and must share n_mirrors.
+ * Workgroups are numbered level after level in the order given.  Results are bit-identical to the per-level calls. */
+typedef struct GsTileLevel {
+    int R, n_mirrors, margin, bw, nb, tile_begin, tile_end, reserved;
+    const float* src; const float* scale; const float* out_scale; const float* bounds;
+    const int32_t* tiles; const int32_t* segments; const int64_t* row_begin; const int32_t* row_counts; const int32_t* desc;
+    const float* weights; float* dst; size_t lds_bytes;
+} GsTileLevel;
+int gs_specular_tiles_apply_multi(int n_levels, const GsTileLevel* levels, int backward, void* stream);
 
 /* ------------------------------------------------------------------ M1: MGAdapter (mesh -> Gaussians) */
 /* rfstudio/model/geosplat.py:378-472 (MGAdapter.make, default ratios): every face -> 6 flat Gaussians (two rings
@@ -565,6 +581,12 @@ int gs_tail_bwd_multi_parts(int parts, int N, int n_views, const GsTailView* vie
 size_t gs_tail_priv_ws_bytes(const GsEnv* env /*host*/, int mode);
 int gs_tail_priv_reduce(const GsEnv* env /*host*/, int mode, const void* priv_ws, size_t priv_ws_bytes, const GsEnvGrad* env_grad,
                         void* stream);
+
+/* Chain rule of the per-step activations of GSplatter.render_rgba (rfstudio/model/gsplat.py:336-339: `scales.exp()`,
+ * `sigmoid(opacities)`) applied once to gradients accumulated over the views of a step:
+ *   v_scales[N,3] = g_scales_act * scales_act,   v_opacities[N] = (g_opac_act * opac_act) * (1 - opac_act). */
+int gs_activation_chain(int64_t N, const float* g_scales_act, const float* scales_act, const float* g_opac_act, const float* opac_act,
+                        float* v_scales, float* v_opacities, void* stream);
 
 #ifdef __cplusplus
 }

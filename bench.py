@@ -206,9 +206,9 @@ def time_call_shaped(params, cams, ups, steps, warmup):
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    cap = gs.viewbatch._state(params.means.device).caps.get((params.means.shape[0], cams[0].width, cams[0].height))
+    cap = gs.viewbatch._state(params.means.device).caps.get((cams[0].width, cams[0].height))
     return {"views_per_s": len(cams) * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "views_per_step": len(cams),
-            "n_isects_cap": None if cap is None else cap.i_cap,
+            "n_isects_cap": None if cap is None else cap.i_cap(params.means.shape[0]),
             "what": "as_splitsum(cubemap) [autograd] -> for cam in batch: RenderableAttrs.splat(...) -> loss = sum <img, w> -> ONE "
                     "loss.backward() into .grad of means/scales/quats/opacities/kd/ks/normals/cubemap/exposure; same kernels as `value` "
                     "(fused front, cull-log compositor, batched tails), driven by autograd instead of engine.RenderStep"}
@@ -216,8 +216,9 @@ def time_call_shaped(params, cams, ups, steps, warmup):
 
 def time_d14(params, cam, res, iters):
     """D = 14 deferred rasterization (rfstudio/model/geosplat.py:276-295: 14 feature channels through gsplat.rasterization) forward +
-    backward of one view through `geosplatting_amd.rasterization` -- the D > 3 path (colours outside the record stream, ds_add_f64
-    accumulator rows in the backward), never on the headline path; timed once per bench run so that it has a number."""
+    backward of one view through `geosplatting_amd.rasterization` -- the D > 3 path (the same compositor pair as D <= 3 since round 5:
+    raster_fwd_window_kernel<16> / raster_bwd_lanes2_kernel<16> with the colours of a dense batch staged in LDS planes), never on the
+    headline path; timed once per bench run so that it has a number."""
     import geosplatting_amd as gs
     dev = params.means.device
     g = torch.Generator().manual_seed(14)

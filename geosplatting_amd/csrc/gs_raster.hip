@@ -1741,13 +1741,10 @@ static int launch_fwd(int W, int H, int D, const RasterWs& ws, const float* colo
     {                                                         // sliding window of two dense batches, every D
         const size_t planes = CD > 3 ? 4 * (size_t)2 * (size_t)D * 64 * sizeof(float) : 0;      // colour planes of two batches per wave
         const size_t lds = gs_raster_lds(4 * (size_t)GS_WIN_Q_BYTES + planes);
-        if (lds > 64 * 1024) {                                    // (D > 14 or so: the opt-in for more than 64 KB of dynamic LDS)
-            static size_t attr_fwd = 0;                           // (per instantiation; raised when a larger D comes along)
-            if (lds > attr_fwd) {
-                GS_CHECK_HIP(hipFuncSetAttribute((const void*)raster_fwd_window_kernel<CD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_fwd = lds;
-            }
-        }
+        // (D > 14 or so: the opt-in for more than 64 KB of dynamic LDS -- set on EVERY such launch: the attribute is per device, a
+        //  process may drive several GPUs and threads, so nothing about it is cached here)
+        if (lds > 64 * 1024)
+            GS_CHECK_HIP(hipFuncSetAttribute((const void*)raster_fwd_window_kernel<CD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(raster_fwd_window_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
                            ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, isect_count(n_isects), offsets, render, alphas,
                            last_ids, t_tone_fwd, t_cull_log, t_cull_log.count ? ws.bo : BwdOrder{ nullptr, nullptr });
@@ -1873,11 +1870,8 @@ static int launch_bwd(int W, int H, int D, const RasterWs& ws, const float* colo
     {                                                         // no log (gs_raster_bwd / _acc / _tone_acc), and every D > 3: pair buffer, own cull + masks
         size_t lds = 4 * ((size_t)Lanes2Lds<CD>::WAVE_BYTES + (CD > 3 ? 2 * (size_t)D * 64 * 4 : 0));      // (+ colour and cotangent planes)
         if (lds < gs_raster_lds_pad()) lds = gs_raster_lds_pad();
-        static size_t attr_bwd = 0;                    // > 64 KB of dynamic LDS needs the opt-in (per instantiation, raised with D)
-        if (lds > 64 * 1024 && lds > attr_bwd) {
+        if (lds > 64 * 1024)                           // > 64 KB of dynamic LDS needs the opt-in (per device: set on every such launch)
             GS_CHECK_HIP(hipFuncSetAttribute((const void*)raster_bwd_lanes2_kernel<CD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_bwd = lds;
-        }
         hipLaunchKernelGGL(raster_bwd_lanes2_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
                            ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, isect_count(n_isects), offsets, alphas, last_ids,
                            v_render, v_alphas, v_packed, rec_stride, t_tone_bwd);

@@ -462,22 +462,29 @@ def train_step(model: Stage1Model, cameras: Sequence[Camera], gt_rgba: Sequence[
     Leaves d(loss + regularisation)/d(parameter) of the GLOBAL batch in every parameter's .grad (after the flat
     all-reduce when world_size > 1).  train_bg: fixed per-view backgrounds instead of the trainer's torch.rand_like
     (tests).  Returns detached metrics of the local views."""
+    from .viewbatch import retry_on_capacity
     n_total = len(cameras)
     mine = list(range(rank, n_total, world_size))
-    for p in model.parameters():
-        p.grad = None
-    images, num_gaussians, reg = model.render_report([cameras[i] for i in mine], [gt_rgba[i] for i in mine], batch_size=n_total)
-    smooth = model._last_smoothing                                      # per-view smoothing terms of THIS rank's views
-    total = (reg - smooth) / world_size + smooth                        # the rest is identical on every rank: counted once
-    local = []
-    for i, img in zip(mine, images):
-        gt = gt_rgba[i]
-        bg = train_bg[i] if train_bg is not None else \
-            torch.rand(img.shape[0], img.shape[1], 3, device=img.device, generator=bg_generator)    # :172
-        loss, _ = photo_loss(img[..., :3], img[..., 3:], gt, bg, gt_is_srgb=gt_is_srgb, use_mask_loss=use_mask_loss)
-        local.append(loss.detach())
-        total = total + loss / n_total
-    total.backward()
+
+    def attempt():
+        # (a view that outgrew the capacity the earlier steps taught raises GeoSplatCapacityError from backward(), before anything
+        #  consumed the step: the capacity has been raised, the step is simply repeated -- viewbatch.retry_on_capacity)
+        for p in model.parameters():
+            p.grad = None
+        images, num_gaussians, reg = model.render_report([cameras[i] for i in mine], [gt_rgba[i] for i in mine], batch_size=n_total)
+        smooth = model._last_smoothing                                  # per-view smoothing terms of THIS rank's views
+        total = (reg - smooth) / world_size + smooth                    # the rest is identical on every rank: counted once
+        local = []
+        for i, img in zip(mine, images):
+            gt = gt_rgba[i]
+            bg = train_bg[i] if train_bg is not None else \
+                torch.rand(img.shape[0], img.shape[1], 3, device=img.device, generator=bg_generator)    # :172
+            loss, _ = photo_loss(img[..., :3], img[..., 3:], gt, bg, gt_is_srgb=gt_is_srgb, use_mask_loss=use_mask_loss)
+            local.append(loss.detach())
+            total = total + loss / n_total
+        total.backward()
+        return num_gaussians, reg, local
+    num_gaussians, reg, local = retry_on_capacity(attempt)()
     params = model.parameters()
     for p in params:
         if p.grad is None:

@@ -18,12 +18,19 @@ know about:
     tensors otherwise).  A backward over a subset of the views, several backward calls, views that never get one: all correct
     (whatever is pending when the gather node runs is flushed; nothing pending, nothing returned).
 
-Capacity protocol (include/geosplat_hip.h): the first call for a (N, W, H) shape reads its counts back (exact mode, as gsplat
-does); later calls size their buffers by 1.25 x the largest intersection count seen and leave the counts on the device.  The counts
-of every view still travel to pinned memory; they are checked when the gather node runs (by then the fronts have long finished: the
-wait costs nothing) and a view that exceeded its capacity raises GeoSplatCapacityError THERE -- before any optimizer can consume
-the step -- with the capacity already raised for the retry.  GEOSPLAT_CAPACITY=0 keeps every call exact.  Calls under
-``torch.no_grad()`` (or on tensors that need no gradient) are always exact.
+Capacity protocol (include/geosplat_hip.h): EVERY view of the first step at an image size (W, H) reads its counts back (exact mode,
+as gsplat does); later steps size their buffers by 1.5 x the largest intersections-per-Gaussian RATIO seen at that image size, times
+their own N -- a stage-1 loop that extracts a different number of Gaussians every iteration keeps its capacity -- and leave the
+counts on the device.  The counts of every view still travel to pinned memory; they are checked when the gather node runs (by then
+the fronts have long finished: the wait costs nothing) and a view that exceeded its capacity raises GeoSplatCapacityError THERE --
+from the ``backward()`` of the step that owns the view, before any optimizer can consume it -- with the capacity already raised for
+the retry (``retry_on_capacity`` wraps a step function accordingly; stage1.train_step uses it).  A truncated view that never gets a
+backward is reported by a warning.  GEOSPLAT_CAPACITY=0 keeps every call exact.  Calls under ``torch.no_grad()`` (or on tensors that
+need no gradient) are always exact.
+
+Parameter identity: views join a step when they read the same tensor OBJECTS at the same storage address with the same version
+counters.  An in-place write that bypasses the version counter (``p.data.copy_()`` / a checkpoint load through ``.data``) between
+two calls with NO version bump in between is not seen -- call ``viewbatch.reset()`` after such a load.
 """
 from __future__ import annotations
 
@@ -31,6 +38,7 @@ import collections
 import ctypes as C
 import os
 import threading
+import warnings
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -57,8 +65,7 @@ class _DeviceState:
         n_front = max(1, int(os.environ.get("GEOSPLAT_SPLAT_FRONT_STREAMS", "2")))
         self.fronts = [torch.cuda.Stream(device=dev) for _ in range(n_front)]
         self.tail = torch.cuda.Stream(device=dev)
-        self.status = None                       # int64[4] device word of the capacity protocol (sticky; the host checks the counts)
-        self.caps: Dict[Tuple[int, int, int], "_Capacity"] = {}
+        self.caps: "collections.OrderedDict[Tuple[int, int], _Capacity]" = collections.OrderedDict()   # by image size, least recently used first
         self.current: Optional["_Step"] = None   # the step new splat() calls may join
         self.unchecked = collections.deque()     # capacity-mode views whose counts nobody has looked at yet
         self.cam_cache: Dict[tuple, tuple] = {}
@@ -66,27 +73,39 @@ class _DeviceState:
         self.lock = threading.RLock()            # forward runs on the caller's thread, backward on autograd's: both touch `unchecked`
 
 
+_MAX_CAPS = 64
+
+
 class _Capacity:
-    """What the earlier views of a (N, W, H) shape taught: intersection capacity and the depth-bit range for 24-bit keys."""
-    __slots__ = ("i_cap", "key_lo", "key_hi", "key32", "max_i")
+    """What the earlier views at an image size (W, H) taught: intersections per Gaussian (the capacity of a later view is that
+    ratio x its own N x margin) and the depth-bit range for 24-bit keys.  `first_step`: key of the step whose views taught it --
+    all of them run exact, so the capacity rests on a whole batch of views, not on one."""
+    __slots__ = ("ratio", "key_lo", "key_hi", "key32", "max_i", "first_step")
 
     def __init__(self):
-        self.i_cap = None; self.key_lo = None; self.key_hi = None
+        self.ratio = None; self.key_lo = None; self.key_hi = None
         self.key32 = os.environ.get("GEOSPLAT_KEY_BITS", "24") == "32"
         self.max_i = 0
+        self.first_step = None
 
-    def learn(self, host_counts: Tensor) -> None:
+    def learn(self, host_counts: Tensor, n: int) -> None:
         i = int(host_counts[1])
         self.max_i = max(self.max_i, i)
-        margin = float(os.environ.get("GEOSPLAT_CAPACITY_MARGIN", "1.25"))
-        gran = 65536 if i >= (1 << 20) else 4096               # (stable buffer sizes for the caching allocator)
-        want = ((int(max(i, 1) * margin) + gran - 1) // gran) * gran
-        if self.i_cap is None or want > self.i_cap:
-            self.i_cap = want
+        r = max(i, 1) / float(max(n, 1))
+        if self.ratio is None or r > self.ratio:
+            self.ratio = r
         rng = F.depth_range(host_counts)
         if rng is not None:
             self.key_lo = rng[0] if self.key_lo is None else min(self.key_lo, rng[0])
             self.key_hi = rng[1] if self.key_hi is None else max(self.key_hi, rng[1])
+
+    def i_cap(self, n: int) -> Optional[int]:
+        if self.ratio is None:
+            return None
+        margin = float(os.environ.get("GEOSPLAT_SPLAT_CAPACITY_MARGIN", os.environ.get("GEOSPLAT_CAPACITY_MARGIN", "1.5")))
+        want = int(self.ratio * max(n, 1) * margin) + 1
+        gran = 65536 if want >= (1 << 20) else 4096             # (stable buffer sizes for the caching allocator)
+        return ((want + gran - 1) // gran) * gran
 
     def keys(self) -> Tuple[int, int]:
         """(key_bits, key_base) for the next view: 24-bit keys (three depth passes instead of four) with half an octave of room
@@ -148,7 +167,7 @@ def camera_tensors(st: _DeviceState, cam: Camera, stream: torch.cuda.Stream):
 # ------------------------------------------------------------------------------------------------------------ the step
 class _View:
     __slots__ = ("cam", "W", "H", "V", "I", "state", "render", "alphas", "last_ids", "log_ws", "tone", "exposure", "exact", "cap",
-                 "cap_used", "key_bits", "key_base", "host_counts", "host_status", "event", "done", "index")
+                 "cap_used", "key_bits", "key_base", "host_counts", "host_status", "event", "done", "index", "N", "status", "over", "i_seen", "reported")
 
 
 class _Step:
@@ -202,6 +221,23 @@ class _Step:
                 f.wait_event(ev)
         return self.g
 
+    def discard_pass(self) -> None:
+        """Forget the gradient buffers of a backward pass that did not reach the gather node; the launches that wrote them are joined
+        to the caller's stream first (their buffers go back to the allocator)."""
+        if self.g is None:
+            return
+        main = torch.cuda.current_stream(self.st.dev)
+        main.wait_stream(self.st.tail)
+        for f in self.st.fronts:
+            main.wait_stream(f)
+        for v in self.pending:
+            v.state = v.render = v.alphas = v.last_ids = v.log_ws = None
+        self.g, self.pending, self.n_tail = None, [], 0
+
+    def end_of_backward(self) -> None:
+        if self.g is not None:                             # the gather node did not run in this pass
+            self.discard_pass()
+
     def launch_tail(self, final: bool) -> None:
         """A7 + S1-S3 backward of the pending views in one call pair on the tail stream; `final`: the last launch of this backward
         pass (all CUs, its projection half on a front stream -- idle by now -- beside whatever the caller runs next, e.g. the
@@ -240,52 +276,55 @@ class _Step:
                 g[name].record_stream(s)
 
 
+def _capacity_error(v: "_View") -> GeoSplatCapacityError:
+    return GeoSplatCapacityError(
+        f"splat(): view {v.index} of a step had {v.i_seen} tile intersections (capacity {v.cap_used}) or left the 24-bit depth-key "
+        f"range: its image and gradients come from a truncated list.  The capacity is now {v.cap.i_cap(v.N)}; repeat the step "
+        "(viewbatch.retry_on_capacity does; GEOSPLAT_CAPACITY=0 reads the exact counts back for every view instead).")
+
+
 def _poll_unchecked(st: _DeviceState, wait_views=None) -> None:
-    """Look at the counts of capacity-mode views that have finished (all of `wait_views`: waited for).  Raises for a truncated one."""
+    """Look at the counts of capacity-mode views that have finished (all of `wait_views`: waited for): the capacity learns from them,
+    a truncated view is MARKED (`over`).  Nothing is raised here: the step that owns the view raises from its gather node."""
     with st.lock:
-        bad = _poll_unchecked_locked(st, wait_views)
-    if bad is not None:
-        v, i_seen = bad
-        raise GeoSplatCapacityError(
-            f"splat(): view {v.index} of a step had {i_seen} tile intersections (capacity {v.cap_used}) or left the 24-bit depth-key "
-            f"range: its image and gradients come from a truncated list.  The capacity is now {v.cap.i_cap}; repeat the step "
-            "(GEOSPLAT_CAPACITY=0 reads the exact counts back for every view instead).")
+        keep = collections.deque()
+        while st.unchecked:
+            v = st.unchecked.popleft()
+            if wait_views is not None and any(v is w for w in wait_views):
+                v.event.synchronize()
+            if not v.event.query():
+                keep.append(v)
+                continue
+            hc = v.host_counts
+            v.i_seen = int(hc[1])
+            cap = v.cap
+            over = v.i_seen > v.cap_used
+            if v.key_bits == 24:
+                rng = F.depth_range(hc)
+                if rng is not None and (rng[0] < v.key_base or rng[1] >= v.key_base + (1 << 24)):
+                    over = True
+                    cap.key32 = True
+            hs = v.host_status
+            if hs is not None:                               # the view's OWN device word (nothing shared, nothing to clear)
+                if int(hs[0]) != 0 or int(hs[3]) != 0:
+                    over = True
+                    cap.key32 = cap.key32 or int(hs[3]) != 0
+                F.release_counts4(hs)
+                v.host_status = None
+            cap.learn(hc, v.N)
+            F.release_counts4(hc)
+            v.host_counts = None
+            v.status = None
+            v.over = over
+        st.unchecked = keep
 
 
-def _poll_unchecked_locked(st: _DeviceState, wait_views=None):
-    bad = None
-    keep = collections.deque()
-    while st.unchecked:
-        v = st.unchecked.popleft()
-        if wait_views is not None and any(v is w for w in wait_views):
-            v.event.synchronize()
-        if not v.event.query():
-            keep.append(v)
-            continue
-        hc = v.host_counts
-        i_seen = int(hc[1])
-        cap = v.cap
-        over = i_seen > v.cap_used
-        if v.key_bits == 24:
-            rng = F.depth_range(hc)
-            if rng is not None and (rng[0] < v.key_base or rng[1] >= v.key_base + (1 << 24)):
-                over = True
-                cap.key32 = True
-        hs = v.host_status
-        if hs is not None:
-            if int(hs[0]) != 0 or int(hs[3]) != 0:
-                over = True
-                cap.key32 = cap.key32 or int(hs[3]) != 0
-                st.status.zero_()                          # (sticky on the device: cleared once it has been reported)
-            F.release_counts4(hs)
-            v.host_status = None
-        cap.learn(hc)
-        F.release_counts4(hc)
-        v.host_counts = None
-        if over and bad is None:
-            bad = (v, i_seen)
-    st.unchecked = keep
-    return bad
+def _warn_unreported(step: "_Step") -> None:
+    """A step that can no longer be joined: truncated views of it that no backward has reported (and none may ever) get a warning."""
+    for v in step.views:
+        if v.over and not v.reported:
+            v.reported = True
+            warnings.warn(str(_capacity_error(v)), RuntimeWarning)
 
 
 def _view_forward(step: _Step, cam: Camera, exposure: Tensor, tone: int, want_grad: bool) -> Tuple[Tensor, _View]:
@@ -298,27 +337,40 @@ def _view_forward(step: _Step, cam: Camera, exposure: Tensor, tone: int, want_gr
     main = torch.cuda.current_stream(dev)
     side = st.fronts[st.n_views % len(st.fronts)]
     st.n_views += 1
-    _poll_unchecked(st)                                    # non-blocking
-    cap = st.caps.setdefault((N, W, H), _Capacity())
-    exact = (not want_grad) or (not _use_capacity()) or cap.i_cap is None
+    _poll_unchecked(st)                                    # non-blocking, never raises
+    with st.lock:
+        cap = st.caps.get((W, H))
+        if cap is None:
+            cap = st.caps[(W, H)] = _Capacity()
+            while len(st.caps) > _MAX_CAPS:
+                st.caps.popitem(last=False)
+        else:
+            st.caps.move_to_end((W, H))
+        if cap.first_step is None and want_grad:
+            cap.first_step = step.key
+    # exact: no gradient, protocol off, nothing learnt yet -- or a view of the very step that is teaching the capacity
+    exact = (not want_grad) or (not _use_capacity()) or cap.ratio is None or cap.first_step == step.key
+    i_cap = None if exact else cap.i_cap(N)
     key_bits, key_base = (32, 0) if exact else cap.keys()
-    if not exact and st.status is None:
-        with torch.cuda.stream(side):
-            st.status = torch.zeros(4, dtype=torch.int64, device=dev)
+    status = None
+    if not exact:
+        with torch.cuda.stream(side):                      # the view's own status word: an overflow is attributed to exactly this view
+            status = torch.zeros(4, dtype=torch.int64, device=dev)
     tight = os.environ.get("GEOSPLAT_TIGHT_TILES", "1") != "0"
     side.wait_event(step.ready)                            # parameters / pyramid / activations -- NOT the previous view's compositor
     cam_t = camera_tensors(st, cam, side)
     v = _View()
-    v.cam, v.W, v.H, v.tone, v.exact, v.cap, v.done, v.index = cam_t, W, H, tone, exact, cap, False, len(step.views)
+    v.cam, v.W, v.H, v.tone, v.exact, v.cap, v.done, v.index = cam_t, W, H, tone, exact, cap, (False if want_grad else None), len(step.views)
+    v.N, v.status, v.over, v.i_seen, v.reported = N, status, False, 0, False
     with torch.cuda.stream(side):
         fr = F.front_stage(t["means"], t["quats"], step.scales_act, step.opac_act, t["normals"], t["kd"], t["ks"], cam_t[0], cam_t[1],
-                           cam_t[2], step.e, W, H, mr, mm, mode, key_base, key_bits, None if exact else st.status,
+                           cam_t[2], step.e, W, H, mr, mm, mode, key_base, key_bits, status,
                            want_packed_index=want_grad, tight_tiles=tight)
         # the record stream of the compositor (gs_raster_prepare_vis: 0.1 ms, HBM gather) is built on the CALLER's stream, whose
         # compositor forward (0.29 ms per view) leaves it idle for more than half of the forward phase, while the front streams
         # (0.47 ms of front + binning per view) are its critical path (measured: the same 13.3 ms either way)
         split = True
-        state, V, I = F.bin_stage(fr, None if exact else cap.i_cap, None if exact else st.status, prepare=not split)
+        state, V, I = F.bin_stage(fr, i_cap, status, prepare=not split)
         v_packed = torch.zeros(max(V, 1), lib.gs_raster_grad_stride(3), dtype=torch.float32, device=dev) if want_grad else None
         log_ws = torch.empty(lib.gs_raster_log_ws_bytes(L.i64(I), W, H, 16), dtype=torch.uint8, device=dev)
         v.host_status = None
@@ -326,14 +378,14 @@ def _view_forward(step: _Step, cam: Camera, exposure: Tensor, tone: int, want_gr
             # the device's own word (word 0: a view truncated at its capacity, or a look-back of the front / emission that gave up;
             # word 3: a depth outside the 24-bit key range) follows the view to the host with its counts
             v.host_status = F.pinned_counts4()
-            v.host_status.copy_(st.status, non_blocking=True)
+            v.host_status.copy_(status, non_blocking=True)
         ev = torch.cuda.Event(); ev.record(side)
     if exact:
-        cap.learn(fr.host_counts)                          # (bin_stage waited for them)
+        cap.learn(fr.host_counts, N)                       # (bin_stage waited for them)
         F.release_counts4(fr.host_counts)
         v.host_counts = None
     else:
-        v.host_counts, v.event, v.cap_used, v.key_bits, v.key_base = fr.host_counts, ev, cap.i_cap, key_bits, key_base
+        v.host_counts, v.event, v.cap_used, v.key_bits, v.key_base = fr.host_counts, ev, i_cap, key_bits, key_base
         with st.lock:
             st.unchecked.append(v)
     for x in list(state.values()) + [log_ws, v_packed, step.scales_act, step.opac_act] + list(cam_t):
@@ -344,8 +396,7 @@ def _view_forward(step: _Step, cam: Camera, exposure: Tensor, tone: int, want_gr
         for x in (fr.vis, fr.counts, fr.packed_index):
             if x is not None:
                 x.record_stream(main)
-        state, V, I = F.bin_stage(fr, None if exact else cap.i_cap, None if exact else st.status,
-                                  binned=(state["flatten_ids"], state["isect_offsets"]))
+        state, V, I = F.bin_stage(fr, i_cap, status, binned=(state["flatten_ids"], state["isect_offsets"]))
     if v_packed is not None:
         state["v_packed"] = v_packed
     f32 = torch.float32
@@ -372,7 +423,22 @@ def _view_backward(step: _Step, v: _View, v_img: Tensor) -> Tensor:
     rws = s["raster_ws"]
     gather = step.has_gather                               # (False: only the exposure needs a gradient -- no tail, no gather node)
     if gather:
+        if step.g is None:
+            # the gradient buffers belong to THIS backward pass: if its gather node never runs (autograd.grad w.r.t. the exposure only,
+            # an exception in a later node) the end-of-pass callback drops what was accumulated, so that the next pass starts clean
+            torch.autograd.Variable._execution_engine.queue_callback(step.end_of_backward)
         step.grads()
+    try:
+        return _view_backward_launch(step, v, v_img, g_exp, gather)
+    except BaseException:
+        step.discard_pass()
+        raise
+
+
+def _view_backward_launch(step: _Step, v: _View, v_img: Tensor, g_exp: Tensor, gather: bool) -> Tensor:
+    lib = L.lib()
+    s = v.state
+    rws = s["raster_ws"]
     L.check(lib.gs_raster_bwd_tone_log_acc(v.W, v.H, 16, v.V, None, L.i64(v.I), L.ptr(s["counts"]), L.ptr(s["isect_offsets"]),
                                            L.ptr(v.render), L.ptr(v.alphas), L.ptr(v.last_ids), v.tone, L.ptr(v.exposure), L.ptr(v_img),
                                            L.ptr(s["v_packed"]), L.ptr(g_exp), L.ptr(rws), C.c_size_t(rws.numel()), L.ptr(v.log_ws),
@@ -427,6 +493,11 @@ class _Gather(torch.autograd.Function):
         # the fronts of this step finished long ago: looking at their counts now costs no GPU idle time, and a truncated view
         # stops the step HERE, before an optimizer can consume it
         _poll_unchecked(st, wait_views=[v for v in done if v.host_counts is not None])
+        bad = [v for v in done if v.over and not v.reported]
+        if bad:
+            for v in bad:
+                v.reported = True
+            raise _capacity_error(bad[0])
         out = [g["means"], g_scales, g["quats"], g_opac, g["normals"], g["kd"], g["ks"], g["base"]] + list(g["levels"])
         return (None, *[x.reshape(s) for x, s in zip(out, ctx.shapes)])
 
@@ -460,7 +531,7 @@ def splat_view(means: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor, 
     st = _state(means.device)
     srcs = list(raw.values()) + [envmap.base] + list(envmap.levels)
     cfg = (float(min_roughness), float(max_metallic), int(mode))
-    key = (tuple((id(x), x._version) for x in srcs), cfg, id(lut), float(envmap.min_roughness), float(envmap.max_roughness),
+    key = (tuple((id(x), x._version, x.data_ptr()) for x in srcs), cfg, id(lut), float(envmap.min_roughness), float(envmap.max_roughness),
            torch.is_grad_enabled() and any(x.requires_grad for x in srcs))
     exposure = torch.as_tensor(exposure, dtype=torch.float32, device=st.dev)
     params_grad = key[-1]
@@ -472,6 +543,7 @@ def splat_view(means: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor, 
         det = dict(zip(_PARAMS, (x.detach() for x in conv[:7])))
         env_d = TextureSplitSum(conv[7].detach(), [x.detach() for x in conv[8:]], envmap.min_roughness, envmap.max_roughness)
         if step is not None:
+            _warn_unreported(step)
             # the step that can no longer be joined lets go of its gather outputs: step -> outputs -> grad_fn -> ctx -> step is a cycle
             # through C++ ownership that Python's collector cannot see (56 MB per step -- activations + pyramid -- leaked without this;
             # scripts/soak_callshape.py).  Its view nodes keep their own edges to the gather node.
@@ -489,9 +561,25 @@ def splat_view(means: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor, 
 
 
 def reset() -> None:
-    """Forget the joinable step and the learnt capacities (tests)."""
+    """Forget the joinable step and the learnt capacities (tests; after a checkpoint load through `.data`)."""
     for st in _states.values():
-        if st.current is not None:
-            st.current.gathered = None
-        st.current = None
-        st.caps.clear()
+        with st.lock:
+            if st.current is not None:
+                st.current.gathered = None
+            st.current = None
+            st.caps.clear()
+
+
+def retry_on_capacity(step_fn, max_retries: int = 2):
+    """Wrap a training-step function `step_fn(*a, **k)` (forward: the loop of `splat()` calls; `loss.backward()`; NO optimizer step
+    inside, or only behind the backward) so that a GeoSplatCapacityError -- a view had more tile intersections than the capacity the
+    earlier steps taught -- repeats the step: the capacity has been raised when the error is raised, gradients accumulated by the
+    failed attempt must be dropped by the caller's usual `zero_grad` inside `step_fn`."""
+    def wrapped(*a, **k):
+        for attempt in range(max_retries + 1):
+            try:
+                return step_fn(*a, **k)
+            except GeoSplatCapacityError:
+                if attempt == max_retries:
+                    raise
+    return wrapped

@@ -86,8 +86,8 @@ def test_fused_splat_equals_op_by_op(cuda, monkeypatch, mode, tone):
             assert torch.equal(a, b)
         print(f"\n pass {it} ({mode}, {tone})")
         _compare(gr, ref_g)
-    cap = gs.viewbatch._state(cuda).caps[(sc.splats.num, 160, 160)]
-    assert cap.i_cap is not None and cap.max_i > 0
+    cap = gs.viewbatch._state(cuda).caps[(160, 160)]
+    assert cap.i_cap(sc.splats.num) is not None and cap.max_i > 0
 
 
 def test_autograd_contract_of_the_gather_node(cuda):
@@ -148,11 +148,11 @@ def test_capacity_overflow_raises_in_backward_and_the_retry_is_right(cuda, monke
     monkeypatch.setenv("GEOSPLAT_SPLAT", "fused")
     gs.viewbatch.reset()
     _run(sc, far, ups, cuda)                                          # learns a capacity from the far views
-    cap = gs.viewbatch._state(cuda).caps[(sc.splats.num, 128, 128)]
-    small = cap.i_cap
+    cap = gs.viewbatch._state(cuda).caps[(128, 128)]
+    small = cap.i_cap(sc.splats.num)
     with pytest.raises(gs.viewbatch.GeoSplatCapacityError):
-        _run(sc, near, ups, cuda)                                     # far more intersections than 1.25 x what the far views had
-    assert cap.i_cap > small
+        _run(sc, near, ups, cuda)                                     # far more intersections than 1.5 x what the far views had
+    assert cap.i_cap(sc.splats.num) > small
     _, got = _run(sc, near, ups, cuda)                                # the retry runs with the raised capacity (32-bit keys if the range moved)
     print()
     _compare(got, want)
@@ -215,3 +215,121 @@ def test_fused_splat_on_large_overlapping_splats(cuda, monkeypatch):
             assert torch.equal(a, b)
         print(f"\n pass {it}")
         _compare(gr, ref_g, tol=5e-5)
+
+
+def test_first_step_is_exact_and_capacity_follows_n(cuda):
+    """every view of the first step at an image size runs exact (no view of it can overflow a capacity learnt from one
+    view), later steps run on the ratio learnt -- also with a DIFFERENT number of Gaussians (a stage-1 loop), and the table of
+    capacities is bounded."""
+    import geosplatting_amd as gs
+    vb = gs.viewbatch
+    sc, _ = sphere_case(4, 128, cubemap_res=64)
+    cams = _cams(128, 3)
+    g = torch.Generator().manual_seed(3)
+    ups = [(torch.rand(128, 128, 4, generator=g) * 2 - 1).to(cuda) for _ in cams]
+    vb.reset()
+    seen = []
+    orig = vb._view_forward
+
+    def spy(step, cam, exposure, tone, want_grad):
+        img, v = orig(step, cam, exposure, tone, want_grad)
+        seen.append(v.exact)
+        return img, v
+    vb._view_forward = spy
+    try:
+        _run(sc, cams, ups, cuda)
+        assert seen == [True, True, True]                            # the whole first step
+        del seen[:]
+        _run(sc, cams, ups, cuda)
+        assert seen == [False, False, False]
+        sc5, _ = sphere_case(5, 128, cubemap_res=64)                  # four times the Gaussians, same image size: capacity scales with N
+        del seen[:]
+        _run(sc5, cams, ups, cuda)
+        assert seen == [False, False, False]
+    finally:
+        vb._view_forward = orig
+    st = vb._state(cuda)
+    assert list(st.caps.keys()) == [(128, 128)]
+    r = st.caps[(128, 128)]
+    assert r.i_cap(sc5.splats.num) > 3 * r.i_cap(sc.splats.num) // 1
+    for k in range(vb._MAX_CAPS + 8):                                  # bounded: the least recently used sizes go when a new one arrives
+        st.caps[(10000 + k, 1)] = vb._Capacity()
+    st.caps.move_to_end((128, 128))
+    _run(sc, _cams(96, 1), [torch.rand(96, 96, 4, device=cuda)], cuda)
+    assert len(st.caps) == vb._MAX_CAPS and (128, 128) in st.caps and (96, 96) in st.caps
+    vb.reset()
+
+
+def test_backward_that_skips_the_gather_node_leaves_no_stale_sums(cuda):
+    """a backward pass that runs view nodes but not the gather node (autograd.grad w.r.t. the exposure only) must not leave
+    its partial sums behind for the next pass over the same step."""
+    import geosplatting_amd as gs
+    sc, _ = sphere_case(3, 96, cubemap_res=64)
+    cams = _cams(96, 2)
+    g, lv = _leaves(sc, cuda)
+    attrs = gs.RenderableAttrs(kd=lv["kd"], ks=lv["ks"], normals=lv["normals"])
+    gen = torch.Generator().manual_seed(5)
+    ups = [(torch.rand(96, 96, 4, generator=gen) * 2 - 1).to(cuda) for _ in cams]
+    gs.viewbatch.reset()
+    env = gs.as_splitsum(lv["cubemap"])
+    imgs = [attrs.splat(g, [c], exposure=lv["exposure"], envmap=env, min_roughness=0.1, max_metallic=1.0) for c in cams]
+    # pass 1: view 0 only, w.r.t. the exposure only: the gather node is not part of this pass
+    ge, = torch.autograd.grad((imgs[0] * ups[0]).sum(), [lv["exposure"]], retain_graph=False)
+    step = gs.viewbatch._state(cuda).current
+    assert step.g is None and step.pending == []
+    # pass 2: view 1 into every parameter == a fresh one-view step on view 1
+    (imgs[1] * ups[1]).sum().backward()
+    got = {k: (v.grad.clone() if v.grad is not None else None) for k, v in lv.items()}
+    _, want = _run(sc, [cams[1]], [ups[1]], cuda)
+    print()
+    _compare(got, want)
+
+
+def test_backward_on_a_worker_thread_while_the_next_step_is_issued(cuda):
+    """what a prefetching trainer does -- `backward()` of step k on a worker thread while the main thread already
+    issues the `splat()` calls of step k + 1 on the same device.  Gradients equal the serial run; an overflow of step k is raised from
+    ITS backward (on the worker), never from step k + 1's forward."""
+    import threading
+    import geosplatting_amd as gs
+    vb = gs.viewbatch
+    sc, _ = sphere_case(4, 128, cubemap_res=64)
+    cams = _cams(128, 4)
+    gen = torch.Generator().manual_seed(12)
+    ups = [(torch.rand(128, 128, 4, generator=gen) * 2 - 1).to(cuda) for _ in cams]
+    vb.reset()
+    _, want = _run(sc, cams, ups, cuda)                                # serial reference (also teaches the capacity: exact step)
+    _, want2 = _run(sc, cams, ups, cuda)                               # capacity step, serial
+    _compare(want2, want)
+
+    def forward(lv, g):
+        attrs = gs.RenderableAttrs(kd=lv["kd"], ks=lv["ks"], normals=lv["normals"])
+        env = gs.as_splitsum(lv["cubemap"])
+        imgs = [attrs.splat(g, [c], exposure=lv["exposure"], envmap=env, min_roughness=0.1, max_metallic=1.0) for c in cams]
+        return sum((i * u).sum() for i, u in zip(imgs, ups))
+
+    errors = []
+    for rep in range(3):
+        gA, lvA = _leaves(sc, cuda)
+        gB, lvB = _leaves(sc, cuda)
+        lossA = forward(lvA, gA)
+        ev = torch.cuda.Event(); ev.record()
+
+        def work():
+            try:
+                with torch.cuda.device(cuda):
+                    torch.cuda.current_stream().wait_event(ev)
+                    lossA.backward()
+                    torch.cuda.current_stream().synchronize()
+            except BaseException as e:                                 # noqa: BLE001
+                errors.append(e)
+        th = threading.Thread(target=work)
+        th.start()
+        lossB = forward(lvB, gB)                                       # step k + 1's forward while step k's backward runs
+        th.join()
+        lossB.backward()
+        torch.cuda.synchronize()
+        assert not errors, errors
+        print(f"\n rep {rep}: threaded step A / following step B vs serial")
+        _compare({k: v.grad for k, v in lvA.items()}, want)
+        _compare({k: v.grad for k, v in lvB.items()}, want)
+    vb.reset()

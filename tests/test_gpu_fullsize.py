@@ -377,8 +377,8 @@ def test_step_fullsize_vs_oracle(cuda, level, path):
             imgs = [attrs.splat(gsn, [c], exposure=et, envmap=env, min_roughness=0.1, max_metallic=1.0) for c in cams]
             sum((i * u).sum() for i, u in zip(imgs, ups_d)).backward()
             torch.cuda.synchronize()
-        cap = gs.viewbatch._state(cuda).caps[(sp.num, 800, 800)]
-        assert cap.i_cap is not None and cap.keys()[0] == 24
+        cap = gs.viewbatch._state(cuda).caps[(800, 800)]
+        assert cap.i_cap(sp.num) is not None and cap.keys()[0] == 24
         images = [i.detach() for i in imgs]
         got = {"means": gsn.means.grad, "scales": gsn.scales.grad, "quats": gsn.quats.grad, "opacities": gsn.opacities.grad,
                "kd": attrs.kd.grad, "ks": attrs.ks.grad, "normals": attrs.normals.grad, "exposure": et.grad}

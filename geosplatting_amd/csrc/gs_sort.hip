@@ -797,6 +797,13 @@ static int isect_bin_impl(int V, const float* means2d, const int32_t* radii, con
 //     tile pass writes 4 bytes per intersection (flatten id) instead of 8.  (More than 8 192 tiles: the tile ids are kept and the
 //     offsets come from them.)
 // 18 launches (setup, 3 x 3 depth passes, emission, offset scan, 2 x 3 tile passes) against 25.
+// Round 6, built, bit-identical, measured and removed (`git show 3d98652:geosplatting_amd/csrc/gs_sort.hip`): every pass as ONE kernel
+// -- ticketed blocks publish {flag | count} rows, offsets from a two-level look-back over <= 31 block rows + the group totals, items held
+// in registers meanwhile, global digit histograms from one read of the keys / from the tile counters, the tile rectangle carried through
+// the depth passes as 12-byte items so that the emission reads in order (48 instead of 84 us) -- 9 launches instead of 18.  A fused pass
+// took 36 us (depth) / 53 us (tiles) alone against 8 + 6 + 16 / 8 + 6 + 18 for the three kernels it replaces: with every block resident
+// and publishing at the same moment the look-back is ~10 dependent global round trips, where a kernel boundary costs 1.5 us; 281 against
+// 252 us per view alone, 640 against 649 views/s inside the step (608 with 32 loads in flight and 21 KB blocks).
 struct KeyIn {                                                     // (depth key, packed index) straight from the key array
     const unsigned* keys;
     __device__ __forceinline__ uint2 load(int64_t i) const { return make_uint2(keys[i], (unsigned)i); }
@@ -966,19 +973,11 @@ bin_offsets_tiles_kernel(GsCount nc, const int32_t* __restrict__ tiles, int n_ti
 
 static size_t bf_state_bytes(int V) { return align256(16 + 2 * (size_t)((V + EM_TILE - 1) / EM_TILE + 1) * sizeof(u64)); }
 
-static size_t bin2_ws_bytes(int V, int64_t n_isects);
-static bool bin2_eligible(int tile_w, int tile_h, const uint32_t* tile_counts);
-static int isect_bin_front2(int V, const uint32_t* depth_keys, const uint32_t* tile_rects, const uint32_t* tile_counts, const int64_t* counts_dev,
-                            int64_t n_isects, int key_bits, int tile_w, int tile_h, int32_t* flatten_ids_sorted, int32_t* isect_offsets, void* ws,
-                            int64_t* status_dev, hipStream_t s);
-
 extern "C" size_t gs_isect_bin_front_ws_bytes(int V, int64_t n_isects, int tile_w, int tile_h)
 {
     const size_t v = V > 0 ? (size_t)V : 1, n = n_isects > 0 ? (size_t)n_isects : 1;
     const size_t tb = table_bytes((int64_t)(v > n ? v : n));
-    const size_t old_path = tb + 2 * align256(v * 8) + 2 * align256(n * 8) + bf_state_bytes((int)v) + align256(n * 4) + 256;   // (tile ids: only without tile_counts)
-    const size_t fused = bin2_ws_bytes(V, n_isects);
-    return old_path > fused ? old_path : fused;
+    return tb + 2 * align256(v * 8) + 2 * align256(n * 8) + bf_state_bytes((int)v) + align256(n * 4) + 256;   // (tile ids: only without tile_counts)
 }
 
 extern "C" int gs_isect_bin_front(int V_cap, const uint32_t* depth_keys, const uint32_t* tile_rects, const uint32_t* tile_counts,
@@ -996,9 +995,6 @@ extern "C" int gs_isect_bin_front(int V_cap, const uint32_t* depth_keys, const u
     if (V == 0 || n_isects == 0) { GS_CHECK_HIP(gs_zero_async(isect_offsets, sizeof(int32_t) * (size_t)n_tiles, s)); return GS_OK; }
     GS_CHECK_ARG(depth_keys != nullptr && tile_rects != nullptr && flatten_ids_sorted != nullptr && ws != nullptr, "null argument");
     if (ws_bytes < gs_isect_bin_front_ws_bytes(V, n_isects, tile_w, tile_h)) { gs_set_error("gs_isect_bin_front: workspace too small"); return GS_ENOSPC; }
-    if (bin2_eligible(tile_w, tile_h, tile_counts))                          // round 6: fused passes (9 launches), same result
-        return isect_bin_front2(V, depth_keys, tile_rects, tile_counts, counts_dev, n_isects, key_bits, tile_w, tile_h, flatten_ids_sorted,
-                                isect_offsets, ws, status_dev, s);
     const GsCount vc{ (long long)V, (const long long*)counts_dev }, ic{ (long long)n_isects, counts_dev ? (const long long*)counts_dev + 1 : nullptr };
     const bool hist = tile_counts != nullptr && n_tiles <= BF_HIST_MAX;     // otherwise the offsets come from the sorted tile ids
     char* p = (char*)ws;
@@ -1059,475 +1055,6 @@ extern "C" int gs_isect_bin_front(int V_cap, const uint32_t* depth_keys, const u
     if (!hist) {
         hipLaunchKernelGGL(bin_offsets_tiles_kernel, dim3(gs_cdiv(n_isects, 256)), dim3(256), 0, s, ic, tile_ids, n_tiles, isect_offsets);
         GS_CHECK_LAUNCH();
-    }
-    return GS_OK;
-}
-
-// =====================================================================================================================================
-// Round 6: gs_isect_bin_front on FUSED passes.  Same result as the 18-launch sequence above -- `flatten_ids` in (tile, depth key, packed
-// index) order and the clamped tile offsets, bit for bit -- in 9 launches that read every item ONCE per pass:
-//   * one radix pass = ONE kernel (radix_fused_kernel): a block takes a ticket, loads and ranks its 2 048 items (ballots, as
-//     radix_scatter_kernel), publishes its per-digit counts as {flag | count} words, and finds its offsets by a TWO-LEVEL look-back with
-//     a bounded number of independent loads: the blocks of its group of 32 before it (<= 31 rows) + the totals of the groups before
-//     its own (published by each group's last block from the very sums it needs itself).  No chain from block to block: the latency is
-//     four global round trips whatever the block count (the one-level chained look-back -- all ~1 000 blocks resident, all publishing
-//     together -- walked back hundreds of rows, round 3: 265 vs 238 us).  The items stay in registers meanwhile: the histogram and
-//     row-scan kernels of a pass and their second read of the items are gone.  Blocks only ever wait for LOWER tickets.
-//   * the global digit histograms a block adds to its look-back result are known BEFORE the passes: the depth digits of all passes
-//     from one read of the key array, the tile digits from the front kernel's per-tile counters (bin2_prep_kernel, which also scans
-//     those counters into the tile offsets);
-//   * the depth passes carry the Gaussian's tile rectangle packed into 32 bits (12-byte items): the emission reads them in order
-//     instead of gathering 8 bytes per Gaussian from a 16 MB array in depth order (265 MB of fabric reads per view for 16 MB of
-//     payload, profiles/r05_pmc_traffic.json emit_chained_kernel).  Needs <= 255 tiles per image axis (<= 4 080 px); larger images
-//     take the sequence above.
-#define RF_GROUP 32
-#define RF_FLAG 0x80000000u
-#define RF_SPIN_LIMIT (1 << 22)
-#ifndef RF_ITEMS_D
-#define RF_ITEMS_D 5                       // 12-byte depth items: 1 280 per block = 15 KB of staging, 21 KB of LDS per block (fits beside the
-#endif                                     // compositor forward's 4 x 33.8 KB on a CU; 8 per thread = 30 KB did not: 640 against 710 views/s)
-#ifndef RF_ITEMS_T
-#define RF_ITEMS_T 8                       // 8-byte tile items: 2 048 per block = 16 KB + counters
-#endif
-
-struct D3 { unsigned key, idx, rect; };                             // depth key, packed index, x0 | y0 << 8 | x1 << 16 | y1 << 24
-struct D3In {
-    const D3* p;
-    __device__ __forceinline__ D3 load(int64_t i) const { return p[i]; }
-};
-struct KeyRectIn {                                                  // first depth pass: straight from the front kernel's arrays
-    const unsigned* keys; const uint2* rects;
-    __device__ __forceinline__ D3 load(int64_t i) const
-    {
-        const uint2 q = rects[i];
-        return D3{ keys[i], (unsigned)i, (q.x & 0xffu) | ((q.x >> 16) << 8) | ((q.y & 0xffu) << 16) | ((q.y >> 16) << 24) };
-    }
-};
-struct D3Out {
-    D3* p;
-    __device__ __forceinline__ void store(int64_t i, const D3& it) const { p[i] = it; }
-};
-struct D3Digit {
-    int shift; unsigned mask;
-    __device__ __forceinline__ unsigned operator()(const D3& it) const { return (it.key >> shift) & mask; }
-};
-
-struct RfState {
-    unsigned* ticket;            // arrival counter of the pass
-    unsigned* blk;               // [blocks][NB]  RF_FLAG | items of digit d in block b
-    unsigned* grp;               // [groups][NB]  RF_FLAG | items of digit d in group g (published by the group's last block)
-    const unsigned* ghist;       // [NB] items of digit d in the whole input
-    long long* status;           // capacity-protocol word (look-back time-out -> reported as a truncated view) or NULL
-};
-
-__device__ __forceinline__ unsigned rf_ld(unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void rf_st(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned rf_wait(unsigned* p, unsigned v, long long* status)
-{
-    int spins = 0;
-    while (!(v & RF_FLAG)) {
-        if (++spins > RF_SPIN_LIMIT) { if (status) status[0] = GS_ENOSPC; return 0u; }
-        __builtin_amdgcn_s_sleep(1);
-        v = rf_ld(p);
-    }
-    return v & ~RF_FLAG;
-}
-// sum of rows [0, count) of a {flag | value} table for digit d: B independent loads in flight, then the waits (B = 32 while more than
-// 16 rows remain, else 16; the trip structure is uniform over the block)
-template <int NB, int B>
-__device__ __forceinline__ unsigned rf_sum_batch(unsigned* table, unsigned first_row, unsigned q0, unsigned count, int d, long long* status)
-{
-    unsigned v[B];
-#pragma unroll
-    for (int u = 0; u < B; ++u) {
-        const unsigned q = q0 + u < count ? q0 + u : count - 1;                 // (clamped: no branch around a load)
-        v[u] = rf_ld(table + (size_t)(first_row + q) * NB + d);
-    }
-    unsigned acc = 0u;
-#pragma unroll
-    for (int u = 0; u < B; ++u) {
-        unsigned val = v[u];
-        if (!(val & RF_FLAG)) {
-            const unsigned q = q0 + u < count ? q0 + u : count - 1;
-            val = rf_wait(table + (size_t)(first_row + q) * NB + d, val, status) | RF_FLAG;
-        }
-        acc += (q0 + u < count) ? (val & ~RF_FLAG) : 0u;
-    }
-    return acc;
-}
-template <int NB>
-__device__ __forceinline__ unsigned rf_sum_rows(unsigned* table, unsigned first_row, unsigned count, int d, long long* status)
-{
-    unsigned acc = 0u, q0 = 0u;
-    while (q0 < count) {
-        if (count - q0 > 16u) { acc += rf_sum_batch<NB, 32>(table, first_row, q0, count, d, status); q0 += 32u; }
-        else { acc += rf_sum_batch<NB, 16>(table, first_row, q0, count, d, status); q0 += 16u; }
-    }
-    return acc;
-}
-
-template <typename Item, typename In, typename Digit, typename Out, int NBITS, int RF_ITEMS>
-__global__ void __launch_bounds__(RS_THREADS)
-radix_fused_kernel(GsCount nc, In in, Digit digit, Out out, RfState st, long long out_cap)
-{
-    const int64_t n = gs_count(nc);
-    constexpr int NB = 1 << NBITS;
-    constexpr int RF_TILE = RS_THREADS * RF_ITEMS;
-    __shared__ unsigned cnt[RS_WAVES][NB];
-    __shared__ unsigned dstart[NB];
-    __shared__ unsigned gbase[NB];
-    __shared__ unsigned wtot[RS_WAVES];
-    __shared__ unsigned s_block;
-    __shared__ Item stage[RF_TILE];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_block = atomicAdd(st.ticket, 1u);
-    for (int i = threadIdx.x; i < RS_WAVES * NB; i += RS_THREADS) (&cnt[0][0])[i] = 0u;
-    __syncthreads();
-    const unsigned block = s_block;
-    const int64_t bbase = (int64_t)block * RF_TILE;
-    const int64_t wbase = bbase + (int64_t)wave * (64 * RF_ITEMS);
-    const int n_here = (n - bbase) < RF_TILE ? (int)((n - bbase) > 0 ? (n - bbase) : 0) : RF_TILE;
-    const u64 lane_lt = (1ull << lane) - 1ull;
-    Item item[RF_ITEMS];
-    unsigned dig[RF_ITEMS];
-    unsigned rank[RF_ITEMS];
-#pragma unroll
-    for (int k = 0; k < RF_ITEMS; ++k) {
-        const int64_t i = wbase + (int64_t)k * 64 + lane;
-        const bool valid = i < n;
-        if (valid) item[k] = in.load(i);
-        const unsigned d = valid ? digit(item[k]) : 0u;
-        u64 m = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < NBITS; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const u64 bal = __ballot(bit);
-            m &= bit ? bal : ~bal;
-        }
-        const unsigned old = cnt[wave][d];                       // running count of this wave for digit d (same for the group)
-        __builtin_amdgcn_wave_barrier();
-        const unsigned r = __popcll(m & lane_lt);
-        if (valid && r == 0u) cnt[wave][d] = old + (unsigned)__popcll(m);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        dig[k] = d;
-        rank[k] = old + r;
-    }
-    __syncthreads();
-    {
-        const int d = threadIdx.x;
-        unsigned tot = 0u;
-        if (d < NB) for (int w = 0; w < RS_WAVES; ++w) tot += cnt[w][d];
-        // ---- publish, then the two-level look-back (thread d: digit d)
-        unsigned prefix = 0u;
-        if (d < NB) {
-            const unsigned g = block / RF_GROUP, j = block % RF_GROUP;
-            rf_st(st.blk + (size_t)block * NB + d, RF_FLAG | tot);
-            const unsigned in_group = rf_sum_rows<NB>(st.blk, g * RF_GROUP, j, d, st.status);
-            if (j == RF_GROUP - 1) rf_st(st.grp + (size_t)g * NB + d, RF_FLAG | (in_group + tot));
-            // (a block past the end of the input -- capacity protocol -- has published zeros; nobody reads its offsets)
-            if (n_here > 0) prefix = in_group + rf_sum_rows<NB>(st.grp, 0u, g, d, st.status);
-        }
-        // ---- block-local digit starts and the global digit starts (exclusive scans over the digits)
-        unsigned incl = tot;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
-        if (lane == 63) wtot[wave] = incl;
-        __syncthreads();
-        unsigned before = 0u;
-        for (int w = 0; w < wave; ++w) before += wtot[w];
-        if (d < NB) dstart[d] = before + incl - tot;
-        __syncthreads();
-        const unsigned gh = d < NB ? st.ghist[d] : 0u;
-        unsigned gincl = gh;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned t = __shfl_up(gincl, off, 64);
-            if (lane >= off) gincl += t;
-        }
-        if (lane == 63) wtot[wave] = gincl;
-        __syncthreads();
-        unsigned gbefore = 0u;
-        for (int w = 0; w < wave; ++w) gbefore += wtot[w];
-        if (d < NB) gbase[d] = gbefore + gincl - gh + prefix;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < RF_ITEMS; ++k) {
-        const int64_t i = wbase + (int64_t)k * 64 + lane;
-        if (i < n) {
-            const unsigned d = dig[k];
-            unsigned off = dstart[d] + rank[k];
-            for (int w = 0; w < wave; ++w) off += cnt[w][d];
-            stage[off] = item[k];
-        }
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int k = 0; k < RF_ITEMS; ++k) {
-        const int p = k * RS_THREADS + (int)threadIdx.x;
-        if (p < n_here) {
-            const Item it = stage[p];
-            const unsigned d = digit(it);
-            const long long pos = (long long)gbase[d] + (long long)(p - (int)dstart[d]);
-            if (pos < out_cap) out.store(pos, it);             // (only an overflowing view -- counters above the capacity -- is ever cut here)
-        }
-    }
-}
-
-template <typename Item, typename In, typename Digit, typename Out>
-static int fused_pass8(GsCount nc, In in, Digit digit, Out out, const RfState& st, long long out_cap, hipStream_t s)
-{
-    const int nblocks = (int)((nc.n + RS_THREADS * RF_ITEMS_D - 1) / (RS_THREADS * RF_ITEMS_D));
-    hipLaunchKernelGGL((radix_fused_kernel<Item, In, Digit, Out, 8, RF_ITEMS_D>), dim3(nblocks), dim3(RS_THREADS), 0, s, nc, in, digit, out, st, out_cap);
-    GS_CHECK_LAUNCH();
-    return GS_OK;
-}
-
-template <typename Item, typename In, typename Digit, typename Out>
-static int fused_pass(GsCount nc, In in, Digit digit, Out out, int nbits, const RfState& st, long long out_cap, hipStream_t s)
-{
-    const int nblocks = (int)((nc.n + RS_THREADS * RF_ITEMS_T - 1) / (RS_THREADS * RF_ITEMS_T));
-    switch (nbits) {
-#define RF_CASE(B) case B: hipLaunchKernelGGL((radix_fused_kernel<Item, In, Digit, Out, B, RF_ITEMS_T>), dim3(nblocks), dim3(RS_THREADS), 0, s, nc, in, digit, out, st, out_cap); break;
-        RF_CASE(1) RF_CASE(2) RF_CASE(3) RF_CASE(4) RF_CASE(5) RF_CASE(6) RF_CASE(7) RF_CASE(8)
-#undef RF_CASE
-        default: gs_set_error("fused_pass: bad digit width %d", nbits); return GS_EINVAL;
-    }
-    GS_CHECK_LAUNCH();
-    return GS_OK;
-}
-
-// Before the passes (one launch): block 0 turns the front kernel's per-tile counters into the tile offsets (clamped scan, as
-// tile_offsets_scan_kernel) and into the global histograms of the two tile digits; the other blocks count the depth digits of every
-// pass from one read of the key array (LDS histograms, one atomic per non-empty bin and block).
-__global__ void __launch_bounds__(1024)
-bin2_prep_kernel(GsCount vc, const unsigned* __restrict__ keys, int n_depth, unsigned* __restrict__ dhist /*[n_depth][256], zeroed*/,
-                 int n_tiles, const unsigned* __restrict__ tile_counts, GsCount ic, int32_t* __restrict__ offsets, int width, int n_tpass,
-                 unsigned* __restrict__ thist /*[n_tpass][256]*/)
-{
-    __shared__ unsigned h[4][256];
-    for (int i = threadIdx.x; i < 1024; i += 1024) (&h[0][0])[i] = 0u;
-    __syncthreads();
-    if (blockIdx.x == 0) {
-        __shared__ unsigned wsum[16];
-        const unsigned n = (unsigned)gs_count(ic);
-        const unsigned dmask = (1u << width) - 1u;
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        unsigned carry = 0u;
-        for (int i0 = 0; i0 < n_tiles; i0 += 1024) {
-            const int i = i0 + threadIdx.x;
-            const unsigned v = i < n_tiles ? tile_counts[i] : 0u;
-            if (v) {
-                atomicAdd(&h[0][(unsigned)i & dmask], v);
-                if (n_tpass > 1) atomicAdd(&h[1][((unsigned)i >> width) & dmask], v);
-            }
-            unsigned incl = v;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned t = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += t;
-            }
-            if (lane == 63) wsum[wave] = incl;
-            __syncthreads();
-            unsigned before = 0u, all = 0u;
-            for (int w = 0; w < 16; ++w) { if (w < wave) before += wsum[w]; all += wsum[w]; }
-            if (i < n_tiles) { const unsigned o = carry + before + incl - v; offsets[i] = (int32_t)(o < n ? o : n); }
-            carry += all;
-            __syncthreads();
-        }
-        for (int i = threadIdx.x; i < 256 * n_tpass; i += 1024) thist[i] = (&h[0][0])[i];
-        return;
-    }
-    const int V = (int)gs_count(vc);
-    for (int v = (blockIdx.x - 1) * 1024 + threadIdx.x; v < V; v += (gridDim.x - 1) * 1024) {
-        const unsigned k = keys[v];
-        atomicAdd(&h[0][k & 255u], 1u); atomicAdd(&h[1][(k >> 8) & 255u], 1u); atomicAdd(&h[2][(k >> 16) & 255u], 1u);
-        if (n_depth > 3) atomicAdd(&h[3][k >> 24], 1u);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 256 * n_depth; i += 1024) { const unsigned c = (&h[0][0])[i]; if (c) atomicAdd(dhist + i, c); }
-}
-
-// emission from the depth-sorted 12-byte items (the rectangle travels with the Gaussian): otherwise emit_chained_kernel
-__global__ void __launch_bounds__(EM_THREADS)
-emit_seq_kernel(GsCount vc, const D3* __restrict__ order, unsigned* __restrict__ ctrl, u64* __restrict__ desc, int n_blocks, int tile_w,
-                uint2* __restrict__ items, unsigned item_cap, long long* __restrict__ status /* nullable: capacity protocol word */)
-{
-    const int V = (int)gs_count(vc);
-    __shared__ unsigned ws[EM_THREADS / 64];
-    __shared__ unsigned s_block;
-    __shared__ unsigned long long s_base;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_block = atomicAdd(ctrl, 1u);
-    __syncthreads();
-    const int block = (int)s_block;
-    u64* agg = desc; u64* pre = desc + n_blocks;
-    const int r0 = block * EM_TILE + (int)threadIdx.x * EM_PER;
-    unsigned v[EM_PER], c[EM_PER], q[EM_PER];
-    unsigned mine = 0u;
-#pragma unroll
-    for (int k = 0; k < EM_PER; ++k) {
-        const int r = r0 + k;
-        const D3 it = order[r < V ? r : (V > 0 ? V - 1 : 0)];
-        v[k] = it.idx; q[k] = it.rect;
-        const int w = (int)((q[k] >> 16) & 0xffu) - (int)(q[k] & 0xffu), h = (int)(q[k] >> 24) - (int)((q[k] >> 8) & 0xffu);
-        c[k] = (r < V && w > 0 && h > 0) ? (unsigned)(w * h) : 0u;
-        mine += c[k];
-    }
-    unsigned incl = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
-    if (lane == 63) ws[wave] = incl;
-    __syncthreads();
-    unsigned before = 0u, total = 0u;
-    for (int w = 0; w < EM_THREADS / 64; ++w) { if (w < wave) before += ws[w]; total += ws[w]; }
-    if (wave == 0) {
-        unsigned long long base = 0ull;
-        if (block > 0) {
-            if (lane == 0) __hip_atomic_store(&agg[block], (u64)total | BF_VALID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int pos = block - 1;
-            for (;;) {
-                const int idx = pos - lane;
-                bool isP = idx < 0;
-                u64 val = 0ull;
-                if (idx >= 0) {
-                    int spins = 0;
-                    for (;;) {
-                        const u64 pv = __hip_atomic_load(&pre[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (pv & BF_VALID) { isP = true; val = pv; break; }
-                        const u64 av = __hip_atomic_load(&agg[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (av & BF_VALID) { val = av; break; }
-                        if (++spins > BF_SPIN_LIMIT) { atomicExch(ctrl + 1, 1u); if (status) status[0] = GS_ENOSPC; break; }
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-                }
-                const u64 pmask = __ballot(isP);
-                const int first = pmask ? __builtin_ctzll(pmask) : 64;
-                unsigned long long cv = lane <= first ? (val & ~BF_VALID) : 0ull;
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) cv += (unsigned long long)__shfl_xor((long long)cv, off, 64);
-                base += cv;
-                if (pmask) break;
-                pos -= 64;
-            }
-        }
-        if (lane == 0) {
-            __hip_atomic_store(&pre[block], (u64)(base + total) | BF_VALID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_base = base;
-        }
-    }
-    __syncthreads();
-    unsigned long long cur = s_base + before + incl - mine;
-#pragma unroll
-    for (int k = 0; k < EM_PER; ++k) {
-        if (c[k] == 0u) continue;
-        const int x0 = (int)(q[k] & 0xffu), y0 = (int)((q[k] >> 8) & 0xffu), x1 = (int)((q[k] >> 16) & 0xffu), y1 = (int)(q[k] >> 24);
-        for (int i = y0; i < y1; ++i)
-            for (int j = x0; j < x1; ++j) {
-                const unsigned t = (unsigned)(i * tile_w + j);
-                if (cur < (unsigned long long)item_cap) items[cur] = make_uint2(t, v[k]);   // (capacity protocol: an overflowing view is reported, not written)
-                ++cur;
-            }
-    }
-}
-
-// state of the fused passes, zeroed once per view: [8 tickets + 2 emission control words | depth hist 4 x 256 | tile hist 2 x 256 |
-// per depth pass: blk [bv][256], grp [gv][256] | per tile pass: blk [bi][256], grp [gi][256] | emission look-back 2 x (eblocks + 1) u64]
-struct Bin2Layout { size_t tickets, dhist, thist, dblk[4], dgrp[4], tblk[2], tgrp[2], desc, words; int bv, gv, bi, gi, eblocks; };
-static Bin2Layout bin2_layout(int V, int64_t n_isects)
-{
-    Bin2Layout L;
-    L.bv = (int)(((int64_t)(V > 0 ? V : 1) + RS_THREADS * RF_ITEMS_D - 1) / (RS_THREADS * RF_ITEMS_D)); L.gv = (L.bv + RF_GROUP - 1) / RF_GROUP;
-    L.bi = (int)(((n_isects > 0 ? n_isects : 1) + RS_THREADS * RF_ITEMS_T - 1) / (RS_THREADS * RF_ITEMS_T)); L.gi = (L.bi + RF_GROUP - 1) / RF_GROUP;
-    L.eblocks = ((V > 0 ? V : 1) + EM_TILE - 1) / EM_TILE;
-    size_t w = 0;
-    L.tickets = w; w += 16;
-    L.dhist = w; w += 4 * 256;
-    L.thist = w; w += 2 * 256;
-    for (int p = 0; p < 4; ++p) { L.dblk[p] = w; w += (size_t)L.bv * 256; L.dgrp[p] = w; w += (size_t)L.gv * 256; }
-    for (int p = 0; p < 2; ++p) { L.tblk[p] = w; w += (size_t)L.bi * 256; L.tgrp[p] = w; w += (size_t)L.gi * 256; }
-    w = (w + 1) & ~(size_t)1;
-    L.desc = w; w += 4 * ((size_t)L.eblocks + 1);
-    L.words = (w + 63) & ~(size_t)63;
-    return L;
-}
-
-static size_t bin2_ws_bytes(int V, int64_t n_isects)
-{
-    const size_t v = V > 0 ? (size_t)V : 1, n = n_isects > 0 ? (size_t)n_isects : 1;
-    return 2 * align256(v * 12) + 2 * align256(n * 8) + align256(bin2_layout(V, n_isects).words * 4) + 256;
-}
-
-static bool bin2_eligible(int tile_w, int tile_h, const uint32_t* tile_counts)
-{
-    static const bool off = [] { const char* e = getenv("GEOSPLAT_BIN"); return e && !strcmp(e, "passes3"); }();
-    return !off && tile_counts != nullptr && tile_w <= 255 && tile_h <= 255 && tile_w * tile_h <= BF_HIST_MAX;
-}
-
-static int isect_bin_front2(int V, const uint32_t* depth_keys, const uint32_t* tile_rects, const uint32_t* tile_counts, const int64_t* counts_dev,
-                            int64_t n_isects, int key_bits, int tile_w, int tile_h, int32_t* flatten_ids_sorted, int32_t* isect_offsets, void* ws,
-                            int64_t* status_dev, hipStream_t s)
-{
-    const GsCount vc{ (long long)V, (const long long*)counts_dev }, ic{ (long long)n_isects, counts_dev ? (const long long*)counts_dev + 1 : nullptr };
-    const int n_tiles = tile_w * tile_h;
-    const Bin2Layout L = bin2_layout(V, n_isects);
-    char* p = (char*)ws;
-    D3* da = (D3*)p; p += align256((size_t)V * 12);
-    D3* db = (D3*)p; p += align256((size_t)V * 12);
-    uint2* ia = (uint2*)p; p += align256((size_t)n_isects * 8);
-    uint2* ib = (uint2*)p; p += align256((size_t)n_isects * 8);
-    unsigned* state = (unsigned*)p;
-    long long* status = (long long*)status_dev;
-    // 0. clear the state (tickets, histograms, look-back tables); capacity check
-    hipLaunchKernelGGL(bin_setup_kernel, dim3(gs_cdiv((int64_t)L.words, 256 * 16) < 1024 ? gs_cdiv((int64_t)L.words, 256 * 16) : 1024), dim3(256), 0, s,
-                       state, (int)L.words, (const long long*)counts_dev, (long long)V, (long long)n_isects, status);
-    GS_CHECK_LAUNCH();
-    // 1. tile offsets, tile-digit and depth-digit histograms
-    int tb = 0;
-    while ((1 << tb) < n_tiles) ++tb;
-    if (tb < 1) tb = 1;
-    const int npass = (tb + 7) / 8, width = (tb + npass - 1) / npass;
-    const int n_depth = key_bits / 8;
-    const int hist_blocks = gs_cdiv(V, 1024 * 8) < 255 ? gs_cdiv(V, 1024 * 8) : 255;
-    hipLaunchKernelGGL(bin2_prep_kernel, dim3(1 + (hist_blocks > 0 ? hist_blocks : 1)), dim3(1024), 0, s, vc, (const unsigned*)depth_keys, n_depth,
-                       state + L.dhist, n_tiles, (const unsigned*)tile_counts, ic, isect_offsets, width, npass, state + L.thist);
-    GS_CHECK_LAUNCH();
-    // 2. depth order of the Gaussians: key_bits / 8 fused passes over (key, index, rectangle)
-    int rc = GS_OK;
-    D3* src = nullptr; D3* dst = da;
-    for (int pass = 0; pass < n_depth; ++pass) {
-        const RfState st{ state + L.tickets + pass, state + L.dblk[pass], state + L.dgrp[pass], state + L.dhist + 256 * pass, status };
-        if (pass == 0)
-            rc = fused_pass8<D3>(vc, KeyRectIn{ (const unsigned*)depth_keys, (const uint2*)tile_rects }, D3Digit{ 0, 255u }, D3Out{ dst }, st, (long long)V, s);
-        else
-            rc = fused_pass8<D3>(vc, D3In{ src }, D3Digit{ 8 * pass, 255u }, D3Out{ dst }, st, (long long)V, s);
-        if (rc != GS_OK) return rc;
-        src = dst; dst = (dst == da) ? db : da;
-    }
-    // 3. emission in depth order
-    hipLaunchKernelGGL(emit_seq_kernel, dim3(L.eblocks), dim3(EM_THREADS), 0, s, vc, (const D3*)src, state + L.tickets + 8, (u64*)(state + L.desc),
-                       L.eblocks + 1, tile_w, ia, (unsigned)n_isects, status);
-    GS_CHECK_LAUNCH();
-    // 4. stable split by tile id, the last pass writes the sorted flatten ids
-    uint2* isrc = ia; uint2* idst = ib;
-    for (int pass = 0; pass < npass; ++pass) {
-        const int shift = pass * width;
-        const int nbits = (tb - shift) < width ? (tb - shift) : width;
-        const RfState st{ state + L.tickets + 4 + pass, state + L.tblk[pass], state + L.tgrp[pass], state + L.thist + 256 * pass, status };
-        if (pass == npass - 1)
-            rc = fused_pass<uint2>(ic, U2In{ isrc }, XDigit{ shift, (1u << nbits) - 1u }, FinalFlat{ flatten_ids_sorted }, nbits, st, (long long)n_isects, s);
-        else
-            rc = fused_pass<uint2>(ic, U2In{ isrc }, XDigit{ shift, (1u << nbits) - 1u }, U2Out{ idst }, nbits, st, (long long)n_isects, s);
-        if (rc != GS_OK) return rc;
-        uint2* t = isrc; isrc = idst; idst = t;
     }
     return GS_OK;
 }

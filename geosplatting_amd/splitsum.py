@@ -554,18 +554,10 @@ def _fused_eligible(cubemap: Tensor, min_resolution: int) -> bool:
 def _as_splitsum_fused(cubemap: Tensor, cutoff: float, min_resolution: int, min_roughness: float, max_roughness: float):
     mips = mip_chain(cubemap, min_resolution)
     n = len(mips)
-    # the diffuse map (one workgroup per texel of the coarsest mip, 20-70 us) on a stream of its own BESIDE the levels' launch: only
-    # the shading reads it (GEOSPLAT_DIFFUSE_STREAM=0: in line, between the chain and the levels)
-    cur = torch.cuda.current_stream(cubemap.device)
-    side = _diffuse_stream(cubemap.device) if not torch.cuda.is_current_stream_capturing() else None
-    if side is not None:
-        side.wait_stream(cur)
-        with torch.cuda.stream(side), torch.no_grad():
-            base = diffuse_cubemap(mips[-1])
-        mips[-1].record_stream(side)
-    else:
-        with torch.no_grad():
-            base = diffuse_cubemap(mips[-1])
+    # (round 6, measured and removed: the diffuse map on a stream of its own beside the levels' launch -- a fifth stream shares one of
+    #  HIP's four hardware queues with a front stream: 649 against 710 views/s)
+    with torch.no_grad():
+        base = diffuse_cubemap(mips[-1])
     roughs = _level_roughness(n, min_roughness, max_roughness)
     sizes = [m.numel() for m in mips]
     flat = torch.empty(sum(sizes), dtype=torch.float32, device=cubemap.device)
@@ -575,22 +567,7 @@ def _as_splitsum_fused(cubemap: Tensor, cutoff: float, min_resolution: int, min_
         e = specular_tiles(int(m.shape[1]), rough, cutoff, cubemap.device)
         jobs.append((e, m, out, 0, None))
     _tiles_apply_multi(jobs, "fwd")
-    if side is not None:
-        cur.wait_stream(side)
-        base.record_stream(cur)
     return base, levels
-
-
-_diffuse_streams: Dict[int, "torch.cuda.Stream"] = {}
-
-
-def _diffuse_stream(device: torch.device):
-    if os.environ.get("GEOSPLAT_DIFFUSE_STREAM", "1") == "0":
-        return None
-    key = device.index or 0
-    if key not in _diffuse_streams:
-        _diffuse_streams[key] = torch.cuda.Stream(device=device)
-    return _diffuse_streams[key]
 
 
 def as_splitsum(cubemap: Tensor, *, cutoff: float = 0.99, min_resolution: int = 16, min_roughness: float = 0.08,

@@ -77,7 +77,7 @@ def time_dominant_kernels(params, env, cam, res, iters):
     rectangles, binning from its outputs), with HIP events on the stream they are launched on (torch's current stream):
     `gs_raster_composite_tone_log` (raster_fwd_window_kernel with S4 in its epilogue, writing the cull log) on a prepared workspace
     and `gs_raster_bwd_tone_log_acc` (raster_bwd_log_kernel); the workspace preparation (sorted record stream, tile order) is timed
-    as its own entry.  GEOSPLAT_RASTER_LOG=0: the plain pair (raster_bwd_lanes2_kernel).  Returns (times, I of the engine's list)."""
+    as its own entry.  Returns (times, I of the engine's list)."""
     import geosplatting_amd as gs
     import geosplatting_amd._lib as L
     from geosplatting_amd import front as F
@@ -86,7 +86,7 @@ def time_dominant_kernels(params, env, cam, res, iters):
     dev = params.means.device
     W = H = res
     f32 = torch.float32
-    use_log = os.environ.get("GEOSPLAT_RASTER_LOG", "1") != "0"
+    use_log = True
     tight = os.environ.get("GEOSPLAT_TIGHT_TILES", "1") != "0"
     env_d = gs.TextureSplitSum(env.base.detach(), [l.detach().contiguous() for l in env.levels], env.min_roughness, env.max_roughness)
     e = _make_env(gs.get_fg_lut(dev), env_d)
@@ -247,7 +247,7 @@ def file_sha16(path):
 
 
 LAUNCHED_AS = {"raster_fwd_kernel": "raster_fwd_window_kernel<3>",
-               "raster_bwd_kernel": "raster_bwd_log_kernel<3>" if os.environ.get("GEOSPLAT_RASTER_LOG", "1") != "0" else "raster_bwd_lanes2_kernel<3>"}
+               "raster_bwd_kernel": "raster_bwd_log_kernel<3>"}
 
 
 def committed_profile(name, kernel_source):
@@ -524,8 +524,17 @@ def main():
         acc = {}
         for name, a, b in step.kernel_events:
             acc.setdefault(name, []).append(a.elapsed_time(b))
+        # the step's ENDS: from the end of the last view's compositor backward to the start of the next step's first compositor forward
+        # (last tail, prefilter backward + mip links, zero fill / activations, mip chain, diffuse map, prefilter forward, first view's
+        # shaded front + record stream) -- the part of a step in which the compositor chain, its critical path, does not run
+        ev = step.kernel_events
+        nv = len(cams)
+        bounds = [ev[2 * nv * (k + 1) - 1][2].elapsed_time(ev[2 * nv * (k + 1)][1]) for k in range(len(ev) // (2 * nv) - 1)
+                  if ev[2 * nv * (k + 1) - 1][0] == "raster_bwd_kernel" and ev[2 * nv * (k + 1)][0] == "raster_fwd_kernel"]
         step.kernel_events = None
         engine_ms = {k: sum(v) / len(v) for k, v in acc.items()} or None
+        if engine_ms is not None and bounds:
+            engine_ms["step_boundary_last_bwd_end_to_next_first_fwd_start"] = sum(bounds) / len(bounds)
     # the same timed loop with gsplat's SQUARE tile rectangles (GEOSPLAT_TIGHT_TILES=0): `value` runs on rectangles clipped to the
     # alpha >= 1/255 extents -- a pixel-neutral subsequence of gsplat's intersection list, not the list itself (config.I_engine vs I)
     square = None
@@ -653,7 +662,9 @@ def main():
             "config": {"workload": f"surface splats (HIP MGAdapter on icosphere level {args.level}) N={N}, {args.res}x{args.res}, "
                                    f"split-sum GGX envmap {args.cubemap_res}^2, "
                                    + (f"{views_total} views/step over all GPUs (strong scaling)" if strong else f"{args.views} views/step/GPU")
-                                   + f", prefilter fwd+bwd {'in' if not args.no_prefilter else 'EXCLUDED from'} every step",
+                                   + f", prefilter fwd+bwd {'in' if not args.no_prefilter else 'EXCLUDED from'} every step"
+                                   + f"; `value` is timed over {args.steps} steps that FOLLOW {n_settle} untimed settle steps (--settle-seconds "
+                                     f"{args.settle_seconds:g}: clock ramp of an idle GPU, allocator, capacity protocol) + the {args.warmup} warm-up steps",
                        "N": N, "V": V, "I": I, "I_engine": I_engine, "P": P, "views_per_step_total": views_total,
                        "parallelism": f"dp{world} (views sharded, prefilter sharded, flat RCCL all-reduce of per-Gaussian grads)"
                                       + (" -- --rccl-world1: every collective issued through RCCL on a one-rank group" if args.rccl_world1 else "")},

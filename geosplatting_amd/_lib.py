@@ -131,40 +131,3 @@ def require_cuda(*tensors: torch.Tensor) -> None:
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise GeoSplatHipError("geosplatting_amd ops run on the GPU only (tensor on %s); there is no CPU path" % t.device)
-
-
-_hip = None
-_masked_streams = []          # (handle, torch stream): kept alive for the life of the process
-
-
-def masked_stream(device: torch.device, cu_lo: int, cu_hi: int) -> "torch.cuda.Stream":
-    """A HIP stream restricted to CUs [cu_lo, cu_hi) of EVERY XCD (hipExtStreamCreateWithCUMask), wrapped for torch.  On MI355X
-    bit i of the mask is CU i / 8 of XCD i % 8 (scripts/micro/cumask_probe.hip: bits 0..31 = four CUs on each of the eight XCDs; a
-    mask that leaves an XCD without any CU is ignored by the runtime), so a stream can be given a SLICE of every XCD -- it keeps
-    every L2 -- but not whole XCDs."""
-    global _hip
-    if _hip is None:
-        _hip = C.CDLL("libamdhip64.so")
-    if not (0 <= cu_lo < cu_hi <= 32):
-        raise GeoSplatHipError(f"CU range {cu_lo}:{cu_hi} outside 0..32")
-    words = (C.c_uint32 * 8)()
-    for i in range(8 * cu_lo, 8 * cu_hi):
-        words[i // 32] |= 1 << (i % 32)
-    h = C.c_void_p()
-    with torch.cuda.device(device):
-        rc = _hip.hipExtStreamCreateWithCUMask(C.byref(h), C.c_uint32(8), words)
-    if rc != 0:
-        raise GeoSplatHipError(f"hipExtStreamCreateWithCUMask failed ({rc})")
-    st = torch.cuda.ExternalStream(h.value, device=device)
-    _masked_streams.append((h, st))
-    return st
-
-
-def stream_from_env(role: str, device: torch.device, priority: int = 0) -> "torch.cuda.Stream":
-    """A new stream for the engine: plain, or -- GEOSPLAT_CU_SLICES="front=24:32,tail=16:32,main=0:24" -- restricted to CUs lo..hi-1 of
-    every XCD for the roles named there (the round-5 partition experiment, profiles/r05_cu_partition_sweep.txt: every split loses)."""
-    for item in os.environ.get("GEOSPLAT_CU_SLICES", "").split(","):
-        if item.startswith(role + "=") and ":" in item:
-            lo, hi = (int(x) for x in item[len(role) + 1:].split(":"))
-            return masked_stream(device, lo, hi)
-    return torch.cuda.Stream(device=device, priority=priority)

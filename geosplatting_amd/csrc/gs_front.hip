@@ -442,8 +442,8 @@ tail_bwd_kernel(GsCount vc, const float* __restrict__ means, const float* __rest
 // persistent blocks of a BACKGROUND tail launch (bit 2 of `parts`): a launch that is not the last of the step runs beside the
 // compositor of the following views; its 134 KB blocks cannot share a CU with the compositor's, so it takes half of the CUs and
 // leaves the others (measured at 8 views, batches of 3: 96 / 128 / 160 / 192 / 256 blocks -> 669 / 678 / 675 / 675 / 652 views/s)
-static int tail_background_blocks() { static const int r = [] { const char* v = getenv("GEOSPLAT_TAIL_EARLY_BLOCKS"); const int n = v ? atoi(v) : 0; return n > 0 ? n : 128; }(); return r; }
-static int tail_priv_maxres() { static const int r = [] { const char* v = getenv("GEOSPLAT_TAIL_PRIV_MAXRES"); return v ? atoi(v) : 128; }(); return r; }
+static int tail_background_blocks() { return 128; }            // workgroups of a background tail launch: half of the CUs (96 / 160 / 192 / 256: 669 / 675 / 675 / 652 against 678 views/s)
+static int tail_priv_maxres() { return 128; }
 static size_t tail_priv_floats(const EnvDev& e, int mode, long long* level_off)
 {
     long long off = 0;

@@ -376,9 +376,8 @@ static inline int shade_bwd_plan(const EnvDev& e, int mode, int N, void* ws, siz
                                  bool force_stage = false, int force_block = 0)
 {
     // LDS layout: privatise every level of at most maxres^2 texels per face (and the diffuse base) within 128 KB
-    static const int s_block_env = [] { const char* v = getenv("GEOSPLAT_SHADE_BWD_BLOCK"); const int b = v ? atoi(v) : 512; return (b == 256 || b == 768 || b == 1024) ? b : 512; }();
-    const int s_block = force_block > 0 ? force_block : s_block_env;
-    static const int s_maxres = [] { const char* v = getenv("GEOSPLAT_SHADE_LDS_MAXRES"); const int r = v ? atoi(v) : 32; return r; }();
+    const int s_block = force_block > 0 ? force_block : 512;       // (256 / 768 / 1024-thread blocks and other LDS cut-offs: measured)
+    const int s_maxres = 32;
     const int lds_budget_floats = 128 * 1024 / 4;
     int used = 0;
     eg.lds_base = -1;
@@ -393,8 +392,8 @@ static inline int shade_bwd_plan(const EnvDev& e, int mode, int N, void* ws, siz
         }
     }
     eg.lds_floats = used;
-    static const bool s_stage = [] { const char* v = getenv("GEOSPLAT_SHADE_COMMIT_LDS"); return !(v && v[0] == '0'); }();
-    const bool staged = s_stage || force_stage;
+    const bool staged = true;
+    (void)force_stage;
     eg.stage_off = staged ? ((used + 3) & ~3) : -1;
     const int stage_floats = staged ? (eg.stage_off - used) + (s_block / 64) * 640 : 0;
     // XCD-private accumulators for the big levels (optional workspace)

@@ -139,32 +139,6 @@ radix_rowscan_kernel(int nblocks, unsigned* __restrict__ table, unsigned* __rest
     if (threadIdx.x == 0) row_total[blockIdx.x] = carry;
 }
 
-// exclusive scan of a short array (<= a few thousand entries) by one workgroup: per-block bases of the emission
-__global__ void __launch_bounds__(1024)
-small_scan_kernel(int total, unsigned* __restrict__ a)
-{
-    __shared__ unsigned wsum[16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned carry = 0u;
-    for (int i0 = 0; i0 < total; i0 += 1024) {
-        const int i = i0 + threadIdx.x;
-        const unsigned v = i < total ? a[i] : 0u;
-        unsigned incl = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        unsigned before = 0u, all = 0u;
-        for (int w = 0; w < 16; ++w) { if (w < wave) before += wsum[w]; all += wsum[w]; }
-        if (i < total) a[i] = carry + before + incl - v;
-        carry += all;
-        __syncthreads();
-    }
-}
-
 // Scatter of one pass.  Ranks come from ballots (see the file header); the items are then staged through LDS in their
 // block-local sorted order, so that the global stores of a digit run are contiguous (a wave writing 64 items of 64 different
 // digits straight from registers is 64 partial-sector stores).
@@ -290,171 +264,6 @@ static int radix_pass(GsCount nc, In in, Digit digit, Out out, int nbits, unsign
     return GS_OK;
 }
 
-// ---- one-kernel pass (decoupled look-back) ----------------------------------------------------------------------------
-// EXPERIMENT (off by default, GEOSPLAT_RADIX=onesweep): the three-kernel pass above costs two extra launches and a second read of
-// the items.  `radix_onesweep_kernel` does a pass in ONE launch: the
-// global digit histogram is known beforehand (all four depth digits from one read of the depth array; the tile digits are
-// counted while the intersections are emitted), blocks take a TICKET (arrival order, so a block only ever waits for blocks that
-// are already running), publish their per-digit counts as {flag, value} words and thread d looks back over the predecessors of
-// digit d until it meets an inclusive prefix -- the chained-scan hand-off of gs_project.hip (relaxed agent-scope granules, the
-// data is the flag).
-#define OS_AGG  (1u << 30)
-#define OS_INCL (2u << 30)
-#define OS_MASK ((1u << 30) - 1u)
-#define OS_SPIN_LIMIT (1 << 24)
-
-template <typename Item, typename In, typename Digit, typename Out, int NBITS>
-__global__ void __launch_bounds__(RS_THREADS)
-radix_onesweep_kernel(int64_t n, In in, Digit digit, unsigned* __restrict__ ticket, unsigned* __restrict__ status,
-                      const unsigned* __restrict__ ghist, Out out)
-{
-    constexpr int NB = 1 << NBITS;
-    __shared__ unsigned cnt[RS_WAVES][NB];
-    __shared__ unsigned dstart[NB];
-    __shared__ unsigned gbase[NB];
-    __shared__ unsigned wtot[RS_WAVES];
-    __shared__ unsigned s_block;
-    __shared__ Item stage[RS_TILE];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_block = atomicAdd(ticket, 1u);
-    for (int i = threadIdx.x; i < RS_WAVES * NB; i += RS_THREADS) (&cnt[0][0])[i] = 0u;
-    __syncthreads();
-    const unsigned block = s_block;
-    const int64_t bbase = (int64_t)block * RS_TILE;
-    const int64_t wbase = bbase + (int64_t)wave * RS_WCHUNK;
-    const int n_here = (int)((n - bbase) < RS_TILE ? (n - bbase) : RS_TILE);
-    const u64 lane_lt = (1ull << lane) - 1ull;
-    Item item[RS_ITEMS];
-    unsigned dig[RS_ITEMS];
-    unsigned rank[RS_ITEMS];
-#pragma unroll
-    for (int k = 0; k < RS_ITEMS; ++k) {
-        const int64_t i = wbase + (int64_t)k * 64 + lane;
-        const bool valid = i < n;
-        if (valid) item[k] = in.load(i);
-        const unsigned d = valid ? digit(item[k]) : 0u;
-        u64 m = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < NBITS; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const u64 bal = __ballot(bit);
-            m &= bit ? bal : ~bal;
-        }
-        const unsigned old = cnt[wave][d];
-        __builtin_amdgcn_wave_barrier();
-        const unsigned r = __popcll(m & lane_lt);
-        if (valid && r == 0u) cnt[wave][d] = old + (unsigned)__popcll(m);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        dig[k] = d;
-        rank[k] = old + r;
-    }
-    __syncthreads();
-    {
-        const int d = threadIdx.x;
-        unsigned tot = 0u;
-        if (d < NB) for (int w = 0; w < RS_WAVES; ++w) tot += cnt[w][d];
-        // ---- publish, then look back (thread d handles digit d)
-        unsigned prefix = 0u;
-        if (d < NB) {
-            unsigned* mine = status + (size_t)block * NB + d;
-            __hip_atomic_store(mine, (block == 0u ? OS_INCL : OS_AGG) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (block > 0u) {
-                for (int p = (int)block - 1; p >= 0; --p) {
-                    unsigned* q = status + (size_t)p * NB + d;
-                    unsigned v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    int spins = 0;
-                    while ((v >> 30) == 0u && ++spins < OS_SPIN_LIMIT) {
-                        __builtin_amdgcn_s_sleep(1);
-                        v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    prefix += v & OS_MASK;
-                    if ((v >> 30) == 2u) break;
-                }
-                __hip_atomic_store(mine, OS_INCL | (prefix + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        // ---- block-local digit starts and the global digit starts (exclusive scans over the digits)
-        unsigned incl = tot;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
-        if (lane == 63) wtot[wave] = incl;
-        __syncthreads();
-        unsigned before = 0u;
-        for (int w = 0; w < wave; ++w) before += wtot[w];
-        if (d < NB) dstart[d] = before + incl - tot;
-        __syncthreads();
-        const unsigned gh = d < NB ? ghist[d] : 0u;
-        unsigned gincl = gh;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned t = __shfl_up(gincl, off, 64);
-            if (lane >= off) gincl += t;
-        }
-        if (lane == 63) wtot[wave] = gincl;
-        __syncthreads();
-        unsigned gbefore = 0u;
-        for (int w = 0; w < wave; ++w) gbefore += wtot[w];
-        if (d < NB) gbase[d] = gbefore + gincl - gh + prefix;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < RS_ITEMS; ++k) {
-        const int64_t i = wbase + (int64_t)k * 64 + lane;
-        if (i < n) {
-            const unsigned d = dig[k];
-            unsigned off = dstart[d] + rank[k];
-            for (int w = 0; w < wave; ++w) off += cnt[w][d];
-            stage[off] = item[k];
-        }
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int k = 0; k < RS_ITEMS; ++k) {
-        const int p = k * RS_THREADS + (int)threadIdx.x;
-        if (p < n_here) {
-            const Item it = stage[p];
-            const unsigned d = digit(it);
-            out.store((int64_t)gbase[d] + (int64_t)(p - (int)dstart[d]), it);
-        }
-    }
-}
-
-template <typename Item, typename In, typename Digit, typename Out>
-static int onesweep_pass(int64_t n, In in, Digit digit, Out out, int nbits, unsigned* ticket, unsigned* status, const unsigned* ghist,
-                         hipStream_t s)
-{
-    const int nblocks = (int)((n + RS_TILE - 1) / RS_TILE);
-    switch (nbits) {
-#define OS_CASE(B) case B: hipLaunchKernelGGL((radix_onesweep_kernel<Item, In, Digit, Out, B>), dim3(nblocks), dim3(RS_THREADS), 0, s, n, in, digit, ticket, status, ghist, out); break;
-        OS_CASE(1) OS_CASE(2) OS_CASE(3) OS_CASE(4) OS_CASE(5) OS_CASE(6) OS_CASE(7) OS_CASE(8)
-#undef OS_CASE
-        default: gs_set_error("onesweep_pass: bad digit width %d", nbits); return GS_EINVAL;
-    }
-    GS_CHECK_LAUNCH();
-    return GS_OK;
-}
-
-// all four digit histograms of the depth keys from one read of the depth array: ghist[pass][256]
-__global__ void __launch_bounds__(256)
-depth_hist4_kernel(int V, const float* __restrict__ depths, unsigned* __restrict__ ghist)
-{
-    __shared__ unsigned h[4][256];
-    for (int i = threadIdx.x; i < 1024; i += 256) (&h[0][0])[i] = 0u;
-    __syncthreads();
-    for (int v = blockIdx.x * 256 + threadIdx.x; v < V; v += gridDim.x * 256) {
-        const unsigned k = __float_as_uint(depths[v]);
-        atomicAdd(&h[0][k & 255u], 1u); atomicAdd(&h[1][(k >> 8) & 255u], 1u);
-        atomicAdd(&h[2][(k >> 16) & 255u], 1u); atomicAdd(&h[3][k >> 24], 1u);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 1024; i += 256) { const unsigned c = (&h[0][0])[i]; if (c) atomicAdd(ghist + i, c); }
-}
-
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t table_bytes(int64_t n) { return align256(((size_t)256 * (size_t)((n + RS_TILE - 1) / RS_TILE + 1) + 512) * sizeof(unsigned)); }
 
@@ -540,99 +349,14 @@ __device__ __forceinline__ unsigned rect_count(uint2 q)
     return (w > 0 && h > 0) ? (unsigned)(w * h) : 0u;
 }
 
-// per-block totals of the tile counts in DEPTH order
-__global__ void __launch_bounds__(EM_THREADS)
-emit_blocksum_kernel(GsCount vc, const uint2* __restrict__ order, const uint2* __restrict__ rect, unsigned* __restrict__ blocksum)
-{
-    const int V = (int)gs_count(vc);
-    __shared__ unsigned ws[EM_THREADS / 64];
-    unsigned s = 0u;
-#pragma unroll
-    for (int k = 0; k < EM_PER; ++k) {
-        const int r = blockIdx.x * EM_TILE + k * EM_THREADS + threadIdx.x;
-        if (r < V) s += rect_count(rect[order[r].y]);
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned t = 0u;
-        for (int w = 0; w < EM_THREADS / 64; ++w) t += ws[w];
-        blocksum[blockIdx.x] = t;
-    }
-}
-
-// thread r (depth rank) writes the (tile, index) items of its Gaussian, tiles row-major, at the exclusive prefix of the
-// tile counts in depth order
-__global__ void __launch_bounds__(EM_THREADS)
-emit_sorted_kernel(GsCount vc, const uint2* __restrict__ order, const uint2* __restrict__ rect, const unsigned* __restrict__ blockbase,
-                   int tile_w, uint2* __restrict__ items, unsigned item_cap, int npass, int width,
-                   unsigned* __restrict__ tile_hist /*[npass][256] or NULL*/)
-{
-    const int V = (int)gs_count(vc);
-    __shared__ unsigned ws[EM_THREADS / 64];
-    __shared__ unsigned th[2][256];                          // digit histograms of the tile ids this block emits (<= 2 passes)
-    if (tile_hist) { th[0][threadIdx.x] = 0u; th[1][threadIdx.x] = 0u; }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // blocked arrangement: thread t owns ranks base + t*EM_PER .. +EM_PER-1 (consecutive: the scan stays in index order)
-    const int r0 = blockIdx.x * EM_TILE + (int)threadIdx.x * EM_PER;
-    int v[EM_PER]; unsigned c[EM_PER]; uint2 q[EM_PER];
-    unsigned mine = 0u;
-#pragma unroll
-    for (int k = 0; k < EM_PER; ++k) {
-        const int r = r0 + k;
-        v[k] = r < V ? (int)order[r].y : -1;
-        q[k] = v[k] >= 0 ? rect[v[k]] : make_uint2(0u, 0u);
-        c[k] = rect_count(q[k]);
-        mine += c[k];
-    }
-    unsigned incl = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
-    if (lane == 63) ws[wave] = incl;
-    __syncthreads();
-    unsigned cur = blockbase[blockIdx.x] + incl - mine;
-    for (int w = 0; w < wave; ++w) cur += ws[w];
-#pragma unroll
-    for (int k = 0; k < EM_PER; ++k) {
-        if (v[k] < 0 || c[k] == 0u) continue;
-        const int x0 = (int)(q[k].x & 0xffffu), y0 = (int)(q[k].x >> 16), x1 = (int)(q[k].y & 0xffffu), y1 = (int)(q[k].y >> 16);
-        const unsigned dmask = (1u << width) - 1u;
-        for (int i = y0; i < y1; ++i)
-            for (int j = x0; j < x1; ++j) {
-                const unsigned t = (unsigned)(i * tile_w + j);
-                if (cur < item_cap) items[cur] = make_uint2(t, (unsigned)v[k]);       // (capacity protocol: an overflowing view is reported, not written)
-                ++cur;
-                if (tile_hist) {
-                    atomicAdd(&th[0][t & dmask], 1u);
-                    if (npass > 1) atomicAdd(&th[1][(t >> width) & dmask], 1u);
-                }
-            }
-    }
-    if (tile_hist) {
-        __syncthreads();
-        for (int p = 0; p < npass && p < 2; ++p) { const unsigned hc = th[p][threadIdx.x]; if (hc) atomicAdd(tile_hist + p * 256 + threadIdx.x, hc); }
-    }
-}
-
-// look-back state of the one-kernel passes: [depth hist 4 x 256 | tile hist 2 x 256 | 8 tickets | status of the 4 depth passes |
-// status of the <= 2 tile passes], zeroed by one memset per call
-static size_t onesweep_bytes(int V, int64_t n_isects)
-{
-    const size_t bv = (size_t)(((int64_t)(V > 0 ? V : 1) + RS_TILE - 1) / RS_TILE), bi = (size_t)(((n_isects > 0 ? n_isects : 1) + RS_TILE - 1) / RS_TILE);
-    return align256((6 * 256 + 8 + 4 * bv * 256 + 2 * bi * 256) * sizeof(unsigned));
-}
+static size_t bf_state_bytes(int V) { return align256(16 + 2 * (size_t)((V + EM_TILE - 1) / EM_TILE + 1) * sizeof(u64)); }
 
 extern "C" size_t gs_isect_bin_ws_bytes(int V, int64_t n_isects, int tile_w, int tile_h)
 {
     (void)tile_w; (void)tile_h;
     const size_t v = V > 0 ? (size_t)V : 1, n = n_isects > 0 ? (size_t)n_isects : 1;
     const size_t tb = table_bytes((int64_t)(v > n ? v : n));
-    return tb + 3 * align256(v * 8) + align256(((v + EM_TILE - 1) / EM_TILE + 1) * 4) + 2 * align256(n * 8) + 256 + onesweep_bytes(V, n_isects);
+    return tb + 3 * align256(v * 8) + bf_state_bytes((int)v) + 2 * align256(n * 8) + 256;
 }
 
 // status word of the capacity protocol: {code, required n_isects}; written only on overflow (the caller zeroes it once)
@@ -685,103 +409,6 @@ extern "C" int gs_isect_bin_tiles_cap(int V_cap, const float* means2d, const int
     GS_CHECK_LAUNCH();
     return isect_bin_impl(V_cap, means2d, radii, depths, n_isects_cap, (const long long*)counts_dev, tile_size, tile_w, tile_h,
                           nullptr, flatten_ids_sorted, ws, ws_bytes, stream, tile_ids_sorted);
-}
-
-static int isect_bin_impl(int V, const float* means2d, const int32_t* radii, const float* depths, int64_t n_isects,
-                          const long long* counts_dev, int tile_size, int tile_w, int tile_h, int64_t* isect_ids_sorted,
-                          int32_t* flatten_ids_sorted, void* ws, size_t ws_bytes, void* stream, int32_t* tile_ids_sorted)
-{
-    const GsCount vc{ (long long)V, counts_dev }, ic{ (long long)n_isects, counts_dev ? counts_dev + 1 : nullptr };
-    GS_CHECK_ARG(V >= 0 && n_isects >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0, "bad sizes");
-    GS_CHECK_ARG(n_isects < (1ll << 31), "n_isects must fit int32");
-    GS_CHECK_ARG((int64_t)tile_w * tile_h < (1ll << 24), "more than 2^24 tiles");
-    if (V == 0 || n_isects == 0) return GS_OK;
-    GS_CHECK_ARG(ws != nullptr, "workspace must not be NULL");
-    if (ws_bytes < gs_isect_bin_ws_bytes(V, n_isects, tile_w, tile_h)) { gs_set_error("gs_isect_bin: workspace too small"); return GS_ENOSPC; }
-    hipStream_t s = (hipStream_t)stream;
-    char* p = (char*)ws;
-    unsigned* table = (unsigned*)p; p += table_bytes((int64_t)V > n_isects ? (int64_t)V : n_isects);
-    uint2* da = (uint2*)p; p += align256((size_t)V * 8);
-    uint2* db = (uint2*)p; p += align256((size_t)V * 8);
-    uint2* rect = (uint2*)p; p += align256((size_t)V * 8);
-    const int eblocks = (V + EM_TILE - 1) / EM_TILE;
-    unsigned* blocksum = (unsigned*)p; p += align256(((size_t)eblocks + 1) * 4);
-    uint2* ia = (uint2*)p; p += align256((size_t)n_isects * 8);
-    uint2* ib = (uint2*)p; p += align256((size_t)n_isects * 8);
-    // default: three kernels per pass.  GEOSPLAT_RADIX=onesweep selects the one-kernel look-back passes (bit-identical, measured
-    // SLOWER on this workload: 265 vs 238 us of pass kernels per view)
-    static const bool three_kernel_env = [] { const char* e = getenv("GEOSPLAT_RADIX"); return !(e && !strcmp(e, "onesweep")); }();
-    const bool three_kernel = three_kernel_env || counts_dev != nullptr;   // (the look-back experiment sizes its state by the exact counts)
-    int tb = 0;
-    while ((1 << tb) < tile_w * tile_h) ++tb;
-    if (tb < 1) tb = 1;
-    const int npass = (tb + 7) / 8, width = (tb + npass - 1) / npass;
-    const bool onesweep = !three_kernel && npass <= 2;
-    unsigned* os = (unsigned*)p;                                 // look-back state (see onesweep_bytes)
-    const size_t bv = (size_t)(((int64_t)V + RS_TILE - 1) / RS_TILE), bi = (size_t)((n_isects + RS_TILE - 1) / RS_TILE);
-    unsigned* dhist = os; unsigned* thist = os + 4 * 256; unsigned* tickets = os + 6 * 256;
-    unsigned* dstatus = tickets + 8; unsigned* tstatus = dstatus + 4 * bv * 256;
-    int rc = GS_OK;
-    if (onesweep) {
-        GS_CHECK_HIP(gs_zero_async(os, onesweep_bytes(V, n_isects), s));
-        hipLaunchKernelGGL(depth_hist4_kernel, dim3(gs_cdiv(V, 256 * 8) < 1024 ? gs_cdiv(V, 256 * 8) : 1024), dim3(256), 0, s, V, depths, dhist);
-        GS_CHECK_LAUNCH();
-        // 1. depth order of the Gaussians: four stable 8-bit passes over (depth bits, index), one launch each
-        rc = onesweep_pass<uint2>((int64_t)V, DepthIn{ depths }, XDigit{ 0, 255u }, U2Out{ da }, 8, tickets + 0, dstatus + 0 * bv * 256, dhist + 0, s);
-        if (rc != GS_OK) return rc;
-        rc = onesweep_pass<uint2>((int64_t)V, U2In{ da }, XDigit{ 8, 255u }, U2Out{ db }, 8, tickets + 1, dstatus + 1 * bv * 256, dhist + 256, s);
-        if (rc != GS_OK) return rc;
-        rc = onesweep_pass<uint2>((int64_t)V, U2In{ db }, XDigit{ 16, 255u }, U2Out{ da }, 8, tickets + 2, dstatus + 2 * bv * 256, dhist + 512, s);
-        if (rc != GS_OK) return rc;
-        rc = onesweep_pass<uint2>((int64_t)V, U2In{ da }, XDigit{ 24, 255u }, U2Out{ db }, 8, tickets + 3, dstatus + 3 * bv * 256, dhist + 768, s);
-        if (rc != GS_OK) return rc;
-    } else {
-        // 1. depth order of the Gaussians: four stable 8-bit passes over (depth bits, index); the first reads the depth array
-        rc = radix_pass<uint2>(vc, DepthIn{ depths }, XDigit{ 0, 255u }, U2Out{ da }, 8, table, s);
-        if (rc != GS_OK) return rc;
-        rc = radix_pass<uint2>(vc, U2In{ da }, XDigit{ 8, 255u }, U2Out{ db }, 8, table, s);
-        if (rc != GS_OK) return rc;
-        rc = radix_pass<uint2>(vc, U2In{ db }, XDigit{ 16, 255u }, U2Out{ da }, 8, table, s);
-        if (rc != GS_OK) return rc;
-        rc = radix_pass<uint2>(vc, U2In{ da }, XDigit{ 24, 255u }, U2Out{ db }, 8, table, s);
-        if (rc != GS_OK) return rc;
-    }
-    // 2. emission in depth order
-    GS_CHECK_ARG(tile_w < 65536 && tile_h < 65536, "tile grid too large");
-    hipLaunchKernelGGL(tile_rect_kernel, dim3(gs_cdiv(V, 256)), dim3(256), 0, s, vc, means2d, radii, tile_size, tile_w, tile_h, rect);
-    GS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(emit_blocksum_kernel, dim3(eblocks), dim3(EM_THREADS), 0, s, vc, db, rect, blocksum);
-    GS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(1024), 0, s, eblocks, blocksum);
-    GS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(emit_sorted_kernel, dim3(eblocks), dim3(EM_THREADS), 0, s, vc, db, rect, blocksum, tile_w, ia, (unsigned)n_isects, npass, width,
-                       onesweep ? thist : nullptr);
-    GS_CHECK_LAUNCH();
-    // 3. stable split by tile id: npass digits of `width` bits, the last one writes the sorted meta arrays
-    uint2* src = ia; uint2* dst = ib;
-    for (int pass = 0; pass < npass; ++pass) {
-        const int shift = pass * width;
-        const int nbits = (tb - shift) < width ? (tb - shift) : width;
-        if (onesweep) {
-            unsigned* st = tstatus + (size_t)pass * bi * 256;
-            if (pass == npass - 1)
-                rc = onesweep_pass<uint2>(n_isects, U2In{ src }, XDigit{ shift, (1u << nbits) - 1u },
-                                          FinalOut{ (u64*)isect_ids_sorted, flatten_ids_sorted, depths }, nbits, tickets + 4 + pass, st, thist + pass * 256, s);
-            else
-                rc = onesweep_pass<uint2>(n_isects, U2In{ src }, XDigit{ shift, (1u << nbits) - 1u }, U2Out{ dst }, nbits, tickets + 4 + pass, st,
-                                          thist + pass * 256, s);
-        } else if (pass == npass - 1 && tile_ids_sorted != nullptr)
-            rc = radix_pass<uint2>(ic, U2In{ src }, XDigit{ shift, (1u << nbits) - 1u },
-                                   FinalTiles{ tile_ids_sorted, flatten_ids_sorted }, nbits, table, s);
-        else if (pass == npass - 1)
-            rc = radix_pass<uint2>(ic, U2In{ src }, XDigit{ shift, (1u << nbits) - 1u },
-                                   FinalOut{ (u64*)isect_ids_sorted, flatten_ids_sorted, depths }, nbits, table, s);
-        else
-            rc = radix_pass<uint2>(ic, U2In{ src }, XDigit{ shift, (1u << nbits) - 1u }, U2Out{ dst }, nbits, table, s);
-        if (rc != GS_OK) return rc;
-        uint2* t = src; src = dst; dst = t;
-    }
-    return GS_OK;
 }
 
 // ---- gs_isect_bin_front: binning of the engine's fused front (round 4) ---------------------------------------------------------
@@ -971,7 +598,6 @@ bin_offsets_tiles_kernel(GsCount nc, const int32_t* __restrict__ tiles, int n_ti
         for (int t = cur + 1; t < n_tiles; ++t) offsets[t] = (int32_t)n;
 }
 
-static size_t bf_state_bytes(int V) { return align256(16 + 2 * (size_t)((V + EM_TILE - 1) / EM_TILE + 1) * sizeof(u64)); }
 
 extern "C" size_t gs_isect_bin_front_ws_bytes(int V, int64_t n_isects, int tile_w, int tile_h)
 {
@@ -1055,6 +681,74 @@ extern "C" int gs_isect_bin_front(int V_cap, const uint32_t* depth_keys, const u
     if (!hist) {
         hipLaunchKernelGGL(bin_offsets_tiles_kernel, dim3(gs_cdiv(n_isects, 256)), dim3(256), 0, s, ic, tile_ids, n_tiles, isect_offsets);
         GS_CHECK_LAUNCH();
+    }
+    return GS_OK;
+}
+
+// ---- gs_isect_bin / _cap / _tiles_cap: the rasterization() call shape (emitted keys are never materialised) -----------------------
+static int isect_bin_impl(int V, const float* means2d, const int32_t* radii, const float* depths, int64_t n_isects,
+                          const long long* counts_dev, int tile_size, int tile_w, int tile_h, int64_t* isect_ids_sorted,
+                          int32_t* flatten_ids_sorted, void* ws, size_t ws_bytes, void* stream, int32_t* tile_ids_sorted)
+{
+    const GsCount vc{ (long long)V, counts_dev }, ic{ (long long)n_isects, counts_dev ? counts_dev + 1 : nullptr };
+    GS_CHECK_ARG(V >= 0 && n_isects >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0, "bad sizes");
+    GS_CHECK_ARG(n_isects < (1ll << 31), "n_isects must fit int32");
+    GS_CHECK_ARG((int64_t)tile_w * tile_h < (1ll << 24), "more than 2^24 tiles");
+    if (V == 0 || n_isects == 0) return GS_OK;
+    GS_CHECK_ARG(ws != nullptr, "workspace must not be NULL");
+    if (ws_bytes < gs_isect_bin_ws_bytes(V, n_isects, tile_w, tile_h)) { gs_set_error("gs_isect_bin: workspace too small"); return GS_ENOSPC; }
+    hipStream_t s = (hipStream_t)stream;
+    char* p = (char*)ws;
+    unsigned* table = (unsigned*)p; p += table_bytes((int64_t)V > n_isects ? (int64_t)V : n_isects);
+    uint2* da = (uint2*)p; p += align256((size_t)V * 8);
+    uint2* db = (uint2*)p; p += align256((size_t)V * 8);
+    uint2* rect = (uint2*)p; p += align256((size_t)V * 8);
+    const int eblocks = (V + EM_TILE - 1) / EM_TILE;
+    unsigned* state = (unsigned*)p; p += bf_state_bytes(V);     // look-back state of the emission
+    uint2* ia = (uint2*)p; p += align256((size_t)n_isects * 8);
+    uint2* ib = (uint2*)p; p += align256((size_t)n_isects * 8);
+    int tb = 0;
+    while ((1 << tb) < tile_w * tile_h) ++tb;
+    if (tb < 1) tb = 1;
+    const int npass = (tb + 7) / 8, width = (tb + npass - 1) / npass;
+    int rc = GS_OK;
+    // 1. depth order of the Gaussians: four stable 8-bit passes over (depth bits, index); the first reads the depth array
+    rc = radix_pass<uint2>(vc, DepthIn{ depths }, XDigit{ 0, 255u }, U2Out{ da }, 8, table, s);
+    if (rc != GS_OK) return rc;
+    rc = radix_pass<uint2>(vc, U2In{ da }, XDigit{ 8, 255u }, U2Out{ db }, 8, table, s);
+    if (rc != GS_OK) return rc;
+    rc = radix_pass<uint2>(vc, U2In{ db }, XDigit{ 16, 255u }, U2Out{ da }, 8, table, s);
+    if (rc != GS_OK) return rc;
+    rc = radix_pass<uint2>(vc, U2In{ da }, XDigit{ 24, 255u }, U2Out{ db }, 8, table, s);
+    if (rc != GS_OK) return rc;
+    // 2. emission in depth order: positions from a chained scan inside the launch (emit_chained_kernel, as gs_isect_bin_front)
+    GS_CHECK_ARG(tile_w < 65536 && tile_h < 65536, "tile grid too large");
+    hipLaunchKernelGGL(tile_rect_kernel, dim3(gs_cdiv(V, 256)), dim3(256), 0, s, vc, means2d, radii, tile_size, tile_w, tile_h, rect);
+    GS_CHECK_LAUNCH();
+    {
+        const int n_state_words = (int)(bf_state_bytes(V) / 4);
+        hipLaunchKernelGGL(bin_setup_kernel, dim3(gs_cdiv(n_state_words, 256) < 64 ? gs_cdiv(n_state_words, 256) : 64), dim3(256), 0, s, state,
+                           n_state_words, (const long long*)nullptr, 0ll, 0ll, (long long*)nullptr);
+        GS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(emit_chained_kernel, dim3(eblocks), dim3(EM_THREADS), 0, s, vc, (const uint2*)db, (const uint2*)rect, state,
+                           (u64*)((char*)state + 16), eblocks + 1, tile_w, ia, (unsigned)n_isects, (long long*)nullptr);
+        GS_CHECK_LAUNCH();
+    }
+    // 3. stable split by tile id: npass digits of `width` bits, the last one writes the sorted meta arrays
+    uint2* src = ia; uint2* dst = ib;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int shift = pass * width;
+        const int nbits = (tb - shift) < width ? (tb - shift) : width;
+        if (pass == npass - 1 && tile_ids_sorted != nullptr)
+            rc = radix_pass<uint2>(ic, U2In{ src }, XDigit{ shift, (1u << nbits) - 1u },
+                                   FinalTiles{ tile_ids_sorted, flatten_ids_sorted }, nbits, table, s);
+        else if (pass == npass - 1)
+            rc = radix_pass<uint2>(ic, U2In{ src }, XDigit{ shift, (1u << nbits) - 1u },
+                                   FinalOut{ (u64*)isect_ids_sorted, flatten_ids_sorted, depths }, nbits, table, s);
+        else
+            rc = radix_pass<uint2>(ic, U2In{ src }, XDigit{ shift, (1u << nbits) - 1u }, U2Out{ dst }, nbits, table, s);
+        if (rc != GS_OK) return rc;
+        uint2* t = src; src = dst; dst = t;
     }
     return GS_OK;
 }

@@ -25,10 +25,8 @@ import ctypes as C
 from . import _lib as L
 from .cameras import Camera
 from .parallel import GradBucket, collectives_active
-from .rasterization import (_bin_stage, _bin_stage_cap, _composite_stage, _composite_stage_cap, _forward_stages, _prepare_stage,
-                            _prepare_stage_cap, _project_stage)
 from . import front as F
-from .shading import _MODE, _TONE, RenderableAttrs, _make_env, get_fg_lut, shade_private_copies
+from .shading import _MODE, _TONE, RenderableAttrs, _make_env, get_fg_lut
 from .splitsum import (TextureSplitSum, as_splitsum, as_splitsum_backward, as_splitsum_backward_sharded,
                        as_splitsum_sharded, can_shard_prefilter)
 from .splats import SplatSet
@@ -80,12 +78,8 @@ class RenderStep:
         self._cam_cache: Dict[tuple, tuple] = {}
         self._side_stream = None
         self._tail_stream = None
-        self._pre_stream = None
         # capacity protocol state (see _step_fused / poll_capacity)
         self._use_capacity = os.environ.get("GEOSPLAT_CAPACITY", "1") != "0"
-        # GEOSPLAT_FRONT=split keeps the round-3 launch sequence (gs_shade_fwd -> gs_project_fwd_vis -> gs_isect_bin_tiles_cap ...,
-        # gs_project_bwd -> gs_shade_bwd); default: the fused front / tail kernels of csrc/gs_front.hip (front.py)
-        self._front_fused = os.environ.get("GEOSPLAT_FRONT", "fused") != "split"
         self._key_lo = self._key_hi = None     # depth-bit range seen so far (asynchronous read-back): sizes the 24-bit binning keys
         self._key32 = os.environ.get("GEOSPLAT_KEY_BITS", "24") == "32"   # forced by a key-range overflow, or by the environment
         self._cap_margin = float(os.environ.get("GEOSPLAT_CAPACITY_MARGIN", "1.25"))   # capacity = margin x the largest count seen
@@ -150,11 +144,16 @@ class RenderStep:
         self._cam_cache.clear()
 
     def _step_fused(self, cameras, upstream, all_reduce, keep_images, _env=None, _stop_after_views=False, _geo_only=False, _geo=None):
-        """Same arithmetic as the autograd path, driven directly through the C-ABI: every per-view backward ADDS into
-        the flat gradient bucket (accumulate flags of gs_project_bwd / gs_shade_bwd / gs_tonemap_bwd), the exp /
-        sigmoid activations of GSplatter.render_rgba (rfstudio/model/gsplat.py:336-339) are applied once per step and
-        chained once per step (their Jacobians do not depend on the view), and the prefilter backward runs once on the
-        texel gradients summed over the views."""
+        """Same arithmetic as the autograd path, driven directly through the C-ABI: every tail launch ADDS into the flat gradient
+        bucket, the exp / sigmoid activations of GSplatter.render_rgba (rfstudio/model/gsplat.py:336-339) are applied once per step
+        and chained once per step (their Jacobians do not depend on the view), and the prefilter backward runs once on the texel
+        gradients summed over the views.
+
+        HIP streams of a step: two FRONT streams run the memory / latency-bound front of every view (gs_front_fwd, the binning, the
+        record stream: ~22 short kernels, none of which fills the chip), the fronts of consecutive views alternating between them
+        (one: 638 views/s, two: 690, three: 655); the caller's stream runs the VALU-bound compositor forward / backward -- the step's
+        critical path; a tail stream runs the gradient kernels of the views in batches.  In capacity mode nothing makes the host wait,
+        so the fronts run as far ahead of the compositor as their inputs allow."""
         lib = L.lib()
         p = self.p
         dev = p.means.device
@@ -162,15 +161,12 @@ class RenderStep:
         f32 = torch.float32
         st = L.stream
         mode, tone = _MODE[self.mode], _TONE[self.tone_type]
-        # explicit prefilter backward (as_splitsum_backward) instead of autograd: it can then be split in two halves and
-        # the first half placed on its own stream, under the compositor of the remaining views
-        explicit_pre = self.prefilter
-        cubemap = p.cubemap.detach().requires_grad_(self.prefilter and not explicit_pre)
+        cubemap = p.cubemap.detach()
         import torch.distributed as dist
         world = dist.get_world_size() if (all_reduce and dist.is_available() and dist.is_initialized()) else 1
-        # S5 sharded over the ranks (each applies 1/world of every level's texels, all-gather): splitsum.py
+        # S5 sharded over the ranks (each applies 1/world of every level's tiles, all-reduce of the disjoint pieces): splitsum.py
         # (collectives_active(): more than one rank, or the one-rank RCCL run of GEOSPLAT_COLLECTIVES_AT_WORLD1=1)
-        sharded = (explicit_pre and all_reduce and collectives_active() and os.environ.get("GEOSPLAT_SHARD_PREFILTER", "1") != "0"
+        sharded = (self.prefilter and all_reduce and collectives_active() and os.environ.get("GEOSPLAT_SHARD_PREFILTER", "1") != "0"
                    and can_shard_prefilter(int(cubemap.shape[1]), world))
         # ---- what does not need the pyramid comes first: activations, streams, key width -- and, in capacity mode, the GEOMETRY of
         # the first view (projection, keys, binning: gs_front_fwd without records) on a front stream, so that it runs UNDER the
@@ -183,64 +179,49 @@ class RenderStep:
         means, quats = p.means.detach(), p.quats.detach()
         normals, kd, ks = p.normals.detach(), p.kd.detach(), p.ks.detach()
         main = torch.cuda.current_stream(dev)
-        if self._use_capacity and self._status is None:      # zero-filled on the main stream BEFORE the side stream forks from it
+        if self._use_capacity and self._status is None:      # zero-filled on the main stream BEFORE the side streams fork from it
             self._status = torch.zeros(4, dtype=torch.int64, device=dev)
         if self._side_stream is None:
-            # GEOSPLAT_FRONT_STREAMS=2: the fronts of consecutive views alternate between two streams (see start_view)
-            # (GEOSPLAT_CU_SLICES="front=lo:hi,...": streams on a slice of every XCD, _lib.masked_stream; measured, not the default)
-            self._side_stream = [L.stream_from_env("front", dev, int(os.environ.get("GEOSPLAT_SIDE_PRIO", "0")))
-                                 for _ in range(max(1, int(os.environ.get("GEOSPLAT_FRONT_STREAMS", "2"))))]
+            self._side_stream = [torch.cuda.Stream(device=dev) for _ in range(2)]
         sides = self._side_stream
-        fused_front = self._front_fused
         # tile rectangles clipped to the {alpha >= 1/255} extents (GEOSPLAT_TIGHT_TILES=0: gsplat's squares): 18 % fewer intersections
-        # on the bench scene, identical pixels (gs_front_fwd; the engine never returns gsplat's `meta`).  Stream build 106 -> 88 us,
-        # emission 89 -> 83, tile passes 47 -> 43 per view.  First measured as a loss (574 vs 581 views/s): the backward ran 20 %
-        # longer because its longest-first tile order came from the RAW list lengths, which the clipping decorrelates from the
-        # backward's work; with the order taken from the cull log (struct BwdOrder, gs_raster.hip) it is 660 against 645.
+        # on the bench scene, identical pixels (gs_front_fwd; the engine never returns gsplat's `meta`)
         tight = os.environ.get("GEOSPLAT_TIGHT_TILES", "1") != "0"
         # binning keys: 24 bits (three depth passes instead of four) once the depth range of earlier views is known -- key = depth
         # bits - key_base with half an octave of room below the smallest depth seen; a view outside the range is reported through
         # the status word (poll_capacity) and the engine falls back to 32-bit keys
         key_bits, key_base = 32, 0
-        if fused_front and self._use_capacity and self._i_cap is not None and not self._key32 and self._key_lo is not None:
+        if self._use_capacity and self._i_cap is not None and not self._key32 and self._key_lo is not None:
             base = max(0, self._key_lo - (1 << 22))
             if self._key_hi - base < (1 << 24) - (1 << 21):
                 key_bits, key_base = 24, base
         i_cap = self._i_cap if self._use_capacity else None
+        status = self._status if (key_bits == 24 or self._use_capacity) else None
         seen = []                                            # (pinned counts, event) of this step's views
         early = {}                                           # view index -> (flatten_ids, isect_offsets) binned under the prefilter
-        n_early = int(os.environ.get("GEOSPLAT_EARLY_BIN", "1"))
-        if _geo_only:
-            n_early = max(n_early, 1)                        # (its own graph: the first view(s), as in the eager step -- the geometry
-                                                             #  of two views beside the prefilter costs more than it hides)
         if _geo is not None:
             early = _geo["early"]
-        elif fused_front and i_cap is not None and (_env is None or _geo_only) and self.prefilter and n_early > 0:
+        elif i_cap is not None and (_env is None or _geo_only) and self.prefilter and len(cameras) > 0:
+            # (the geometry of ONE view: of two, beside the prefilter, costs more than it hides -- 563 against 580 views/s)
             ev_a = torch.cuda.Event(); ev_a.record(main)
-            for j in range(min(n_early, len(cameras))):
-                cam_j = cameras[j]
-                vm_j, K_j, cp_j = self._camera_tensors(cam_j)
-                side = sides[j % len(sides)]
-                side.wait_event(ev_a)
-                with torch.cuda.stream(side):
-                    # (round 5, measured and removed: the early front also writing the RECORDS -- colours left out -- and the record stream
-                    #  built here, so that only a colour pass is left behind the pyramid: 675 against 695 views/s.  What runs beside the
-                    #  prefilter's table stream slows IT down by more than it takes off the path behind it, as with a second view's geometry.)
-                    fr_g = F.front_stage(means, quats, scales_act, opac_act, normals, kd, ks, vm_j, K_j, cp_j, None, cam_j.width, cam_j.height,
-                                         self.min_roughness, self.max_metallic, mode, key_base, key_bits,
-                                         self._status if (key_bits == 24 or self._use_capacity) else None, records=False, tight_tiles=tight)
-                    gstate, _, _ = F.bin_stage(fr_g, i_cap, self._status, prepare=False)
-                seen.append((fr_g.host_counts, fr_g.event))
-                early[j] = (gstate["flatten_ids"], gstate["isect_offsets"])
-                for t in (scales_act, opac_act):
-                    t.record_stream(side)
+            vm_0, K_0, cp_0 = self._camera_tensors(cameras[0])
+            sides[0].wait_event(ev_a)
+            with torch.cuda.stream(sides[0]):
+                fr_g = F.front_stage(means, quats, scales_act, opac_act, normals, kd, ks, vm_0, K_0, cp_0, None, cameras[0].width,
+                                     cameras[0].height, self.min_roughness, self.max_metallic, mode, key_base, key_bits, status,
+                                     records=False, tight_tiles=tight)
+                gstate, _, _ = F.bin_stage(fr_g, i_cap, self._status, prepare=False)
+            seen.append((fr_g.host_counts, fr_g.event))
+            early[0] = (gstate["flatten_ids"], gstate["isect_offsets"])
+            for t in (scales_act, opac_act):
+                t.record_stream(sides[0])
         if _geo_only:
             for sd in sides:
                 main.wait_stream(sd)                         # (a captured phase: every forked stream joins before the capture ends)
             self._seen_counts.extend(seen)
             return dict(early=early, scales_act=scales_act, opac_act=opac_act)
-        # (zero fills of the step: issued BEFORE the prefilter, i.e. off the path pyramid -> first compositor launch -- 0.06 ms)
-        # ONE fill: the bucket, the activation-gradient accumulators and the texel-gradient accumulators share an allocation
+        # ONE fill, issued before the prefilter: the bucket, the activation-gradient accumulators and the texel-gradient accumulators
+        # share an allocation
         cres = int(p.cubemap.shape[1])
         tex_res = [cres]
         while tex_res[-1] > 16:
@@ -255,11 +236,9 @@ class RenderStep:
         elif self.prefilter:
             if sharded:
                 env = as_splitsum_sharded(cubemap, dist.get_rank(), world, self._prefilter_group())
-            elif explicit_pre:
+            else:
                 with torch.no_grad():
                     env = as_splitsum(cubemap)
-            else:
-                env = as_splitsum(cubemap)
         else:
             if self._static_env is None:
                 with torch.no_grad():
@@ -269,302 +248,144 @@ class RenderStep:
                                 env.max_roughness)
         lut = get_fg_lut(dev) if self.fg_lut is None else self.fg_lut
         e = _make_env(lut, env_d)
-        # texel-gradient accumulators.  Two sets (views [0, n/2) and [n/2, n)) with the first half's prefilter backward
-        # on its own stream under the remaining compositor work was measured: 30.4 vs 28.7 ms per step -- the backward is
-        # linear, so splitting it doubles its 2.4 ms and the overlap does not pay that back.  One set.
-        n_sets = 2 if (explicit_pre and not sharded and len(cameras) >= 4 and os.environ.get("GEOSPLAT_SPLIT_PREFILTER_BWD") == "1") else 1
-        g_sets = []
-        for k_set in range(n_sets):
-            # one flat buffer behind the base + level gradients: the sharded prefilter sums them over the ranks in ONE all-reduce
-            sizes = [env_d.base.numel()] + [l.numel() for l in env_d.levels]
-            g_flat = sc[2] if (k_set == 0 and sizes == tex_sizes) else torch.zeros(sum(sizes), dtype=f32, device=dev)
-            parts = torch.split(g_flat, sizes)
-            gb = parts[0].view_as(env_d.base); gl = [q.view_as(l) for q, l in zip(parts[1:], env_d.levels)]
-            egs = L.GsEnvGrad(); egs.base = gb.data_ptr()
-            for i, g in enumerate(gl):
-                egs.levels[i] = g.data_ptr()
-            g_sets.append((gb, gl, egs, g_flat))
-        g_base, g_levels, eg, _ = g_sets[0]
+        # texel-gradient accumulators: one flat buffer behind the base + level gradients (the sharded prefilter sums them over the
+        # ranks in ONE all-reduce).  (Two sets with the first half's prefilter backward under the remaining compositor work were
+        # measured: the backward is linear, splitting it doubles it, the overlap does not pay that back.)
+        sizes = [env_d.base.numel()] + [l.numel() for l in env_d.levels]
+        g_flat = sc[2] if sizes == tex_sizes else torch.zeros(sum(sizes), dtype=f32, device=dev)
+        parts = torch.split(g_flat, sizes)
+        g_base = parts[0].view_as(env_d.base); g_levels = [q.view_as(l) for q, l in zip(parts[1:], env_d.levels)]
+        eg = L.GsEnvGrad(); eg.base = g_base.data_ptr()
+        for i, g in enumerate(g_levels):
+            eg.levels[i] = g.data_ptr()
         self.last_texel_grads = (g_base, g_levels)           # d loss / d pyramid of this step (summed over the local views): tests read it
-        half = (len(cameras) + 1) // 2 if n_sets == 2 else len(cameras)
-        g_cube_first = None
-        ws_bytes = lib.gs_shade_bwd_ws_bytes(C.byref(e), mode) if shade_private_copies() else 0
-        # fused tail, GEOSPLAT_TAIL_PRIV=1: XCD-private copies of the MID-SIZED levels (64^2 / 128^2: 12 MB for all eight), zeroed here,
-        # accumulated by every view's tail, folded once after the last one (front.tail_priv_reduce).  Measured: 551 vs 553 views/s
-        # without -- the tail is bound by its 1.2 KB of traffic per Gaussian at one block per CU, not by the texel atomics: off.
-        tail_priv = (F.tail_priv_alloc(e, mode, dev) if (self._front_fused and n_sets == 1 and os.environ.get("GEOSPLAT_TAIL_PRIV", "0") == "1")
-                     else None)
-        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
 
         images = []
-
-        # HIP streams of a step.  The FRONT streams run the memory / latency-bound front of every view (shading, projection,
-        # intersection emit, radix passes, tile offsets, record stream: ~0.75 ms of ~22 short kernels, none of which fills the
-        # chip), the main stream the VALU-bound compositor forward / backward (~0.9 ms), a tail stream the gradient kernels.
-        # Fronts of consecutive views ALTERNATE between two streams: one front stream was the step's critical path (1.3 ms per
-        # view under contention against 0.98 ms of compositor work); with two, 496 -> 525 views/s (three: 502).  In capacity mode
-        # nothing makes the host wait, so the fronts run as far ahead of the compositor as their inputs allow.
         tail = self._tail_stream
         if tail is None:
-            tail = self._tail_stream = L.stream_from_env("tail", dev, int(os.environ.get("GEOSPLAT_TAIL_PRIO", "0")))
+            tail = self._tail_stream = torch.cuda.Stream(device=dev)
         for sd in sides:
             sd.wait_stream(main)                             # prefilter pyramid, activations, zeroed buckets
         tail.wait_stream(main)
 
-        # the tails of the views in ONE call per `tail_batch` views (gs_tail_bwd_multi_parts: the views of a Gaussian on adjacent lanes,
-        # its gradients stored once); 0 = one tail launch per view (gs_tail_bwd)
-        # Batches of 3 (8 views: after views 2, 5 and 7): the launches that are not the last run as BACKGROUND launches (parts + 4:
-        # half of the CUs) beside the compositor of the following views, and the last one, alone on the GPU, covers 2 views instead
-        # of 8 -- 670 -> 679 views/s (batches of 4: the same; one batch of 8: 670-676; per view: 640).
-        # Other view counts (8 views over 2 GPUs: 4 per rank): 4 views 2 + 2 568 against 552 (one batch) / 533-551 (3 + 1), 6 views
-        # 2 + 2 + 2 646 against 627 / 639 (3 + 3): the batch before the last has to be done when the last compositor backward ends.
-        tb = os.environ.get("GEOSPLAT_TAIL_BATCH", "auto")                                       # "auto", "3" or a schedule "3,4,1" (last repeats)
-        tail_sched = _auto_tail_schedule(len(cameras)) if tb == "auto" else [int(x) for x in tb.split(",")]
-        tail_batch = tail_sched[0] if (fused_front and n_sets == 1) else 0
+        # the tails of the views in ONE call per batch of views (gs_tail_bwd_multi_parts: the views of a Gaussian on adjacent lanes, its
+        # gradients stored once).  The launches that are not the last run as BACKGROUND launches (parts + 4: half of the CUs) beside the
+        # compositor of the following views, and the last one, alone on the GPU, covers 2 views instead of 8 (_auto_tail_schedule).
+        tb = os.environ.get("GEOSPLAT_TAIL_BATCH", "auto")                                       # "auto" or a schedule "3,4,1" (last repeats)
+        tail_sched = _auto_tail_schedule(len(cameras)) if tb == "auto" else [max(1, int(x)) for x in tb.split(",")]
         pending_tails = []
         n_tail_launches = 0
-        # the projection half of the LAST tail launch on a front stream (idle by then), beside the prefilter backward, which needs only
-        # the shading half (texel gradients): GEOSPLAT_TAIL_PROJ_STREAM=0 keeps both halves on the tail stream
-        proj_split = tail_batch > 0 and os.environ.get("GEOSPLAT_TAIL_PROJ_STREAM", "1") != "0"
         pstream = None
+
         def start_view(cam, j):                              # S1-S3 + A1; (V, I) travel to the host asynchronously
             vm, K, cam_pos = self._camera_tensors(cam)
             side = sides[j % len(sides)]
-            if fused_front:
-                with torch.cuda.stream(side):
-                    if j in early:                           # binned under the prefilter: only the records (shading) are still missing
-                        fr = F.front_stage(means, quats, scales_act, opac_act, normals, kd, ks, vm, K, cam_pos, e, cam.width, cam.height,
-                                           self.min_roughness, self.max_metallic, mode, want_packed_index=tail_batch > 0, binning=False,
-                                           tight_tiles=tight)
-                    else:
-                        fr = F.front_stage(means, quats, scales_act, opac_act, normals, kd, ks, vm, K, cam_pos, e, cam.width, cam.height,
-                                           self.min_roughness, self.max_metallic, mode, key_base, key_bits,
-                                           self._status if (key_bits == 24 or self._use_capacity) else None, want_packed_index=tail_batch > 0, tight_tiles=tight)
-                return fr, j, side
             with torch.cuda.stream(side):
-                col = torch.empty(N, 3, dtype=f32, device=dev)
-                L.check(lib.gs_shade_fwd(N, L.ptr(means), L.ptr(normals), L.ptr(kd), L.ptr(ks), L.ptr(cam_pos),
-                                         L.f32(self.min_roughness), L.f32(self.max_metallic), mode, C.byref(e), L.ptr(col),
-                                         st()), "gs_shade_fwd")
-                pr = _project_stage(means, quats, scales_act, opac_act, col, vm, K, cam.width, cam.height, 16, 0.3, 0.01,
-                                    1e10, 0.0)
-            return pr, col, side
+                if j in early:                               # binned under the prefilter: only the records (shading) are still missing
+                    fr = F.front_stage(means, quats, scales_act, opac_act, normals, kd, ks, vm, K, cam_pos, e, cam.width, cam.height,
+                                       self.min_roughness, self.max_metallic, mode, want_packed_index=True, binning=False, tight_tiles=tight)
+                else:
+                    fr = F.front_stage(means, quats, scales_act, opac_act, normals, kd, ks, vm, K, cam_pos, e, cam.width, cam.height,
+                                       self.min_roughness, self.max_metallic, mode, key_base, key_bits, status, want_packed_index=True,
+                                       tight_tiles=tight)
+            return fr, j, side
 
         # Capacity protocol (include/geosplat_hip.h): once the engine has seen the intersection counts of a step, the later
         # steps size every per-view buffer by (N, I_cap) and leave (V, I) on the device -- no read-back, no host wait inside
         # the step.  The counts still travel to pinned memory asynchronously; poll_capacity() looks at them (and at the
         # overflow status word) without blocking.
-        def bin_view(item):                                  # A2-A4 on the side stream (exact mode: host waits for that view's counts)
-            pr, col, side = item
-            if fused_front:
-                with torch.cuda.stream(side):
-                    if i_cap is not None:
-                        seen.append((pr.host_counts, pr.event))
-                    state, V, I = F.bin_stage(pr, i_cap, self._status, binned=early.get(col))   # (`col` carries the view index here)
-                    if i_cap is None:
-                        self._exact_max_i = max(self._exact_max_i, I)
-                        rng = F.depth_range(pr.host_counts)
-                        if rng is not None:
-                            self._key_lo = rng[0] if self._key_lo is None else min(self._key_lo, rng[0])
-                            self._key_hi = rng[1] if self._key_hi is None else max(self._key_hi, rng[1])
-                        F.release_counts4(pr.host_counts)
-                    state["colors"] = None                       # (D = 3: the colours travel in the record stream)
-                    state["v_packed"] = torch.zeros(max(V, 1), lib.gs_raster_grad_stride(3), dtype=f32, device=dev)
-                    ev = torch.cuda.Event(); ev.record(side)
-                for t in state.values():
-                    if isinstance(t, torch.Tensor):
-                        t.record_stream(main)
-                return state, V, I, 3, pr.whs, ev, None
+        def bin_view(item):                                  # A2-A4 + record stream on the front stream (exact mode: the host waits for that view's counts)
+            fr, j, side = item
             with torch.cuda.stream(side):
                 if i_cap is not None:
-                    seen.append((pr.host_counts, pr.event))       # read a step later by poll_capacity (never waited for here)
-                    state, V, I, D, whs = _bin_stage_cap(pr, i_cap, self._status, want_ids=False)   # no `meta` here: int32 tile ids do
-                    state = _prepare_stage_cap(state, V, I, D, whs)
-                else:
-                    state, V, I, D, whs = _bin_stage(pr)
+                    seen.append((fr.host_counts, fr.event))
+                state, V, I = F.bin_stage(fr, i_cap, self._status, binned=early.get(j))
+                if i_cap is None:
                     self._exact_max_i = max(self._exact_max_i, I)
-                    state = _prepare_stage(state, V, I, D, whs)  # record stream: HBM-bound, belongs on this stream too
+                    rng = F.depth_range(fr.host_counts)
+                    if rng is not None:
+                        self._key_lo = rng[0] if self._key_lo is None else min(self._key_lo, rng[0])
+                        self._key_hi = rng[1] if self._key_hi is None else max(self._key_hi, rng[1])
+                    F.release_counts4(fr.host_counts)
                 # the packed gradient records of this view, zeroed HERE (front stream, under the compositor of the previous view)
-                # instead of by a 126 MB memset in front of the compositor backward
-                state["v_packed"] = torch.zeros(V, lib.gs_raster_grad_stride(3), dtype=f32, device=dev)
+                state["v_packed"] = torch.zeros(max(V, 1), lib.gs_raster_grad_stride(3), dtype=f32, device=dev)
                 ev = torch.cuda.Event(); ev.record(side)
-            for t in list(state.values()) + [col] + list(pr.bufs):
+            for t in state.values():
                 if isinstance(t, torch.Tensor):
-                    t.record_stream(main)                    # allocated on the side stream, consumed on the main one
-            return state, V, I, D, whs, ev, col
+                    t.record_stream(main)
+            return state, V, I, ev
 
         n_views = len(cameras)
-        front_first = os.environ.get("GEOSPLAT_ENQUEUE", "main_first") == "front_first"
-        # S4 inside the compositor kernels (default): GEOSPLAT_FUSED_TONE=0 keeps the two tone-map launches
-        fused_tone = os.environ.get("GEOSPLAT_FUSED_TONE", "1") != "0"
-        use_log = fused_tone and os.environ.get("GEOSPLAT_RASTER_LOG", "1") != "0"      # forward -> backward cull log (csrc/gs_raster.hip)
         proj = [start_view(cameras[j], j) for j in range(min(2, n_views))]   # prologue: A(0), A(1), B1(0)
         binned = bin_view(proj.pop(0)) if n_views else None
         for i, cam in enumerate(cameras):
             vm, K, cam_pos = self._camera_tensors(cam)
             W, H = cam.width, cam.height
-            state, V, I, D, whs, ev, colors = binned
+            s, V, I, ev = binned
             main.wait_event(ev)
-            P = W * H
             kev = self.kernel_events
             if kev is not None:
                 k0 = torch.cuda.Event(enable_timing=True); k0.record(main)
-            if fused_tone:
-                # compositor with S4 in its epilogue: `img` comes out of the same launch (gs_raster_composite_tone)
-                render = torch.empty(H, W, 3, dtype=f32, device=dev); alphas = torch.empty(H, W, dtype=f32, device=dev)
-                last_ids = torch.empty(H, W, dtype=torch.int32, device=dev)
-                img = torch.empty(H, W, 4, dtype=f32, device=dev)
-                rws0 = state["raster_ws"]
-                if use_log:
-                    # the forward leaves its cull log (stream index + pixel mask of every record that entered a dense batch) for the
-                    # backward of this view, which then neither culls nor builds ellipse masks (raster_bwd_log_kernel)
-                    log_ws = torch.empty(lib.gs_raster_log_ws_bytes(L.i64(I), W, H, 16), dtype=torch.uint8, device=dev)
-                    L.check(lib.gs_raster_composite_tone_log(W, H, 16, V, L.ptr(state["colors"]), L.i64(I),
-                                                             L.ptr(state["counts"]) if i_cap is not None else None,
-                                                             L.ptr(state["isect_offsets"]), L.ptr(render), L.ptr(alphas), L.ptr(last_ids), tone,
-                                                             L.ptr(exposure), L.ptr(img), L.ptr(rws0), C.c_size_t(rws0.numel()),
-                                                             L.ptr(log_ws), C.c_size_t(log_ws.numel()), st()), "gs_raster_composite_tone_log")
-                else:
-                    L.check(lib.gs_raster_composite_tone(W, H, 16, V, L.ptr(state["colors"]), L.i64(I),
-                                                         L.ptr(state["counts"]) if i_cap is not None else None,
-                                                         L.ptr(state["isect_offsets"]), L.ptr(render), L.ptr(alphas), L.ptr(last_ids), tone,
-                                                         L.ptr(exposure), L.ptr(img), L.ptr(rws0), C.c_size_t(rws0.numel()), st()),
-                            "gs_raster_composite_tone")
-                s = dict(state, last_ids=last_ids)
-            elif i_cap is not None:
-                render, alphas, s = _composite_stage_cap(state, V, I, D, whs, None)
-            else:
-                render, alphas, s, V, I = _composite_stage(state, V, I, D, whs, None)
+            # compositor with S4 in its epilogue (`img` comes out of the same launch); it leaves its cull log (stream index + pixel mask
+            # of every record that entered a dense batch) for the backward of this view, which then neither culls nor builds masks
+            render = torch.empty(H, W, 3, dtype=f32, device=dev); alphas = torch.empty(H, W, dtype=f32, device=dev)
+            last_ids = torch.empty(H, W, dtype=torch.int32, device=dev)
+            img = torch.empty(H, W, 4, dtype=f32, device=dev)
+            rws = s["raster_ws"]
+            counts = L.ptr(s["counts"]) if i_cap is not None else None
+            log_ws = torch.empty(lib.gs_raster_log_ws_bytes(L.i64(I), W, H, 16), dtype=torch.uint8, device=dev)
+            L.check(lib.gs_raster_composite_tone_log(W, H, 16, V, None, L.i64(I), counts, L.ptr(s["isect_offsets"]), L.ptr(render),
+                                                     L.ptr(alphas), L.ptr(last_ids), tone, L.ptr(exposure), L.ptr(img), L.ptr(rws),
+                                                     C.c_size_t(rws.numel()), L.ptr(log_ws), C.c_size_t(log_ws.numel()), st()),
+                    "gs_raster_composite_tone_log")
             if kev is not None:
                 k1 = torch.cuda.Event(enable_timing=True); k1.record(main)
                 kev.append(("raster_fwd_kernel", k0, k1))
-            # keep the side streams two views ahead: A(i+2), then B1(i+1).  Their ~35 launches cost the host 0.2-0.3 ms: issued
-            # HERE (GEOSPLAT_ENQUEUE=front_first, the round-2 order) the compositor forward of this view has finished before the
-            # host reaches its backward -- the main stream, the step's critical path, idled 0.13-0.28 ms per view
-            # (profiles/r03_concurrency_one_step.txt).  Default: the rest of this view's main-stream chain first, the fronts after it.
-            if front_first:
-                if i + 2 < n_views:
-                    proj.append(start_view(cameras[i + 2], i + 2))
-                binned = bin_view(proj.pop(0)) if i + 1 < n_views else None
-            if not fused_tone:
-                img = torch.empty(H, W, 4, dtype=f32, device=dev)
-                L.check(lib.gs_tonemap_fwd3(L.i64(P), tone, L.ptr(render), L.ptr(alphas), L.ptr(exposure), L.ptr(img), st()), "gs_tonemap_fwd3")
             v_img = upstream(i, img).contiguous()
             v_packed = s["v_packed"]
-            rws = s["raster_ws"]
             if kev is not None:
                 k2 = torch.cuda.Event(enable_timing=True); k2.record(main)
-            if fused_tone and use_log:
-                L.check(lib.gs_raster_bwd_tone_log_acc(W, H, 16, V, L.ptr(s["colors"]), L.i64(I),
-                                                       L.ptr(s["counts"]) if i_cap is not None else None, L.ptr(s["isect_offsets"]),
-                                                       L.ptr(render), L.ptr(alphas), L.ptr(s["last_ids"]), tone, L.ptr(exposure), L.ptr(v_img),
-                                                       L.ptr(v_packed), L.ptr(b["exposure"]), L.ptr(rws), C.c_size_t(rws.numel()),
-                                                       L.ptr(log_ws), C.c_size_t(log_ws.numel()), st()), "gs_raster_bwd_tone_log_acc")
-            elif fused_tone:
-                # ... and S4 backward in the prologue of the compositor backward (gs_raster_bwd_tone_acc)
-                L.check(lib.gs_raster_bwd_tone_acc(W, H, 16, V, L.ptr(s["colors"]), L.i64(I),
-                                                   L.ptr(s["counts"]) if i_cap is not None else None, L.ptr(s["isect_offsets"]),
-                                                   L.ptr(render), L.ptr(alphas), L.ptr(s["last_ids"]), tone, L.ptr(exposure), L.ptr(v_img),
-                                                   L.ptr(v_packed), L.ptr(b["exposure"]), L.ptr(rws), C.c_size_t(rws.numel()), st()),
-                        "gs_raster_bwd_tone_acc")
-            else:
-                v_render = torch.empty(H, W, 3, dtype=f32, device=dev); v_alpha = torch.empty(H, W, dtype=f32, device=dev)
-                L.check(lib.gs_tonemap_bwd3(L.i64(P), tone, L.ptr(render), L.ptr(alphas), L.ptr(exposure), L.ptr(v_img), L.ptr(v_render),
-                                            L.ptr(v_alpha), L.ptr(b["exposure"]), 1, st()), "gs_tonemap_bwd3")
-                if i_cap is not None:
-                    L.check(lib.gs_raster_bwd_acc_cap(W, H, 16, 3, V, L.ptr(s["colors"]), None, L.i64(I), L.ptr(s["counts"]),
-                                                      L.ptr(s["isect_offsets"]), L.ptr(alphas), L.ptr(s["last_ids"]), L.ptr(v_render),
-                                                      L.ptr(v_alpha), L.ptr(v_packed), L.ptr(rws), C.c_size_t(rws.numel()), st()),
-                            "gs_raster_bwd_acc_cap")
-                else:
-                    L.check(lib.gs_raster_bwd_acc(W, H, 16, 3, V, L.ptr(s["colors"]), None, L.i64(I), L.ptr(s["isect_offsets"]),
-                                                  L.ptr(alphas), L.ptr(s["last_ids"]), L.ptr(v_render), L.ptr(v_alpha), L.ptr(v_packed),
-                                                  L.ptr(rws), C.c_size_t(rws.numel()), st()), "gs_raster_bwd_acc")
-            if kev is not None and fused_tone:                # (with the separate tone-map launches the bracket would include them)
+            L.check(lib.gs_raster_bwd_tone_log_acc(W, H, 16, V, None, L.i64(I), counts, L.ptr(s["isect_offsets"]), L.ptr(render),
+                                                   L.ptr(alphas), L.ptr(last_ids), tone, L.ptr(exposure), L.ptr(v_img), L.ptr(v_packed),
+                                                   L.ptr(b["exposure"]), L.ptr(rws), C.c_size_t(rws.numel()), L.ptr(log_ws),
+                                                   C.c_size_t(log_ws.numel()), st()), "gs_raster_bwd_tone_log_acc")
+            if kev is not None:
                 k3 = torch.cuda.Event(enable_timing=True); k3.record(main)
                 kev.append(("raster_bwd_kernel", k2, k3))
-            if not front_first:
-                if i + 2 < n_views:
-                    proj.append(start_view(cameras[i + 2], i + 2))
-                binned = bin_view(proj.pop(0)) if i + 1 < n_views else None
-            # gradient tail of the view (A7 + S1-S3 backward: HBM / atomic-rate bound) on a third stream, so that it
-            # overlaps the VALU-bound compositor of the next view; the tail kernels of successive views stay in order
-            # on that stream (they accumulate into the same gradient buffers)
-            g_colors = None if fused_front else torch.empty(N, 3, dtype=f32, device=dev)
-            eg = g_sets[0 if i < half else n_sets - 1][2]
-            if tail_batch > 0:
-                pending_tails.append((vm, K, cam_pos, s["vis_records"], v_packed, s["packed_index"], W, H))
-                if len(pending_tails) == tail_sched[min(n_tail_launches, len(tail_sched) - 1)] or i == n_views - 1:
-                    ev_r = torch.cuda.Event(); ev_r.record(main)
-                    split_now = proj_split and i == n_views - 1
-                    with torch.cuda.stream(tail):
-                        tail.wait_event(ev_r)
-                        F.tail_multi_stage(pending_tails, means, quats, scales_act, opac_act, normals, kd, ks, e, eg, self.min_roughness,
-                                           self.max_metallic, mode, b["means"], b["quats"], g_scales_act, g_opac_act, b["normals"], b["kd"],
-                                           b["ks"], accumulate=n_tail_launches > 0, priv=tail_priv,
-                                           parts=1 if split_now else (3 if i == n_views - 1 else 7))
-                    if split_now:
-                        ev_sh = torch.cuda.Event(); ev_sh.record(tail)
-                        pstream = sides[0]
-                        with torch.cuda.stream(pstream):
-                            pstream.wait_event(ev_sh)              # (v_means: the projection half adds to what the shading half stored)
-                            F.tail_multi_stage(pending_tails, means, quats, scales_act, opac_act, normals, kd, ks, e, eg, self.min_roughness,
-                                               self.max_metallic, mode, b["means"], b["quats"], g_scales_act, g_opac_act, b["normals"],
-                                               b["kd"], b["ks"], accumulate=n_tail_launches > 0, priv=tail_priv, parts=2)
-                    n_tail_launches += 1
-                    for tv in pending_tails:
-                        for t in tv[:6]:
-                            t.record_stream(tail)
-                            if split_now:
-                                t.record_stream(pstream)
-                    pending_tails = []
-                if keep_images:
-                    images.append(img)
-                continue
-            ev_r = torch.cuda.Event(); ev_r.record(main)
-            with torch.cuda.stream(tail):
-                tail.wait_event(ev_r)
-                if fused_front:
-                    F.tail_stage(V, s["counts"], means, quats, scales_act, opac_act, normals, kd, ks, vm, K, cam_pos, e, eg, W, H,
-                                 self.min_roughness, self.max_metallic, mode, s["vis_records"], v_packed, b["means"], b["quats"],
-                                 g_scales_act, g_opac_act, b["normals"], b["kd"], b["ks"], priv=tail_priv)
-                elif i_cap is not None:
-                    L.check(lib.gs_project_bwd_cap(N, L.ptr(s["counts"]), 3, L.ptr(means), L.ptr(quats), L.ptr(scales_act),
-                                                   L.ptr(opac_act), L.ptr(vm), L.ptr(K), W, H, L.f32(0.3),
-                                                   L.ptr(s["gaussian_ids_i32"]), L.ptr(s["conics"]), L.ptr(s["compensations"]),
-                                                   L.ptr(v_packed), 0, None, L.ptr(b["means"]), L.ptr(b["quats"]),
-                                                   L.ptr(g_scales_act), L.ptr(g_opac_act), L.ptr(g_colors), 1, st()),
-                            "gs_project_bwd_cap")
-                else:
-                    L.check(lib.gs_project_bwd(N, V, 3, L.ptr(means), L.ptr(quats), L.ptr(scales_act), L.ptr(opac_act), L.ptr(vm),
-                                               L.ptr(K), W, H, L.f32(0.3), L.ptr(s["gaussian_ids_i32"]), L.ptr(s["conics"]),
-                                               L.ptr(s["compensations"]), L.ptr(v_packed), 0, None,
-                                               L.ptr(b["means"]), L.ptr(b["quats"]), L.ptr(g_scales_act), L.ptr(g_opac_act),
-                                               L.ptr(g_colors), 1, st()), "gs_project_bwd")
-                if not fused_front:
-                    L.check(lib.gs_shade_bwd(N, L.ptr(means), L.ptr(normals), L.ptr(kd), L.ptr(ks), L.ptr(cam_pos),
-                                             L.f32(self.min_roughness), L.f32(self.max_metallic), mode, C.byref(e), L.ptr(g_colors),
-                                             L.ptr(b["means"]), L.ptr(b["normals"]), L.ptr(b["kd"]), L.ptr(b["ks"]), C.byref(eg), 1,
-                                             L.ptr(ws) if ws_bytes else None, C.c_size_t(ws_bytes), st()), "gs_shade_bwd")
-            for t in (v_packed, g_colors, s.get("gaussian_ids_i32"), s.get("conics"), s.get("compensations"), s.get("counts"), s.get("vis_records")):
-                if t is not None:
-                    t.record_stream(tail)                    # (`counts` too: gs_project_bwd_cap reads {V, I} on the tail stream)
-            if n_sets == 2 and i == half - 1:
-                # the first half of the texel gradients is complete: its prefilter backward (2.4 ms, latency-bound
-                # streaming) runs on its own stream under the compositor of the remaining views
-                pre = self._pre_stream
-                if pre is None:
-                    pre = self._pre_stream = torch.cuda.Stream(device=dev)
-                pre.wait_stream(tail)
-                with torch.cuda.stream(pre):
-                    g_cube_first = as_splitsum_backward(g_sets[0][0], g_sets[0][1], min_roughness=env.min_roughness,
-                                                        max_roughness=env.max_roughness)
+            # keep the front streams two views ahead: A(i+2), then B1(i+1) -- AFTER this view's main-stream chain has been enqueued
+            # (their ~35 launches cost the host 0.2-0.3 ms; issued first, the compositor stream idled that long per view)
+            if i + 2 < n_views:
+                proj.append(start_view(cameras[i + 2], i + 2))
+            binned = bin_view(proj.pop(0)) if i + 1 < n_views else None
+            # gradient tail (A7 + S1-S3 backward: HBM / atomic-rate bound) on the tail stream, beside the compositor of the next views
+            pending_tails.append((vm, K, cam_pos, s["vis_records"], v_packed, s["packed_index"], W, H))
+            last = i == n_views - 1
+            if len(pending_tails) == tail_sched[min(n_tail_launches, len(tail_sched) - 1)] or last:
+                ev_r = torch.cuda.Event(); ev_r.record(main)
+                targs = (pending_tails, means, quats, scales_act, opac_act, normals, kd, ks, e, eg, self.min_roughness, self.max_metallic,
+                         mode, b["means"], b["quats"], g_scales_act, g_opac_act, b["normals"], b["kd"], b["ks"])
+                with torch.cuda.stream(tail):
+                    tail.wait_event(ev_r)
+                    # (the LAST launch: its projection half on a front stream -- idle by then -- beside the prefilter backward, which
+                    #  needs only the shading half's texel gradients)
+                    F.tail_multi_stage(*targs, accumulate=n_tail_launches > 0, parts=1 if last else 7)
+                used = [tail]
+                if last:
+                    ev_sh = torch.cuda.Event(); ev_sh.record(tail)
+                    pstream = sides[0]
+                    with torch.cuda.stream(pstream):
+                        pstream.wait_event(ev_sh)              # (v_means: the projection half adds to what the shading half stored)
+                        F.tail_multi_stage(*targs, accumulate=n_tail_launches > 0, parts=2)
+                    used.append(pstream)
+                n_tail_launches += 1
+                for tv in pending_tails:
+                    for t in tv[:6]:
+                        for u in used:
+                            t.record_stream(u)
+                pending_tails = []
             if keep_images:
                 images.append(img)
         main.wait_stream(tail)
-        if tail_priv is not None:
-            F.tail_priv_reduce(e, g_sets[0][2], mode, tail_priv)
-            tail_priv.record_stream(tail)
         self._seen_counts.extend(seen)                       # entries of earlier steps the host has not looked at yet stay pending
         if i_cap is not None:                                # the overflow word follows the step to the host, asynchronously
             if torch.cuda.is_current_stream_capturing():      # a replayed graph refreshes ONE pinned buffer; replay.check() reads it
@@ -581,16 +402,16 @@ class RenderStep:
                 self._status.fill_(0)
                 ev_s = torch.cuda.Event(); ev_s.record()
                 self._status_pending.append((snap, ev_s))
-        # chain the once-per-step activations; the per-Gaussian gradients are now final, so their all-reduce (RCCL on
-        # the communication stream) overlaps the prefilter backward, whose cubemap gradient is reduced afterwards
-        with torch.cuda.stream(pstream if pstream is not None else main):      # (behind the projection half of the tail)
+        # chain the once-per-step activations (behind the projection half of the last tail); the per-Gaussian gradients are then
+        # final, so their all-reduce (RCCL on the communication stream) overlaps the prefilter backward
+        with torch.cuda.stream(pstream if pstream is not None else main):
             L.check(lib.gs_activation_chain(L.i64(N), L.ptr(g_scales_act), L.ptr(scales_act), L.ptr(g_opac_act), L.ptr(opac_act),
                                             L.ptr(b["scales"]), L.ptr(b["opacities"]), st()), "gs_activation_chain")
         if pstream is not None:
-            for t in (g_scales_act, g_opac_act, scales_act, opac_act):
+            for t in (scales_act, opac_act):
                 t.record_stream(pstream)
-        ctx = dict(b=b, images=(images if keep_images else None), g_sets=g_sets, n_sets=n_sets, g_cube_first=g_cube_first, env=env,
-                   sharded=sharded, world=world, explicit_pre=explicit_pre, cubemap=cubemap, all_reduce=all_reduce, main=main, pstream=pstream)
+        ctx = dict(b=b, images=(images if keep_images else None), g_base=g_base, g_levels=g_levels, g_flat=g_flat, env=env, sharded=sharded,
+                   world=world, all_reduce=all_reduce, main=main, pstream=pstream)
         if _stop_after_views:                                 # (a captured views segment: every forked stream joins before the capture ends)
             if pstream is not None:
                 main.wait_stream(pstream)
@@ -602,20 +423,17 @@ class RenderStep:
         """What follows the views of a step: gradient all-reduce (its per-Gaussian part under the prefilter backward) and the
         prefilter backward on the texel gradients summed over the views (and, sharded, over the ranks)."""
         import torch.distributed as dist
-        b, images, g_sets, n_sets, g_cube_first, env = (ctx[k] for k in ("b", "images", "g_sets", "n_sets", "g_cube_first", "env"))
-        sharded, world, explicit_pre, cubemap, all_reduce, main = (ctx[k] for k in ("sharded", "world", "explicit_pre", "cubemap", "all_reduce", "main"))
+        b, images, g_base, g_levels, g_flat, env = (ctx[k] for k in ("b", "images", "g_base", "g_levels", "g_flat", "env"))
+        sharded, world, all_reduce, main = (ctx[k] for k in ("sharded", "world", "all_reduce", "main"))
         pstream = ctx.get("pstream")                          # the per-Gaussian gradients become final on this stream (None: on main)
         head_stream = pstream if pstream is not None else main
-        g_base, g_levels = g_sets[0][0], g_sets[0][1]
-        keep_images = images is not None
         if sharded:
             grp = self._prefilter_group()
-            gb, gl, _, g_flat = g_sets[0]                       # (the split-backward experiment is single-GPU only: n_sets == 1 here)
             dist.all_reduce(g_flat, op=dist.ReduceOp.SUM, group=grp)             # texel gradients of ALL views: needed by every share
             start_head, _ = self.bucket.all_reduce_split("cubemap")
             with torch.cuda.stream(head_stream):
                 start_head()                                    # per-Gaussian segments: communication stream, default communicator
-            g_cube = as_splitsum_backward_sharded(gb, gl, dist.get_rank(), world, grp, min_roughness=env.min_roughness,
+            g_cube = as_splitsum_backward_sharded(g_base, g_levels, dist.get_rank(), world, grp, min_roughness=env.min_roughness,
                                                   max_roughness=env.max_roughness)
             b["cubemap"].copy_(g_cube)                          # identical on every rank: not reduced again
             if pstream is not None:
@@ -625,21 +443,8 @@ class RenderStep:
         start_head, finish = self.bucket.all_reduce_split("cubemap") if all_reduce else ((lambda: None), (lambda: None))
         with torch.cuda.stream(head_stream):
             start_head()
-        if self.prefilter and explicit_pre:
-            gb, gl, _, _ = g_sets[n_sets - 1]
-            if g_cube_first is not None:
-                g_cube = as_splitsum_backward(gb, gl, min_roughness=env.min_roughness, max_roughness=env.max_roughness)
-                main.wait_stream(self._pre_stream)
-                g_cube_first.record_stream(main)
-                torch.add(g_cube, g_cube_first, out=b["cubemap"])
-            else:                                               # (the finest level's transposed apply writes the bucket's slice itself)
-                as_splitsum_backward(gb, gl, min_roughness=env.min_roughness, max_roughness=env.max_roughness, out=b["cubemap"])
-        elif self.prefilter:
-            outs = [env.base] + list(env.levels)
-            gouts = [g_base] + g_levels
-            keep = [(o, g) for o, g in zip(outs, gouts) if o.requires_grad]
-            torch.autograd.backward([o for o, _ in keep], [g for _, g in keep])
-            b["cubemap"].copy_(cubemap.grad)
+        if self.prefilter:                                      # (the finest level's transposed apply writes the bucket's slice itself)
+            as_splitsum_backward(g_base, g_levels, min_roughness=env.min_roughness, max_roughness=env.max_roughness, out=b["cubemap"])
         if pstream is not None:
             main.wait_stream(pstream)
         finish()
@@ -747,7 +552,7 @@ class RenderStep:
         # pyramid -- replays on its own stream BESIDE the eager prefilter forward and its all-reduce, the rest behind both.  With one
         # view per GPU the chain front -> binning -> record stream -> compositor -> tail is serial; this takes ~0.5 ms of it off
         # the step's critical path (as the eager step does with its first view).
-        two = self._front_fused and os.environ.get("GEOSPLAT_GEO_GRAPH", "1") != "0"
+        two = os.environ.get("GEOSPLAT_GEO_GRAPH", "1") != "0"
         F.reserve_pinned(4 * len(cameras) + 2)                 # (the geometry fronts carry their own count read-backs)
         warm = torch.cuda.Stream(device=dev)
         warm.wait_stream(torch.cuda.current_stream(dev))
@@ -897,20 +702,6 @@ class RenderStep:
         """Forward + backward for `cameras`; `upstream(i, image)` returns d(loss)/d(image) for local view i.
         Returns (grads dict of views into the flat bucket, images or None)."""
         if self.fused and self.mode == "pbr":
-            if "main=" in os.environ.get("GEOSPLAT_CU_SLICES", "") and not getattr(self, "_in_masked_main", False):
-                # experiment: the compositor's stream on a slice of every XCD too (the caller's stream waits for it)
-                if getattr(self, "_masked_main", None) is None:
-                    self._masked_main = L.stream_from_env("main", self.p.means.device)
-                cur = torch.cuda.current_stream(self.p.means.device)
-                self._masked_main.wait_stream(cur)
-                self._in_masked_main = True
-                try:
-                    with torch.cuda.stream(self._masked_main):
-                        out = self.__call__(cameras, upstream, all_reduce, keep_images)
-                finally:
-                    self._in_masked_main = False
-                cur.wait_stream(self._masked_main)
-                return out
             self._throttle()                                 # first: the step that just left the window has finished, its word is readable
             self.poll_capacity(_internal=True)               # non-blocking: counts / overflow words of the finished steps (an overflow
                                                              # seen here is kept for the caller's next poll_capacity())

@@ -17,8 +17,6 @@ from torch import Tensor
 
 from . import _lib as L
 
-import os
-_FRONT_HIST = os.environ.get("GEOSPLAT_FRONT_HIST", "1") != "0"
 _pinned_pool4 = []           # pinned int64[4] buffers for the asynchronous {V, I, ~min depth bits, max depth bits} read-back
 
 
@@ -59,9 +57,8 @@ def front_stage(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor,
     fr.rects = torch.empty(max(N, 1), 2, dtype=torch.int32, device=dev) if binning else None
     fr.counts = torch.empty(4, dtype=torch.int64, device=dev)
     tw, th = (W + tile_size - 1) // tile_size, (H + tile_size - 1) // tile_size
-    # (GEOSPLAT_FRONT_HIST=0: no per-tile histogram in the front kernel -- it then needs no LDS -- and the binning derives the
-    #  offsets from the sorted tile ids; also what happens by itself above 8 192 tiles)
-    fr.tile_counts = torch.empty(tw * th, dtype=torch.int32, device=dev) if (_FRONT_HIST and binning and tw * th <= 8192) else None
+    # (above 8 192 tiles the front kernel keeps no per-tile histogram and the binning derives the offsets from the sorted tile ids)
+    fr.tile_counts = torch.empty(tw * th, dtype=torch.int32, device=dev) if (binning and tw * th <= 8192) else None
     fr.packed_index = torch.empty(max(N, 1), dtype=torch.int32, device=dev) if want_packed_index else None
     ws_bytes = lib.gs_front_ws_bytes(N)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)

@@ -30,6 +30,10 @@ class _Projected:
 _pinned_pool = []
 
 
+# "depth_major" (gs_isect_bin) or "emit_sort" (gs_isect_emit + gs_isect_sort: the upstream call shape, kept for callers that hold
+# emitted keys; tests compare the two bit for bit)
+BINNING = "depth_major"
+
 def _project_stage(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Optional[Tensor],
                    viewmat: Tensor, K: Tensor, W: int, H: int, tile_size: int, eps2d: float, near: float,
                    far: float, radius_clip: float) -> _Projected:
@@ -91,7 +95,7 @@ def _bin_stage(pr: _Projected, depth_channel: bool = False):
     colors_p = colors_p.contiguous()
 
     ids_s = torch.empty(I, dtype=torch.int64, device=dev); flat_s = torch.empty(I, dtype=i32, device=dev)
-    if os.environ.get("GEOSPLAT_BINNING", "depth_major") == "emit_sort":        # the upstream call shape: emit, then sort the pairs
+    if BINNING == "emit_sort":                                                   # the upstream call shape: emit, then sort the pairs
         ids = torch.empty(I, dtype=torch.int64, device=dev); flat = torch.empty(I, dtype=i32, device=dev)
         L.check(lib.gs_isect_emit(V, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(cum), tile_size, tw, th,
                                   L.ptr(ids), L.ptr(flat), st), "gs_isect_emit")

@@ -43,13 +43,11 @@ def specular_bounds(res: int, roughness: float, cutoff: float, device: torch.dev
     if key not in _bounds_cache:
         ct = ndf_cutoff(roughness, cutoff)
         b = torch.empty(6, res, res, 24, dtype=torch.float32, device=device)
-        if os.environ.get("GEOSPLAT_BOUNDS", "fast") == "reference":     # the kernel shaped like SpecularBoundsKernel (0.2 s at 512^2)
-            L.check(L.lib().gs_specular_bounds(res, L.f32(ct), L.ptr(b), L.stream()), "gs_specular_bounds")
-        else:
-            nbytes = L.lib().gs_specular_bounds_ws_bytes(res)
-            ws = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
-            L.check(L.lib().gs_specular_bounds_fast(res, L.f32(ct), L.ptr(dir_table(res, device)), L.ptr(b), L.ptr(ws), C.c_size_t(nbytes),
-                                                    L.stream()), "gs_specular_bounds_fast")
+        # (gs_specular_bounds is the kernel shaped like the reference's SpecularBoundsKernel, 0.2 s at 512^2; tests compare the two)
+        nbytes = L.lib().gs_specular_bounds_ws_bytes(res)
+        ws = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+        L.check(L.lib().gs_specular_bounds_fast(res, L.f32(ct), L.ptr(dir_table(res, device)), L.ptr(b), L.ptr(ws), C.c_size_t(nbytes),
+                                                L.stream()), "gs_specular_bounds_fast")
         _bounds_cache[key] = (ct, b)
     return _bounds_cache[key]
 
@@ -68,7 +66,7 @@ def dir_table(res: int, device: torch.device) -> Tensor:
 
 
 # ----------------------------------------------------------------------------- tiled pair-weight tables (levels with R >= 64)
-TILED_PREFILTER = os.environ.get("GEOSPLAT_PREFILTER_TILES", "1") != "0"     # 0: every level through the direct kernels
+TILED_PREFILTER = True            # False (tests): every level through the direct kernels
 BWD_MARGIN = 2                    # candidate outputs of a source texel: its own lobe box grown by this (csrc GS_SPECULAR_BWD_MARGIN)
 _ROW_PAD = 8                      # csrc GS_TILE_ROW_PAD
 
@@ -83,14 +81,7 @@ def tile_geometry(res: int) -> Tuple[int, int]:
     """(bw, nb): blocks per tile row, blocks per tile, for the 16 waves of a workgroup.  Large tiles where the lobes are small
     against the face (the staged rectangle grows by the lobe diameter once per tile), one 8x8 block split over all 16 waves
     where a lobe covers most of a face and the level has few texels."""
-    override = os.environ.get("GEOSPLAT_TILE_GEOMETRY")       # experiments: "512:4,16;256:2,4" = res:bw,nb;...
-    if override:
-        for item in override.split(";"):
-            r, g = item.split(":")
-            if int(r) == res:
-                bw, nb = (int(v) for v in g.split(","))
-                return bw, nb
-    # measured per level with scripts/prefilter_bench.py (GEOSPLAT_TILE_GEOMETRY sweeps, profiles/r03_prefilter_geometry.txt)
+    # measured per level with scripts/prefilter_bench.py (profiles/r03_prefilter_geometry.txt)
     if res >= 512:
         return 4, 16          # 32 x 32 texels, one wave per block (32x16: 217 us instead of 161; 16x16: 273)
     if res >= 128:
@@ -232,12 +223,12 @@ def _tiles_apply(entry: Dict, direction: str, src: Tensor, dst: Tensor, tile_beg
                                             L.ptr(dst), tile_begin, te, C.c_size_t(d["lds_bytes"]), L.stream()), "gs_specular_tiles_apply")
 
 
-MERGED_APPLY = os.environ.get("GEOSPLAT_PREFILTER_MERGED", "1") != "0"     # 0: one launch per level (rounds 3-5)
+MERGED_APPLY = True               # False (tests): one launch per level, the launch sequence of rounds 3-5
 
 
 def _tiles_apply_multi(jobs, direction: str, world: int = 1) -> None:
     """All levels of one direction in ONE launch (gs_specular_tiles_apply_multi): jobs = [(entry, src, dst, tile_begin, tile_end)].
-    Falls back to one launch per level when the levels do not share n_mirrors (or GEOSPLAT_PREFILTER_MERGED=0)."""
+    Falls back to one launch per level when the levels do not share n_mirrors (or MERGED_APPLY is off)."""
     jobs = [j for j in jobs if (j[4] if j[4] is not None else j[0]["n_tiles"]) > j[3]]
     if not jobs:
         return
@@ -245,6 +236,8 @@ def _tiles_apply_multi(jobs, direction: str, world: int = 1) -> None:
         for e, src, dst, t0, t1 in jobs:
             _tiles_apply(e, direction, src, dst, t0, t1, world)
         return
+    # (measured and removed: two launches by LDS class -- levels that need less than half of a CU's LDS, two workgroups per CU, apart
+    #  from the ones that need more: 0.710 + 0.747 ms against 0.696 + 0.728 for ONE launch at the largest level's LDS)
     bwd = direction == "bwd"
     arr = (L.GsTileLevel * len(jobs))()
     keep = []
@@ -276,7 +269,7 @@ def mip_chain(cubemap: Tensor, min_resolution: int = 16) -> List[Tensor]:
         res.append(r)
     if not res:
         return [cubemap]
-    if len(res) <= 5 and cubemap.shape[3] == 3 and R % (1 << len(res)) == 0 and os.environ.get("GEOSPLAT_MIP_CHAIN", "1") != "0":
+    if len(res) <= 5 and cubemap.shape[3] == 3 and R % (1 << len(res)) == 0:
         sizes = [6 * q * q * 3 for q in res]
         flat = torch.empty(sum(sizes), dtype=torch.float32, device=cubemap.device)
         outs = [t.view(6, q, q, 3) for t, q in zip(torch.split(flat, sizes), res)]

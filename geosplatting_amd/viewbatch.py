@@ -62,8 +62,7 @@ class _DeviceState:
         # two front streams (+ the caller's stream + the tail stream = the four hardware queues HIP maps its streams onto by default:
         # a third front stream is 2 % faster alone in a process -- 608 against 596 views/s -- and 13 % SLOWER, 520 against 595, in a
         # process that holds other streams, where two of them then share a queue)
-        n_front = max(1, int(os.environ.get("GEOSPLAT_SPLAT_FRONT_STREAMS", "2")))
-        self.fronts = [torch.cuda.Stream(device=dev) for _ in range(n_front)]
+        self.fronts = [torch.cuda.Stream(device=dev) for _ in range(2)]
         self.tail = torch.cuda.Stream(device=dev)
         self.caps: "collections.OrderedDict[Tuple[int, int], _Capacity]" = collections.OrderedDict()   # by image size, least recently used first
         self.current: Optional["_Step"] = None   # the step new splat() calls may join
@@ -102,7 +101,7 @@ class _Capacity:
     def i_cap(self, n: int) -> Optional[int]:
         if self.ratio is None:
             return None
-        margin = float(os.environ.get("GEOSPLAT_SPLAT_CAPACITY_MARGIN", os.environ.get("GEOSPLAT_CAPACITY_MARGIN", "1.5")))
+        margin = float(os.environ.get("GEOSPLAT_CAPACITY_MARGIN", "1.5"))
         want = int(self.ratio * max(n, 1) * margin) + 1
         gran = 65536 if want >= (1 << 20) else 4096             # (stable buffer sizes for the caching allocator)
         return ((want + gran - 1) // gran) * gran
@@ -252,7 +251,7 @@ class _Step:
         ev = torch.cuda.Event(); ev.record(main)
         tail.wait_event(ev)
         tv = [(v.cam[0], v.cam[1], v.cam[2], v.state["vis_records"], v.state["v_packed"], v.state["packed_index"], v.W, v.H) for v in views]
-        split = final and os.environ.get("GEOSPLAT_TAIL_PROJ_STREAM", "1") != "0"
+        split = final
         args = (tv, t["means"], t["quats"], self.scales_act, self.opac_act, t["normals"], t["kd"], t["ks"], self.e, g["eg"], mr, mm, mode,
                 g["means"], g["quats"], g["scales_act"], g["opac_act"], g["normals"], g["kd"], g["ks"])
         with torch.cuda.stream(tail):
@@ -479,7 +478,7 @@ class _Gather(torch.autograd.Function):
         g, step.g = step.g, None
         main = torch.cuda.current_stream(st.dev)
         done = [v for v in step.views if v.done]
-        tail_stream = st.fronts[0] if os.environ.get("GEOSPLAT_TAIL_PROJ_STREAM", "1") != "0" else st.tail
+        tail_stream = st.fronts[0]
         tail_stream.wait_stream(st.tail)
         with torch.cuda.stream(tail_stream):                # behind the projection half; chains the once-per-step activations
             g_scales = g["scales_act"] * step.scales_act

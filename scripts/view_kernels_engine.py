@@ -19,4 +19,4 @@ step.poll_capacity(wait=True)
 for _ in range(reps):
     step([cam], lambda i, img: up, all_reduce=False)
     torch.cuda.synchronize()
-print("front:", "fused" if step._front_fused else "split", "i_cap", step._i_cap, "key32", step._key32, "key_lo/hi", step._key_lo, step._key_hi)
+print("i_cap", step._i_cap, "key32", step._key32, "key_lo/hi", step._key_lo, step._key_hi)

@@ -443,39 +443,39 @@ def test_tail_multi_equals_sum_of_view_tails(cuda, mode):
     close(t, tb, tl, *snaps[8], "background 3 + 3 + 2")
 
 
-def test_engine_front_modes_agree(cuda, monkeypatch):
-    """One step of the engine with the fused front / tail against the round-3 launch sequence (GEOSPLAT_FRONT=split): the same
-    images bit for bit, gradients to the order of the float atomics; and a second step runs with 24-bit keys."""
+def test_engine_equals_op_by_op_autograd_step(cuda, monkeypatch):
+    """One step of the engine (fused front, cull-log compositor, batched tails under several tail schedules) against the op-by-op
+    autograd step (RenderStep(fused=False) with GEOSPLAT_SPLAT=ops: shade -> rasterization -> tone_map, each checked against the oracle
+    elsewhere): the same images bit for bit, gradients to the order of the float atomics; and a second step runs on the capacity
+    protocol with 24-bit keys."""
     import geosplatting_amd.synthetic as syn
     from geosplatting_amd.engine import RenderStep, params_from_scene
     scene = syn.sphere_scene(4, seed=1, cubemap_res=64, device=cuda)
     cams = syn.blender_cameras(num=3, width=160, height=160)
     g = torch.Generator().manual_seed(0)
     ups = [(torch.rand(160, 160, 4, generator=g) * 2 - 1).to(cuda) for _ in cams]
-    out = {}
-    for mode in ("split", "fused", "fused_per_view"):
-        monkeypatch.setenv("GEOSPLAT_FRONT", "split" if mode == "split" else "fused")
-        monkeypatch.setenv("GEOSPLAT_TAIL_BATCH", "0" if mode == "fused_per_view" else "2")     # 3 views: a batch of two, then one that adds
+    monkeypatch.setenv("GEOSPLAT_SPLAT", "ops")
+    ref = RenderStep(params_from_scene(scene, cuda, exposure=1.2), fused=False)
+    rg, ri = ref(cams, lambda i, img: ups[i], all_reduce=False, keep_images=True)
+    torch.cuda.synchronize()
+    rg = {k: v.clone() for k, v in rg.items()}; ri = [im.clone() for im in ri]
+    monkeypatch.delenv("GEOSPLAT_SPLAT")
+    for sched in ("auto", "1", "2", "3"):                              # 3 views: 2 + 1 (auto), 1 + 1 + 1, 2 + 1, one launch
+        monkeypatch.setenv("GEOSPLAT_TAIL_BATCH", sched)
         step = RenderStep(params_from_scene(scene, cuda, exposure=1.2))
-        grads, images = step(cams, lambda i, img: ups[i], all_reduce=False, keep_images=True)
-        torch.cuda.synchronize()
-        first = ({k: v.clone() for k, v in grads.items()}, [im.clone() for im in images])
-        assert step.poll_capacity(wait=True)
-        grads, images = step(cams, lambda i, img: ups[i], all_reduce=False, keep_images=True)    # capacity mode (24-bit keys when fused)
-        torch.cuda.synchronize()
-        assert step.poll_capacity(wait=True) and step.truncated_steps == 0
-        if mode != "split":
-            assert step._key_lo is not None and not step._key32
-        out[mode] = (first, ({k: v.clone() for k, v in grads.items()}, [im.clone() for im in images]))
-    for other in ("fused", "fused_per_view"):
-        for which in (0, 1):
-            (ga, ia), (gb, ib) = out["split"][which], out[other][which]
-            for a, b in zip(ia, ib):
+        for which in (0, 1):                                          # exact counts, then the capacity protocol
+            grads, images = step(cams, lambda i, img: ups[i], all_reduce=False, keep_images=True)
+            torch.cuda.synchronize()
+            assert step.poll_capacity(wait=True) and step.truncated_steps == 0
+            for a, b in zip(images, ri):
                 assert torch.equal(a, b)
-            for k in ga:
+            for k in rg:
                 # float atomics in another order, and the projection backward is compiled with contraction on: its fused
                 # multiply-adds differ between the kernels it is inlined into (2.7e-5 on the scale gradients)
-                assert rel_err(gb[k].cpu().numpy(), ga[k].cpu().numpy()) < 5e-5, (other, which, k)
+                err = rel_err(grads[k].cpu().numpy(), rg[k].cpu().numpy())
+                # (quats / scales of flat disks: cancellation noise of a rotation gradient -- the 1e-4 bar of the full-size tests)
+                assert err < (1e-4 if k in ("quats", "scales") else 5e-5), (sched, which, k, err)
+        assert step._key_lo is not None and not step._key32 and step._i_cap is not None
 
 
 @pytest.mark.parametrize("n,res,mode", [(20000, 256, "exact"), (60000, 64, "exact"), (60000, 64, "capacity"), (90000, 32, "capacity")])

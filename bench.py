@@ -164,6 +164,15 @@ def time_view_without_prefilter(params, cam, up, iters):
     out = {"eager_ms": clock(fn), "graph_ms": None}
     try:
         if step.poll_capacity(wait=True) and step._i_cap is not None:
+            # the LAST (here: only) tail launch alone: shading half, then projection half -- what the multi-GPU step chunks and overlaps
+            # with its all-reduce (engine._chunked_tail)
+            step.tail_events = []
+            for _ in range(iters):
+                fn()
+            torch.cuda.synchronize()
+            tev, step.tail_events = step.tail_events, None
+            out["tail_shade_ms"] = sum(a.elapsed_time(b) for a, b, _ in tev) / len(tev)
+            out["tail_proj_ms"] = sum(b.elapsed_time(c) for _, b, c in tev) / len(tev)
             replay = step.capture([cam], lambda i, img: up)
             replay(); replay()
             out["graph_ms"] = clock(replay)
@@ -171,6 +180,23 @@ def time_view_without_prefilter(params, cam, up, iters):
                 out["graph_ms"] = None
     except Exception as e:                                   # the diagnostic must never take the bench line down
         out["graph_error"] = repr(e)[:200]
+    # the three graphs of the multi-GPU shape (engine.capture_views: geometry | records | views), each replayed ALONE: the terms of the
+    # strong-scaling model's critical path
+    try:
+        if out.get("graph_ms"):
+            step2 = RenderStep(params, prefilter=True)
+            for _ in range(2):
+                step2([cam], lambda i, img: up, all_reduce=False)
+            if step2.poll_capacity(wait=True) and step2._i_cap is not None:
+                seg = step2.capture_views([cam], lambda i, img: up, all_reduce=False)
+                seg(); seg()
+                torch.cuda.synchronize()
+                if seg.geo_graph is not None:
+                    out["geo_graph_ms"] = clock(seg.geo_graph.replay)
+                    out["rec_graph_ms"] = clock(seg.rec_graph.replay)
+                    out["views_graph_ms"] = clock(seg.graph.replay)
+    except Exception as e:
+        out["segments_error"] = repr(e)[:200]
     return out
 
 
@@ -306,24 +332,34 @@ def prefilter_report(cubemap, iters):
 XGMI_LINK_GBS = 153.0       # one xGMI link, one direction (MI355X: 7 links per GPU, fully connected 8-GPU node)
 
 
-def scale_model(view_ms, pre, n_gauss, cubemap_res, views_total, measured_1gpu_ms):
-    """Prediction of the STRONG-scaling step (views_total views over G GPUs, view i -> rank i mod G) from single-GPU measurements,
-    to be read beside the hardware curve: ceil(views/G) views at the time of one view alone (graph replay, pyramid fixed), the
-    tiled prefilter at 1/G, and the collectives of a step at the xGMI rate.  all-reduce of S bytes over G fully connected GPUs as
-    reduce-scatter + all-gather with every peer link in use: 2 (G-1)/G S / ((G-1) x 153 GB/s); on ONE link (a ring): x (G-1).
-    The per-Gaussian all-reduce overlaps the prefilter backward (engine._finish)."""
+def scale_model(view_ms, pre, n_gauss, cubemap_res, views_total, measured_1gpu_ms, detail=None, tail_chunks=4):
+    """Prediction of the STRONG-scaling step (views_total views over G GPUs, view i -> rank i mod G) from single-GPU measurements of
+    THIS run, to be read beside a hardware curve that the build loop never had: every term is a timed quantity or bytes / link rate.
+    all-reduce of S bytes over G fully connected GPUs as reduce-scatter + all-gather with every peer link in use:
+    2 (G-1)/G S / ((G-1) x 153 GB/s); on ONE link (a ring): x (G-1).
+    Critical path of a rank with ONE view (engine.capture_views + _finish, what the code does):
+        max( geometry graph ,  prefilter forward / G + pyramid all-reduce + records graph )        <- three graphs, two streams
+      + views graph without its last tail                                                           <- stream build .. compositor backward
+      + last tail in `tail_chunks` Gaussian ranges, chunk k's all-reduce under chunk k + 1's tail   <- _chunked_tail
+        beside: (behind the last shading half) texel all-reduce + prefilter backward / G + cubemap-piece all-reduce
+    Ranks with several views: views x (one view alone), the same ends (pessimistic: the fronts of a rank's views overlap its
+    compositor, as on one GPU)."""
     if view_ms is None:
         return None
+    d = detail or {}
     res, tiled = cubemap_res, []
     while res >= 16:
         tiled.append(res); res //= 2
-    pyramid = sum(6 * r * r * 3 * 4 for r in tiled if r >= 64)               # levels the tiled operator covers (splitsum.tiles_eligible)
-    texel = sum(6 * r * r * 3 * 4 for r in tiled) + 6 * 16 * 16 * 3 * 4        # base + every level: one flat buffer
+    pyramid = sum(6 * r * r * 3 * 4 for r in tiled)                          # every level goes through the tiled operator (R >= 16)
+    texel = pyramid + 6 * 16 * 16 * 3 * 4                                    # base + every level: one flat buffer
     per_gauss = 76 * n_gauss
     pre_fwd = pre["fwd_ms"] if pre else 0.0
     pre_bwd = pre["bwd_ms"] if pre else 0.0
     coll = {"pyramid_allreduce_bytes": pyramid, "texel_grad_allreduce_bytes": texel, "per_gaussian_grad_allreduce_bytes": per_gauss,
-            "cubemap_grad_pieces_allreduce_bytes": pyramid, "exposure_allreduce_bytes": 4}
+            "cubemap_grad_pieces_allreduce_bytes": pyramid, "exposure_allreduce_bytes": 4, "tail_chunks": tail_chunks}
+    t_geo, t_rec, t_views = d.get("geo_graph_ms"), d.get("rec_graph_ms"), d.get("views_graph_ms")
+    t_sh, t_pj = d.get("tail_shade_ms"), d.get("tail_proj_ms")
+    have = all(x is not None for x in (t_geo, t_rec, t_views, t_sh, t_pj))
     rows = []
     for G in (1, 2, 4, 8):
         vpr = -(-views_total // G)
@@ -332,18 +368,29 @@ def scale_model(view_ms, pre, n_gauss, cubemap_res, views_total, measured_1gpu_m
                          "views_per_s": None if not measured_1gpu_ms else views_total / measured_1gpu_ms * 1e3,
                          "basis": "measured (this run)" if measured_1gpu_ms else "not measured in this run"})
             continue
-        t = lambda S: 2.0 * (G - 1) / G * S / ((G - 1) * XGMI_LINK_GBS * 1e9) * 1e3       # ms, every peer link in use
-        small = t(pyramid) + t(texel) + t(pyramid)
-        tail = max(pre_bwd / G, t(per_gauss))                                            # the 76 B x N all-reduce runs under the prefilter backward
-        step = vpr * view_ms + pre_fwd / G + small + tail
-        ring = vpr * view_ms + pre_fwd / G + (G - 1) * small + max(pre_bwd / G, (G - 1) * t(per_gauss))
-        rows.append({"gpus": G, "views_per_gpu": vpr, "view_ms": vpr * view_ms, "prefilter_ms": (pre_fwd + pre_bwd) / G,
-                     "collectives_ms_all_links": small + t(per_gauss), "collectives_ms_one_link_ring": (G - 1) * (small + t(per_gauss)),
-                     "step_ms": step, "views_per_s": views_total / step * 1e3,
-                     "step_ms_one_link_ring": ring, "views_per_s_one_link_ring": views_total / ring * 1e3})
+        row = {"gpus": G, "views_per_gpu": vpr}
+        for links, tag in ((G - 1, ""), (1, "_one_link_ring")):
+            t = lambda S: 2.0 * (G - 1) / G * S / (links * XGMI_LINK_GBS * 1e9) * 1e3        # ms
+            if have:
+                tail = t_sh + t_pj
+                head = max(t_geo, pre_fwd / G + t(pyramid) + t_rec)
+                body = (t_views - tail) + (vpr - 1) * view_ms
+                a, r = tail / tail_chunks, t(per_gauss) / tail_chunks
+                tail_comm = (tail + r) if r <= a else (a + tail_chunks * r)                    # chunk pipeline: tail k + 1 over all-reduce k
+                ends = max(tail_comm, t_sh + t(texel) + pre_bwd / G + t(pyramid))
+                step = head + body + ends
+                row.update({"head_ms" + tag: head, "body_ms" + tag: body, "ends_ms" + tag: ends})
+            else:                                                                               # (no segment timings: the serial sum)
+                step = vpr * view_ms + pre_fwd / G + 2 * t(pyramid) + t(texel) + max(pre_bwd / G, t(per_gauss))
+            row.update({"step_ms" + tag: step, "views_per_s" + tag: views_total / step * 1e3,
+                        "speedup_vs_measured_1gpu" + tag: None if not measured_1gpu_ms else measured_1gpu_ms / step})
+        rows.append(row)
     return {"link_GBs": XGMI_LINK_GBS, "collectives": coll, "view_ms_alone": view_ms, "prefilter_fwd_ms": pre_fwd, "prefilter_bwd_ms": pre_bwd,
-            "rows": rows, "note": "prediction, not a measurement: latency of the five collectives (tens of microseconds each) and the host's "
-                                  "eager launches around the graph replay are not modelled"}
+            "segments_ms": {k: d.get(k) for k in ("geo_graph_ms", "rec_graph_ms", "views_graph_ms", "tail_shade_ms", "tail_proj_ms")},
+            "critical_path_model": have,
+            "rows": rows, "note": "prediction from this run's single-GPU timings, not a measurement (no multi-GPU box was ever available to the "
+                                  "build loop): latency of the collectives (tens of microseconds each), rank skew and the host's eager launches "
+                                  "around the graph replays are not modelled"}
 
 
 def cpu_baseline_cfg1():
@@ -704,7 +751,7 @@ def main():
             "call_shaped": call_shaped,
             "d14_deferred": d14,
             "strong_1gpu_ms": ms_per_step if (world == 1 and strong) else None,
-            "scale_model": scale_model(view_ms, pre, N, args.cubemap_res, views_total, ms_per_step if world == 1 else None),
+            "scale_model": scale_model(view_ms, pre, N, args.cubemap_res, views_total, ms_per_step if world == 1 else None, view_detail),
             "gpu_view_ms_without_prefilter": view_ms,
             "gpu_view_ms_detail": view_detail,
             "prefilter": pre,

@@ -21,7 +21,6 @@
 #include "gs_common.h"
 #include "gs_tone.h"
 #include <stdlib.h>
-#include <string.h>
 
 #pragma clang fp contract(off)   // sigma / compositing are spelled with explicit fmaf (bit-exact vs oracle)
 
@@ -1199,6 +1198,15 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
 //   * the queue needs 64 slots instead of 128, which buys 798 (+ 2 spare) pair slots instead of 448 in the same 9 984 bytes of LDS per wave:
 //     a dense batch is 64 records almost always (lanes2: 47 on average, i.e. 36 % more batches with their fixed costs).
 // Walk, record-lane reduction and commit are those of lanes2 (same arithmetic, same per-pixel order).
+// Round 6, built, correct (every gradient test green), measured and removed (`git show 35b5b24:geosplatting_amd/csrc/gs_raster.hip`,
+// raster_bwd_flat_kernel): the walk FLATTENED -- the pairs of a sub-batch laid out pixel after pixel as slots of two consecutive
+// candidates, every trip working 64 slots of whatever pixels, the transmittance / accumulator recurrences as two segmented scans over
+// the wave (DPP inside the rows, read-lanes across them, scalar flag masks), pixel state carried between chunks.  80.5 % of its candidate
+// slots hold a pair (per-pixel walk: 35.8 %) and it takes 333 k trips of 179 VALU instructions instead of 747 k of ~115 -- but the slot
+// codes cost an expansion loop per sub-batch, the codes' LDS leaves 616 instead of 790 pair slots (more sub-batches, each with its
+// transposes, scans, reduction set-up and commit), and the kernel ends at 169 M VALU wave instructions against 152 M: 0.43 ms alone
+// (0.45 with the chunks decoupled through carried state and late pulls) against 0.385, 671-684 against 698-702 views/s.  LDS bank
+// conflicts were NOT the reason (20.0 M against 20.8 M conflict cycles, rocprofv3 --pmc).
 #ifndef GS_LOG_PAIR_SLOTS
 #define GS_LOG_PAIR_SLOTS 790
 #endif
@@ -1653,483 +1661,6 @@ raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Backward from the cull log with a FLAT walk (round 6): see the comment at the walk.  LDS per wave: the queue, the masks and pair
-// bases of the dense batch, 616 (+ 2 spare) pair slots and the slot codes of a sub-batch -- 9 904 bytes, four workgroups per CU.
-#ifndef GS_FLAT_PAIR_SLOTS
-#define GS_FLAT_PAIR_SLOTS 616
-#endif
-static constexpr int GS_FLAT_PAIR_CAP = GS_FLAT_PAIR_SLOTS;
-static constexpr int GS_FLAT_SLOTS = GS_FLAT_PAIR_CAP / 2 + 32;       // slots of a sub-batch at most: sum of ceil(len / 2) over 64 pixels
-struct FlatLds {
-    static constexpr int Q_BYTES = 64 * (16 + 16 + 8 + 4);
-    static constexpr int OFF_MSK = Q_BYTES;
-    static constexpr int OFF_BASE = OFF_MSK + 64 * 8;
-    static constexpr int OFF_PAIR = OFF_BASE + 64 * 4;
-    static constexpr int OFF_CODE = OFF_PAIR + (GS_FLAT_PAIR_CAP + 2) * 8;
-    static constexpr int WAVE_BYTES = OFF_CODE + (GS_FLAT_SLOTS + 2) * 4;
-};
-
-// inclusive sum over the lanes in front (and the lane itself) without LDS: four DPP shifts inside the 16-lane rows, then the row totals
-// of the rows in front through row_bcast:15 / row_bcast:31 (the scan idiom of the GCN ISA guide)
-__device__ __forceinline__ int gs_wave_scan_i32(int x)
-{
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);      // row_shr:1 (lanes without a source inside the row add 0)
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
-    return x;
-}
-
-// select by a SCALAR lane mask: bit l of m set -> if_set, else if_clear (one v_cndmask_b32 with the mask in an SGPR pair)
-__device__ __forceinline__ float gs_sel_mask(unsigned long long m, float if_set, float if_clear)
-{
-    float r;
-    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
-    return r;
-}
-
-// Lane masks of a segmented scan over the wave, all scalar: F0..F3 = "the partial result of this lane already starts at a segment head
-// or at the start of its 16-lane row" before the in-row steps of distance 1, 2, 4, 8; NC = lanes whose segment started in an earlier
-// row (they take the carry of the rows in front); R1 / R2 = rows 1 / 2 in which no segment starts (their carry passes through).
-struct SegMasks { unsigned long long F0, F1, F2, F3, NC, H; bool open1, open2; };
-__device__ __forceinline__ SegMasks seg_masks(unsigned long long H)
-{
-    SegMasks m;
-    m.H = H;
-    m.F0 = H | 0x0001000100010001ull;
-    m.F1 = m.F0 | (m.F0 << 1);
-    m.F2 = m.F1 | (m.F1 << 2);
-    m.F3 = m.F2 | (m.F2 << 4);
-    unsigned long long g = H;                                      // in-row inclusive OR-prefix of the real heads
-    g |= (g << 1) & 0xfffefffefffefffeull;
-    g |= (g << 2) & 0xfffcfffcfffcfffcull;
-    g |= (g << 4) & 0xfff0fff0fff0fff0ull;
-    g |= (g << 8) & 0xff00ff00ff00ff00ull;
-    m.NC = ~g & ~0xffffull;
-    m.open1 = ((H >> 16) & 0xffffull) == 0ull;
-    m.open2 = ((H >> 32) & 0xffffull) == 0ull;
-    return m;
-}
-
-// EXCLUSIVE segmented scan of x over the wave (PRODUCT ? multiply : add): lane t gets the combination of the x of the lanes of its
-// segment in front of it (identity at a segment head).
-template <bool PRODUCT>
-__device__ __forceinline__ float seg_exclusive(float x, const SegMasks& m, int lane)
-{
-    const float ident = PRODUCT ? 1.0f : 0.0f;
-    auto op = [](float a, float b) { return PRODUCT ? a * b : a + b; };
-    // inclusive, inside the 16-lane rows
-    x = gs_sel_mask(m.F0, x, op(x, gs_row_shr<0x111>(ident, x)));
-    x = gs_sel_mask(m.F1, x, op(x, gs_row_shr<0x112>(ident, x)));
-    x = gs_sel_mask(m.F2, x, op(x, gs_row_shr<0x114>(ident, x)));
-    x = gs_sel_mask(m.F3, x, op(x, gs_row_shr<0x118>(ident, x)));
-    // carries of the rows in front (wave-uniform values)
-    const float r0 = gs_readlane(x, 15), r1 = gs_readlane(x, 31), r2 = gs_readlane(x, 47);
-    const float c1 = r0;
-    const float c2 = m.open1 ? op(r1, c1) : r1;
-    const float c3 = m.open2 ? op(r2, c2) : r2;
-    const float carry = lane < 32 ? c1 : (lane < 48 ? c2 : c3);
-    x = gs_sel_mask(m.NC, op(x, carry), x);
-    // exclusive: the inclusive value of the lane in front, identity at a head
-    const float prev = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, false));
-    return gs_sel_mask(m.H, ident, prev);
-}
-
-template <int CD>
-__global__ void __launch_bounds__(256)
-raster_bwd_flat_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* __restrict__ tile_order,
-                      const float4* __restrict__ rec0, const float4* __restrict__ rec1, const float4* __restrict__ rec2,
-                      const float* __restrict__ background, GsCount ic, const int32_t* __restrict__ offsets,
-                      const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
-                      const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-                      float* __restrict__ v_packed, int rec_stride, ToneBwd tone, CullLog log, BwdOrder bo)
-{
-    const int n_isects = (int)gs_count(ic);
-    static_assert(CD <= 3, "colours come from the record stream (D <= 3)");
-    using LD = FlatLds;
-    constexpr int NV = 6 + CD;
-    constexpr int RPI = 64 / NV;
-    static_assert(64 * NV * 4 <= GS_FLAT_PAIR_CAP * 8, "the commit staging aliases the pair buffer");
-    extern __shared__ __align__(16) unsigned char gs_lds_raw[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    int tile;
-    if (bo.bcount) {                                               // block b = the b-th tile of the bucket lists, longest bucket first
-        const int c = bo.bcount[lane];
-        int incl = c;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
-        const unsigned long long above = __ballot(incl > (int)blockIdx.x);
-        const int b = above ? __builtin_ctzll(above) : 63;
-        const int before = __builtin_amdgcn_readlane(incl - c, b);
-        // (the lists hold every tile once when ONE forward ran behind gs_raster_prepare*; anything else: the forward's own order)
-        tile = __builtin_amdgcn_readlane(incl, 63) == n_tiles
-                   ? __builtin_amdgcn_readfirstlane(bo.blist[(size_t)b * n_tiles + ((int)blockIdx.x - before)]) : tile_order[blockIdx.x];
-    } else {
-        tile = tile_order[blockIdx.x];
-    }
-    const int tx = tile % tile_w, ty = tile / tile_w;
-    const int qx0 = tx * GS_TILE + (wave & 1) * 8, qy0 = ty * GS_TILE + (wave >> 1) * 8;
-    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
-    const bool inside = pxi < W && pyi < H;
-    const float px = (float)pxi + 0.5f, py = (float)pyi + 0.5f;
-    const v2f pxy = v2f{px, py};
-
-    const int start = offsets[tile];
-    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
-    GS_TL_BEGIN(end - start);
-    if (end <= start) { GS_TL_END(); return; }
-
-    unsigned char* wbase = gs_lds_raw + (size_t)wave * LD::WAVE_BYTES;
-    float4* qa = (float4*)wbase; float4* qc = qa + 64; float2* qb = (float2*)(qc + 64); int* qidx = (int*)(qb + 64);
-    unsigned long long* msk = (unsigned long long*)(wbase + LD::OFF_MSK);
-    int* pbase = (int*)(wbase + LD::OFF_BASE);
-    float2* pairbuf = (float2*)(wbase + LD::OFF_PAIR);
-    int* codes = (int*)(wbase + LD::OFF_CODE);
-    float* stage = (float*)(wbase + LD::OFF_PAIR);              // aliases pairbuf (separated by wave syncs)
-
-    float T_final = 1.0f, v_a = 0.0f, v_exp = 0.0f;
-    int bin_final = -1;
-    float v_rc[CD];
-#pragma unroll
-    for (int k = 0; k < CD; ++k) v_rc[k] = 0.0f;
-    if (inside) {
-        const size_t pid = (size_t)pyi * W + pxi;
-        const float a_out = alphas[pid];
-        T_final = 1.0f - a_out;
-        bin_final = last_ids[pid];
-        if (CD == 3 && tone.v_image) {                            // S4 backward here (tonemap_bwd3_kernel's arithmetic, same order)
-#pragma clang fp contract(off)
-            const float e = tone.exposure[0];
-            const float r = tone.render[3 * pid], gch = tone.render[3 * pid + 1], bl = tone.render[3 * pid + 2];
-            const float4 g = tone.v_image[pid];
-            const float gx = g.x * tone_grad(tone.mode, r * e), gy = g.y * tone_grad(tone.mode, gch * e), gz = g.z * tone_grad(tone.mode, bl * e);
-            v_rc[0] = gx * e; v_rc[1] = gy * e; v_rc[2] = gz * e;
-            v_a = tone.mode == GS_TONE_NONE ? g.w * e : g.w;
-            v_exp = gx * r + gy * gch + gz * bl + (tone.mode == GS_TONE_NONE ? g.w * a_out : 0.0f);
-        } else {
-            v_a = v_alphas[pid];
-#pragma unroll
-            for (int k = 0; k < CD; ++k) if (k < D) v_rc[k] = v_render[pid * D + k];
-        }
-    }
-    if (CD == 3 && tone.v_image) {                                // one exposure-gradient atomic per quadrant wave
-        v_exp = gs_wave_sum(v_exp);
-        if (lane == 0 && v_exp != 0.0f) gs_atomic_add(tone.v_exposure, v_exp);
-    }
-    float bg_dot = 0.0f;
-    if (background) {
-#pragma unroll
-        for (int k = 0; k < CD; ++k) if (k < D) bg_dot += background[k] * v_rc[k];
-    }
-    float T = T_final;
-    float zacc = T_final * v_a - T_final * bg_dot;              // see raster_bwd_lanes2_kernel
-    const unsigned long long lane_lt = (1ull << lane) - 1ull;
-
-    int pos = __builtin_amdgcn_readfirstlane(log.count[4 * tile + wave]);       // log entries not yet taken (wave-uniform)
-    if (pos <= 0) { GS_TL_END(); return; }
-    const size_t log_base = 4 * (size_t)start + (size_t)wave * (size_t)(end - start);
-    const int32_t* lidx = log.idx + log_base;
-    const unsigned long long* lmsk = log.mask + log_base;
-    // software pipeline: entries two batches ahead, records one batch ahead.  Lanes past the log's start re-read entry 0 (a valid
-    // record: finite numbers for the zero-weight slots) and are masked out.
-    int e_idx, g_idx; unsigned long long e_msk, g_msk;
-    float4 g0, g1, g2;
-    {
-        const int e = pos - 1 - lane;
-        const int es = e >= 0 ? e : 0;
-        g_idx = lidx[es]; g_msk = e >= 0 ? lmsk[es] : 0ull;
-        g0 = rec0[g_idx]; g1 = rec1[g_idx]; g2 = rec2[g_idx];
-        const int e2 = pos - 65 - lane;
-        const int es2 = e2 >= 0 ? e2 : 0;
-        e_idx = lidx[es2]; e_msk = e2 >= 0 ? lmsk[es2] : 0ull;
-    }
-    while (pos > 0) {
-        const int nb = pos < 64 ? pos : 64;
-        // ---- issue the loads of the batches behind this one, then publish this batch's records in the queue
-        const float4 c0 = g0, c1 = g1, c2 = g2;
-        const int c_idx = g_idx;
-        const unsigned long long c_msk = g_msk;
-        g_idx = e_idx; g_msk = e_msk;
-        g0 = rec0[g_idx]; g1 = rec1[g_idx]; g2 = rec2[g_idx];
-        {
-            const int e2 = pos - 129 - lane;
-            const int es2 = e2 >= 0 ? e2 : 0;
-            e_idx = lidx[es2]; e_msk = e2 >= 0 ? lmsk[es2] : 0ull;
-        }
-        pos -= nb;
-        GS_PHASE_BEGIN();
-        lanes_lds_sync();                                           // (the previous batch's commit has read its queue slots)
-        qa[lane] = c0; qb[lane] = make_float2(c1.x, c1.y); qc[lane] = c2; qidx[lane] = c_idx;
-        GS_STAT(5, nb);
-        const int idx_low = __builtin_amdgcn_readlane(c_idx, nb - 1);
-        const bool live = bin_final >= idx_low;
-        const unsigned long long act = __ballot(live);
-        const unsigned long long pm = lane < nb ? (c_msk & act) : 0ull;
-        if (__ballot(pm != 0ull) == 0ull) { GS_PHASE_END(1); continue; }
-        const float4 ra4 = c0;                                     // the record this lane OWNS in the reduction
-        const float2 rb4 = make_float2(c1.x, c1.y);
-        const int cnt = __popcll(pm);
-        int cum = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int up = __shfl_up(cum, off, 64);
-            if (lane >= off) cum += up;
-        }
-        GS_PHASE_END(1);
-        // ---- sub-batches: as many records as the pair buffer holds (almost always all 64)
-        int r0 = 0, cumbase = 0;
-        while (r0 < nb) {
-            const int r1 = r0 + __popcll(__ballot(lane >= r0 && lane < nb && (cum - cumbase) <= GS_FLAT_PAIR_CAP));
-            const bool mine = lane >= r0 && lane < r1;
-            const unsigned long long pms = mine ? pm : 0ull;
-            lanes_lds_sync();
-            msk[lane] = pms;
-            pbase[lane] = cum - cnt - cumbase;
-            const unsigned long long list = gs_bit_transpose64(pms, lane);
-            // ---- FLAT walk (round 6).  The per-pixel walk popped two candidates per lane and trip until the LONGEST list of the
-            // quadrant was empty: 36 % of its candidate slots held a pair.  Here the pairs of a sub-batch are laid out flat, pixel after
-            // pixel, as SLOTS of two consecutive candidates of one pixel (a list of odd length leaves half a slot empty), and every trip
-            // works 64 slots whatever pixel they belong to:
-            //   * expansion: pixel lane p writes ceil(len / 2) codes {p, j0, j1} from the exclusive scan of the slot counts -- the one
-            //     loop that still runs to the longest list, at ~12 instructions per trip;
-            //   * per chunk of 64 slots every lane evaluates ITS two candidates (the packed arithmetic of the per-pixel walk), which
-            //     gives the slot's transmittance multiplier P = m0 m1 and its accumulator decrement per unit of transmittance S;
-            //   * the recurrences across the slots of a pixel are two SEGMENTED scans over the wave (segment = pixel): the exclusive
-            //     product of P gives the transmittance in front of a slot, the exclusive sum of T_start S the accumulator; inside a
-            //     16-lane row with DPP shifts, across rows through three read-lanes; the flags are scalar lane masks;
-            //   * the pixel's lane takes the state behind its last slot of the chunk.
-            // Same candidates in the same order as before; the products are associated differently (a gradient, 1e-5).
-            const int ns = (__popcll(list) + 1) >> 1;
-            int so = gs_wave_scan_i32(ns);
-            const int n_slots = __builtin_amdgcn_readlane(so, 63);
-            so -= ns;                                                  // first slot of this pixel
-            lanes_lds_sync();                                          // (msk / pbase of this sub-batch are visible; the codes of the last one are dead)
-            {
-                unsigned long long l = list;
-                int w = so;
-                if (__ballot(l != 0ull) != 0ull) do {
-                    const bool h0 = l != 0ull;
-                    const int j0 = gs_pop_lowest(l);
-                    const bool h1 = l != 0ull;
-                    const int j1 = gs_pop_lowest(l);
-                    codes[h0 ? w : GS_FLAT_SLOTS] = (lane << 13) | ((h1 ? 1 : 0) << 12) | (j1 << 6) | j0;   // (no candidate: the spare word)
-                    w += h0 ? 1 : 0;
-                } while (__ballot(l != 0ull) != 0ull);
-            }
-            lanes_lds_sync();
-            long long _pw0 = 0;
-#ifdef GS_RASTER_PHASES
-            if (blockIdx.x == 0 && threadIdx.x == 0) { _pw0 = (long long)__builtin_readcyclecounter(); atomicAdd(&g_raster_stats[6], 1ull); }
-#endif
-            // A pixel's slots are contiguous, so inside a sub-batch the state a slot starts from is either the pixel's state in front of
-            // the sub-batch (T0, Z0: read-only here) or -- for the ONE pixel that continues across a chunk boundary -- the state behind
-            // the last slot of the previous chunk (cT, cZ: wave-uniform).  No chunk waits for the pixel lanes' update of the one before.
-            const float T0 = T, Z0 = zacc;
-            float cT = 0.0f, cZ = 0.0f;
-            int cp = -1;
-            float pT = 0.0f, pZ = 0.0f;                               // the pixel lanes' update of the previous chunk, applied one chunk late
-            bool ptouched = false;
-            int code = codes[n_slots > lane ? lane : n_slots - 1];
-            for (int s0 = 0; s0 < n_slots; s0 += 64) {
-                GS_STAT(6, 1);
-#ifdef GS_RASTER_PHASES
-                if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_raster_stats[5], 1ull);
-#endif
-                const int t = s0 + lane;
-                const bool hs = t < n_slots;
-                const int p = code >> 13, j0 = code & 63, j1 = (code >> 6) & 63;
-                const bool has0 = hs, has1 = hs & (((code >> 12) & 1) != 0);
-                const float4 a0 = qa[j0], a1 = qa[j1];
-                const float2 b0 = qb[j0], b1 = qb[j1];
-                const float4 cc0 = qc[j0], cc1 = qc[j1];
-                const int idx0 = qidx[j0], idx1 = qidx[j1];
-                const unsigned long long below = (1ull << p) - 1ull;
-                const int e0 = pbase[j0] + __popcll(msk[j0] & below), e1 = pbase[j1] + __popcll(msk[j1] & below);
-                // the pixel's constants and its state in front of the sub-batch, from the pixel's own lane
-                const int pa = p << 2;
-                const int bf = __builtin_amdgcn_ds_bpermute(pa, bin_final);
-                float vr[CD];
-#pragma unroll
-                for (int c = 0; c < CD; ++c) vr[c] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(pa, __builtin_bit_cast(int, v_rc[c])));
-                float T_pix = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(pa, __builtin_bit_cast(int, T0)));
-                float Z_pix = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(pa, __builtin_bit_cast(int, Z0)));
-                {
-                    const int tn = t + 64;                            // the next chunk's code travels under this chunk's arithmetic
-                    code = codes[tn < n_slots ? tn : n_slots - 1];
-                }
-                T = ptouched ? pT : T;                                // (the previous chunk's pulls have long arrived)
-                zacc = ptouched ? pZ : zacc;
-                const v2f ppx = v2f{(float)(qx0 + (p & 7)) + 0.5f, (float)(qy0 + (p >> 3)) + 0.5f};
-                v2f sigma, ov, alpha, ra;
-                {
-#pragma clang fp contract(off)
-                    const v2f d0 = v2f{a0.x, a0.y} - ppx, d1 = v2f{a1.x, a1.y} - ppx;                 // {dx, dy}
-                    const v2f p0 = v2f{a0.z, a0.w} * v2f{d0.x, d0.x}, p1 = v2f{a1.z, a1.w} * v2f{d1.x, d1.x};   // {ha dx, cb dx}
-                    sigma.x = gs_sigma_xy(d0, p0, b0.x);
-                    sigma.y = gs_sigma_xy(d1, p1, b1.x);
-#ifndef GS_BWD_LOG_EXACT_MATH
-                    ov = v2f{b0.y, b1.y} * v2f{__builtin_amdgcn_exp2f(sigma.x * -1.4426950408889634f), __builtin_amdgcn_exp2f(sigma.y * -1.4426950408889634f)};
-                    alpha = __builtin_elementwise_min(ov, (v2f)(0.999f));
-                    {
-                        const v2f x = (v2f)(1.0f) - alpha;
-                        const v2f r0 = v2f{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)};
-                        ra = __builtin_elementwise_fma(r0, __builtin_elementwise_fma(-x, r0, (v2f)(1.0f)), r0);
-                    }
-#else
-                    ov = v2f{b0.y, b1.y} * gs_exp_neg_live2(sigma);
-                    alpha = __builtin_elementwise_min(ov, (v2f)(0.999f));
-                    ra = gs_rcp_exact2((v2f)(1.0f) - alpha);
-#endif
-                }
-                const bool ok0 = has0 & (idx0 <= bf) & (sigma.x >= 0.0f) & (alpha.x >= GS_ALPHA_MIN);
-                const bool ok1 = has1 & (idx1 <= bf) & (sigma.y >= 0.0f) & (alpha.y >= GS_ALPHA_MIN);
-#ifdef GS_RASTER_STATS
-                if (ok0) GS_STAT_ALL(7, 1);
-                if (ok1) GS_STAT_ALL(7, 1);
-#endif
-                float cv0 = cc0.x * vr[0], cv1 = cc1.x * vr[0];
-                if (CD > 1) { cv0 = fmaf(cc0.y, vr[1], cv0); cv1 = fmaf(cc1.y, vr[1], cv1); }
-                if (CD > 2) { cv0 = fmaf(cc0.z, vr[2], cv0); cv1 = fmaf(cc1.z, vr[2], cv1); }
-                // the slot as ONE step of the pixel's recurrences: T -> T P,  zacc -> zacc - T S
-                const float m0 = ok0 ? ra.x : 1.0f, m1 = ok1 ? ra.y : 1.0f;
-                const float P = m0 * m1;
-                const float S = (ok0 ? alpha.x * m0 * cv0 : 0.0f) + (ok1 ? alpha.y * P * cv1 : 0.0f);
-                // segment heads as scalar lane masks (H: a slot whose predecessor belongs to another pixel)
-                const int p_prev = __builtin_amdgcn_update_dpp(-1, p, 0x138, 0xf, 0xf, false);      // wave_shr:1
-                const unsigned long long H = __ballot(p != p_prev) | 1ull;
-                const SegMasks sm = seg_masks(H);
-                {
-                    // the first segment continues the previous chunk's last pixel?  Then it starts from the carry.
-                    const unsigned long long rest = H & ~1ull;
-                    const unsigned long long first_seg = rest ? ((1ull << __builtin_ctzll(rest)) - 1ull) : ~0ull;
-                    const unsigned long long cont = (__builtin_amdgcn_readfirstlane(p) == cp) ? first_seg : 0ull;
-                    T_pix = gs_sel_mask(cont, cT, T_pix);
-                    Z_pix = gs_sel_mask(cont, cZ, Z_pix);
-                }
-                const float E = seg_exclusive<true>(P, sm, lane);          // product of the P of the pixel's earlier slots in this chunk
-                const float T_start = T_pix * E;
-                const float Cn = T_start * S;
-                const float Zs = seg_exclusive<false>(Cn, sm, lane);
-                const float Z_start = Z_pix - Zs;
-                {
-                    const float Tn = T_start * m0;
-                    const float fac = ok0 ? alpha.x * Tn : 0.0f;
-                    const float v_alpha = fmaf(Tn, cv0, ra.x * Z_start);
-                    const float s_out = (ok0 && ov.x <= 0.999f) ? -ov.x * v_alpha : 0.0f;
-                    pairbuf[has0 ? e0 : GS_FLAT_PAIR_CAP] = make_float2(s_out, fac);      // (a lane without a candidate writes the spare slot)
-                    const float z1 = fmaf(-fac, cv0, Z_start);
-                    const float Tn1 = Tn * m1;
-                    const float fac1 = ok1 ? alpha.y * Tn1 : 0.0f;
-                    const float v_alpha1 = fmaf(Tn1, cv1, ra.y * z1);
-                    const float s_out1 = (ok1 && ov.y <= 0.999f) ? -ov.y * v_alpha1 : 0.0f;
-                    pairbuf[has1 ? e1 : GS_FLAT_PAIR_CAP] = make_float2(s_out1, fac1);
-                }
-                // the state behind this chunk: the carry for the pixel that continues, and -- pulled by the pixel lanes, consumed one
-                // chunk late -- the final state of the pixels whose last slot lies in this chunk
-                {
-                    const float T_end = T_start * P, Z_end = Z_start - Cn;
-                    cT = gs_readlane(T_end, 63); cZ = gs_readlane(Z_end, 63); cp = __builtin_amdgcn_readlane(p, 63);
-                    const int last = min(so + ns, s0 + 64) - 1;            // this pixel's last slot inside the chunk (if any)
-                    ptouched = ns > 0 && last >= s0 && last >= so;
-                    const int src = (ptouched ? last - s0 : 0) << 2;
-                    pT = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, T_end)));
-                    pZ = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, Z_end)));
-                }
-            }
-            T = ptouched ? pT : T;
-            zacc = ptouched ? pZ : zacc;
-            lanes_lds_sync();
-#ifdef GS_RASTER_PHASES
-            if (blockIdx.x == 0 && threadIdx.x == 0) { const long long _t = (long long)__builtin_readcyclecounter(); atomicAdd(&g_raster_stats[2], (unsigned long long)(_t - _pw0)); _pw0 = _t; }
-#endif
-            // ---- reduction: lane j sums the pairs of record j over the set bits of its pixel mask (pixel order)
-            float sum[NV];
-            {
-                const float X = ra4.x - ((float)qx0 + 0.5f), Y = ra4.y - ((float)qy0 + 0.5f);    // dx = X - x,  dy = Y - y
-                unsigned long long m = pms;
-                int e = cum - cnt - cumbase;
-                float m0 = 0.0f, mxy = 0.0f, c2s = 0.0f;
-                v2f m1 = (v2f)(0.0f), m2 = (v2f)(0.0f), c01 = (v2f)(0.0f);
-                if (__ballot(m != 0ull) != 0ull) do {                 // (rotated by hand: the while form copied all nine accumulators every trip)
-                    GS_STAT2(7, 1);
-#ifdef GS_RASTER_PHASES
-                    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_raster_stats[7], 1ull);
-#endif
-                    const bool has = m != 0ull;
-                    const int p = gs_pop_lowest(m);
-                    const float2 sfr = pairbuf[has ? e : 0];
-                    float4 vr;
-                    vr.x = __shfl(v_rc[0], p, 64); vr.y = CD > 1 ? __shfl(v_rc[1], p, 64) : 0.0f; vr.z = CD > 2 ? __shfl(v_rc[2], p, 64) : 0.0f; vr.w = 0.0f;
-                    e += has ? 1 : 0;
-                    const float s_w = has ? sfr.x : 0.0f, f_w = has ? sfr.y : 0.0f;
-                    const v2f d = v2f{X, Y} - v2f{(float)(p & 7), (float)(p >> 3)};
-                    const v2f sd = d * s_w;
-                    m0 += s_w;
-                    m1 += sd;
-                    m2 = __builtin_elementwise_fma(sd, d, m2);
-                    mxy = fmaf(sd.x, d.y, mxy);
-                    c01 = __builtin_elementwise_fma((v2f)(f_w), v2f{vr.x, vr.y}, c01);
-                    if (CD > 2) c2s = fmaf(f_w, vr.z, c2s);
-                } while (__ballot(m != 0ull) != 0ull);
-                sum[0] = m0; sum[1] = m1.x; sum[2] = m1.y; sum[3] = m2.x; sum[4] = mxy; sum[5] = m2.y;
-                sum[6] = c01.x;
-                if (CD > 1) sum[7] = c01.y;
-                if (CD > 2) sum[8] = c2s;
-            }
-            lanes_lds_sync();                                          // pairbuf is dead: its space becomes the commit staging
-#ifdef GS_RASTER_PHASES
-            if (blockIdx.x == 0 && threadIdx.x == 0) { const long long _t = (long long)__builtin_readcyclecounter(); atomicAdd(&g_raster_stats[3], (unsigned long long)(_t - _pw0)); _pw0 = _t; }
-#endif
-            {
-                const float ga = ra4.z, gb = ra4.w, gc = rb4.x, go = rb4.y;
-                const float M0 = sum[0], Mx = sum[1], My = sum[2];
-                float out[NV];
-                out[0] = (2.0f * ga) * Mx + gb * My;
-                out[1] = gb * Mx + (2.0f * gc) * My;
-                out[2] = 0.5f * sum[3]; out[3] = sum[4]; out[4] = 0.5f * sum[5];
-                out[5] = (M0 != 0.0f) ? -M0 / go : 0.0f;             // sum of vis * v_alpha over the uncapped pairs
-#pragma unroll
-                for (int k = 0; k < CD; ++k) out[6 + k] = sum[6 + k];
-                if (mine) {
-#pragma unroll
-                    for (int k = 0; k < NV; ++k) stage[lane * NV + k] = out[k];
-                }
-            }
-            lanes_lds_sync();
-            // ---- commit: RPI records x NV values per atomic instruction; the NV lanes of a record hit one packed gradient record
-            {
-                const int r = lane / NV, k = lane - r * NV;
-                for (int it = 0; r0 + it * RPI < r1; ++it) {
-                    const int j = r0 + it * RPI + r;
-                    if (r < RPI && j < r1 && k < 6 + D) {
-                        const float v = stage[j * NV + k];
-                        if (v != 0.0f) {
-                            const int g = __float_as_int(qc[j].w);
-#ifndef GS_EXP_NOATOMIC
-                            gs_atomic_add(v_packed + (size_t)g * rec_stride + k, v);
-#else
-                            if (v == 123456.0f) v_packed[(size_t)g * rec_stride + k] = v;      /* timing experiment only */
-#endif
-                        }
-                    }
-                }
-            }
-#ifdef GS_RASTER_PHASES
-            if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_raster_stats[4], (unsigned long long)((long long)__builtin_readcyclecounter() - _pw0));
-#endif
-            cumbase = __builtin_amdgcn_readlane(cum, r1 - 1);
-            r0 = r1;
-        }
-    }
-    GS_TL_END();
-}
-
-// ---------------------------------------------------------------------------------------------------
 // Occupancy cap of the two compositor kernels: they use no LDS, so a dynamic LDS request of 160 KB / 4 limits a CU to
 // FOUR resident 256-thread blocks (4 waves per SIMD instead of 8).  Measured on the bench workload: backward
 // 1.48 -> 1.19 ms, forward 0.68 -> 0.64 ms per view (3 blocks: same; 2 blocks: back to 1.49 ms; wave priorities for
@@ -2329,18 +1860,10 @@ static int launch_bwd(int W, int H, int D, const RasterWs& ws, const float* colo
     }
     if constexpr (CD <= 3) {                                  // colours travel in the record stream only for D <= 3
         if (t_cull_log.idx) {                                   // the forward left its cull log: no fill, no masks
-            static const bool s_flat = [] { const char* v = getenv("GEOSPLAT_BWD_WALK"); return !(v && !strcmp(v, "pixel")); }();
-            if (s_flat) {
-                const size_t lds = gs_raster_lds(4 * (size_t)FlatLds::WAVE_BYTES);
-                hipLaunchKernelGGL(raster_bwd_flat_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
-                                   ws.order, ws.rec0, ws.rec1, ws.rec2, background, isect_count(n_isects), offsets, alphas, last_ids,
-                                   v_render, v_alphas, v_packed, rec_stride, t_tone_bwd, t_cull_log, ws.bo);
-            } else {
-                const size_t lds = gs_raster_lds(4 * (size_t)LogLds::WAVE_BYTES);
-                hipLaunchKernelGGL(raster_bwd_log_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
-                                   ws.order, ws.rec0, ws.rec1, ws.rec2, background, isect_count(n_isects), offsets, alphas, last_ids,
-                                   v_render, v_alphas, v_packed, rec_stride, t_tone_bwd, t_cull_log, ws.bo);
-            }
+            const size_t lds = gs_raster_lds(4 * (size_t)LogLds::WAVE_BYTES);
+            hipLaunchKernelGGL(raster_bwd_log_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
+                               ws.order, ws.rec0, ws.rec1, ws.rec2, background, isect_count(n_isects), offsets, alphas, last_ids,
+                               v_render, v_alphas, v_packed, rec_stride, t_tone_bwd, t_cull_log, ws.bo);
             GS_CHECK_LAUNCH();
             return GS_OK;
         }

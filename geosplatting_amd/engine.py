@@ -90,10 +90,12 @@ class RenderStep:
         self._status_pending = collections.deque()   # eager steps: (pinned snapshot of the word, event), one per step, each looked at ONCE
         self._status_pool = []             # pinned int64[4] buffers waiting for reuse
         self.kernel_events = None          # set to a list: (name, start event, end event) around the compositor launches (bench.py)
+        self.tail_events = None            # set to a list: (start, end of the shading half, end of the projection half) of the LAST tail launch
         self._seen_counts = []
         self._exact_max_i = 0              # largest intersection count read back by an exact-mode step
         self._pre_group = None
         self.truncated_steps = 0           # steps whose overflow word was seen set (each was composited from a truncated list)
+        self.chunked_tails = 0             # steps whose last tail ran in Gaussian-range chunks under their all-reduce (_chunked_tail)
         self._overflow_unreported = False  # an overflow seen by the poll inside __call__ that no caller has been told about yet
         n_fly = int(os.environ.get("GEOSPLAT_STEPS_IN_FLIGHT", "3"))
         self._max_in_flight = max(1, n_fly)
@@ -143,7 +145,8 @@ class RenderStep:
         """Forget every cached (view matrix, K, position) triple: for callers that rewrite DEVICE-resident poses behind autograd's back."""
         self._cam_cache.clear()
 
-    def _step_fused(self, cameras, upstream, all_reduce, keep_images, _env=None, _stop_after_views=False, _geo_only=False, _geo=None):
+    def _step_fused(self, cameras, upstream, all_reduce, keep_images, _env=None, _stop_after_views=False, _geo_only=False, _geo=None,
+                    _rec_only=False, _rec=None):
         """Same arithmetic as the autograd path, driven directly through the C-ABI: every tail launch ADDS into the flat gradient
         bucket, the exp / sigmoid activations of GSplatter.render_rgba (rfstudio/model/gsplat.py:336-339) are applied once per step
         and chained once per step (their Jacobians do not depend on the view), and the prefilter backward runs once on the texel
@@ -220,6 +223,19 @@ class RenderStep:
                 main.wait_stream(sd)                         # (a captured phase: every forked stream joins before the capture ends)
             self._seen_counts.extend(seen)
             return dict(early=early, scales_act=scales_act, opac_act=opac_act)
+        if _rec_only:
+            # capture_views: the RECORDS (shading) of the views whose geometry came from the geometry graph, as a graph of their own --
+            # it needs the pyramid but not the binning, so it replays BESIDE the rest of the geometry graph (projection keys, five
+            # radix passes, emission: 0.25 ms per view) instead of behind it
+            env_r = TextureSplitSum(_env.base.detach(), [l.detach().contiguous() for l in _env.levels], _env.min_roughness, _env.max_roughness)
+            e_r = _make_env(get_fg_lut(dev) if self.fg_lut is None else self.fg_lut, env_r)
+            recs = {}
+            for j in sorted(early):
+                cam = cameras[j]
+                vm, K, cam_pos = self._camera_tensors(cam)
+                recs[j] = F.front_stage(means, quats, scales_act, opac_act, normals, kd, ks, vm, K, cam_pos, e_r, cam.width, cam.height,
+                                        self.min_roughness, self.max_metallic, mode, want_packed_index=True, binning=False, tight_tiles=tight)
+            return dict(recs=recs, e=e_r, env_d=env_r)
         # ONE fill, issued before the prefilter: the bucket, the activation-gradient accumulators and the texel-gradient accumulators
         # share an allocation
         cres = int(p.cubemap.shape[1])
@@ -259,7 +275,6 @@ class RenderStep:
         for i, g in enumerate(g_levels):
             eg.levels[i] = g.data_ptr()
         self.last_texel_grads = (g_base, g_levels)           # d loss / d pyramid of this step (summed over the local views): tests read it
-
         images = []
         tail = self._tail_stream
         if tail is None:
@@ -276,10 +291,17 @@ class RenderStep:
         pending_tails = []
         n_tail_launches = 0
         pstream = None
+        # with collectives in the step the LAST tail launch is left to _finish, which runs it in Gaussian-range chunks and sums chunk k
+        # over the ranks while chunk k + 1 is still being computed (_chunked_tail)
+        n_chunks = max(1, int(os.environ.get("GEOSPLAT_TAIL_CHUNKS", "4")))
+        defer_tail = all_reduce and collectives_active() and n_chunks > 1 and N >= 4096
+        tail_job = None
 
         def start_view(cam, j):                              # S1-S3 + A1; (V, I) travel to the host asynchronously
             vm, K, cam_pos = self._camera_tensors(cam)
             side = sides[j % len(sides)]
+            if _rec is not None and j in _rec["recs"]:       # (capture_views: the records graph has run)
+                return _rec["recs"][j], j, side
             with torch.cuda.stream(side):
                 if j in early:                               # binned under the prefilter: only the records (shading) are still missing
                     fr = F.front_stage(means, quats, scales_act, opac_act, normals, kd, ks, vm, K, cam_pos, e, cam.width, cam.height,
@@ -364,18 +386,29 @@ class RenderStep:
                 ev_r = torch.cuda.Event(); ev_r.record(main)
                 targs = (pending_tails, means, quats, scales_act, opac_act, normals, kd, ks, e, eg, self.min_roughness, self.max_metallic,
                          mode, b["means"], b["quats"], g_scales_act, g_opac_act, b["normals"], b["kd"], b["ks"])
+                if last and defer_tail:
+                    tail_job = dict(targs=targs, accumulate=n_tail_launches > 0, n_chunks=n_chunks)
+                    if keep_images:
+                        images.append(img)
+                    continue
+                tev = self.tail_events if last else None
                 with torch.cuda.stream(tail):
                     tail.wait_event(ev_r)
+                    if tev is not None:
+                        t0 = torch.cuda.Event(enable_timing=True); t0.record(tail)
                     # (the LAST launch: its projection half on a front stream -- idle by then -- beside the prefilter backward, which
                     #  needs only the shading half's texel gradients)
                     F.tail_multi_stage(*targs, accumulate=n_tail_launches > 0, parts=1 if last else 7)
                 used = [tail]
                 if last:
-                    ev_sh = torch.cuda.Event(); ev_sh.record(tail)
+                    ev_sh = torch.cuda.Event(enable_timing=tev is not None); ev_sh.record(tail)
                     pstream = sides[0]
                     with torch.cuda.stream(pstream):
                         pstream.wait_event(ev_sh)              # (v_means: the projection half adds to what the shading half stored)
                         F.tail_multi_stage(*targs, accumulate=n_tail_launches > 0, parts=2)
+                        if tev is not None:
+                            t2 = torch.cuda.Event(enable_timing=True); t2.record(pstream)
+                            tev.append((t0, ev_sh, t2))
                     used.append(pstream)
                 n_tail_launches += 1
                 for tv in pending_tails:
@@ -404,14 +437,15 @@ class RenderStep:
                 self._status_pending.append((snap, ev_s))
         # chain the once-per-step activations (behind the projection half of the last tail); the per-Gaussian gradients are then
         # final, so their all-reduce (RCCL on the communication stream) overlaps the prefilter backward
-        with torch.cuda.stream(pstream if pstream is not None else main):
-            L.check(lib.gs_activation_chain(L.i64(N), L.ptr(g_scales_act), L.ptr(scales_act), L.ptr(g_opac_act), L.ptr(opac_act),
-                                            L.ptr(b["scales"]), L.ptr(b["opacities"]), st()), "gs_activation_chain")
-        if pstream is not None:
-            for t in (scales_act, opac_act):
-                t.record_stream(pstream)
+        if tail_job is None:
+            with torch.cuda.stream(pstream if pstream is not None else main):
+                L.check(lib.gs_activation_chain(L.i64(N), L.ptr(g_scales_act), L.ptr(scales_act), L.ptr(g_opac_act), L.ptr(opac_act),
+                                                L.ptr(b["scales"]), L.ptr(b["opacities"]), st()), "gs_activation_chain")
+            if pstream is not None:
+                for t in (scales_act, opac_act):
+                    t.record_stream(pstream)
         ctx = dict(b=b, images=(images if keep_images else None), g_base=g_base, g_levels=g_levels, g_flat=g_flat, env=env, sharded=sharded,
-                   world=world, all_reduce=all_reduce, main=main, pstream=pstream)
+                   world=world, all_reduce=all_reduce, main=main, pstream=pstream, tail_job=tail_job)
         if _stop_after_views:                                 # (a captured views segment: every forked stream joins before the capture ends)
             if pstream is not None:
                 main.wait_stream(pstream)
@@ -426,13 +460,18 @@ class RenderStep:
         b, images, g_base, g_levels, g_flat, env = (ctx[k] for k in ("b", "images", "g_base", "g_levels", "g_flat", "env"))
         sharded, world, all_reduce, main = (ctx[k] for k in ("sharded", "world", "all_reduce", "main"))
         pstream = ctx.get("pstream")                          # the per-Gaussian gradients become final on this stream (None: on main)
+        chunked = ctx.get("tail_job") is not None
+        if chunked:                                           # last tail in Gaussian-range chunks, each summed over the ranks as it ends
+            pstream = self._chunked_tail(ctx)
+            main.wait_stream(self._tail_stream)               # the texel gradients are complete behind the last chunk's shading half
         head_stream = pstream if pstream is not None else main
         if sharded:
             grp = self._prefilter_group()
             dist.all_reduce(g_flat, op=dist.ReduceOp.SUM, group=grp)             # texel gradients of ALL views: needed by every share
-            start_head, _ = self.bucket.all_reduce_split("cubemap")
-            with torch.cuda.stream(head_stream):
-                start_head()                                    # per-Gaussian segments: communication stream, default communicator
+            if not chunked:
+                start_head, _ = self.bucket.all_reduce_split("cubemap")
+                with torch.cuda.stream(head_stream):
+                    start_head()                                # per-Gaussian segments: communication stream, default communicator
             g_cube = as_splitsum_backward_sharded(g_base, g_levels, dist.get_rank(), world, grp, min_roughness=env.min_roughness,
                                                   max_roughness=env.max_roughness)
             b["cubemap"].copy_(g_cube)                          # identical on every rank: not reduced again
@@ -441,14 +480,63 @@ class RenderStep:
             self.bucket.all_reduce_names(["exposure"])          # queues behind the head on the communication stream, then joins it
             return b, images
         start_head, finish = self.bucket.all_reduce_split("cubemap") if all_reduce else ((lambda: None), (lambda: None))
-        with torch.cuda.stream(head_stream):
-            start_head()
+        if not chunked:
+            with torch.cuda.stream(head_stream):
+                start_head()
         if self.prefilter:                                      # (the finest level's transposed apply writes the bucket's slice itself)
             as_splitsum_backward(g_base, g_levels, min_roughness=env.min_roughness, max_roughness=env.max_roughness, out=b["cubemap"])
         if pstream is not None:
             main.wait_stream(pstream)
         finish()
         return b, images
+
+    def _chunked_tail(self, ctx):
+        """The last tail launch of a step with collectives, in `n_chunks` Gaussian ranges: shading half of chunk k on the tail stream,
+        its projection half + the activation chain of those rows on a front stream behind it, and -- as soon as they are final -- the
+        all-reduce of exactly those rows of the seven per-Gaussian segments on the communication stream (GradBucket.all_reduce_rows),
+        while the tail stream already computes chunk k + 1.  The tail kernels index every per-Gaussian array by the Gaussian, so a
+        chunk is the same launch on pointers moved to the range's first row.  With one view per rank (BASELINE config 4) the 149 MB
+        all-reduce is otherwise fully exposed behind a 0.33 ms tail; here all but the last quarter of it runs under the tail.
+        Returns the stream on which the per-Gaussian gradients became final."""
+        job = ctx["tail_job"]
+        lib = L.lib()
+        b = ctx["b"]
+        self.chunked_tails += 1
+        (views, means, quats, scales_act, opac_act, normals, kd, ks, e, eg, mr, mm, mode, g_means, g_quats, g_scales_act, g_opac_act,
+         g_normals, g_kd, g_ks) = job["targs"]
+        N = means.shape[0]
+        C_ = job["n_chunks"]
+        bounds = [min(N, ((N * k // C_ + 1023) // 1024) * 1024) for k in range(C_)] + [N]
+        tail, pstream = self._tail_stream, self._side_stream[0]
+        names = [k for k in PARAM_NAMES if k not in ("cubemap", "exposure")]
+        tail.wait_stream(ctx["main"])                         # (behind the last compositor backward; a captured views segment: behind its replay)
+        captured = ctx.get("captured", False)
+        for c in range(C_):
+            n0, n1 = bounds[c], bounds[c + 1]
+            if n1 <= n0:
+                continue
+            sl = lambda t: t[n0:n1]
+            vc = [(vm, K, cp, vis, vp, pidx[n0:n1], W, H) for (vm, K, cp, vis, vp, pidx, W, H) in views]
+            args = (vc, sl(means), sl(quats), sl(scales_act), sl(opac_act), sl(normals), sl(kd), sl(ks), e, eg, mr, mm, mode, sl(g_means),
+                    sl(g_quats), sl(g_scales_act), sl(g_opac_act), sl(g_normals), sl(g_kd), sl(g_ks))
+            with torch.cuda.stream(tail):
+                F.tail_multi_stage(*args, accumulate=job["accumulate"], parts=1)
+                ev_sh = torch.cuda.Event(); ev_sh.record(tail)
+            with torch.cuda.stream(pstream):
+                pstream.wait_event(ev_sh)                      # (v_means: the projection half adds to what the shading half stored)
+                F.tail_multi_stage(*args, accumulate=job["accumulate"], parts=2)
+                L.check(lib.gs_activation_chain(L.i64(n1 - n0), L.ptr(sl(g_scales_act)), L.ptr(sl(scales_act)), L.ptr(sl(g_opac_act)),
+                                                L.ptr(sl(opac_act)), L.ptr(b["scales"][n0:n1]), L.ptr(b["opacities"][n0:n1]), L.stream()),
+                        "gs_activation_chain")
+                ev_c = torch.cuda.Event(); ev_c.record(pstream)
+            self.bucket.all_reduce_rows(names, n0, n1, after=ev_c)
+        if not captured:                                      # (a captured segment's tensors live in the graph's private pool)
+            for tv in views:
+                for t in tv[:6]:
+                    t.record_stream(tail); t.record_stream(pstream)
+            for t in (scales_act, opac_act, g_scales_act, g_opac_act):
+                t.record_stream(tail); t.record_stream(pstream)
+        return pstream
 
     def capture(self, cameras: List[Camera], upstream: Callable[[int, Tensor], Tensor], keep_images: bool = False):
         """One fused step over a FIXED camera list recorded into a HIP graph (torch.cuda.CUDAGraph): possible because in
@@ -548,28 +636,37 @@ class RenderStep:
         pyramid = TextureSplitSum(first.base.detach().clone(), [l.detach().clone() for l in first.levels], first.min_roughness,
                                   first.max_roughness)
         slots = [pyramid.base] + list(pyramid.levels)
-        # TWO graphs (GEOSPLAT_GEO_GRAPH=0: one): the GEOMETRY of the views -- projection, depth keys, binning: nothing that needs the
-        # pyramid -- replays on its own stream BESIDE the eager prefilter forward and its all-reduce, the rest behind both.  With one
-        # view per GPU the chain front -> binning -> record stream -> compositor -> tail is serial; this takes ~0.5 ms of it off
-        # the step's critical path (as the eager step does with its first view).
+        # THREE graphs (GEOSPLAT_GEO_GRAPH=0: one).  With one view per GPU the chain front -> binning -> record stream -> compositor ->
+        # tail is serial; two pieces of it need less than the whole chain has:
+        #   geometry graph: projection, depth keys, binning of the views -- nothing that needs the pyramid -- on its own stream BESIDE the
+        #                   eager (sharded) prefilter forward and its all-reduce;
+        #   records graph : the shading of those views -- needs the pyramid, NOT the binning -- behind the prefilter, beside whatever is
+        #                   left of the geometry graph (0.39 ms of front + binning against 0.1 ms of sharded prefilter at 8 GPUs);
+        #   views graph   : record stream, compositor, loss cotangent, compositor backward, background tails -- behind both.
+        # The last tail launch and every collective stay eager (_finish): its Gaussian-range chunks are summed over the ranks while the
+        # next chunk is computed.
         two = os.environ.get("GEOSPLAT_GEO_GRAPH", "1") != "0"
-        F.reserve_pinned(4 * len(cameras) + 2)                 # (the geometry fronts carry their own count read-backs)
+        F.reserve_pinned(6 * len(cameras) + 2)                 # (the geometry and records fronts carry their own count read-backs)
         warm = torch.cuda.Stream(device=dev)
         warm.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(warm):                          # (allocator warm-up on a side stream, as torch.cuda.graph asks)
             geo = self._step_fused(cameras, upstream, all_reduce, keep_images, _geo_only=True) if two else None
-            self._step_fused(cameras, upstream, all_reduce, keep_images, _env=pyramid, _stop_after_views=True, _geo=geo)
+            rec = self._step_fused(cameras, upstream, all_reduce, keep_images, _env=pyramid, _geo=geo, _rec_only=True) if two else None
+            self._step_fused(cameras, upstream, all_reduce, keep_images, _env=pyramid, _stop_after_views=True, _geo=geo, _rec=rec)
         torch.cuda.current_stream(dev).wait_stream(warm)
         torch.cuda.synchronize(dev)
         self.poll_capacity(_internal=True)                    # an overflow of the warm-up step stays pending for the caller's next poll
-        geo_graph, geo = None, None
+        geo_graph, geo, rec_graph, rec = None, None, None, None
         if two:
             geo_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(geo_graph):
                 geo = self._step_fused(cameras, upstream, all_reduce, keep_images, _geo_only=True)
+            rec_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(rec_graph, pool=geo_graph.pool()):
+                rec = self._step_fused(cameras, upstream, all_reduce, keep_images, _env=pyramid, _geo=geo, _rec_only=True)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, pool=geo_graph.pool() if two else None):
-            ctx = self._step_fused(cameras, upstream, all_reduce, keep_images, _env=pyramid, _stop_after_views=True, _geo=geo)
+            ctx = self._step_fused(cameras, upstream, all_reduce, keep_images, _env=pyramid, _stop_after_views=True, _geo=geo, _rec=rec)
         geo_stream = torch.cuda.Stream(device=dev) if two else None
         counts = [hc for hc, _ in self._seen_counts]          # refreshed by every replay (D2H copies are graph nodes)
         self._seen_counts = []
@@ -577,6 +674,7 @@ class RenderStep:
         cap = self._i_cap
         status_host = self._status_host
         ctx["main"] = None
+        ctx["captured"] = True
 
         stale = [False]
 
@@ -591,6 +689,7 @@ class RenderStep:
             env = filter_env()
             torch._foreach_copy_(slots, [env.base] + list(env.levels))
             if two:
+                rec_graph.replay()                             # shading of the views: beside the geometry graph
                 cur.wait_stream(geo_stream)
             graph.replay()
             ctx["main"] = cur
@@ -610,6 +709,7 @@ class RenderStep:
         step.check = check
         step.graph = graph
         step.geo_graph = geo_graph
+        step.rec_graph = rec_graph
         return step
 
     def _throttle(self) -> None:

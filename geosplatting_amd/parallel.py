@@ -141,6 +141,30 @@ class GradBucket:
                 dist.all_reduce(tail, op=dist.ReduceOp.SUM)
         return start_head, finish
 
+    def all_reduce_rows(self, names: Sequence[str], n0: int, n1: int, after=None) -> None:
+        """Sum rows [n0, n1) of the listed segments (one Gaussian RANGE of the per-Gaussian gradients) on the communication stream,
+        which first waits for `after` (an event: the tail launches that made those rows final).  The slices go out as ONE coalesced
+        group call where the backend has one (RCCL: a single launch for the seven slices), else one after the other.  Chunk k's sum
+        then runs while the tail still computes chunk k + 1 (engine._chunked_tail); `join_comm()` orders the caller behind them."""
+        if not collectives_active():
+            return
+        views = [self.view(k)[n0:n1] for k in names]
+        cs = self.comm_stream
+        if cs is None:
+            for v in views:
+                dist.all_reduce(v, op=dist.ReduceOp.SUM)
+            return
+        if after is not None:
+            cs.wait_event(after)
+        else:
+            cs.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cs):
+            _all_reduce_coalesced(views)
+
+    def join_comm(self) -> None:
+        if self.comm_stream is not None and collectives_active():
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
     def all_reduce_names(self, names: Sequence[str], group=None) -> None:
         """Sum only the listed segments (on the communication stream, joined before returning)."""
         if not collectives_active():
@@ -158,6 +182,21 @@ class GradBucket:
 
     def unpack(self) -> Dict[str, Tensor]:
         return {k: self.view(k) for k in self.names}
+
+
+def _all_reduce_coalesced(tensors: Sequence[Tensor]) -> None:
+    """SUM every tensor over the ranks, as one group call when the backend coalesces (RCCL: ncclGroupStart / End around the calls)."""
+    mgr = getattr(dist, "_coalescing_manager", None)
+    if mgr is not None and tensors[0].is_cuda and dist.get_backend() == "nccl":
+        try:
+            with mgr(device=tensors[0].device):
+                for t in tensors:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return
+        except TypeError:
+            pass                                               # (a different signature, raised before any call went out: single calls)
+    for t in tensors:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
 
 def init_distributed_from_env(device_type: str = "cuda"):

@@ -291,6 +291,7 @@ def _rccl_worker(rank, port, out_dir):
         grads, _ = step(cams, up, all_reduce=True)                    # sharded prefilter (own communicator) + two-phase all-reduce: RCCL
         torch.cuda.synchronize()
     assert step._pre_group is not None                                # dist.new_group() of the prefilter exchange really ran
+    assert step.chunked_tails == 3                                    # the last tail in Gaussian-range chunks, each chunk's rows summed at once
     out = {"eager": {k: v.detach().cpu().clone() for k, v in grads.items()}}
     assert step.poll_capacity(wait=True)
     graphed = step.capture_views(cams[:2], lambda j, img: ups[j].reshape(img.shape), all_reduce=True)   # graph replay beside the collectives
@@ -298,6 +299,7 @@ def _rccl_worker(rank, port, out_dir):
         g2, _ = graphed()
         torch.cuda.synchronize()
     assert graphed.check()
+    assert graphed.rec_graph is not None and step.chunked_tails == 5  # three graphs + the eager chunked tail behind them
     out["graph2"] = {k: v.detach().cpu().clone() for k, v in g2.items()}
     torch.save(out, os.path.join(out_dir, "rccl.pt"))
     dist.barrier()
@@ -307,8 +309,9 @@ def _rccl_worker(rank, port, out_dir):
 def test_rccl_one_rank_executes_the_multi_gpu_path(tmp_path):
     """RCCL itself (torch.distributed backend "nccl") on the GPU box: one rank -- two ranks cannot share a GPU under RCCL -- runs
     the COMPLETE multi-GPU step: sharded prefilter forward / backward with its own communicator (dist.new_group), the all-reduce of
-    the texel gradients, the two-phase all-reduce of the flat gradient bucket on the communication stream, and the views of a step
-    replayed as HIP graphs between eager collectives (capture_views).  With one rank every sum is the identity, so the results
+    the texel gradients, the last tail in Gaussian-range chunks with the all-reduce of each chunk's rows on the communication stream
+    (engine._chunked_tail), and the views of a step replayed as three HIP graphs between eager collectives (capture_views: geometry,
+    records, views).  With one rank every sum is the identity, so the results
     must equal the plain single-process step."""
     mp.spawn(_rccl_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
     got = torch.load(os.path.join(tmp_path, "rccl.pt"))

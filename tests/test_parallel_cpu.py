@@ -49,6 +49,22 @@ def _worker(rank, world, port, out_dir):
     finish()
     for k, v in bucket.unpack().items():
         assert torch.allclose(v, out[k]), k
+    # the chunked schedule of engine._chunked_tail: the per-Gaussian segments summed in Gaussian-range chunks (rows [n0, n1) of every
+    # per-Gaussian segment per call), cubemap + exposure afterwards -- the same sums again
+    bucket.pack(local)
+    per_gaussian = ["means", "quats", "ks"]
+    bounds = [0, 16, 16, 30, 37]                          # (an empty chunk included)
+    for n0, n1 in zip(bounds[:-1], bounds[1:]):
+        if n1 > n0:
+            bucket.all_reduce_rows(per_gaussian, n0, n1)
+            assert torch.allclose(bucket.view("means")[:n1], out["means"][:n1])
+            if n1 < 37:
+                assert not torch.allclose(bucket.view("means")[n1:], out["means"][n1:])      # rows behind the chunk: still local
+    bucket.join_comm()
+    _, finish = bucket.all_reduce_split("cubemap")
+    finish()
+    for k, v in bucket.unpack().items():
+        assert torch.allclose(v, out[k]), k
     torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

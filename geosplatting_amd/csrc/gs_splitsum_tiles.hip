@@ -428,17 +428,21 @@ tile_apply_body(int wg /*workgroup of this level's launch*/, int R, int E, int b
             } while (0)
             // one step of the rotation: prefetch into the set that was consumed last, consume set WC with descriptor set (DA, DB),
             // then refill that descriptor set for two chunks later
+#ifndef GS_DESC_AHEAD
+#define GS_DESC_AHEAD 4                      // descriptor sets in flight (scalar loads): 2 until round 6
+#endif
 #define GS_STEP(WP, JP, WC, JC, DA, DB)                                                                             \
             do {                                                                                                    \
                 GS_ROWS_LOAD(WP, JP);                                                                               \
                 if ((JC) < nj) GS_ROWS_USE(WC, DA, DB);                                                             \
-                GS_DESC_LOAD(DA, DB, (JC) + 2);                                                                     \
+                GS_DESC_LOAD(DA, DB, (JC) + GS_DESC_AHEAD);                                                         \
             } while (0)
 #if GS_TILE_DEPTH == 8
             gs_f2 w0[4], w1[4], w2[4], w3[4], w4[4], w5[4], w6[4], w7[4];
-            int4 a0, a1, b0, b1;
             GS_ROWS_LOAD(w0, 0); GS_ROWS_LOAD(w1, 1); GS_ROWS_LOAD(w2, 2); GS_ROWS_LOAD(w3, 3);
             GS_ROWS_LOAD(w4, 4); GS_ROWS_LOAD(w5, 5); GS_ROWS_LOAD(w6, 6);
+#if GS_DESC_AHEAD == 2
+            int4 a0, a1, b0, b1;
             GS_DESC_LOAD(a0, a1, 0); GS_DESC_LOAD(b0, b1, 1);
             for (int j = 0; j < nj; j += 8) {
                 GS_STEP(w7, j + 7, w0, j + 0, a0, a1);
@@ -450,10 +454,42 @@ tile_apply_body(int wg /*workgroup of this level's launch*/, int R, int E, int b
                 GS_STEP(w5, j + 13, w6, j + 6, a0, a1);
                 GS_STEP(w6, j + 14, w7, j + 7, b0, b1);
             }
+#elif GS_DESC_AHEAD == 4
+            // The row descriptors are SCALAR loads of 32 bytes per chunk from a list that every wave walks once: every second chunk
+            // misses the scalar cache, and with two sets in flight the miss (an L2 round trip) was exposed in front of most chunks --
+            // with the weight loads compiled out the kernel still took 70 % of its time (profiles/r06_prefilter_removal.txt).
+            int4 a0, a1, b0, b1, c0, c1, d0, d1;
+            GS_DESC_LOAD(a0, a1, 0); GS_DESC_LOAD(b0, b1, 1); GS_DESC_LOAD(c0, c1, 2); GS_DESC_LOAD(d0, d1, 3);
+            for (int j = 0; j < nj; j += 8) {
+                GS_STEP(w7, j + 7, w0, j + 0, a0, a1);
+                GS_STEP(w0, j + 8, w1, j + 1, b0, b1);
+                GS_STEP(w1, j + 9, w2, j + 2, c0, c1);
+                GS_STEP(w2, j + 10, w3, j + 3, d0, d1);
+                GS_STEP(w3, j + 11, w4, j + 4, a0, a1);
+                GS_STEP(w4, j + 12, w5, j + 5, b0, b1);
+                GS_STEP(w5, j + 13, w6, j + 6, c0, c1);
+                GS_STEP(w6, j + 14, w7, j + 7, d0, d1);
+            }
+#else
+            int4 a0, a1, b0, b1, c0, c1, d0, d1, e0, e1, f0, f1, g0, g1, h0, h1;
+            GS_DESC_LOAD(a0, a1, 0); GS_DESC_LOAD(b0, b1, 1); GS_DESC_LOAD(c0, c1, 2); GS_DESC_LOAD(d0, d1, 3);
+            GS_DESC_LOAD(e0, e1, 4); GS_DESC_LOAD(f0, f1, 5); GS_DESC_LOAD(g0, g1, 6); GS_DESC_LOAD(h0, h1, 7);
+            for (int j = 0; j < nj; j += 8) {
+                GS_STEP(w7, j + 7, w0, j + 0, a0, a1);
+                GS_STEP(w0, j + 8, w1, j + 1, b0, b1);
+                GS_STEP(w1, j + 9, w2, j + 2, c0, c1);
+                GS_STEP(w2, j + 10, w3, j + 3, d0, d1);
+                GS_STEP(w3, j + 11, w4, j + 4, e0, e1);
+                GS_STEP(w4, j + 12, w5, j + 5, f0, f1);
+                GS_STEP(w5, j + 13, w6, j + 6, g0, g1);
+                GS_STEP(w6, j + 14, w7, j + 7, h0, h1);
+            }
+#endif
 #else
             gs_f2 w0[4], w1[4], w2[4], w3[4];
-            int4 a0, a1, b0, b1;
             GS_ROWS_LOAD(w0, 0); GS_ROWS_LOAD(w1, 1); GS_ROWS_LOAD(w2, 2);
+#if GS_DESC_AHEAD == 2
+            int4 a0, a1, b0, b1;
             GS_DESC_LOAD(a0, a1, 0); GS_DESC_LOAD(b0, b1, 1);
             for (int j = 0; j < nj; j += 4) {
                 GS_STEP(w3, j + 3, w0, j + 0, a0, a1);
@@ -461,6 +497,30 @@ tile_apply_body(int wg /*workgroup of this level's launch*/, int R, int E, int b
                 GS_STEP(w1, j + 5, w2, j + 2, a0, a1);
                 GS_STEP(w2, j + 6, w3, j + 3, b0, b1);
             }
+#elif GS_DESC_AHEAD == 4
+            int4 a0, a1, b0, b1, c0, c1, d0, d1;
+            GS_DESC_LOAD(a0, a1, 0); GS_DESC_LOAD(b0, b1, 1); GS_DESC_LOAD(c0, c1, 2); GS_DESC_LOAD(d0, d1, 3);
+            for (int j = 0; j < nj; j += 4) {
+                GS_STEP(w3, j + 3, w0, j + 0, a0, a1);
+                GS_STEP(w0, j + 4, w1, j + 1, b0, b1);
+                GS_STEP(w1, j + 5, w2, j + 2, c0, c1);
+                GS_STEP(w2, j + 6, w3, j + 3, d0, d1);
+            }
+#else
+            int4 a0, a1, b0, b1, c0, c1, d0, d1, e0, e1, f0, f1, g0, g1, h0, h1;
+            GS_DESC_LOAD(a0, a1, 0); GS_DESC_LOAD(b0, b1, 1); GS_DESC_LOAD(c0, c1, 2); GS_DESC_LOAD(d0, d1, 3);
+            GS_DESC_LOAD(e0, e1, 4); GS_DESC_LOAD(f0, f1, 5); GS_DESC_LOAD(g0, g1, 6); GS_DESC_LOAD(h0, h1, 7);
+            for (int j = 0; j < nj; j += 8) {
+                GS_STEP(w3, j + 3, w0, j + 0, a0, a1);
+                GS_STEP(w0, j + 4, w1, j + 1, b0, b1);
+                GS_STEP(w1, j + 5, w2, j + 2, c0, c1);
+                GS_STEP(w2, j + 6, w3, j + 3, d0, d1);
+                GS_STEP(w3, j + 7, w0, j + 4, e0, e1);
+                GS_STEP(w0, j + 8, w1, j + 5, f0, f1);
+                GS_STEP(w1, j + 9, w2, j + 6, g0, g1);
+                GS_STEP(w2, j + 10, w3, j + 7, h0, h1);
+            }
+#endif
 #endif
 #undef GS_STEP
 #undef GS_DESC_LOAD

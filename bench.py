@@ -662,7 +662,7 @@ def main():
         dom_tf = None if not pairs_valid else pairs_valid * dom_flops / (kt[dom] * 1e-3) / 1e12
         dom_tf_engine = None if not (pairs_valid and engine_ms and engine_ms.get(dom)) else pairs_valid * dom_flops / (engine_ms[dom] * 1e-3) / 1e12
         # committed counter summaries, quoted only while gs_raster.hip is the source they were measured on
-        first = lambda stem: next((f"r{r:02d}_{stem}" for r in (5, 4, 3, 2) if committed_profile(f"r{r:02d}_{stem}", "gs_raster.hip")), f"r05_{stem}")
+        first = lambda stem: next((f"r{r:02d}_{stem}" for r in (6, 5, 4, 3, 2) if committed_profile(f"r{r:02d}_{stem}", "gs_raster.hip")), f"r06_{stem}")
         stats_name, pmc_name = first("raster_stats.json"), first("pmc_traffic.json")
         stats = committed_profile(stats_name, "gs_raster.hip")
         pmc = committed_profile(pmc_name, "gs_raster.hip")

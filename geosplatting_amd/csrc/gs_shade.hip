@@ -43,7 +43,7 @@ shade_fwd_kernel(int N, const float* __restrict__ means, const float* __restrict
 // 160 KB LDS).  2 M Gaussians send ~13 M atomics at the 4 608 floats of the 16^2 level alone: in HBM/L2 that
 // serialises per address (5.5 ms per view measured); in LDS it is a ds_add_f32 and the block flushes its
 // copy once at the end.
-// Block size and the largest LDS-privatised level are run-time choices (GEOSPLAT_SHADE_BWD_BLOCK / GEOSPLAT_SHADE_LDS_MAXRES):
+// Block size (512) and the largest LDS-privatised level (32^2) were run-time choices while they were being measured:
 // the round-1 shape -- 1024-thread blocks, one per CU, levels <= 32^2 in 92 KB of LDS -- caps the kernel at 128 VGPRs and it
 // SPILLS (264 bytes of scratch per lane, -Rpass-analysis): the recomputed forward then runs at a fifth of the forward
 // kernel's rate.  Smaller blocks lift the cap (256 registers at 2 waves per SIMD).  Measured at the bench workload (scripts/shade_ab.py):

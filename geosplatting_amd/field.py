@@ -60,10 +60,9 @@ class _HashGrid(torch.autograd.Function):
         fixed_bytes = lib.gs_hashgrid_bwd_fixed_ws_bytes(N, L, F, log2_T) if mode == "2" else 0
         if fixed_bytes:
             # the binned path reserves a worst-case queue of N ints per (level, slab) pair (4.3 GB at N = 2 M, 2^18 rows):
-            # fine on a 288 GB MI355X, but never let it crowd out the model -- beyond the budget (default: a quarter of the
-            # free memory, GEOSPLAT_HASHGRID_WS_GB overrides) fall back to the float-slab kernel, whose workspace is 4*N*L*F bytes
-            budget = os.environ.get("GEOSPLAT_HASHGRID_WS_GB")
-            budget_bytes = int(float(budget) * 2 ** 30) if budget else torch.cuda.mem_get_info(xd.device)[0] // 4
+            # fine on a 288 GB MI355X, but never let it crowd out the model -- beyond a quarter of the free memory fall back to the
+            # float-slab kernel, whose workspace is 4*N*L*F bytes
+            budget_bytes = torch.cuda.mem_get_info(xd.device)[0] // 4
             if fixed_bytes > budget_bytes:
                 fixed_bytes = 0
         if fixed_bytes:

@@ -66,16 +66,14 @@ def configure_allocator() -> None:
     buffer has a size PyTorch's caching allocator has never seen: it answered each with a fresh hipMalloc and kept the old blocks
     (scripts/soak_stage1.py, 128^3 grid: 253 GiB reserved after 100 iterations for 8.5 GiB of live memory, 77-160 ms per iteration).
     Rounding request sizes up to an eighth of a power of two makes the sizes repeat: 26 GiB flat, 40 ms per iteration.  Applied once,
-    unless the user configured the allocator through the environment; GEOSPLAT_ALLOC_CONF overrides the setting ("" = leave alone)."""
+    unless the user configured the allocator through PyTorch's own environment variables (PYTORCH_HIP_ALLOC_CONF / PYTORCH_ALLOC_CONF)."""
     global _allocator_configured
     if _allocator_configured:
         return
     _allocator_configured = True
     if os.environ.get("PYTORCH_HIP_ALLOC_CONF") or os.environ.get("PYTORCH_CUDA_ALLOC_CONF") or os.environ.get("PYTORCH_ALLOC_CONF"):
         return
-    conf = os.environ.get("GEOSPLAT_ALLOC_CONF", "roundup_power2_divisions:8")
-    if not conf:
-        return
+    conf = "roundup_power2_divisions:8"
     setter = getattr(torch._C, "_accelerator_setAllocatorSettings", None) or getattr(torch.cuda.memory, "_set_allocator_settings", None)
     if setter is not None:
         try:
@@ -83,7 +81,7 @@ def configure_allocator() -> None:
             # process-wide and therefore said out loud: every allocation of the host application is
             # rounded up to an eighth of a power of two (<= 12.5 % internal fragmentation) from here on
             print(f"[geosplatting_amd.stage1] caching allocator set to '{conf}' for the whole process "
-                  f"(GEOSPLAT_ALLOC_CONF='' leaves it alone)", file=sys.stderr)
+                  f"(set PYTORCH_HIP_ALLOC_CONF yourself to keep your own)", file=sys.stderr)
         except Exception as e:                               # an allocator without this knob: nothing lost but the optimisation
             print(f"[geosplatting_amd.stage1] allocator setting '{conf}' not applied: {e!r}", file=sys.stderr)
 
@@ -367,7 +365,7 @@ def train_step_fused(model: Stage1Model, cameras: Sequence[Camera], gt_rgba: Seq
     The all-reduce happens at the per-Gaussian cut (every rank extracted the same Gaussians), after which each rank
     runs the same field / MGAdapter / FlexiCubes backward: no second collective.  Replicas must start identical
     (`broadcast_parameters`) and stay so: the backward kernels behind the cut use fp32 atomics, so callers re-broadcast
-    every few hundred steps (`_main`: GEOSPLAT_RESYNC_EVERY); the Gaussian count is checked across ranks before every
+    every few hundred steps (`_main`: every 200); the Gaussian count is checked across ranks before every
     collective (a topology that differs on one rank would otherwise reduce buffers of different sizes)."""
     from .engine import PathParams, RenderStep
     from .loss import TrainerUpstream
@@ -509,7 +507,7 @@ def _main() -> None:
     dev = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world)
-    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    iters = next((int(a) for a in sys.argv[1:] if a.isdigit()), 20)      # [iters] [--autograd]
     R, HW, n_views = 64, 256, max(8, world)
     cams = syn.blender_cameras(n_views, HW, HW)
     grid = FlexiCubes.from_resolution(R, device=dev, random_sdf=False, scale=1.05)
@@ -527,7 +525,7 @@ def _main() -> None:
                         sdf_init=grid.vertices.norm(dim=-1, keepdim=True) - 0.5)
     model.sdf_weight = 0.1
     opt = torch.optim.Adam(model.parameters(), lr=5e-3)
-    resync = int(os.environ.get("GEOSPLAT_RESYNC_EVERY", "200"))
+    resync = 200
     if world > 1:
         broadcast_parameters(model)
     import time
@@ -535,7 +533,7 @@ def _main() -> None:
     for it in range(iters):
         if it == 2:                                          # after the table builds / allocator warm-up
             torch.cuda.synchronize(); t0 = time.time()
-        m = (train_step if os.environ.get("GEOSPLAT_STAGE1_AUTOGRAD") == "1" else train_step_fused)(
+        m = (train_step if "--autograd" in sys.argv else train_step_fused)(
             model, cams, gts, gt_is_srgb=False, rank=rank, world_size=world)
         opt.step()
         if world > 1 and resync > 0 and (it + 1) % resync == 0:

@@ -131,3 +131,17 @@ def require_cuda(*tensors: torch.Tensor) -> None:
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise GeoSplatHipError("geosplatting_amd ops run on the GPU only (tensor on %s); there is no CPU path" % t.device)
+
+
+_shared_streams = {}
+
+
+def shared_stream(device: torch.device, role: str) -> "torch.cuda.Stream":
+    """ONE HIP stream per (device, role) for the whole process -- "front0", "front1", "tail", "comm": the step engine, the call shape
+    (viewbatch) and the gradient buckets all take theirs from here.  HIP maps its streams onto four hardware queues; with a private
+    set per object a process that holds an engine AND renders through the call shape had eight streams, two per queue."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), role)
+    st = _shared_streams.get(key)
+    if st is None:
+        st = _shared_streams[key] = torch.cuda.Stream(device=device)
+    return st

@@ -185,7 +185,7 @@ class RenderStep:
         if self._use_capacity and self._status is None:      # zero-filled on the main stream BEFORE the side streams fork from it
             self._status = torch.zeros(4, dtype=torch.int64, device=dev)
         if self._side_stream is None:
-            self._side_stream = [torch.cuda.Stream(device=dev) for _ in range(2)]
+            self._side_stream = [L.shared_stream(dev, "front0"), L.shared_stream(dev, "front1")]
         sides = self._side_stream
         # tile rectangles clipped to the {alpha >= 1/255} extents (GEOSPLAT_TIGHT_TILES=0: gsplat's squares): 18 % fewer intersections
         # on the bench scene, identical pixels (gs_front_fwd; the engine never returns gsplat's `meta`)
@@ -278,7 +278,7 @@ class RenderStep:
         images = []
         tail = self._tail_stream
         if tail is None:
-            tail = self._tail_stream = torch.cuda.Stream(device=dev)
+            tail = self._tail_stream = L.shared_stream(dev, "tail")
         for sd in sides:
             sd.wait_stream(main)                             # prefilter pyramid, activations, zeroed buckets
         tail.wait_stream(main)
@@ -667,7 +667,7 @@ class RenderStep:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, pool=geo_graph.pool() if two else None):
             ctx = self._step_fused(cameras, upstream, all_reduce, keep_images, _env=pyramid, _stop_after_views=True, _geo=geo, _rec=rec)
-        geo_stream = torch.cuda.Stream(device=dev) if two else None
+        geo_stream = L.shared_stream(dev, "geo") if two else None
         counts = [hc for hc, _ in self._seen_counts]          # refreshed by every replay (D2H copies are graph nodes)
         self._seen_counts = []
         self._status_event = None

@@ -54,8 +54,11 @@ class GradBucket:
         self.numel = off
         self.storage = torch.zeros(off, dtype=torch.float32, device=device)   # bucket + per-step scratch behind it (zero_with_scratch)
         self.flat = self.storage[:off]
-        self.comm_stream = (comm_stream if comm_stream is not None else torch.cuda.Stream(device=device)) \
-            if device.type == "cuda" else None
+        if device.type == "cuda":
+            from ._lib import shared_stream
+            self.comm_stream = comm_stream if comm_stream is not None else shared_stream(device, "comm")
+        else:
+            self.comm_stream = None
 
     def zero_with_scratch(self, sizes: Sequence[int]) -> List[Tensor]:
         """Zero the bucket AND `len(sizes)` scratch tensors (float counts) that live behind it in the same allocation with ONE fill

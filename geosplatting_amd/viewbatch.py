@@ -62,8 +62,8 @@ class _DeviceState:
         # two front streams (+ the caller's stream + the tail stream = the four hardware queues HIP maps its streams onto by default:
         # a third front stream is 2 % faster alone in a process -- 608 against 596 views/s -- and 13 % SLOWER, 520 against 595, in a
         # process that holds other streams, where two of them then share a queue)
-        self.fronts = [torch.cuda.Stream(device=dev) for _ in range(2)]
-        self.tail = torch.cuda.Stream(device=dev)
+        self.fronts = [L.shared_stream(dev, "front0"), L.shared_stream(dev, "front1")]
+        self.tail = L.shared_stream(dev, "tail")
         self.caps: "collections.OrderedDict[Tuple[int, int], _Capacity]" = collections.OrderedDict()   # by image size, least recently used first
         self.current: Optional["_Step"] = None   # the step new splat() calls may join
         self.unchecked = collections.deque()     # capacity-mode views whose counts nobody has looked at yet

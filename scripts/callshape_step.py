@@ -53,6 +53,24 @@ if not os.environ.get("CALLSHAPE_NO_SYNC_LOOP"):
     for _ in range(steps):
         a = time.perf_counter(); step(); torch.cuda.synchronize(); ts.append(time.perf_counter() - a)
     print(f"step by step with a synchronise after each: mean {1e3 * sum(ts) / steps:.2f} ms, min {1e3 * min(ts):.2f}")
+if os.environ.get("CALLSHAPE_HOST_TIMES"):
+    # host clock at the entry of every splat() of ONE step that starts on an idle GPU, and the GPU's clock (events) at the end of each
+    # view's forward on the caller's stream: how far ahead of the GPU does the host enqueue the front chains?
+    torch.cuda.synchronize()
+    for t in leaves:
+        t.grad = None
+    e0 = torch.cuda.Event(enable_timing=True); e0.record()
+    h0 = time.perf_counter()
+    env = gs.as_splitsum(cubemap)
+    hs, evs, images = [], [], []
+    for cam in cams:
+        hs.append(time.perf_counter() - h0)
+        images.append(attrs.splat(gsn, [cam], exposure=exposure, envmap=env, min_roughness=0.1, max_metallic=1.0))
+        e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e)
+    h_end = time.perf_counter() - h0
+    torch.cuda.synchronize()
+    print("host ms at splat() entry:", " ".join(f"{1e3 * x:.2f}" for x in hs), f"| all enqueued at {1e3 * h_end:.2f}")
+    print("GPU  ms at forward end  :", " ".join(f"{e0.elapsed_time(e):.2f}" for e in evs))
 if os.environ.get("CALLSHAPE_CPROFILE"):
     import cProfile, pstats
     pr = cProfile.Profile(); pr.enable()

@@ -92,6 +92,44 @@ __device__ __forceinline__ float gs_wave_sum(float v)
     return gs_readlane(v, 63);
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave: row_shr:1/2/4/8 inside the 16-lane rows, row_bcast:15 and :31 across them, each
+// move fused into its add -- six VALU instructions.  (`__shfl_up` compiles to ds_bpermute_b32: six dependent trips through the LDS
+// crossbar, ~10x the latency, on kernels that are a few microseconds of dependent steps.)  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned gs_dpp_add_u32(unsigned v)
+{
+    return v + (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);      // (lanes without a source add 0)
+}
+__device__ __forceinline__ unsigned gs_wave_incl_scan(unsigned v)
+{
+    v = gs_dpp_add_u32<0x111, 0xf>(v);    // row_shr:1
+    v = gs_dpp_add_u32<0x112, 0xf>(v);    // row_shr:2
+    v = gs_dpp_add_u32<0x114, 0xf>(v);    // row_shr:4
+    v = gs_dpp_add_u32<0x118, 0xf>(v);    // row_shr:8   -> inclusive scan inside every row
+    v = gs_dpp_add_u32<0x142, 0xa>(v);    // row_bcast:15: rows 1 and 3 += the total of the row before
+    v = gs_dpp_add_u32<0x143, 0xc>(v);    // row_bcast:31: rows 2 and 3 += the total of rows 0 + 1
+    return v;
+}
+__device__ __forceinline__ int gs_wave_incl_scan(int v) { return (int)gs_wave_incl_scan((unsigned)v); }
+// Sum over the wave (every lane active), returned in all lanes through an SGPR
+__device__ __forceinline__ unsigned gs_wave_sum_u32(unsigned v)
+{
+    v = gs_dpp_add_u32<0xB1, 0xf>(v);     // quad_perm [1,0,3,2]
+    v = gs_dpp_add_u32<0x4E, 0xf>(v);     // quad_perm [2,3,0,1]
+    v = gs_dpp_add_u32<0x141, 0xf>(v);    // row_half_mirror
+    v = gs_dpp_add_u32<0x140, 0xf>(v);    // row_mirror
+    v = gs_dpp_add_u32<0x142, 0xa>(v);    // row_bcast:15
+    v = gs_dpp_add_u32<0x143, 0xc>(v);    // row_bcast:31
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// ... of non-negative 64-bit values below 2^62: three 21-bit limbs, whose 64-lane sums fit 32 bits
+__device__ __forceinline__ unsigned long long gs_wave_sum_u64(unsigned long long v)
+{
+    const unsigned a = gs_wave_sum_u32((unsigned)(v & 0x1fffffull)), b = gs_wave_sum_u32((unsigned)((v >> 21) & 0x1fffffull)),
+                   c = gs_wave_sum_u32((unsigned)(v >> 42));
+    return (unsigned long long)a + ((unsigned long long)b << 21) + ((unsigned long long)c << 42);
+}
+
 // ---- butterfly reduce-scatter over a wave --------------------------------------------------------------
 // Sums NV per-lane values over the 64 lanes in ~3*NV/2 + 6 VALU ops instead of 6*NV: at every stage a lane
 // hands HALF of its values to its partner and keeps the other half, so the value count halves while the

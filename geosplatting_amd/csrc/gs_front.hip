@@ -26,11 +26,22 @@
 #include "gs_project_dev.h"
 #include "gs_shade_dev.h"
 
-// one u64 max per wave: lanes without a value pass 0
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+// max over the 64 lanes of a wave, valid in lane 63 (lanes without a value pass 0): DPP moves fused into the VALU max, no LDS
+// crossbar (twelve ds_bpermute per wave as __shfl_xor)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_max_u32(unsigned v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)v, off, 64); v = o > v ? o : v; }
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned wave_max_u32_lane63(unsigned v)
+{
+    v = dpp_max_u32<0xB1, 0xf>(v);     // quad_perm [1,0,3,2]
+    v = dpp_max_u32<0x4E, 0xf>(v);     // quad_perm [2,3,0,1]
+    v = dpp_max_u32<0x141, 0xf>(v);    // row_half_mirror
+    v = dpp_max_u32<0x140, 0xf>(v);    // row_mirror: every lane of a 16-lane row holds the row's max
+    v = dpp_max_u32<0x142, 0xa>(v);    // row_bcast:15 into rows 1 and 3
+    v = dpp_max_u32<0x143, 0xc>(v);    // row_bcast:31 into rows 2 and 3
     return v;
 }
 
@@ -55,6 +66,7 @@ front_fwd_kernel(int N, const float* __restrict__ means, const float* __restrict
     __shared__ int s_chunk;
     __shared__ int s_wv[GS_PROJ_WAVES];
     __shared__ int s_wi[GS_PROJ_WAVES];
+    __shared__ unsigned s_wmx[GS_PROJ_WAVES], s_wmn[GS_PROJ_WAVES];
     __shared__ long long s_base[2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -110,12 +122,12 @@ front_fwd_kernel(int N, const float* __restrict__ means, const float* __restrict
     const u64 bal = __ballot(p.valid);
     const int v_excl_wave = __popcll(bal & ((1ull << lane) - 1ull));
     int i_incl = ntiles;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_up(i_incl, off, 64);
-        if (lane >= off) i_incl += t;
+    i_incl = gs_wave_incl_scan(i_incl);
+    const unsigned dbits = p.valid ? __float_as_uint(p.depth) : 0u;
+    {
+        const unsigned mx = wave_max_u32_lane63(dbits), mn = wave_max_u32_lane63(p.valid ? ~dbits : 0u);
+        if (lane == 63) { s_wv[wave] = __popcll(bal); s_wi[wave] = i_incl; s_wmx[wave] = mx; s_wmn[wave] = mn; }
     }
-    if (lane == 63) { s_wv[wave] = __popcll(bal); s_wi[wave] = i_incl; }
     __syncthreads();
     int v_before = 0, i_before = 0, aggV = 0, aggI = 0;
 #pragma unroll
@@ -124,6 +136,13 @@ front_fwd_kernel(int N, const float* __restrict__ means, const float* __restrict
         aggV += s_wv[w]; aggI += s_wi[w];
     }
     if (wave == 0 && lane == 0 && chunk > 0) { desc_store(&agg_v[chunk], (u64)aggV); desc_store(&agg_i[chunk], (u64)aggI); }
+
+    const bool range_wave = wave == GS_PROJ_WAVES - 1;        // (not the first one: that one walks the look-back)
+    unsigned long long cur_mx = 0ull, cur_mn = 0ull;
+    if (range_wave && lane == 0 && aggV != 0) {
+        cur_mx = __hip_atomic_load(counts + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cur_mn = __hip_atomic_load(counts + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     // ---- shading of the visible Gaussians (texture taps in flight while the predecessors publish)
     float color[3] = { 0.f, 0.f, 0.f };
@@ -136,18 +155,19 @@ front_fwd_kernel(int N, const float* __restrict__ means, const float* __restrict
         ShadeTmp t;
         shade_one<false>(mean, nrm, kdn, ksn, cp, min_roughness, max_metallic, mode, env, color, t);
     }
-    // depth range of the view (the engine sizes its 24-bit keys by it, one step later) and the key of this Gaussian
-    // (one atomic pair per WAVE on the same two words serialised at the L2: 61 k same-address atomics made this kernel 730 us instead of
-    // 260.  The maxima only grow, so a relaxed -- possibly stale, never too large -- read of the current value decides whether this wave
-    // can still raise it: a handful of atomics per launch)
-    const unsigned dbits = p.valid ? __float_as_uint(p.depth) : 0u;
-    {
-        const unsigned mx = wave_max_u32(dbits), mn = wave_max_u32(p.valid ? ~dbits : 0u);
-        if (lane == 0 && bal != 0ull) {
-            // (agent-scope loads: served past the CU's vector L1, which another CU's atomics never refresh)
-            if ((unsigned long long)mx > __hip_atomic_load(counts + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(counts + 3, (unsigned long long)mx);
-            if ((unsigned long long)mn > __hip_atomic_load(counts + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(counts + 2, (unsigned long long)mn);
-        }
+    // depth range of the view (the engine sizes its 24-bit keys by it, one step later).  The maxima only grow, so a relaxed -- possibly
+    // stale, never too large -- read of the current value decides whether this BLOCK can still raise it: a handful of atomics per
+    // launch.  The reads are agent-scope (served past the CU's vector L1, which another CU's atomics never refresh), all of the same
+    // L2 line: one wave per block issues them BEFORE its shading (cur_mx / cur_mn above) and uses them here.  Round 6 (removal
+    // experiments, scripts/xp/front_alone.py): the per-wave version of this block -- twelve ds_bpermute for the two wave maxima, a
+    // load pair per wave consumed at once -- cost 14 us of the kernel's 197 alone; per block, with DPP maxima and DPP scans: 187.
+    // [One atomic pair per wave, unconditionally: 730 us instead of 260.]
+    if (range_wave && lane == 0 && aggV != 0) {
+        unsigned mx = 0u, mn = 0u;
+#pragma unroll
+        for (int w = 0; w < GS_PROJ_WAVES; ++w) { mx = s_wmx[w] > mx ? s_wmx[w] : mx; mn = s_wmn[w] > mn ? s_wmn[w] : mn; }
+        if ((unsigned long long)mx > cur_mx) atomicMax(counts + 3, (unsigned long long)mx);
+        if ((unsigned long long)mn > cur_mn) atomicMax(counts + 2, (unsigned long long)mn);
     }
     unsigned key = dbits;
     if (key_limit != 0u) {

@@ -85,11 +85,7 @@ project_fwd_kernel(int N, const float* __restrict__ means, const float* __restri
     const u64 bal = __ballot(p.valid);
     const int v_excl_wave = __popcll(bal & ((1ull << lane) - 1ull));
     int i_incl = ntiles;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_up(i_incl, off, 64);
-        if (lane >= off) i_incl += t;
-    }
+    i_incl = gs_wave_incl_scan(i_incl);
     if (lane == 63) { s_wv[wave] = __popcll(bal); s_wi[wave] = i_incl; }
     __syncthreads();
     int v_before = 0, i_before = 0, aggV = 0, aggI = 0;

@@ -168,11 +168,9 @@ __device__ __forceinline__ u64 desc_load(u64* p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ long long wave_sum_i64(long long v)
+__device__ __forceinline__ long long wave_sum_i64(long long v)          // (counts: non-negative, far below 2^62)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    return (long long)gs_wave_sum_u64((unsigned long long)v);
 }
 
 // ---------------------------------------------------------------------------------------------------

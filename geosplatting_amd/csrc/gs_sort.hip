@@ -123,11 +123,7 @@ radix_rowscan_kernel(int nblocks, unsigned* __restrict__ table, unsigned* __rest
         const int i = i0 + threadIdx.x;
         const unsigned v = i < nblocks ? row[i] : 0u;
         unsigned incl = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
+        incl = gs_wave_incl_scan(incl);
         if (lane == 63) wsum[wave] = incl;
         __syncthreads();
         unsigned before = 0u, all = 0u;
@@ -193,11 +189,7 @@ radix_scatter_kernel(GsCount nc, In in, Digit digit, int nblocks, const unsigned
         unsigned tot = 0u;
         if (d < NB) for (int w = 0; w < RS_WAVES; ++w) tot += cnt[w][d];
         unsigned incl = tot;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
+        incl = gs_wave_incl_scan(incl);
         __shared__ unsigned wtot[RS_WAVES];
         if (lane == 63) wtot[wave] = incl;
         __syncthreads();
@@ -209,11 +201,7 @@ radix_scatter_kernel(GsCount nc, In in, Digit digit, int nblocks, const unsigned
         __syncthreads();
         const unsigned rt = d < NB ? row_total[d] : 0u;
         unsigned rincl = rt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned t = __shfl_up(rincl, off, 64);
-            if (lane >= off) rincl += t;
-        }
+        rincl = gs_wave_incl_scan(rincl);
         if (lane == 63) wtot[wave] = rincl;
         __syncthreads();
         unsigned rbefore = 0u;
@@ -325,6 +313,7 @@ __device__ __forceinline__ void tile_range_sorted(float mx, float my, int radius
 #define EM_THREADS 256
 #ifndef EM_PER
 #define EM_PER 4
+#define EM_LOOK 4                            // x 64 predecessors per look-back round
 #endif
 #define EM_TILE (EM_THREADS * EM_PER)        // ranks per block
 
@@ -490,45 +479,58 @@ emit_chained_kernel(GsCount vc, const uint2* __restrict__ order, const uint2* __
         mine += c[k];
     }
     unsigned incl = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
+    incl = gs_wave_incl_scan(incl);
     if (lane == 63) ws[wave] = incl;
     __syncthreads();
     unsigned before = 0u, total = 0u;
     for (int w = 0; w < EM_THREADS / 64; ++w) { if (w < wave) before += ws[w]; total += ws[w]; }
     if (wave == 0) {
-        unsigned long long base = 0ull;
+        // look-back over EM_LOOK x 64 predecessors per round, nearest first: every lane has EM_LOOK descriptor pairs in flight and
+        // keeps a private partial sum; ONE wave reduction at the end.  (All 1 920 blocks of a 2 M-Gaussian view are resident at once
+        // and publish their aggregates together: nobody has a prefix yet, and block b walks all the way back -- b / 64 rounds of
+        // dependent L2 round trips with a 64-bit wave sum each was most of this kernel's 84 us, round 6.)
+        unsigned long long acc = 0ull;
         if (block > 0) {
             if (lane == 0) __hip_atomic_store(&agg[block], (u64)total | BF_VALID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int pos = block - 1;
-            for (;;) {
-                const int idx = pos - lane;
-                bool isP = idx < 0;
-                u64 val = 0ull;
-                if (idx >= 0) {
-                    int spins = 0;
-                    for (;;) {
-                        const u64 pv = __hip_atomic_load(&pre[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (pv & BF_VALID) { isP = true; val = pv; break; }
-                        const u64 av = __hip_atomic_load(&agg[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (av & BF_VALID) { val = av; break; }
-                        if (++spins > BF_SPIN_LIMIT) { atomicExch(ctrl + 1, 1u); if (status) status[0] = GS_ENOSPC; break; }   // (reported as a truncated view)
-                        __builtin_amdgcn_s_sleep(2);
+            bool done = false;
+            while (!done) {
+                u64 pv[EM_LOOK], av[EM_LOOK];
+#pragma unroll
+                for (int j = 0; j < EM_LOOK; ++j) {
+                    const int idx = pos - 64 * j - lane;
+                    pv[j] = av[j] = 0ull;
+                    if (idx >= 0) {
+                        pv[j] = __hip_atomic_load(&pre[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        av[j] = __hip_atomic_load(&agg[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
-                const u64 pmask = __ballot(isP);
-                const int first = pmask ? __builtin_ctzll(pmask) : 64;
-                unsigned long long cv = lane <= first ? (val & ~BF_VALID) : 0ull;
 #pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) cv += (unsigned long long)__shfl_xor((long long)cv, off, 64);
-                base += cv;
-                if (pmask) break;
-                pos -= 64;
+                for (int j = 0; j < EM_LOOK; ++j) {
+                    if (done) break;                         // (wave-uniform: the groups behind the first prefix are neither awaited nor summed)
+                    const int idx = pos - 64 * j - lane;
+                    bool isP = idx < 0;                      // (virtual predecessors before block 0: prefix 0)
+                    u64 val = 0ull;
+                    if (idx >= 0) {
+                        int spins = 0;
+                        for (;;) {
+                            if (pv[j] & BF_VALID) { isP = true; val = pv[j]; break; }
+                            if (av[j] & BF_VALID) { val = av[j]; break; }
+                            if (++spins > BF_SPIN_LIMIT) { atomicExch(ctrl + 1, 1u); if (status) status[0] = GS_ENOSPC; break; }   // (reported as a truncated view)
+                            __builtin_amdgcn_s_sleep(2);
+                            pv[j] = __hip_atomic_load(&pre[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            av[j] = __hip_atomic_load(&agg[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                    const u64 pmask = __ballot(isP);
+                    const int first = pmask ? __builtin_ctzll(pmask) : 64;
+                    if (lane <= first) acc += val & ~BF_VALID;
+                    if (pmask) done = true;
+                }
+                pos -= 64 * EM_LOOK;
             }
         }
+        const unsigned long long base = gs_wave_sum_u64(acc);
         if (lane == 0) {
             __hip_atomic_store(&pre[block], (u64)(base + total) | BF_VALID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_base = base;
@@ -563,11 +565,7 @@ tile_offsets_scan_kernel(int n_tiles, const unsigned* __restrict__ tile_counts, 
         const int i = i0 + threadIdx.x;
         const unsigned v = i < n_tiles ? tile_counts[i] : 0u;
         unsigned incl = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
+        incl = gs_wave_incl_scan(incl);
         if (lane == 63) wsum[wave] = incl;
         __syncthreads();
         unsigned before = 0u, all = 0u;

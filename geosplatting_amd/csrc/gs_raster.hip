@@ -978,11 +978,7 @@ raster_bwd_lanes2_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
         // pair slots: exclusive scan of the mask sizes; records whose pairs do not fit wait for the next dense batch
         const int cnt = __popcll(pm);
         int cum = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int up = __shfl_up(cum, off, 64);
-            if (lane >= off) cum += up;
-        }
+        cum = gs_wave_incl_scan(cum);
         if (__ballot(cum > GS_PAIR_CAP) != 0ull) {
             nb = min(nb, __popcll(__ballot(cum <= GS_PAIR_CAP)));   // cum is monotone: a prefix of the records fits (>= 8 of them)
             if (lane >= nb) pm = 0ull;
@@ -1254,11 +1250,7 @@ raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_
     if (bo.bcount) {                                               // block b = the b-th tile of the bucket lists, longest bucket first
         const int c = bo.bcount[lane];
         int incl = c;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
+        incl = gs_wave_incl_scan(incl);
         const unsigned long long above = __ballot(incl > (int)blockIdx.x);
         const int b = above ? __builtin_ctzll(above) : 63;
         const int before = __builtin_amdgcn_readlane(incl - c, b);
@@ -1371,11 +1363,7 @@ raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_
         const float2 rb4 = make_float2(c1.x, c1.y);
         const int cnt = __popcll(pm);
         int cum = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int up = __shfl_up(cum, off, 64);
-            if (lane >= off) cum += up;
-        }
+        cum = gs_wave_incl_scan(cum);
         GS_PHASE_END(1);
         // ---- sub-batches: as many records as the pair buffer holds (almost always all 64)
         int r0 = 0, cumbase = 0;

@@ -517,7 +517,7 @@ def main():
         t_s = time.perf_counter()
         one_step(); torch.cuda.synchronize()
         per = max(time.perf_counter() - t_s, 1e-3)
-        n_settle = int(min(200, max(0, args.settle_seconds / per)))
+        n_settle = int(min(200, max(40, args.settle_seconds / per)))    # (scripts/xp/ramp.py: a cold process reaches its steady rate after ~20 steps)
         if world > 1:
             t_n = torch.tensor([n_settle], device=dev); dist.all_reduce(t_n, op=dist.ReduceOp.MAX); n_settle = int(t_n.item())
         for _ in range(n_settle):

@@ -42,7 +42,7 @@ class GsEnvGrad(C.Structure):
 # every symbol include/geosplat_hip.h declares (tests/test_abi.py checks the list against the header)
 SYMBOLS = [
     "gs_last_error", "gs_version", "gs_project_ws_bytes", "gs_project_fwd", "gs_project_fwd_vis", "gs_isect_emit", "gs_sort_ws_bytes",
-    "gs_isect_sort", "gs_isect_bin_ws_bytes", "gs_isect_bin", "gs_isect_offsets", "gs_raster_order_ws_bytes", "gs_raster_log_gather_ws_bytes", "gs_raster_prepare_order", "gs_raster_composite_tone_log_gather", "gs_raster_bwd_tone_log_acc_gather", "gs_raster_ws_bytes", "gs_raster_fwd", "gs_raster_prepare", "gs_raster_prepare_vis", "gs_raster_composite", "gs_raster_grad_stride", "gs_raster_bwd", "gs_raster_bwd_acc", "gs_selftest_rcp", "gs_selftest_exp", "gs_selftest_cube_edges", "gs_isect_bin_cap", "gs_isect_offsets_cap", "gs_isect_bin_tiles_cap", "gs_isect_offsets_tiles_cap", "gs_raster_prepare_vis_cap", "gs_raster_composite_cap", "gs_raster_bwd_cap", "gs_raster_bwd_acc_cap", "gs_raster_composite_tone", "gs_raster_bwd_tone_acc", "gs_raster_log_ws_bytes", "gs_raster_composite_tone_log", "gs_raster_bwd_tone_log_acc", "gs_project_bwd_cap", "gs_project_bwd", "gs_shade_fwd",
+    "gs_isect_sort", "gs_isect_bin_ws_bytes", "gs_isect_bin", "gs_isect_offsets", "gs_raster_ws_bytes", "gs_raster_fwd", "gs_raster_prepare", "gs_raster_prepare_vis", "gs_raster_composite", "gs_raster_grad_stride", "gs_raster_bwd", "gs_raster_bwd_acc", "gs_selftest_rcp", "gs_selftest_exp", "gs_selftest_cube_edges", "gs_isect_bin_cap", "gs_isect_offsets_cap", "gs_isect_bin_tiles_cap", "gs_isect_offsets_tiles_cap", "gs_raster_prepare_vis_cap", "gs_raster_composite_cap", "gs_raster_bwd_cap", "gs_raster_bwd_acc_cap", "gs_raster_composite_tone", "gs_raster_bwd_tone_acc", "gs_raster_log_ws_bytes", "gs_raster_composite_tone_log", "gs_raster_bwd_tone_log_acc", "gs_project_bwd_cap", "gs_project_bwd", "gs_shade_fwd",
     "gs_shade_bwd_ws_bytes", "gs_shade_bwd", "gs_tonemap_fwd", "gs_tonemap_bwd", "gs_tonemap_fwd3", "gs_tonemap_bwd3", "gs_cubemap_mip_fwd", "gs_cubemap_mip_chain_fwd", "gs_cube_sample_linear",
     "gs_cubemap_mip_bwd", "gs_diffuse_cubemap_fwd", "gs_diffuse_cubemap_bwd", "gs_specular_bounds", "gs_specular_bounds_ws_bytes", "gs_specular_bounds_fast", "gs_cube_dir_table",
     "gs_specular_cubemap_fwd", "gs_specular_cubemap_bwd", "gs_specular_tiles_count", "gs_specular_tiles_fill",
@@ -97,10 +97,6 @@ def lib() -> C.CDLL:
         l.gs_tail_priv_ws_bytes.argtypes = [C.c_void_p, C.c_int]
         l.gs_raster_log_ws_bytes.restype = C.c_size_t
         l.gs_raster_log_ws_bytes.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int]
-        l.gs_raster_order_ws_bytes.restype = C.c_size_t
-        l.gs_raster_order_ws_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
-        l.gs_raster_log_gather_ws_bytes.restype = C.c_size_t
-        l.gs_raster_log_gather_ws_bytes.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int]
         l.gs_raster_ws_bytes.restype = C.c_size_t
         l.gs_raster_ws_bytes.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib = l

@@ -21,7 +21,6 @@
 #include "gs_common.h"
 #include "gs_tone.h"
 #include <stdlib.h>
-#include <type_traits>
 
 #pragma clang fp contract(off)   // sigma / compositing are spelled with explicit fmaf (bit-exact vs oracle)
 
@@ -449,48 +448,6 @@ __device__ __forceinline__ void raw_wait(RawBatch& b)
     asm volatile(GS_RAW_WAIT : "+v"(b.r0), "+v"(b.r1), "+v"(b.r2) : : "memory");
 }
 
-// ---- the same pipeline WITHOUT a record stream (round 6): the compositor gathers the 64-byte per-visible records itself ----------
-// The stream (48 bytes per intersection, written by build_stream_packed_kernel: 425 MB of traffic and 90 us per 2 M-Gaussian view,
-// on the chain in front of the compositor) only exists to make these loads coalesced.  Here a lane loads the packed slot of its
-// intersection (flatten_ids, coalesced, 4 bytes) THREE steps before the step that loads the three quarters of that slot's record
-// (one 64-byte line per lane).  Issue order per step s, consuming batch s out of B = raw[s % 3]:
-//     ... R(s) ID(s+3) | R(s+1) ID(s+4) | R(s+2) ID(s+5) |   <- in flight when step s starts
-// R(s) and ID(s+3) are needed (the refill R(s+3) takes its addresses from ID(s+3)); behind ID(s+3) there are 3 + 1 + 3 + 1 = 8
-// younger loads, loads return in order: vmcnt(8) -- two record batches stay in flight, as in the stream version.
-struct RawBatchG { v4f r0, r1, r2; int gid, nid; };                // gid: the slot of the records in r0..r2; nid: of the next refill
-// (nid is an IN-OUT operand of its load and gid is produced from it by an opaque move: the two keep their registers for the whole
-//  kernel.  With a plain `b.gid = b.nid` the register allocator swapped their roles at every refill and repaired the loop with copies --
-//  copies of a register whose load is still in flight, i.e. of the previous contents: wild record addresses.)
-__device__ __forceinline__ void rawg_ids(RawBatchG& b, const int32_t* __restrict__ flat, int idx, bool in_range)
-{
-    const int32_t* p = flat + (in_range ? idx : 0);
-    asm volatile("global_load_dword %0, %1, off" : "+v"(b.nid) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void rawg_load(RawBatchG& b, const float4* __restrict__ vis, const int32_t* __restrict__ flat, int idx_next, bool next_in_range)
-{
-    asm volatile("v_mov_b32 %0, %1" : "=v"(b.gid) : "v"(b.nid));
-    const float4* p = vis + 4 * (size_t)(unsigned)b.gid;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(b.r0) : "v"(p) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=&v"(b.r1) : "v"(p) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=&v"(b.r2) : "v"(p) : "memory");
-    rawg_ids(b, flat, idx_next, next_in_range);
-}
-__device__ __forceinline__ void rawg_wait(RawBatchG& b)
-{
-    asm volatile("s_waitcnt vmcnt(8)" : "+v"(b.r0), "+v"(b.r1), "+v"(b.r2), "+v"(b.nid) : : "memory");
-    b.r2.w = __int_as_float(b.gid);                              // (the stream carries the slot in this pad word; the record holds 0)
-}
-__device__ __forceinline__ void rawg_wait_ids(RawBatchG& a, RawBatchG& b, RawBatchG& c)
-{
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a.nid), "+v"(b.nid), "+v"(c.nid) : : "memory");
-}
-__device__ __forceinline__ void rawg_drain(RawBatchG& a, RawBatchG& b, RawBatchG& c)
-{
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(a.r0), "+v"(a.r1), "+v"(a.r2), "+v"(b.r0), "+v"(b.r1), "+v"(b.r2), "+v"(c.r0), "+v"(c.r1), "+v"(c.r2),
-                   "+v"(a.nid), "+v"(b.nid), "+v"(c.nid) : : "memory");
-}
-
 // centre and half-extent (pixel-centre coordinates) of the bounding rectangle of the active lanes of a quadrant wave
 __device__ __forceinline__ void active_rect_c(unsigned long long act, int qx0, int qy0, float& cx, float& cy, float& ex, float& ey)
 {
@@ -568,7 +525,7 @@ struct ToneBwd { int mode; const float* exposure; const float* render; const flo
 //     [4 * offsets[tile] + q * (tile list length) + k],   k = 0 .. count[4 * tile + q) in stream order.
 // The backward walks that list from its end: no raw-batch fill, no cull, no ellipse masks, and a pixel never pops a record that
 // lies behind its own termination (5 % of the popped candidates) -- see raster_bwd_log_kernel.
-struct CullLog { int32_t* idx; unsigned long long* mask; int32_t* count; int32_t* gid /* packed slot of the entry: written and read by the gather variants only */; };
+struct CullLog { int32_t* idx; unsigned long long* mask; int32_t* count; };
 
 #ifndef GS_WIN_Q_SLOTS
 #define GS_WIN_Q_SLOTS 192
@@ -578,8 +535,7 @@ static constexpr int GS_WIN_Q_BYTES = GS_WIN_Q * (16 + 16 + 8 + 4);
 
 __device__ __forceinline__ int win_wrap(int s) { return s >= GS_WIN_Q ? s - GS_WIN_Q : s; }
 
-template <typename Batch>
-__device__ __forceinline__ int win_cull_append(const LaneQueue& q, const Batch& cur, bool in_range, int idx, int lane, float cx,
+__device__ __forceinline__ int win_cull_append(const LaneQueue& q, const RawBatch& cur, bool in_range, int idx, int lane, float cx,
                                                float cy, float ex, float ey, int qtail)
 {
     const float mx = cur.r0.x, my = cur.r0.y, hx = cur.r1.z, hy = cur.r1.w;
@@ -593,7 +549,7 @@ __device__ __forceinline__ int win_cull_append(const LaneQueue& q, const Batch& 
     return __popcll(hmask);
 }
 
-template <int CD, bool GATHER = false /* rec0 = the per-visible records, rec1 = flatten_ids: no record stream (rawg_load) */>
+template <int CD>
 __global__ void __launch_bounds__(256)
 raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* __restrict__ tile_order,
                          const float4* __restrict__ rec0, const float4* __restrict__ rec1, const float4* __restrict__ rec2,
@@ -639,22 +595,10 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
     int base = start;
     int log_n = 0;                                                // wave-uniform: entries of this quadrant's cull log
     const size_t log_base = 4 * (size_t)start + (size_t)wave * (size_t)(end > start ? end - start : 0);
-    typename std::conditional<GATHER, RawBatchG, RawBatch>::type raw0{}, raw1{}, raw2{};
-    const int32_t* const flat = reinterpret_cast<const int32_t*>(rec1);
-    if constexpr (GATHER) {
-        rawg_ids(raw0, flat, start + lane, start + lane < end);
-        rawg_ids(raw1, flat, start + 64 + lane, start + 64 + lane < end);
-        rawg_ids(raw2, flat, start + 128 + lane, start + 128 + lane < end);
-        rawg_wait_ids(raw0, raw1, raw2);
-        rawg_load(raw0, rec0, flat, start + 192 + lane, start + 192 + lane < end);
-        rawg_load(raw1, rec0, flat, start + 256 + lane, start + 256 + lane < end);
-        rawg_load(raw2, rec0, flat, start + 320 + lane, start + 320 + lane < end);
-        rawg_drain(raw0, raw1, raw2);                            // (whatever the compiler copies at the loop's entry has arrived)
-    } else {
-        raw_load(raw0, rec0, rec1, rec2, start + lane, start + lane < end);
-        raw_load(raw1, rec0, rec1, rec2, start + 64 + lane, start + 64 + lane < end);
-        raw_load(raw2, rec0, rec1, rec2, start + 128 + lane, start + 128 + lane < end);
-    }
+    RawBatch raw0, raw1, raw2;
+    raw_load(raw0, rec0, rec1, rec2, start + lane, start + lane < end);
+    raw_load(raw1, rec0, rec1, rec2, start + 64 + lane, start + 64 + lane < end);
+    raw_load(raw2, rec0, rec1, rec2, start + 128 + lane, start + 128 + lane < end);
     int phase = 0;
     for (;;) {
         const unsigned long long act = __ballot(!done);
@@ -666,10 +610,9 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
 #define WIN_FILL_STEP(B)                                                                                               \
         {                                                                                                              \
             GS_STAT(0, 1);                                                                                             \
-            if constexpr (GATHER) rawg_wait(B); else raw_wait(B);                                                      \
+            raw_wait(B);                                                                                               \
             const int n_hit = win_cull_append(q, B, base + lane < end, base + lane, lane, rcx, rcy, rex, rey, qhead + qcount); \
-            if constexpr (GATHER) rawg_load(B, rec0, flat, base + 384 + lane, base + 384 + lane < end);                \
-            else raw_load(B, rec0, rec1, rec2, base + 192 + lane, base + 192 + lane < end);                            \
+            raw_load(B, rec0, rec1, rec2, base + 192 + lane, base + 192 + lane < end);                                 \
             qcount += n_hit;                                                                                           \
             base += 64;                                                                                                \
         }
@@ -698,7 +641,6 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
                 if (lm != 0ull) {
                     const size_t at = log_base + (size_t)(log_n + __popcll(keep & ((1ull << lane) - 1ull)));
                     log.idx[at] = q.idx[slot]; log.mask[at] = lm;
-                    if constexpr (GATHER) log.gid[at] = __float_as_int(q.c[slot].w);
                 }
                 log_n += __popcll(keep);
             }
@@ -726,7 +668,6 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
                 if (lm != 0ull) {
                     const size_t at = log_base + (size_t)(log_n + __popcll(keep & ((1ull << lane) - 1ull)));
                     log.idx[at] = q.idx[slot]; log.mask[at] = lm;
-                    if constexpr (GATHER) log.gid[at] = __float_as_int(q.c[slot].w);
                 }
                 log_n += __popcll(keep);
             }
@@ -823,7 +764,7 @@ raster_fwd_window_kernel(int W, int H, int tile_w, int n_tiles, int D, const int
         listB = 0ull; nB = 0;
         parA ^= 1;                                                 // (B's colour planes become A's)
     }
-    if constexpr (GATHER) rawg_drain(raw0, raw1, raw2); else raw_drain(raw0, raw1, raw2);
+    raw_drain(raw0, raw1, raw2);
     if (log.count && lane == 0) log.count[4 * tile + wave] = log_n;
     if (bo.bcount) {                                                // file the tile for the backward (struct BwdOrder): block barrier only
         __shared__ int s_cnt[4];
@@ -1285,7 +1226,7 @@ __device__ __forceinline__ float gs_row_shr(float ident, float src)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, src), CTRL, 0xf, 0xf, false));
 }
 
-template <int CD, bool GATHER = false /* rec0 = the per-visible records, gathered by the log's packed slots (CullLog::gid) */>
+template <int CD>
 __global__ void __launch_bounds__(256)
 raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_t* __restrict__ tile_order,
                       const float4* __restrict__ rec0, const float4* __restrict__ rec1, const float4* __restrict__ rec2,
@@ -1385,36 +1326,28 @@ raster_bwd_log_kernel(int W, int H, int tile_w, int n_tiles, int D, const int32_
     // software pipeline: entries two batches ahead, records one batch ahead.  Lanes past the log's start re-read entry 0 (a valid
     // record: finite numbers for the zero-weight slots) and are masked out.
     int e_idx, g_idx; unsigned long long e_msk, g_msk;
-    int e_gid = 0, g_gid = 0;                                      // GATHER: the packed slots of the entries (the stream carries them in rec2.w)
-    const int32_t* lgid = GATHER ? log.gid + log_base : nullptr;
     float4 g0, g1, g2;
     {
         const int e = pos - 1 - lane;
         const int es = e >= 0 ? e : 0;
         g_idx = lidx[es]; g_msk = e >= 0 ? lmsk[es] : 0ull;
-        if constexpr (GATHER) { g_gid = lgid[es]; const float4* r = rec0 + 4 * (size_t)(unsigned)g_gid; g0 = r[0]; g1 = r[1]; g2 = r[2]; }
-        else { g0 = rec0[g_idx]; g1 = rec1[g_idx]; g2 = rec2[g_idx]; }
+        g0 = rec0[g_idx]; g1 = rec1[g_idx]; g2 = rec2[g_idx];
         const int e2 = pos - 65 - lane;
         const int es2 = e2 >= 0 ? e2 : 0;
         e_idx = lidx[es2]; e_msk = e2 >= 0 ? lmsk[es2] : 0ull;
-        if constexpr (GATHER) e_gid = lgid[es2];
     }
     while (pos > 0) {
         const int nb = pos < 64 ? pos : 64;
         // ---- issue the loads of the batches behind this one, then publish this batch's records in the queue
-        const float4 c0 = g0, c1 = g1;
-        float4 c2 = g2;
-        if constexpr (GATHER) c2.w = __int_as_float(g_gid);        // (the record's pad word; the stream carries the slot there)
+        const float4 c0 = g0, c1 = g1, c2 = g2;
         const int c_idx = g_idx;
         const unsigned long long c_msk = g_msk;
         g_idx = e_idx; g_msk = e_msk;
-        if constexpr (GATHER) { g_gid = e_gid; const float4* r = rec0 + 4 * (size_t)(unsigned)g_gid; g0 = r[0]; g1 = r[1]; g2 = r[2]; }
-        else { g0 = rec0[g_idx]; g1 = rec1[g_idx]; g2 = rec2[g_idx]; }
+        g0 = rec0[g_idx]; g1 = rec1[g_idx]; g2 = rec2[g_idx];
         {
             const int e2 = pos - 129 - lane;
             const int es2 = e2 >= 0 ? e2 : 0;
             e_idx = lidx[es2]; e_msk = e2 >= 0 ? lmsk[es2] : 0ull;
-            if constexpr (GATHER) e_gid = lgid[es2];
         }
         pos -= nb;
         GS_PHASE_BEGIN();
@@ -1781,12 +1714,8 @@ static GsCount isect_count(int64_t n) { return GsCount{ (long long)n, t_counts_d
 // its ToneFwd / ToneBwd to the kernels (zero = plain compositor).
 static thread_local ToneFwd t_tone_fwd = { 0, nullptr, nullptr };
 static thread_local ToneBwd t_tone_bwd = { 0, nullptr, nullptr, nullptr, nullptr };
-static thread_local CullLog t_cull_log = { nullptr, nullptr, nullptr, nullptr };
-// ... and for the compositor that gathers its records itself (gs_raster_*_gather): the per-visible records and the sorted packed slots
-struct GatherSrc { const float4* vis; const int32_t* flat; };
-static thread_local GatherSrc t_gather = { nullptr, nullptr };
-struct GatherScope { explicit GatherScope(const GatherSrc& g) { t_gather = g; } ~GatherScope() { t_gather = GatherSrc{ nullptr, nullptr }; } };
-struct CullLogScope { explicit CullLogScope(const CullLog& l) { t_cull_log = l; } ~CullLogScope() { t_cull_log = CullLog{ nullptr, nullptr, nullptr, nullptr }; } };
+static thread_local CullLog t_cull_log = { nullptr, nullptr, nullptr };
+struct CullLogScope { explicit CullLogScope(const CullLog& l) { t_cull_log = l; } ~CullLogScope() { t_cull_log = CullLog{ nullptr, nullptr, nullptr }; } };
 struct ToneFwdScope { explicit ToneFwdScope(const ToneFwd& t) { t_tone_fwd = t; } ~ToneFwdScope() { t_tone_fwd = ToneFwd{ 0, nullptr, nullptr }; } };
 struct ToneBwdScope { explicit ToneBwdScope(const ToneBwd& t) { t_tone_bwd = t; } ~ToneBwdScope() { t_tone_bwd = ToneBwd{ 0, nullptr, nullptr, nullptr, nullptr }; } };
 
@@ -1807,16 +1736,6 @@ static int launch_fwd(int W, int H, int D, const RasterWs& ws, const float* colo
         //  process may drive several GPUs and threads, so nothing about it is cached here)
         if (lds > 64 * 1024)
             GS_CHECK_HIP(hipFuncSetAttribute((const void*)raster_fwd_window_kernel<CD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (t_gather.vis) {
-            if constexpr (CD == 3) {
-                if (!t_cull_log.gid) { gs_set_error("gs_raster_composite_tone_log_gather: needs the cull log"); return GS_EINVAL; }
-                hipLaunchKernelGGL((raster_fwd_window_kernel<3, true>), dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
-                                   ws.order, t_gather.vis, reinterpret_cast<const float4*>(t_gather.flat), (const float4*)nullptr, colors, background,
-                                   isect_count(n_isects), offsets, render, alphas, last_ids, t_tone_fwd, t_cull_log, ws.bo);
-                GS_CHECK_LAUNCH();
-                return GS_OK;
-            } else { gs_set_error("the gather compositor is built for D <= 3"); return GS_EINVAL; }
-        }
         hipLaunchKernelGGL(raster_fwd_window_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
                            ws.order, ws.rec0, ws.rec1, ws.rec2, colors, background, isect_count(n_isects), offsets, render, alphas,
                            last_ids, t_tone_fwd, t_cull_log, t_cull_log.count ? ws.bo : BwdOrder{ nullptr, nullptr });
@@ -1930,13 +1849,6 @@ static int launch_bwd(int W, int H, int D, const RasterWs& ws, const float* colo
     if constexpr (CD <= 3) {                                  // colours travel in the record stream only for D <= 3
         if (t_cull_log.idx) {                                   // the forward left its cull log: no fill, no masks
             const size_t lds = gs_raster_lds(4 * (size_t)LogLds::WAVE_BYTES);
-            if (t_gather.vis) {
-                hipLaunchKernelGGL((raster_bwd_log_kernel<CD, true>), dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
-                                   ws.order, t_gather.vis, (const float4*)nullptr, (const float4*)nullptr, background, isect_count(n_isects), offsets,
-                                   alphas, last_ids, v_render, v_alphas, v_packed, rec_stride, t_tone_bwd, t_cull_log, ws.bo);
-                GS_CHECK_LAUNCH();
-                return GS_OK;
-            }
             hipLaunchKernelGGL(raster_bwd_log_kernel<CD>, dim3(tile_w * tile_h), dim3(256), lds, s, W, H, tile_w, tile_w * tile_h, D,
                                ws.order, ws.rec0, ws.rec1, ws.rec2, background, isect_count(n_isects), offsets, alphas, last_ids,
                                v_render, v_alphas, v_packed, rec_stride, t_tone_bwd, t_cull_log, ws.bo);
@@ -2083,15 +1995,14 @@ extern "C" int gs_raster_bwd_tone_acc(int W, int H, int tile_size, int V, const 
 // ---------------------------------------------------------------------------------------------------
 // self-test hook: counts the floats with bit patterns in [lo_bits, hi_bits] for which gs_rcp_exact2 differs from IEEE division
 // ---- cull log (forward -> backward), see struct CullLog -----------------------------------------------------------------------
-static CullLog carve_log(void* log_ws, int64_t n_isects, size_t tiles = 0, bool with_gid = false)
+static CullLog carve_log(void* log_ws, int64_t n_isects)
 {
     const size_t n = n_isects > 0 ? (size_t)n_isects : 1;
     char* p = (char*)log_ws;
     CullLog l;
     l.mask = (unsigned long long*)p; p += align256(4 * n * sizeof(unsigned long long));
     l.idx = (int32_t*)p; p += align256(4 * n * sizeof(int32_t));
-    l.count = (int32_t*)p; p += align256(4 * (size_t)tiles * sizeof(int32_t));
-    l.gid = with_gid ? (int32_t*)p : nullptr;
+    l.count = (int32_t*)p;
     return l;
 }
 extern "C" size_t gs_raster_log_ws_bytes(int64_t n_isects, int W, int H, int tile_size)
@@ -2100,65 +2011,6 @@ extern "C" size_t gs_raster_log_ws_bytes(int64_t n_isects, int W, int H, int til
     const size_t n = n_isects > 0 ? (size_t)n_isects : 1;
     const size_t tiles = (size_t)((W + tile_size - 1) / tile_size) * (size_t)((H + tile_size - 1) / tile_size);
     return align256(4 * n * sizeof(unsigned long long)) + align256(4 * n * sizeof(int32_t)) + align256(4 * tiles * sizeof(int32_t));
-}
-
-// ---- the compositor pair WITHOUT a record stream (see RawBatchG): same arguments plus the per-visible records (gs_front_fwd) and the
-// sorted packed slots (gs_isect_bin_front's flatten_ids); `ws` is a gs_raster_order_ws_bytes workspace prepared by gs_raster_prepare_order,
-// `log_ws` has gs_raster_log_gather_ws_bytes (the log also carries the packed slot of every entry)
-static size_t tiles_of(int W, int H, int tile_size) { return (size_t)((W + tile_size - 1) / tile_size) * (size_t)((H + tile_size - 1) / tile_size); }
-extern "C" size_t gs_raster_order_ws_bytes(int W, int H, int tile_size) { return tile_size > 0 ? gs_raster_ws_bytes(0, 0, W, H, tile_size) : 0; }
-extern "C" size_t gs_raster_log_gather_ws_bytes(int64_t n_isects, int W, int H, int tile_size)
-{
-    if (tile_size <= 0) return 0;
-    const size_t n = n_isects > 0 ? (size_t)n_isects : 1;
-    return gs_raster_log_ws_bytes(n_isects, W, H, tile_size) + align256(4 * n * sizeof(int32_t));
-}
-extern "C" int gs_raster_prepare_order(int W, int H, int tile_size, int64_t n_isects, const int64_t* counts_dev, const int32_t* offsets, void* ws,
-                                       size_t ws_bytes, void* stream)
-{
-    GS_CHECK_ARG(W > 0 && H > 0 && tile_size == GS_TILE && ws != nullptr && offsets != nullptr && n_isects >= 0 && n_isects < (1ll << 31), "bad argument");
-    if (ws_bytes < gs_raster_order_ws_bytes(W, H, tile_size)) { gs_set_error("gs_raster_prepare_order: workspace too small"); return GS_ENOSPC; }
-    CountsScope cs(counts_dev);
-    const int tiles = (int)tiles_of(W, H, tile_size);
-    const RasterWs r = carve(ws, 0, 0, tiles);
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, tiles, isect_count(n_isects), offsets, r.order, r.bo);
-    GS_CHECK_LAUNCH();
-    return GS_OK;
-}
-extern "C" int gs_raster_composite_tone_log_gather(int W, int H, int tile_size, int V, const float* vis_records, const int32_t* flatten_ids,
-                                                   int64_t n_isects, const int64_t* counts_dev, const int32_t* offsets, float* render,
-                                                   float* alphas, int32_t* last_ids, int tone_mode, const float* exposure, float* image,
-                                                   const void* ws, size_t ws_bytes, void* log_ws, size_t log_bytes, void* stream)
-{
-    GS_CHECK_ARG(log_ws != nullptr && tile_size == GS_TILE && vis_records != nullptr && flatten_ids != nullptr && ws != nullptr, "null argument");
-    GS_CHECK_ARG(W > 0 && H > 0 && V >= 0 && n_isects >= 0 && n_isects < (1ll << 31) && exposure != nullptr && image != nullptr, "bad argument");
-    if (ws_bytes < gs_raster_order_ws_bytes(W, H, tile_size)) { gs_set_error("gs_raster_composite_tone_log_gather: workspace too small"); return GS_ENOSPC; }
-    if (log_bytes < gs_raster_log_gather_ws_bytes(n_isects, W, H, tile_size)) { gs_set_error("gs_raster_composite_tone_log_gather: log workspace too small"); return GS_ENOSPC; }
-    CullLogScope ls(carve_log(log_ws, n_isects, tiles_of(W, H, tile_size), true));
-    GatherScope gsrc(GatherSrc{ (const float4*)vis_records, flatten_ids });
-    CountsScope cs(counts_dev);
-    ToneFwdScope ts(ToneFwd{ tone_mode, exposure, (float4*)image });
-    const RasterWs r = carve((void*)ws, 0, 0, (int)tiles_of(W, H, tile_size));
-    return launch_fwd<3>(W, H, 3, r, nullptr, nullptr, n_isects, offsets, render, alphas, last_ids, (hipStream_t)stream);
-}
-extern "C" int gs_raster_bwd_tone_log_acc_gather(int W, int H, int tile_size, int V, const float* vis_records, int64_t n_isects,
-                                                 const int64_t* counts_dev, const int32_t* offsets, const float* render, const float* alphas,
-                                                 const int32_t* last_ids, int tone_mode, const float* exposure, const float* v_image,
-                                                 float* v_packed, float* v_exposure, const void* ws, size_t ws_bytes, const void* log_ws,
-                                                 size_t log_bytes, void* stream)
-{
-    GS_CHECK_ARG(log_ws != nullptr && tile_size == GS_TILE && vis_records != nullptr && ws != nullptr, "null argument");
-    GS_CHECK_ARG(W > 0 && H > 0 && V >= 0 && n_isects >= 0 && n_isects < (1ll << 31) && exposure && render && v_image && v_packed && v_exposure, "bad argument");
-    if (ws_bytes < gs_raster_order_ws_bytes(W, H, tile_size)) { gs_set_error("gs_raster_bwd_tone_log_acc_gather: workspace too small"); return GS_ENOSPC; }
-    if (log_bytes < gs_raster_log_gather_ws_bytes(n_isects, W, H, tile_size)) { gs_set_error("gs_raster_bwd_tone_log_acc_gather: log workspace too small"); return GS_ENOSPC; }
-    CullLogScope ls(carve_log((void*)log_ws, n_isects, tiles_of(W, H, tile_size), true));
-    if (n_isects == 0 || V == 0) return GS_OK;
-    GatherScope gsrc(GatherSrc{ (const float4*)vis_records, nullptr });
-    CountsScope cs(counts_dev);
-    ToneBwdScope ts(ToneBwd{ tone_mode, exposure, render, (const float4*)v_image, v_exposure });
-    const RasterWs r = carve((void*)ws, 0, 0, (int)tiles_of(W, H, tile_size));
-    return launch_bwd<3>(W, H, 3, r, nullptr, nullptr, n_isects, offsets, alphas, last_ids, nullptr, nullptr, v_packed, gs_raster_grad_stride(3),
-                         (hipStream_t)stream);
 }
 
 extern "C" int gs_raster_composite_tone_log(int W, int H, int tile_size, int V, const float* colors, int64_t n_isects,

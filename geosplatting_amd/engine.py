@@ -353,8 +353,13 @@ class RenderStep:
             render = torch.empty(H, W, 3, dtype=f32, device=dev); alphas = torch.empty(H, W, dtype=f32, device=dev)
             last_ids = torch.empty(H, W, dtype=torch.int32, device=dev)
             img = torch.empty(H, W, 4, dtype=f32, device=dev)
-            log_ws = torch.empty(F.log_ws_bytes(I, W, H), dtype=torch.uint8, device=dev)
-            F.composite_tone_log(s, W, H, V, I, render, alphas, last_ids, tone, exposure, img, log_ws, st())
+            rws = s["raster_ws"]
+            counts = L.ptr(s["counts"]) if i_cap is not None else None
+            log_ws = torch.empty(lib.gs_raster_log_ws_bytes(L.i64(I), W, H, 16), dtype=torch.uint8, device=dev)
+            L.check(lib.gs_raster_composite_tone_log(W, H, 16, V, None, L.i64(I), counts, L.ptr(s["isect_offsets"]), L.ptr(render),
+                                                     L.ptr(alphas), L.ptr(last_ids), tone, L.ptr(exposure), L.ptr(img), L.ptr(rws),
+                                                     C.c_size_t(rws.numel()), L.ptr(log_ws), C.c_size_t(log_ws.numel()), st()),
+                    "gs_raster_composite_tone_log")
             if kev is not None:
                 k1 = torch.cuda.Event(enable_timing=True); k1.record(main)
                 kev.append(("raster_fwd_kernel", k0, k1))
@@ -362,7 +367,10 @@ class RenderStep:
             v_packed = s["v_packed"]
             if kev is not None:
                 k2 = torch.cuda.Event(enable_timing=True); k2.record(main)
-            F.bwd_tone_log_acc(s, W, H, V, I, render, alphas, last_ids, tone, exposure, v_img, v_packed, b["exposure"], log_ws, st())
+            L.check(lib.gs_raster_bwd_tone_log_acc(W, H, 16, V, None, L.i64(I), counts, L.ptr(s["isect_offsets"]), L.ptr(render),
+                                                   L.ptr(alphas), L.ptr(last_ids), tone, L.ptr(exposure), L.ptr(v_img), L.ptr(v_packed),
+                                                   L.ptr(b["exposure"]), L.ptr(rws), C.c_size_t(rws.numel()), L.ptr(log_ws),
+                                                   C.c_size_t(log_ws.numel()), st()), "gs_raster_bwd_tone_log_acc")
             if kev is not None:
                 k3 = torch.cuda.Event(enable_timing=True); k3.record(main)
                 kev.append(("raster_bwd_kernel", k2, k3))

@@ -34,11 +34,6 @@ def reserve_pinned(n: int) -> None:
         _pinned_pool4.append(torch.empty(4, dtype=torch.int64).pin_memory())
 
 
-# The compositor pair without a record stream (gs_raster_*_gather, round 6); False: gs_raster_prepare_vis builds the 48-byte-per-
-# intersection stream in front of the compositor (tests monkeypatch this to compare the two, bit for bit)
-GATHER_RECORDS = True
-
-
 class Front:
     """What gs_front_fwd left behind for one view; (V, I, depth range) on their way to pinned memory."""
     __slots__ = ("vis", "keys", "rects", "tile_counts", "packed_index", "counts", "host_counts", "event", "whs", "key_bits", "N")
@@ -119,16 +114,6 @@ def bin_stage(fr: Front, i_cap: Optional[int], status: Optional[Tensor], prepare
                                        L.ptr(status) if counts is not None else None, st), "gs_isect_bin_front")
     if not prepare:
         return dict(flatten_ids=flat, isect_offsets=offsets, counts=counts, keys=fr.keys, rects=fr.rects, tile_counts=fr.tile_counts), V, I
-    if GATHER_RECORDS:
-        # no record stream: the compositor pair gathers the per-visible records itself (gs_raster_*_gather); what is left of the
-        # preparation is the longest-first tile orders
-        rws_bytes = lib.gs_raster_order_ws_bytes(W, H, tile_size)
-        rws = torch.empty(rws_bytes, dtype=torch.uint8, device=dev)
-        L.check(lib.gs_raster_prepare_order(W, H, tile_size, L.i64(I), L.ptr(counts), L.ptr(offsets), L.ptr(rws), C.c_size_t(rws_bytes), st),
-                "gs_raster_prepare_order")
-        state = dict(vis_records=fr.vis, flatten_ids=flat, isect_offsets=offsets, raster_ws=rws, counts=counts, keys=fr.keys, rects=fr.rects,
-                     tile_counts=fr.tile_counts, packed_index=fr.packed_index, gather=True)
-        return state, V, I
     rws_bytes = lib.gs_raster_ws_bytes(L.i64(I), V, W, H, tile_size)
     rws = torch.empty(rws_bytes, dtype=torch.uint8, device=dev)
     if counts is None:
@@ -140,47 +125,6 @@ def bin_stage(fr: Front, i_cap: Optional[int], status: Optional[Tensor], prepare
     state = dict(vis_records=fr.vis, flatten_ids=flat, isect_offsets=offsets, raster_ws=rws, counts=counts, keys=fr.keys, rects=fr.rects,
                  tile_counts=fr.tile_counts, packed_index=fr.packed_index)
     return state, V, I
-
-
-def log_ws_bytes(I: int, W: int, H: int) -> int:
-    """Bytes of the cull log of one view (forward -> backward of the compositor pair)."""
-    lib = L.lib()
-    return int(lib.gs_raster_log_gather_ws_bytes(L.i64(I), W, H, 16) if GATHER_RECORDS else lib.gs_raster_log_ws_bytes(L.i64(I), W, H, 16))
-
-
-def composite_tone_log(state, W: int, H: int, V: int, I: int, render: Tensor, alphas: Tensor, last_ids: Tensor, tone: int, exposure: Tensor,
-                       img: Tensor, log_ws: Tensor, stream) -> None:
-    """A5 + S4 of one view on a bin_stage state: the compositor forward with the tone map in its epilogue; leaves the cull log."""
-    lib = L.lib()
-    rws = state["raster_ws"]
-    if state.get("gather"):
-        L.check(lib.gs_raster_composite_tone_log_gather(W, H, 16, V, L.ptr(state["vis_records"]), L.ptr(state["flatten_ids"]), L.i64(I),
-                                                        L.ptr(state["counts"]), L.ptr(state["isect_offsets"]), L.ptr(render), L.ptr(alphas),
-                                                        L.ptr(last_ids), tone, L.ptr(exposure), L.ptr(img), L.ptr(rws), C.c_size_t(rws.numel()),
-                                                        L.ptr(log_ws), C.c_size_t(log_ws.numel()), stream), "gs_raster_composite_tone_log_gather")
-    else:
-        L.check(lib.gs_raster_composite_tone_log(W, H, 16, V, None, L.i64(I), L.ptr(state["counts"]), L.ptr(state["isect_offsets"]), L.ptr(render),
-                                                 L.ptr(alphas), L.ptr(last_ids), tone, L.ptr(exposure), L.ptr(img), L.ptr(rws),
-                                                 C.c_size_t(rws.numel()), L.ptr(log_ws), C.c_size_t(log_ws.numel()), stream),
-                "gs_raster_composite_tone_log")
-
-
-def bwd_tone_log_acc(state, W: int, H: int, V: int, I: int, render: Tensor, alphas: Tensor, last_ids: Tensor, tone: int, exposure: Tensor,
-                     v_img: Tensor, v_packed: Tensor, v_exposure: Tensor, log_ws: Tensor, stream) -> None:
-    """S4 + A6 backward of one view: ACCUMULATES into the view's 64-byte gradient records and into v_exposure."""
-    lib = L.lib()
-    rws = state["raster_ws"]
-    if state.get("gather"):
-        L.check(lib.gs_raster_bwd_tone_log_acc_gather(W, H, 16, V, L.ptr(state["vis_records"]), L.i64(I), L.ptr(state["counts"]),
-                                                      L.ptr(state["isect_offsets"]), L.ptr(render), L.ptr(alphas), L.ptr(last_ids), tone,
-                                                      L.ptr(exposure), L.ptr(v_img), L.ptr(v_packed), L.ptr(v_exposure), L.ptr(rws),
-                                                      C.c_size_t(rws.numel()), L.ptr(log_ws), C.c_size_t(log_ws.numel()), stream),
-                "gs_raster_bwd_tone_log_acc_gather")
-    else:
-        L.check(lib.gs_raster_bwd_tone_log_acc(W, H, 16, V, None, L.i64(I), L.ptr(state["counts"]), L.ptr(state["isect_offsets"]), L.ptr(render),
-                                               L.ptr(alphas), L.ptr(last_ids), tone, L.ptr(exposure), L.ptr(v_img), L.ptr(v_packed),
-                                               L.ptr(v_exposure), L.ptr(rws), C.c_size_t(rws.numel()), L.ptr(log_ws),
-                                               C.c_size_t(log_ws.numel()), stream), "gs_raster_bwd_tone_log_acc")
 
 
 def tail_stage(V: int, counts: Optional[Tensor], means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, normals: Tensor,

@@ -371,7 +371,7 @@ def _view_forward(step: _Step, cam: Camera, exposure: Tensor, tone: int, want_gr
         split = True
         state, V, I = F.bin_stage(fr, i_cap, status, prepare=not split)
         v_packed = torch.zeros(max(V, 1), lib.gs_raster_grad_stride(3), dtype=torch.float32, device=dev) if want_grad else None
-        log_ws = torch.empty(F.log_ws_bytes(I, W, H), dtype=torch.uint8, device=dev)
+        log_ws = torch.empty(lib.gs_raster_log_ws_bytes(L.i64(I), W, H, 16), dtype=torch.uint8, device=dev)
         v.host_status = None
         if not exact:
             # the device's own word (word 0: a view truncated at its capacity, or a look-back of the front / emission that gave up;
@@ -401,7 +401,11 @@ def _view_forward(step: _Step, cam: Camera, exposure: Tensor, tone: int, want_gr
     f32 = torch.float32
     render = torch.empty(H, W, 3, dtype=f32, device=dev); alphas = torch.empty(H, W, dtype=f32, device=dev)
     last_ids = torch.empty(H, W, dtype=torch.int32, device=dev); img = torch.empty(H, W, 4, dtype=f32, device=dev)
-    F.composite_tone_log(state, W, H, V, I, render, alphas, last_ids, tone, exposure, img, log_ws, L.stream())
+    rws = state["raster_ws"]
+    L.check(lib.gs_raster_composite_tone_log(W, H, 16, V, None, L.i64(I), L.ptr(state["counts"]), L.ptr(state["isect_offsets"]),
+                                             L.ptr(render), L.ptr(alphas), L.ptr(last_ids), tone, L.ptr(exposure), L.ptr(img), L.ptr(rws),
+                                             C.c_size_t(rws.numel()), L.ptr(log_ws), C.c_size_t(log_ws.numel()), L.stream()),
+            "gs_raster_composite_tone_log")
     v.V, v.I, v.state, v.render, v.alphas, v.last_ids, v.log_ws, v.exposure = V, I, state, render, alphas, last_ids, log_ws, exposure
     return img, v
 
@@ -433,7 +437,11 @@ def _view_backward(step: _Step, v: _View, v_img: Tensor) -> Tensor:
 def _view_backward_launch(step: _Step, v: _View, v_img: Tensor, g_exp: Tensor, gather: bool) -> Tensor:
     lib = L.lib()
     s = v.state
-    F.bwd_tone_log_acc(s, v.W, v.H, v.V, v.I, v.render, v.alphas, v.last_ids, v.tone, v.exposure, v_img, s["v_packed"], g_exp, v.log_ws, L.stream())
+    rws = s["raster_ws"]
+    L.check(lib.gs_raster_bwd_tone_log_acc(v.W, v.H, 16, v.V, None, L.i64(v.I), L.ptr(s["counts"]), L.ptr(s["isect_offsets"]),
+                                           L.ptr(v.render), L.ptr(v.alphas), L.ptr(v.last_ids), v.tone, L.ptr(v.exposure), L.ptr(v_img),
+                                           L.ptr(s["v_packed"]), L.ptr(g_exp), L.ptr(rws), C.c_size_t(rws.numel()), L.ptr(v.log_ws),
+                                           C.c_size_t(v.log_ws.numel()), L.stream()), "gs_raster_bwd_tone_log_acc")
     v.done = True
     if not gather:
         v.state = v.render = v.alphas = v.last_ids = v.log_ws = None

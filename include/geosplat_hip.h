@@ -232,25 +232,6 @@ int gs_raster_bwd_tone_log_acc(int W, int H, int tile_size, int V, const float* 
                                const int32_t* last_ids, int tone_mode, const float* exposure, const float* v_image,
                                float* v_packed, float* v_exposure, const void* ws, size_t ws_bytes, const void* log_ws,
                                size_t log_bytes, void* stream);
-/* The same compositor pair WITHOUT a record stream (round 6): the kernels gather the 64-byte per-visible records (gs_front_fwd's
- * vis_records) themselves, through the sorted packed slots (flatten_ids of gs_isect_bin_front) in the forward and through the cull log
- * -- which then also holds the slot of every entry -- in the backward; gs_raster_prepare_vis and its 48 bytes per intersection do not
- * exist on this path.  `ws`: gs_raster_order_ws_bytes, filled by gs_raster_prepare_order (longest-first tile orders); `log_ws`:
- * gs_raster_log_gather_ws_bytes.  Images, indices and gradients are bit-identical to the stream pair (tests/test_gpu_front.py).
- * D == 3, no background, tone mapping inside (S4): what RenderableAttrs.splat passes (rfstudio/model/geosplat.py:53-132). */
-size_t gs_raster_order_ws_bytes(int W, int H, int tile_size);
-size_t gs_raster_log_gather_ws_bytes(int64_t n_isects, int W, int H, int tile_size);
-int gs_raster_prepare_order(int W, int H, int tile_size, int64_t n_isects, const int64_t* counts_dev /* nullable: exact n_isects */,
-                            const int32_t* offsets, void* ws, size_t ws_bytes, void* stream);
-int gs_raster_composite_tone_log_gather(int W, int H, int tile_size, int V, const float* vis_records, const int32_t* flatten_ids,
-                                        int64_t n_isects, const int64_t* counts_dev, const int32_t* offsets, float* render,
-                                        float* alphas, int32_t* last_ids, int tone_mode, const float* exposure, float* image,
-                                        const void* ws, size_t ws_bytes, void* log_ws, size_t log_bytes, void* stream);
-int gs_raster_bwd_tone_log_acc_gather(int W, int H, int tile_size, int V, const float* vis_records, int64_t n_isects,
-                                      const int64_t* counts_dev, const int32_t* offsets, const float* render, const float* alphas,
-                                      const int32_t* last_ids, int tone_mode, const float* exposure, const float* v_image,
-                                      float* v_packed, float* v_exposure, const void* ws, size_t ws_bytes, const void* log_ws,
-                                      size_t log_bytes, void* stream);
 int gs_project_bwd_cap(int N, const int64_t* counts_dev, int D, const float* means, const float* quats, const float* scales,
                        const float* opacities, const float* viewmat, const float* K, int W, int H, float eps2d,
                        const int32_t* gaussian_ids, const float* conics, const float* compensations, const float* v_packed,
